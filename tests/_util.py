@@ -1,0 +1,43 @@
+"""Shared helpers for the parity tests (golden loading, oracle construction)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+G_MODS = ("attention", "feature_embedder", "encoder", "decoder")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def state_from(g, prefix):
+    """{'encoder': {key: tensor}, ..., 'D': {...}} from flat 'w0.encoder.embed.weight' keys."""
+    out = {}
+    for k in g.files:
+        if k.startswith(prefix):
+            mod, key = k[len(prefix):].split(".", 1)
+            out.setdefault(mod, {})[key] = torch.from_numpy(np.array(g[k]))
+    return out
+
+
+def as_checkpoint(st, epoch=0):
+    return {'epoch': epoch, 'attentioner_dict': st['attention'], 'feature_embedder_dict': st['feature_embedder'],
+            'encoder_dict': st['encoder'], 'decoder_dict': st['decoder'], 'D_dict': st['D']}
+
+
+def dataset_from(g, prefix="ds."):
+    return dict(obsvs=g[prefix + "obsvs"], preds=g[prefix + "preds"], batches=g[prefix + "batches"])
+
+
+def assert_close(a, b, rtol, atol, what=""):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    if not (err <= tol).all():
+        i = np.unravel_index(np.argmax(err - tol), err.shape)
+        raise AssertionError("%s: max|err|=%.3e at %s (got %.8g want %.8g), rtol=%g atol=%g"
+                             % (what, err.max(), i, a[i], b[i], rtol, atol))
