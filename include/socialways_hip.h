@@ -1,0 +1,150 @@
+/* socialways_hip.h - C ABI of the MI355X (gfx950) Social Ways hot path.
+ *
+ * The reference (crowdbotp/socialways) has no FFI of its own: its hot path is the Python call
+ * surface of train.py.  This header is the boundary UNDER that surface: every
+ * entry point below replaces the stock-PyTorch ops one reference function dispatches to, and the
+ * Python glue in socialways_amd/ (same class / function names as the reference) calls exactly
+ * these symbols through ctypes.  INTEGRATION.md shows the binding a maintainer of the reference
+ * would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 (int32 for scene offsets), 16-byte
+ *     aligned; the caller owns all memory (the library never allocates);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *   - return value: 0 ok, -1 bad argument, -2 unsupported shape, -3 HIP error (sw_last_error());
+ *   - "packed" weight buffers hold the tensors of the reference module's state_dict() in key
+ *     order, row-major, each tensor starting on a 4-float boundary (sw_param_offset() is the
+ *     authority; only Discriminator.classifier.2.bias (1 float) introduces padding);
+ *   - B = agents in the packed batch, H = 64 hidden, Z = 32 noise, To / Tp = obs / pred length,
+ *     scene_off = int32[S+1] prefix offsets of the scenes ("sub_batches" of train.py:446-461).
+ *   - time-major workspaces ("gsave", "dsave", "*delta*") are opaque to the caller except for
+ *     their sizes, which sw_workspace_floats() returns.
+ */
+#ifndef SOCIALWAYS_HIP_H
+#define SOCIALWAYS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SW_OK 0
+#define SW_EARG -1
+#define SW_ESHAPE -2
+#define SW_EHIP -3
+
+#define SW_H 64
+#define SW_Z 32
+
+/* parameter groups for sw_param_offset / sw_param_count */
+enum { SW_GRP_ENC = 0, SW_GRP_EMB = 1, SW_GRP_ATT = 2, SW_GRP_DEC = 3, SW_GRP_DISC = 4 };
+
+/* workspace ids for sw_workspace_floats */
+enum {
+  SW_WS_GSAVE = 0,   /* generator forward saves (LSTM acts, x4, decoder acts, attention weights) */
+  SW_WS_GDELTA = 1,  /* generator backward deltas                                                */
+  SW_WS_DSAVE = 2,   /* discriminator forward saves (per call, nb pred branches)                 */
+  SW_WS_DDELTA = 3,  /* discriminator backward deltas                                            */
+  SW_WS_WGRAD = 4,   /* split-K partials of the weight-gradient GEMMs                            */
+  SW_WS_PAIRS = 5    /* per-pair rows of the social block backward (P pairs)                     */
+};
+
+int sw_version(void);
+const char* sw_last_error(void);
+
+/* Packed-weight layout: number of floats of group `grp` and the float offset of its `idx`-th
+ * state_dict tensor (Tp only matters for SW_GRP_DISC: pred_encoder.0.weight is (32, 4*Tp)). */
+int sw_param_count(int grp, int Tp);
+int sw_param_offset(int grp, int idx, int Tp);
+int sw_param_tensors(int grp);
+size_t sw_workspace_floats(int ws_id, int B, int To, int Tp, int nb, long long P);
+
+/* ---- get_traj_4d (train.py:130-138) ------------------------------------------------------- */
+int sw_traj_4d(const float* obsv /*[B,To,2]*/, const float* pred /*[B,Tp,2] or NULL*/, int B, int To,
+               int Tp, float* obsv4 /*[B,To,4]*/, float* pred4 /*[B,Tp,4] or NULL*/, void* stream);
+
+/* ---- EncoderLstm (train.py:245-269): Linear(4->64) + LSTM(64->64), time-unrolled ----------- */
+/* x_mode 0: `x` = positions [B,T,2], the 4-d state is formed on the fly with the OBSERVATION rule
+ * of get_traj_4d; x_mode 1: `x` = 4-d states [B,T,4].  h0/c0 NULL = zeros (predict(), :399-401).
+ * y/act/x4s may be NULL.  act = [t0+T][B][384] rows (i f g o | c | h), x4s = [..][B][4]; the
+ * kernel writes rows t0 .. t0+T-1.                                                             */
+int sw_enc_lstm_fwd(const float* x, int x_mode, const float* enc_w, const float* h0, const float* c0,
+                    int B, int T, float* hT, float* cT, float* y /*[B,T,64]*/, float* act,
+                    float* x4s, int t0, void* stream);
+/* BPTT over rows t0+T-1 .. t0 of `act`; dhT/dcT = gradient w.r.t. the final state (dcT may be
+ * NULL); dy optional [B,T,64].  Writes dgates rows [t][B][256]; dh0/dc0 optional outputs.       */
+int sw_enc_lstm_bwd(const float* enc_w, const float* act, const float* c0, const float* dhT,
+                    const float* dcT, const float* dy, int B, int T, int t0, float* dgates,
+                    float* dh0, float* dc0, void* stream);
+
+/* ---- SocialFeatures + EmbedSocialFeatures + AttentionPooling (train.py:153-241), fused,
+ *      block-diagonal: only in-scene pairs are formed (identical math) -------- */
+int sw_social_pool_fwd(const float* obsv /*[B,To,2]*/, int To, const float* h /*[B,64]*/,
+                       const int* scene_off, int S, int B, int Amax /*largest scene, <= 64*/,
+                       const float* emb_w, const float* att_w, float* S_out /*[B,64]*/,
+                       float* attn /*[B,64] softmax weights (row i, column j_local) or NULL*/, void* stream);
+/* dense SocialFeatures (train.py:229-241) for the reference's module-level API on small batches */
+int sw_social_features(const float* x4_last /*[B,4]*/, int B, float* feat /*[B,B,3]*/, void* stream);
+/* EmbedSocialFeatures.forward on R rows of 3 features -> [R,64]; AttentionPooling.forward on a
+ * dense (B,B,64) embedding tensor (only the in-scene blocks are read).                           */
+int sw_embed_features(const float* feat /*[R,3]*/, long long R, const float* emb_w, float* out /*[R,64]*/,
+                      void* stream);
+int sw_attention_pool_dense(const float* f /*[B,B,64]*/, const float* h /*[B,64]*/, const int* scene_off,
+                            int S, int B, const float* att_w, float* S_out /*[B,64]*/, void* stream);
+/* pair_off = int64[S+1] prefix sums of n_s^2 over scenes with n_s > 1 (single-agent scenes own no
+ * pair rows), P = pair_off[S].  dh is accumulated into.  d_emb_w / d_att_w are overwritten.
+ * pair_ws holds sw_workspace_floats(SW_WS_PAIRS, ...) floats.                                    */
+int sw_social_pool_bwd(const float* obsv, int To, const float* h, const int* scene_off,
+                       const long long* pair_off, int S, int B, int Amax, long long P,
+                       const float* emb_w, const float* att_w, const float* attn, const float* dS,
+                       float* dh, float* d_emb_w, float* d_att_w, float* pair_ws, float* wgrad_ws,
+                       void* stream);
+
+/* ---- predict() decode loop (train.py:415-432): DecoderFC + position integration + the
+ *      re-fed EncoderLstm step, Tp times, one persistent kernel -------------------------------- */
+int sw_dec_rollout_fwd(const float* obsv /*[B,To,2]*/, int To, const float* z /*[B,32]*/,
+                       const float* S_pool /*[B,64] or NULL = zeros*/, const float* hT, const float* cT,
+                       const float* enc_w, const float* dec_w, int B, int Tp,
+                       float* pred4 /*[B,Tp,4]*/, float* h_end, float* c_end /*[B,64] or NULL*/,
+                       float* gsave /*or NULL*/, void* stream);
+int sw_dec_rollout_bwd(const float* dpred4 /*[B,Tp,4]*/, const float* enc_w, const float* dec_w,
+                       const float* gsave, int B, int To, int Tp, float* gdelta,
+                       float* dhT, float* dcT, float* dS_pool /*[B,64]*/, void* stream);
+/* weight gradients of the whole generator rollout (encoder + decoder) from gsave/gdelta */
+int sw_gen_wgrad(const float* enc_w, const float* gsave, const float* gdelta, const float* z,
+                 const float* S_pool, int B, int To, int Tp, float* d_enc_w, float* d_dec_w,
+                 float* wgrad_ws, void* stream);
+
+/* ---- Discriminator.forward (train.py:294-309) for nb prediction branches sharing one
+ *      observation encoding (fake / real of the same batch) ----------------------------------- */
+/* x_mode 0: obsv = positions [B,To,2] (4-d state formed on the fly); 1: obsv = obsv_4d [B,To,4].   */
+int sw_disc_fwd(const float* obsv, int To, int x_mode, const float* const* pred4 /*nb x [B,Tp,4]*/,
+                int nb, const float* d_w, int B, int Tp, float* const* label /*nb x [B,1]*/,
+                float* const* code /*nb x [B,2]*/, float* dsave /*or NULL*/, void* stream);
+/* dlabel/dcode: nb x gradients of the loss w.r.t. label / code.  d_d_w NULL = skip weight grads
+ * (generator phase), dpred4[k] NULL = skip input grad of branch k.                              */
+int sw_disc_bwd(const float* d_w, const float* dsave, const float* const* dlabel,
+                const float* const* dcode, int nb, int B, int To, int Tp, float* ddelta,
+                float* d_d_w, float* const* dpred4, float* wgrad_ws, void* stream);
+
+/* ---- LSGAN + InfoGAN losses of train.py:484-494 / 512-523 and their gradients -------------- */
+/* out_sums[3] = { sum (label_a - t_a)^2, sum (code_a - z[:, :2])^2, sum (label_b - t_b)^2 } over the
+ * B local rows (label_b may be NULL).  Gradients (any may be NULL):
+ *   dlabel_x = 2 (label_x - t_x) g_label,  dcode_a = 2 (code_a - z) g_code,  dcode_b = 0
+ * with g_label = 1/B_global and g_code = loss_info_w / (2 B_global) for a mean over the global
+ * batch (data-parallel ranks pass the GLOBAL batch size so summed gradients are exact).          */
+int sw_gan_loss(const float* label_a, float t_a, const float* code_a, const float* z /*[B,32]*/,
+                const float* label_b, float t_b, int B, float g_label, float g_code,
+                float* out_sums /*[3]*/, float* dlabel_a, float* dcode_a, float* dlabel_b,
+                float* dcode_b, void* stream);
+
+/* ---- ADE/FDE partial sums of train.py:546-551:
+ *      out[3] = { sum_{b,t} err / Tp, sum_b err[:, -1], sum_{b,t} err^2 },  err = |(p_hat - p) / ss|   */
+int sw_ade_fde(const float* pred4 /*[B,Tp,4]*/, const float* gt /*[B,Tp,2]*/, int B, int Tp, float inv_ss,
+               float* out /*[3]*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,104 @@
+"""ctypes binding of libsocialways_hip.so (the C ABI of include/socialways_hip.h).
+
+The library is the product's only compute path.  There is no CPU fallback: if the shared object
+is missing or a kernel returns an error the call raises, loudly.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsocialways_hip.so")
+
+GRP_ENC, GRP_EMB, GRP_ATT, GRP_DEC, GRP_DISC = 0, 1, 2, 3, 4
+WS_GSAVE, WS_GDELTA, WS_DSAVE, WS_DDELTA, WS_WGRAD, WS_PAIRS = 0, 1, 2, 3, 4, 5
+AMAX = 64
+
+_vp, _i, _f, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
+
+# name -> (restype, argtypes); mirrors include/socialways_hip.h one to one
+PROTOTYPES = {
+    "sw_version": (_i, []),
+    "sw_last_error": (ctypes.c_char_p, []),
+    "sw_param_count": (_i, [_i, _i]),
+    "sw_param_offset": (_i, [_i, _i, _i]),
+    "sw_param_tensors": (_i, [_i]),
+    "sw_workspace_floats": (ctypes.c_size_t, [_i, _i, _i, _i, _i, _ll]),
+    "sw_traj_4d": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "sw_enc_lstm_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "sw_enc_lstm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "sw_social_pool_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "sw_social_features": (_i, [_vp, _i, _vp, _vp]),
+    "sw_embed_features": (_i, [_vp, _ll, _vp, _vp, _vp]),
+    "sw_attention_pool_dense": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "sw_social_pool_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _vp]),
+    "sw_dec_rollout_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "sw_dec_rollout_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "sw_gen_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "sw_disc_fwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "sw_disc_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "sw_gan_loss": (_i, [_vp, _f, _vp, _vp, _vp, _f, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sw_ade_fde": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp]),
+}
+
+_lib = None
+
+
+class SocialWaysHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (import torch first so that its libamdhip64 is the one runtime in the
+    process).  Raises if the library has not been built: there is no other compute path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SocialWaysHipError(
+            "%s not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C socialways_amd/csrc`; socialways_amd has no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "socialways_amd kernels need contiguous tensors"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = {-1: "bad argument", -2: "unsupported shape", -3: "HIP error: " + lib.sw_last_error().decode()}.get(rc, "?")
+        raise SocialWaysHipError("%s failed (%d): %s" % (name, rc, msg))
+
+
+def ptr_array(tensors):
+    """const float* const* argument (host array of device pointers)."""
+    arr = (ctypes.c_void_p * len(tensors))(*[ptr(t) for t in tensors])
+    return ctypes.cast(arr, ctypes.c_void_p), arr
+
+
+def workspace_floats(ws_id, B, To, Tp, nb=1, P=0):
+    return int(load().sw_workspace_floats(ws_id, B, To, Tp, nb, P))
+
+
+def require_gpu(t):
+    if not t.is_cuda:
+        raise SocialWaysHipError("socialways_amd runs on MI355X only: got a %s tensor (no CPU fallback)" % t.device)

@@ -1,0 +1,193 @@
+// sw_common.h - device-side building blocks shared by the Social Ways gfx950 kernels.
+//
+// Everything GEMM-shaped on the hot path is a chain of small fp32 contractions (LSTM 64x256,
+// decoder 160/80/40, pair MLP 32/64/64).  They all run on v_mfma_f32_16x16x4_f32 (exact fp32,
+// bit-for-bit an fmaf chain) with ONE tiling convention:
+//
+//     D[16 output units][16 agents] += W[16 units][K] * X[K][16 agents]
+//
+//   A operand  = weights, row-major W[unit][k]          (lane: unit ln = lane&15, k-group lg = lane>>4)
+//   B operand  = activations, row-major X[agent][k]     (lane: agent ln,          k-group lg)
+//   C/D        = lane holds units 4*lg+r (r=0..3) of agent ln   -> one float4 of a row-major
+//                [agent][unit] array, so every store/LDS write is a 16-byte access.
+//
+// The K order is permuted so that each lane's operands are float4s: k-step (j, r) makes lane
+// group lg contribute k = 16*j + 4*lg + r.  A lane therefore reads W[unit][16j+4lg .. +3] and
+// X[agent][16j+4lg .. +3] as one 16-byte load each and issues 4 MFMAs on them.  A permutation of
+// the summation order is all that changes numerically.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SW_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+#define SW_TILE 16       // agents per workgroup tile
+#define SW_THREADS 256   // 4 waves: one per SIMD
+
+__device__ __forceinline__ int sw_lane() { return threadIdx.x & 63; }
+__device__ __forceinline__ int sw_wave() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+
+__device__ __forceinline__ float sw_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sw_lrelu(float x) { return x > 0.0f ? x : 0.2f * x; }
+__device__ __forceinline__ float sw_lrelu_grad(float a, float g) { return a > 0.0f ? g : 0.2f * g; }
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// acc += W[row][16j+4lg+r] * X[agent][16j+4lg+r], j < KJ.  `wrow` / `xrow` already point at
+// column 4*lg of the lane's weight row / activation row.  Works for LDS and global pointers
+// (the compiler keeps the address space when the caller is inlined).
+template <int KJ>
+__device__ __forceinline__ f32x4 tile_mm(const float* wrow, const float* xrow, f32x4 acc) {
+#pragma unroll
+  for (int j = 0; j < KJ; ++j) {
+    f32x4 a = ld4(wrow + 16 * j);
+    f32x4 b = ld4(xrow + 16 * j);
+    acc = SW_MFMA(a[0], b[0], acc);
+    acc = SW_MFMA(a[1], b[1], acc);
+    acc = SW_MFMA(a[2], b[2], acc);
+    acc = SW_MFMA(a[3], b[3], acc);
+  }
+  return acc;
+}
+
+// Same with the weight operands held in registers (w[j] = float4 of the lane's row).
+template <int KJ>
+__device__ __forceinline__ f32x4 tile_mm_reg(const f32x4* w, const float* xrow, f32x4 acc) {
+#pragma unroll
+  for (int j = 0; j < KJ; ++j) {
+    f32x4 b = ld4(xrow + 16 * j);
+    acc = SW_MFMA(w[j][0], b[0], acc);
+    acc = SW_MFMA(w[j][1], b[1], acc);
+    acc = SW_MFMA(w[j][2], b[2], acc);
+    acc = SW_MFMA(w[j][3], b[3], acc);
+  }
+  return acc;
+}
+
+// Stage a row-major [M][K] weight matrix (global, row stride lds_src) into LDS as [Mp][ld] with
+// zero padding up to Mp rows / ld columns (ld = roundup(K,16)+4).
+__device__ __forceinline__ void stage_w(float* dst, int ld, int Mp, const float* src, int src_ld,
+                                        int M, int K) {
+  for (int i = threadIdx.x; i < Mp * ld; i += blockDim.x) {
+    int r = i / ld, c = i - r * ld;
+    dst[i] = (r < M && c < K) ? src[(size_t)r * src_ld + c] : 0.0f;
+  }
+}
+// Transposed: dst[c][r] = src[r][c]; dst is [Kp][ld] (rows = source columns).
+__device__ __forceinline__ void stage_wT(float* dst, int ld, int Kp, const float* src, int src_ld,
+                                         int M, int K) {
+  for (int i = threadIdx.x; i < Kp * ld; i += blockDim.x) {
+    int c = i / ld, r = i - c * ld;  // c: source column (dst row), r: source row (dst column)
+    dst[i] = (r < M && c < K) ? src[(size_t)r * src_ld + c] : 0.0f;
+  }
+}
+
+// LDS leading dimension for a K-wide operand.
+__host__ __device__ constexpr int sw_ld(int K) { return ((K + 15) / 16) * 16 + 4; }
+
+// ---------------------------------------------------------------------------------------------
+// Packed weight layouts (state_dict order, each tensor on a 4-float boundary).
+// ---------------------------------------------------------------------------------------------
+namespace swp {
+// EncoderLstm (train.py:245-269)
+constexpr int ENC_EMB_W = 0;                    // embed.weight (64,4)
+constexpr int ENC_EMB_B = 256;                  // embed.bias (64)
+constexpr int ENC_WIH = 320;                    // lstm.weight_ih_l0 (256,64)
+constexpr int ENC_WHH = 320 + 16384;            // lstm.weight_hh_l0 (256,64)
+constexpr int ENC_BIH = ENC_WHH + 16384;        // lstm.bias_ih_l0 (256)
+constexpr int ENC_BHH = ENC_BIH + 256;          // lstm.bias_hh_l0 (256)
+constexpr int ENC_N = ENC_BHH + 256;            // 33600
+// EmbedSocialFeatures (train.py:178-189)
+constexpr int EMB_W0 = 0, EMB_B0 = 96, EMB_W1 = 128, EMB_B1 = 128 + 2048, EMB_W2 = EMB_B1 + 64,
+              EMB_B2 = EMB_W2 + 4096, EMB_N = EMB_B2 + 64;  // 6400
+// AttentionPooling (train.py:153-175)
+constexpr int ATT_W = 0, ATT_B = 4096, ATT_N = 4160;
+// DecoderFC(160) (train.py:320-335)
+constexpr int DEC_W1 = 0, DEC_B1 = 25600, DEC_W2 = 25760, DEC_B2 = DEC_W2 + 12800, DEC_W3 = DEC_B2 + 80,
+              DEC_B3 = DEC_W3 + 3200, DEC_W4 = DEC_B3 + 40, DEC_B4 = DEC_W4 + 80, DEC_N = DEC_B4 + 2;  // 41962
+// Discriminator (train.py:272-309); offsets depend on Tp through pred_encoder.0.weight (32,4Tp)
+struct Disc {
+  int wih, whh, bih, bhh, of0w, of0b, of1w, of1b, pe0w, pe0b, pe1w, pe1b, cl0w, cl0b, cl1w, cl1b, la0w,
+      la0b, la1w, la1b, n;
+};
+__host__ __device__ constexpr int al4(int x) { return (x + 3) & ~3; }
+__host__ __device__ constexpr Disc disc(int Tp) {
+  Disc d{};
+  int o = 0;
+  d.wih = o; o = al4(o + 256 * 4);
+  d.whh = o; o = al4(o + 256 * 64);
+  d.bih = o; o = al4(o + 256);
+  d.bhh = o; o = al4(o + 256);
+  d.of0w = o; o = al4(o + 32 * 64);
+  d.of0b = o; o = al4(o + 32);
+  d.of1w = o; o = al4(o + 32 * 32);
+  d.of1b = o; o = al4(o + 32);
+  d.pe0w = o; o = al4(o + 32 * 4 * Tp);
+  d.pe0b = o; o = al4(o + 32);
+  d.pe1w = o; o = al4(o + 32 * 32);
+  d.pe1b = o; o = al4(o + 32);
+  d.cl0w = o; o = al4(o + 32 * 64);
+  d.cl0b = o; o = al4(o + 32);
+  d.cl1w = o; o = al4(o + 32);
+  d.cl1b = o; o = al4(o + 1);
+  d.la0w = o; o = al4(o + 32 * 64);
+  d.la0b = o; o = al4(o + 32);
+  d.la1w = o; o = al4(o + 64);
+  d.la1b = o; o = o + 2;
+  d.n = o;
+  return d;
+}
+}  // namespace swp
+
+// ---------------------------------------------------------------------------------------------
+// Time-major save / delta layouts of the generator (opaque to callers; sizes via the ABI).
+//   T_all = To + Tp - 1 LSTM steps (the LSTM step after the last decode is dead compute).
+// gsave : act  [T_all][B][384]  i f g o | c | h
+//         x4s  [T_all][B][4]
+//         a1   [Tp][B][160]   a2 [Tp][B][80]   a3 [Tp][B][40]
+// gdelta: dgates [T_all][B][256], dz1 [Tp][B][160], dz2 [Tp][B][80], da3 [Tp][B][40],
+//         dv [Tp][B][4] (cols 0,1 used), du [B][160]
+// ---------------------------------------------------------------------------------------------
+struct GSave {
+  size_t act, x4s, a1, a2, a3, total;
+};
+__host__ __device__ inline GSave gsave_layout(int B, int To, int Tp) {
+  GSave g;
+  size_t Ta = (size_t)(To + Tp - 1), b = (size_t)B;
+  g.act = 0;
+  g.x4s = g.act + Ta * b * 384;
+  g.a1 = g.x4s + Ta * b * 4;
+  g.a2 = g.a1 + (size_t)Tp * b * 160;
+  g.a3 = g.a2 + (size_t)Tp * b * 80;
+  g.total = g.a3 + (size_t)Tp * b * 40;
+  return g;
+}
+struct GDelta {
+  size_t dgates, dz1, dz2, da3, dv, du, total;
+};
+__host__ __device__ inline GDelta gdelta_layout(int B, int To, int Tp) {
+  GDelta g;
+  size_t Ta = (size_t)(To + Tp - 1), b = (size_t)B;
+  g.dgates = 0;
+  g.dz1 = g.dgates + Ta * b * 256;
+  g.dz2 = g.dz1 + (size_t)Tp * b * 160;
+  g.da3 = g.dz2 + (size_t)Tp * b * 80;
+  g.dv = g.da3 + (size_t)Tp * b * 40;
+  g.du = g.dv + (size_t)Tp * b * 4;
+  g.total = g.du + b * 160;
+  return g;
+}
+
+// host-side error plumbing ---------------------------------------------------------------------
+void sw_set_error(const char* what, hipError_t e);
+#define SW_CHECK_LAUNCH(name)                         \
+  do {                                                \
+    hipError_t _e = hipGetLastError();                \
+    if (_e != hipSuccess) {                           \
+      sw_set_error(name, _e);                         \
+      return SW_EHIP;                                 \
+    }                                                 \
+  } while (0)

@@ -1,0 +1,423 @@
+// sw_decoder.hip - the decode loop of predict() (reference train.py:415-432): Tp times
+// { DecoderFC on cat[h, S, z] (train.py:320-335) -> v ; p += v ; EncoderLstm step on (p, v) },
+// as ONE persistent kernel per 16-agent tile, forward and backward.
+//
+// Layout of the work inside a workgroup (4 waves, one per SIMD):
+//   * decoder weights live in LDS for the whole kernel (115 KB, zero padded to MFMA tiles);
+//     LSTM W_hh lives in registers (sw_lstm_dev.h);
+//   * cat[h,S,z] W1^T is split: u = W1[:,64:160] [S;z] + b1 is constant over the Tp steps
+//     (train.py:411,421: S and z do not change inside the loop) and computed once; per step only
+//     the 64-wide h part of layer 1 is multiplied;
+//   * every layer's 16-row output tiles are dealt round-robin to the waves; activations move
+//     between layers through small LDS tiles (one barrier per layer).
+#include "../../include/socialways_hip.h"
+#include "sw_lstm_dev.h"
+
+namespace {
+constexpr int LD64 = sw_ld(64);    // 68
+constexpr int LD160 = sw_ld(160);  // 164
+constexpr int LD80 = sw_ld(80);    // 84
+constexpr int LD40 = sw_ld(40);    // 52
+constexpr int LD96 = sw_ld(96);    // 100
+constexpr int LD2 = sw_ld(2);      // 20
+
+// forward LDS carve (floats)
+struct FwdLds {
+  static constexpr int W1h = 0;                        // [160][68]
+  static constexpr int W2 = W1h + 160 * LD64;          // [80][164]
+  static constexpr int W3 = W2 + 80 * LD160;           // [48][84]   rows >= 40 zero
+  static constexpr int W4 = W3 + 48 * LD80;            // [16][52]   rows >= 2 zero
+  static constexpr int hbuf = W4 + 16 * LD40;          // [2][16][68]
+  static constexpr int ubuf = hbuf + 2 * 16 * LD64;    // [16][164]
+  static constexpr int a1buf = ubuf + 16 * LD160;      // [16][164]  (prologue: [S|z] tile [16][100])
+  static constexpr int a2buf = a1buf + 16 * LD160;     // [16][84]   (prologue: wx_lds, bx_lds)
+  static constexpr int a3buf = a2buf + 16 * LD80;      // [16][52]
+  static constexpr int xbuf = a3buf + 16 * LD40;       // [16][4]
+  static constexpr int bbuf = xbuf + 64;               // b2[80] | b3[48] | b4[16]
+  static constexpr int total = bbuf + 144;
+};
+static_assert(16 * LD80 + 16 * LD40 >= 1280, "prologue alias");
+static_assert(FwdLds::total * 4 <= 163840, "LDS budget");
+
+// backward LDS carve
+struct BwdLds {
+  static constexpr int W1hT = 0;                       // [64][164]   W1hT[m][k] = W1[k][m], m < 64
+  static constexpr int W2T = W1hT + 64 * LD160;        // [160][84]
+  static constexpr int W3T = W2T + 160 * LD80;         // [80][52]
+  static constexpr int W4T = W3T + 80 * LD40;          // [48][20]    rows >= 40 zero, cols >= 2 zero
+  static constexpr int dgbuf = W4T + 48 * LD2;         // [16][260]
+  static constexpr int dz1buf = dgbuf + 16 * SW_GLD;   // [16][164]
+  static constexpr int dz2buf = dz1buf + 16 * LD160;   // [16][84]
+  static constexpr int da3buf = dz2buf + 16 * LD80;    // [16][52]
+  static constexpr int dvbuf = da3buf + 16 * LD40;     // [16][20]
+  static constexpr int dxpart = dvbuf + 16 * LD2;      // [4 waves][16][4]
+  static constexpr int total = dxpart + 256;
+};
+static_assert(BwdLds::total * 4 <= 163840, "LDS budget");
+}  // namespace
+
+__global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
+    const float* __restrict__ obsv, int To, const float* __restrict__ z, const float* __restrict__ S_pool,
+    const float* __restrict__ hT, const float* __restrict__ cT, const float* __restrict__ enc_w,
+    const float* __restrict__ dec_w, int B, int Tp, float* __restrict__ pred4, float* __restrict__ h_end,
+    float* __restrict__ c_end, float* __restrict__ gsave) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* W1h = smem + FwdLds::W1h;
+  float* W2 = smem + FwdLds::W2;
+  float* W3 = smem + FwdLds::W3;
+  float* W4 = smem + FwdLds::W4;
+  float* hbuf = smem + FwdLds::hbuf;
+  float* ubuf = smem + FwdLds::ubuf;
+  float* a1buf = smem + FwdLds::a1buf;
+  float* a2buf = smem + FwdLds::a2buf;
+  float* a3buf = smem + FwdLds::a3buf;
+  float* xbuf = smem + FwdLds::xbuf;
+  float* bbuf = smem + FwdLds::bbuf;
+  float* szbuf = a1buf;           // prologue alias
+  float* wx_lds = a2buf;          // prologue alias (1024)
+  float* bx_lds = a2buf + 1024;   // prologue alias (256)
+
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  const int u0 = wave * 16;
+  const int a0 = blockIdx.x * SW_TILE;
+  const int b = min(a0 + ln, B - 1);
+  const bool live = (a0 + ln) < B;
+  const GSave gs = gsave_layout(B, To, Tp);
+
+  // ---- prologue: stage decoder weights, compose the LSTM input matrix, build u ----------------
+  stage_w(W1h, LD64, 160, dec_w + swp::DEC_W1, 160, 160, 64);
+  stage_w(W2, LD160, 80, dec_w + swp::DEC_W2, 160, 80, 160);
+  stage_w(W3, LD80, 48, dec_w + swp::DEC_W3, 80, 40, 80);
+  stage_w(W4, LD40, 16, dec_w + swp::DEC_W4, 40, 2, 40);
+  for (int i = threadIdx.x; i < 144; i += blockDim.x) {
+    float v = 0.f;
+    if (i < 80) v = dec_w[swp::DEC_B2 + i];
+    else if (i < 120) v = dec_w[swp::DEC_B3 + i - 80];
+    else if (i >= 128 && i < 130) v = dec_w[swp::DEC_B4 + i - 128];
+    bbuf[i] = v;
+  }
+  lstm_prep_rows(enc_w + swp::ENC_EMB_W, enc_w + swp::ENC_EMB_B, enc_w + swp::ENC_WIH, enc_w + swp::ENC_BIH,
+                 enc_w + swp::ENC_BHH, true, wx_lds, bx_lds);
+  for (int i = threadIdx.x; i < 16 * 96; i += blockDim.x) {
+    int a = i / 96, c = i - a * 96;
+    int bb = min(a0 + a, B - 1);
+    float v = c < 64 ? (S_pool ? S_pool[(size_t)bb * 64 + c] : 0.f) : z[(size_t)bb * 32 + c - 64];
+    szbuf[a * LD96 + c] = v;
+  }
+  f32x4 c = ld4(cT + (size_t)b * 64 + u0 + 4 * lg);
+  f32x4 h = ld4(hT + (size_t)b * 64 + u0 + 4 * lg);
+  st4(&hbuf[ln * LD64 + u0 + 4 * lg], h);
+  __syncthreads();
+  LstmW W;
+  lstm_load_w(W, enc_w + swp::ENC_WHH, wx_lds, bx_lds, u0, ln, lg);
+  for (int mt = wave; mt < 10; mt += 4) {
+    int m0 = mt * 16;
+    f32x4 acc = ld4(dec_w + swp::DEC_B1 + m0 + 4 * lg);
+    acc = tile_mm<6>(dec_w + swp::DEC_W1 + (size_t)(m0 + ln) * 160 + 64 + 4 * lg, &szbuf[ln * LD96 + 4 * lg], acc);
+    st4(&ubuf[ln * LD160 + m0 + 4 * lg], acc);
+  }
+  // running position: lanes lg==0 of wave 0 own agent ln
+  float px = 0.f, py = 0.f;
+  if (wave == 0 && lg == 0) {
+    px = obsv[((size_t)b * To + To - 1) * 2 + 0];
+    py = obsv[((size_t)b * To + To - 1) * 2 + 1];
+  }
+  __syncthreads();  // szbuf / wx_lds aliases are dead from here on
+
+  int cur = 0;
+  for (int i = 0; i < Tp; ++i) {
+    // ---- layer 1: a1 = lrelu(W1h h + u) -----------------------------------------------------
+    for (int mt = wave; mt < 10; mt += 4) {
+      int m0 = mt * 16;
+      f32x4 acc = ld4(&ubuf[ln * LD160 + m0 + 4 * lg]);
+      acc = tile_mm<4>(&W1h[(m0 + ln) * LD64 + 4 * lg], &hbuf[cur * 16 * LD64 + ln * LD64 + 4 * lg], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu(acc[r]);
+      st4(&a1buf[ln * LD160 + m0 + 4 * lg], acc);
+      if (gsave && live) st4(gsave + gs.a1 + ((size_t)i * B + b) * 160 + m0 + 4 * lg, acc);
+    }
+    __syncthreads();
+    // ---- layer 2: a2 = lrelu(W2 a1 + b2) ----------------------------------------------------
+    for (int mt = wave; mt < 5; mt += 4) {
+      int m0 = mt * 16;
+      f32x4 acc = ld4(&bbuf[m0 + 4 * lg]);
+      acc = tile_mm<10>(&W2[(m0 + ln) * LD160 + 4 * lg], &a1buf[ln * LD160 + 4 * lg], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu(acc[r]);
+      st4(&a2buf[ln * LD80 + m0 + 4 * lg], acc);
+      if (gsave && live) st4(gsave + gs.a2 + ((size_t)i * B + b) * 80 + m0 + 4 * lg, acc);
+    }
+    __syncthreads();
+    // ---- layer 3: a3 = W3 a2 + b3 (no activation, train.py:327-328) -------------------------
+    if (wave < 3) {
+      int m0 = wave * 16;
+      f32x4 acc = ld4(&bbuf[80 + m0 + 4 * lg]);
+      acc = tile_mm<5>(&W3[(m0 + ln) * LD80 + 4 * lg], &a2buf[ln * LD80 + 4 * lg], acc);
+      st4(&a3buf[ln * LD40 + m0 + 4 * lg], acc);
+      if (gsave && live && m0 + 4 * lg < 40) st4(gsave + gs.a3 + ((size_t)i * B + b) * 40 + m0 + 4 * lg, acc);
+    }
+    __syncthreads();
+    // ---- layer 4: v = W4 a3 + b4 ; p += v ---------------------------------------------------
+    if (wave == 0) {
+      f32x4 acc = ld4(&bbuf[128 + 4 * lg]);
+      acc = tile_mm<3>(&W4[ln * LD40 + 4 * lg], &a3buf[ln * LD40 + 4 * lg], acc);
+      if (lg == 0) {
+        px += acc[0];
+        py += acc[1];
+        f32x4 x4 = {px, py, acc[0], acc[1]};
+        st4(&xbuf[ln * 4], x4);
+        if (live) {
+          st4(pred4 + ((size_t)b * Tp + i) * 4, x4);
+          if (gsave && i < Tp - 1) st4(gsave + gs.x4s + ((size_t)(To + i) * B + b) * 4, x4);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- re-fed encoder step (train.py:430); the one after the last decode is dead compute ---
+    if (i < Tp - 1 || h_end) {
+      float xb = xbuf[ln * 4 + lg];
+      f32x4 gate[4];
+      lstm_cell(W, xb, &hbuf[cur * 16 * LD64 + ln * LD64 + 4 * lg], gate, c, h);
+      st4(&hbuf[(cur ^ 1) * 16 * LD64 + ln * LD64 + u0 + 4 * lg], h);
+      if (gsave && live && i < Tp - 1) {
+        float* row = gsave + gs.act + ((size_t)(To + i) * B + b) * 384 + u0 + 4 * lg;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) st4(row + g * 64, gate[g]);
+        st4(row + 256, c);
+        st4(row + 320, h);
+      }
+      cur ^= 1;
+      __syncthreads();
+    }
+  }
+  if (h_end && live) {
+    st4(h_end + (size_t)b * 64 + u0 + 4 * lg, h);
+    if (c_end) st4(c_end + (size_t)b * 64 + u0 + 4 * lg, c);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the decode loop.  Propagates data gradients only; every weight gradient is a
+// deferred GEMM over the time-major delta / activation rows written here (sw_wgrad.hip).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
+    const float* __restrict__ dpred4, const float* __restrict__ enc_w, const float* __restrict__ dec_w,
+    const float* __restrict__ gsave, int B, int To, int Tp, float* __restrict__ gdelta,
+    float* __restrict__ dhT, float* __restrict__ dcT, float* __restrict__ dS_pool) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* W1hT = smem + BwdLds::W1hT;
+  float* W2T = smem + BwdLds::W2T;
+  float* W3T = smem + BwdLds::W3T;
+  float* W4T = smem + BwdLds::W4T;
+  float* dgbuf = smem + BwdLds::dgbuf;
+  float* dz1buf = smem + BwdLds::dz1buf;
+  float* dz2buf = smem + BwdLds::dz2buf;
+  float* da3buf = smem + BwdLds::da3buf;
+  float* dvbuf = smem + BwdLds::dvbuf;
+  float* dxpart = smem + BwdLds::dxpart;
+  float* wx_lds = dz1buf;          // prologue alias (1024)
+  float* bx_lds = dz1buf + 1024;   // prologue alias (256)
+
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  const int u0 = wave * 16;
+  const int a0 = blockIdx.x * SW_TILE;
+  const int b = min(a0 + ln, B - 1);
+  const bool live = (a0 + ln) < B;
+  const GSave gs = gsave_layout(B, To, Tp);
+  const GDelta gd = gdelta_layout(B, To, Tp);
+
+  // ---- prologue: transposed decoder weights into LDS, composed Wx^T, W_hh^T into registers ---
+  stage_wT(W1hT, LD160, 64, dec_w + swp::DEC_W1, 160, 160, 64);
+  stage_wT(W2T, LD80, 160, dec_w + swp::DEC_W2, 160, 80, 160);
+  stage_wT(W3T, LD40, 80, dec_w + swp::DEC_W3, 80, 40, 80);
+  stage_wT(W4T, LD2, 48, dec_w + swp::DEC_W4, 40, 2, 40);
+  lstm_prep_rows(enc_w + swp::ENC_EMB_W, enc_w + swp::ENC_EMB_B, enc_w + swp::ENC_WIH, enc_w + swp::ENC_BIH,
+                 enc_w + swp::ENC_BHH, true, wx_lds, bx_lds);
+  for (int i = threadIdx.x; i < 16 * LD2; i += blockDim.x) dvbuf[i] = 0.f;
+  __syncthreads();
+  // Wx^T slice of this wave's K-quarter as A operands: row c = ln (< 4 live), k = 64*wave + 16j + 4lg + r
+  f32x4 wxT[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wxT[j][r] = ln < 4 ? wx_lds[(64 * wave + 16 * j + 4 * lg + r) * 4 + ln] : 0.f;
+  }
+  LstmWT WT;
+  lstm_load_wT(WT, enc_w + swp::ENC_WHH, u0, ln, lg);
+  __syncthreads();
+
+  f32x4 dh = {0.f, 0.f, 0.f, 0.f}, dc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 du[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) du[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // per-agent running gradient w.r.t. the position (lanes lg==0 of wave 0)
+  float dpx = 0.f, dpy = 0.f;
+
+  for (int i = Tp - 1; i >= 0; --i) {
+    float dxp0 = 0.f, dxp1 = 0.f, dxv0 = 0.f, dxv1 = 0.f;  // gradient through the LSTM input (p_i, v_i)
+    if (i < Tp - 1) {
+      // ---- LSTM step t = To+i (consumed x4_i, produced h_t) --------------------------------
+      const int t = To + i;
+      const float* row = gsave + gs.act + ((size_t)t * B + b) * 384 + u0 + 4 * lg;
+      f32x4 gate[4], dgate[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gate[g] = ld4(row + g * 64);
+      f32x4 ct = ld4(row + 256);
+      f32x4 cprev = ld4(row - (size_t)B * 384 + 256);
+      lstm_cell_bwd(gate, ct, cprev, dh, dc, dgate);
+      float* dgg = gdelta + gd.dgates + ((size_t)t * B + b) * 256 + u0 + 4 * lg;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        st4(&dgbuf[ln * SW_GLD + g * 64 + u0 + 4 * lg], dgate[g]);
+        if (live) st4(dgg + g * 64, dgate[g]);
+      }
+      __syncthreads();
+      dh = lstm_dh_prev(WT, &dgbuf[ln * SW_GLD + 4 * lg]);
+      // dx4 = Wx^T dgates: each wave reduces its own quarter of K, partials through LDS
+      {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = tile_mm_reg<4>(wxT, &dgbuf[ln * SW_GLD + 64 * wave + 4 * lg], acc);
+        if (lg == 0) st4(&dxpart[(wave * 16 + ln) * 4], acc);
+      }
+      __syncthreads();
+      if (wave == 0 && lg == 0) {
+        f32x4 s = ld4(&dxpart[ln * 4]) + ld4(&dxpart[(16 + ln) * 4]) + ld4(&dxpart[(32 + ln) * 4]) +
+                  ld4(&dxpart[(48 + ln) * 4]);
+        dxp0 = s[0]; dxp1 = s[1]; dxv0 = s[2]; dxv1 = s[3];
+      }
+    }
+    // ---- decoder step i ----------------------------------------------------------------------
+    if (wave == 0 && lg == 0) {
+      f32x4 g4 = ld4(dpred4 + ((size_t)b * Tp + i) * 4);
+      dpx += g4[0] + dxp0;  // dL/dp_i  (p_i also feeds p_{i+1}: carried in dpx)
+      dpy += g4[1] + dxp1;
+      float dvx = g4[2] + dxv0 + dpx;  // p_i = p_{i-1} + v_i
+      float dvy = g4[3] + dxv1 + dpy;
+      dvbuf[ln * LD2 + 0] = dvx;
+      dvbuf[ln * LD2 + 1] = dvy;
+      if (live) {
+        f32x4 o = {dvx, dvy, 0.f, 0.f};
+        st4(gdelta + gd.dv + ((size_t)i * B + b) * 4, o);
+      }
+    }
+    __syncthreads();
+    // da3 = W4^T dv  (40)
+    if (wave < 3) {
+      int m0 = wave * 16;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = tile_mm<1>(&W4T[(m0 + ln) * LD2 + 4 * lg], &dvbuf[ln * LD2 + 4 * lg], acc);
+      st4(&da3buf[ln * LD40 + m0 + 4 * lg], acc);
+      if (live && m0 + 4 * lg < 40) st4(gdelta + gd.da3 + ((size_t)i * B + b) * 40 + m0 + 4 * lg, acc);
+    }
+    __syncthreads();
+    // dz2 = (W3^T da3) * lrelu'(a2)   (80)
+    for (int mt = wave; mt < 5; mt += 4) {
+      int m0 = mt * 16;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = tile_mm<3>(&W3T[(m0 + ln) * LD40 + 4 * lg], &da3buf[ln * LD40 + 4 * lg], acc);
+      f32x4 a2 = ld4(gsave + gs.a2 + ((size_t)i * B + b) * 80 + m0 + 4 * lg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(a2[r], acc[r]);
+      st4(&dz2buf[ln * LD80 + m0 + 4 * lg], acc);
+      if (live) st4(gdelta + gd.dz2 + ((size_t)i * B + b) * 80 + m0 + 4 * lg, acc);
+    }
+    __syncthreads();
+    // dz1 = (W2^T dz2) * lrelu'(a1)   (160)
+    {
+      int q = 0;
+      for (int mt = wave; mt < 10; mt += 4, ++q) {
+        int m0 = mt * 16;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = tile_mm<5>(&W2T[(m0 + ln) * LD80 + 4 * lg], &dz2buf[ln * LD80 + 4 * lg], acc);
+        f32x4 a1 = ld4(gsave + gs.a1 + ((size_t)i * B + b) * 160 + m0 + 4 * lg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(a1[r], acc[r]);
+        st4(&dz1buf[ln * LD160 + m0 + 4 * lg], acc);
+        if (live) st4(gdelta + gd.dz1 + ((size_t)i * B + b) * 160 + m0 + 4 * lg, acc);
+        if (q == 0) du[0] += acc;
+        else if (q == 1) du[1] += acc;
+        else du[2] += acc;
+      }
+    }
+    __syncthreads();
+    // dh_{To+i-1} += W1h^T dz1   (wave w owns units 16w.. : same layout as dh)
+    {
+      f32x4 acc = (i < Tp - 1) ? dh : f32x4{0.f, 0.f, 0.f, 0.f};
+      acc = tile_mm<10>(&W1hT[(u0 + ln) * LD160 + 4 * lg], &dz1buf[ln * LD160 + 4 * lg], acc);
+      dh = acc;
+    }
+    // (next iteration's first LDS writes are to dgbuf/dvbuf, whose readers are behind barriers)
+  }
+  // ---- epilogue: state gradients, du and dS = W1[:,64:128]^T du ---------------------------------
+  if (live) {
+    st4(dhT + (size_t)b * 64 + u0 + 4 * lg, dh);
+    st4(dcT + (size_t)b * 64 + u0 + 4 * lg, dc);
+  }
+  __syncthreads();
+  {
+    int q = 0;
+    for (int mt = wave; mt < 10; mt += 4, ++q) {
+      int m0 = mt * 16;
+      f32x4 v = q == 0 ? du[0] : (q == 1 ? du[1] : du[2]);
+      st4(&dz1buf[ln * LD160 + m0 + 4 * lg], v);
+      if (live) st4(gdelta + gd.du + (size_t)b * 160 + m0 + 4 * lg, v);
+    }
+  }
+  __syncthreads();
+  if (dS_pool) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* w1 = dec_w + swp::DEC_W1 + 64 + u0 + ln;  // column 64+unit of fc1.0.weight
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      f32x4 bb = ld4(&dz1buf[ln * LD160 + 16 * j + 4 * lg]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = SW_MFMA(w1[(size_t)(16 * j + 4 * lg + r) * 160], bb[r], acc);
+    }
+    if (live) st4(dS_pool + (size_t)b * 64 + u0 + 4 * lg, acc);
+  }
+}
+
+static int set_lds(const void* fn, int bytes) {
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    sw_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e);
+    return SW_EHIP;
+  }
+  return SW_OK;
+}
+
+extern "C" int sw_dec_rollout_fwd(const float* obsv, int To, const float* z, const float* S_pool,
+                                  const float* hT, const float* cT, const float* enc_w, const float* dec_w,
+                                  int B, int Tp, float* pred4, float* h_end, float* c_end, float* gsave,
+                                  void* stream) {
+  if (!obsv || !z || !hT || !cT || !enc_w || !dec_w || !pred4 || B < 0 || To < 2 || Tp < 1) return SW_EARG;
+  if (B == 0) return SW_OK;
+  static bool attr = false;
+  if (!attr) {
+    if (int rc = set_lds((const void*)dec_rollout_fwd_kernel, FwdLds::total * 4)) return rc;
+    attr = true;
+  }
+  hipLaunchKernelGGL(dec_rollout_fwd_kernel, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS),
+                     FwdLds::total * 4, (hipStream_t)stream, obsv, To, z, S_pool, hT, cT, enc_w, dec_w, B, Tp,
+                     pred4, h_end, c_end, gsave);
+  SW_CHECK_LAUNCH("dec_rollout_fwd_kernel");
+  return SW_OK;
+}
+
+extern "C" int sw_dec_rollout_bwd(const float* dpred4, const float* enc_w, const float* dec_w,
+                                  const float* gsave, int B, int To, int Tp, float* gdelta, float* dhT,
+                                  float* dcT, float* dS_pool, void* stream) {
+  if (!dpred4 || !enc_w || !dec_w || !gsave || !gdelta || !dhT || !dcT || B < 0 || To < 2 || Tp < 1)
+    return SW_EARG;
+  if (B == 0) return SW_OK;
+  static bool attr = false;
+  if (!attr) {
+    if (int rc = set_lds((const void*)dec_rollout_bwd_kernel, BwdLds::total * 4)) return rc;
+    attr = true;
+  }
+  hipLaunchKernelGGL(dec_rollout_bwd_kernel, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS),
+                     BwdLds::total * 4, (hipStream_t)stream, dpred4, enc_w, dec_w, gsave, B, To, Tp, gdelta,
+                     dhT, dcT, dS_pool);
+  SW_CHECK_LAUNCH("dec_rollout_bwd_kernel");
+  return SW_OK;
+}

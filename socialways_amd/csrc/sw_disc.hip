@@ -1,0 +1,497 @@
+// sw_disc.hip - Discriminator.forward (reference train.py:294-309) and its backward:
+//   LSTM(4->64) over the observed 4-d track, FC 64->32->32 on its last output, FC 4Tp->32->32 on
+//   the flattened (predicted or real) future, classifier 64->32->1 (raw LSGAN score) and the
+//   InfoGAN latent-code head 64->32->2.
+// One workgroup per 16-agent tile.  The observation encoding does not depend on the future
+// branch, so the fake and the real branch of a D update (train.py:482,487) share ONE LSTM pass:
+// `nb` branches are evaluated per call.
+#include "../../include/socialways_hip.h"
+#include "sw_lstm_dev.h"
+#include "sw_wgrad.h"
+
+namespace {
+constexpr int LD64 = sw_ld(64);  // 68
+constexpr int LD32 = sw_ld(32);  // 36
+constexpr int LD16 = sw_ld(16);  // 20
+#define SW_DISC_MAXB 2
+
+// time-major / branch-major save + delta layouts (floats)
+struct DSave {
+  size_t act, x4s, o1, both, q1, c1, l1, px, total;
+};
+__host__ __device__ inline DSave dsave_layout(int B, int To, int Tp, int nb) {
+  DSave d;
+  size_t b = (size_t)B;
+  d.act = 0;
+  d.x4s = d.act + (size_t)To * b * 384;
+  d.o1 = d.x4s + (size_t)To * b * 4;
+  d.both = d.o1 + b * 32;
+  d.q1 = d.both + nb * b * 64;
+  d.c1 = d.q1 + nb * b * 32;
+  d.l1 = d.c1 + nb * b * 32;
+  d.px = d.l1 + nb * b * 32;
+  d.total = d.px + nb * b * 4 * Tp;
+  return d;
+}
+struct DDelta {
+  size_t dgates, do1, docode, dpcode, dq1, dc1, dl1, dlab, dcod, total;
+};
+__host__ __device__ inline DDelta ddelta_layout(int B, int To, int Tp, int nb) {
+  DDelta d;
+  size_t b = (size_t)B;
+  d.dgates = 0;
+  d.do1 = d.dgates + (size_t)To * b * 256;
+  d.docode = d.do1 + b * 32;
+  d.dpcode = d.docode + b * 32;
+  d.dq1 = d.dpcode + nb * b * 32;
+  d.dc1 = d.dq1 + nb * b * 32;
+  d.dl1 = d.dc1 + nb * b * 32;
+  d.dlab = d.dl1 + nb * b * 32;
+  d.dcod = d.dlab + nb * b * 4;
+  d.total = d.dcod + nb * b * 4;
+  return d;
+}
+
+// runtime-K tile product (heads are tiny; KJ <= 4 normally)
+__device__ __forceinline__ f32x4 tile_mm_rt(const float* wrow, const float* xrow, int KJ, f32x4 acc) {
+  for (int j = 0; j < KJ; ++j) {
+    f32x4 a = ld4(wrow + 16 * j);
+    f32x4 b = ld4(xrow + 16 * j);
+    acc = SW_MFMA(a[0], b[0], acc);
+    acc = SW_MFMA(a[1], b[1], acc);
+    acc = SW_MFMA(a[2], b[2], acc);
+    acc = SW_MFMA(a[3], b[3], acc);
+  }
+  return acc;
+}
+
+struct HeadLds {  // forward LDS carve for a given padded pred width KP = roundup(4Tp,16)
+  int of0, of1, pe0, pe1, cl0, la0, cl1, la1, bias, hlast, o1, x, q1, both, c1, l1, total, ldp;
+};
+__host__ __device__ inline HeadLds head_lds(int Tp, int base) {
+  HeadLds L;
+  int KP = ((4 * Tp + 15) / 16) * 16;
+  L.ldp = KP + 4;
+  int o = base;
+  L.of0 = o; o += 32 * LD64;
+  L.of1 = o; o += 32 * LD32;
+  L.pe0 = o; o += 32 * L.ldp;
+  L.pe1 = o; o += 32 * LD32;
+  L.cl0 = o; o += 32 * LD64;
+  L.la0 = o; o += 32 * LD64;
+  L.cl1 = o; o += 16 * LD32;
+  L.la1 = o; o += 16 * LD32;
+  L.bias = o; o += 8 * 32;  // of0 of1 pe0 pe1 cl0 la0 cl1(16 used) la1(16 used)
+  L.hlast = o; o += 16 * LD64;
+  L.o1 = o; o += 16 * LD32;
+  L.x = o; o += 16 * L.ldp;
+  L.q1 = o; o += 16 * LD32;
+  L.both = o; o += 16 * LD64;
+  L.c1 = o; o += 16 * LD32;
+  L.l1 = o; o += 16 * LD32;
+  L.total = o;
+  return L;
+}
+}  // namespace
+
+__global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
+    const float* __restrict__ obsv, int To, int x_mode, const float* __restrict__ pred_a,
+    const float* __restrict__ pred_b, int nb, const float* __restrict__ d_w, int B, int Tp, float* __restrict__ label_a, float* __restrict__ label_b,
+    float* __restrict__ code_a, float* __restrict__ code_b, float* __restrict__ dsave) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // LSTM part
+  float* hbuf = smem;                        // [2][16][68]
+  float* wx_lds = smem + 2 * 16 * SW_HLD;    // [256][4]
+  float* bx_lds = wx_lds + 1024;             // [256]
+  const HeadLds L = head_lds(Tp, 2 * 16 * SW_HLD + 1280);
+  const swp::Disc O = swp::disc(Tp);
+  const DSave ds = dsave_layout(B, To, Tp, nb);
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  const int u0 = wave * 16;
+  const int a0 = blockIdx.x * SW_TILE;
+  const int b = min(a0 + ln, B - 1);
+  const bool live = (a0 + ln) < B;
+  const int K4 = 4 * Tp;
+
+  // ---- stage head weights / biases ------------------------------------------------------------
+  stage_w(smem + L.of0, LD64, 32, d_w + O.of0w, 64, 32, 64);
+  stage_w(smem + L.of1, LD32, 32, d_w + O.of1w, 32, 32, 32);
+  stage_w(smem + L.pe0, L.ldp, 32, d_w + O.pe0w, K4, 32, K4);
+  stage_w(smem + L.pe1, LD32, 32, d_w + O.pe1w, 32, 32, 32);
+  stage_w(smem + L.cl0, LD64, 32, d_w + O.cl0w, 64, 32, 64);
+  stage_w(smem + L.la0, LD64, 32, d_w + O.la0w, 64, 32, 64);
+  stage_w(smem + L.cl1, LD32, 16, d_w + O.cl1w, 32, 1, 32);
+  stage_w(smem + L.la1, LD32, 16, d_w + O.la1w, 32, 2, 32);
+  {
+    int i = threadIdx.x;  // 256 = 8 x 32
+    int q = i >> 5, k = i & 31;
+    float v = 0.f;
+    if (q == 0) v = d_w[O.of0b + k];
+    else if (q == 1) v = d_w[O.of1b + k];
+    else if (q == 2) v = d_w[O.pe0b + k];
+    else if (q == 3) v = d_w[O.pe1b + k];
+    else if (q == 4) v = d_w[O.cl0b + k];
+    else if (q == 5) v = d_w[O.la0b + k];
+    else if (q == 6) v = k < 1 ? d_w[O.cl1b + k] : 0.f;
+    else v = k < 2 ? d_w[O.la1b + k] : 0.f;
+    smem[L.bias + i] = v;
+  }
+  lstm_prep_rows(nullptr, nullptr, d_w + O.wih, d_w + O.bih, d_w + O.bhh, false, wx_lds, bx_lds);
+  f32x4 c = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};  // h0 = c0 = 0 (train.py:296-297)
+  st4(&hbuf[ln * SW_HLD + u0 + 4 * lg], h);
+  __syncthreads();
+  LstmW W;
+  lstm_load_w(W, d_w + O.whh, wx_lds, bx_lds, u0, ln, lg);
+
+  // ---- LSTM over the observation (4-d state formed on the fly, train.py:130-133) ---------------
+  for (int t = 0; t < To; ++t) {
+    float xb;
+    if (x_mode == 1) {
+      xb = obsv[((size_t)b * To + t) * 4 + lg];
+    } else {
+      const float* p = obsv + (size_t)b * To * 2;
+      if (lg < 2) xb = p[t * 2 + lg];
+      else { int tt = t == 0 ? 1 : t; xb = p[tt * 2 + lg - 2] - p[(tt - 1) * 2 + lg - 2]; }
+    }
+    f32x4 gate[4];
+    lstm_cell(W, xb, &hbuf[(t & 1) * 16 * SW_HLD + ln * SW_HLD + 4 * lg], gate, c, h);
+    st4(&hbuf[((t + 1) & 1) * 16 * SW_HLD + ln * SW_HLD + u0 + 4 * lg], h);
+    if (dsave && live) {
+      float* row = dsave + ds.act + ((size_t)t * B + b) * 384 + u0 + 4 * lg;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) st4(row + g * 64, gate[g]);
+      st4(row + 256, c);
+      st4(row + 320, h);
+      if (wave == 0) dsave[ds.x4s + ((size_t)t * B + b) * 4 + lg] = xb;
+    }
+    __syncthreads();
+  }
+  const float* hlast = &hbuf[(To & 1) * 16 * SW_HLD];
+
+  // ---- heads ------------------------------------------------------------------------------------
+  // pred branches into LDS rows [16][ldp] (zero padded), saved flat for the pe0 weight gradient
+  // phase A: o1 = lrelu(of0 h + b)  (waves 0,1)
+  if (wave < 2) {
+    int m0 = 16 * wave;
+    f32x4 acc = ld4(smem + L.bias + 0 * 32 + m0 + 4 * lg);
+    acc = tile_mm_rt(smem + L.of0 + (m0 + ln) * LD64 + 4 * lg, hlast + ln * SW_HLD + 4 * lg, 4, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu(acc[r]);
+    st4(smem + L.o1 + ln * LD32 + m0 + 4 * lg, acc);
+    if (dsave && live) st4(dsave + ds.o1 + (size_t)b * 32 + m0 + 4 * lg, acc);
+  }
+  __syncthreads();
+  // phase B: obsv_code = of1 o1 + b  -> both[:, 0:32]  (waves 0,1)
+  if (wave < 2) {
+    int m0 = 16 * wave;
+    f32x4 acc = ld4(smem + L.bias + 1 * 32 + m0 + 4 * lg);
+    acc = tile_mm_rt(smem + L.of1 + (m0 + ln) * LD32 + 4 * lg, smem + L.o1 + ln * LD32 + 4 * lg, 2, acc);
+    st4(smem + L.both + ln * LD64 + m0 + 4 * lg, acc);
+  }
+  for (int k = 0; k < nb; ++k) {
+    const float* pred = k == 0 ? pred_a : pred_b;
+    float* label = k == 0 ? label_a : label_b;
+    float* code = k == 0 ? code_a : code_b;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * L.ldp; i += blockDim.x) {
+      int a = i / L.ldp, cc = i - a * L.ldp;
+      int bb = min(a0 + a, B - 1);
+      float v = cc < K4 ? pred[(size_t)bb * K4 + cc] : 0.f;
+      smem[L.x + i] = v;
+      if (dsave && cc < K4 && a0 + a < B) dsave[ds.px + ((size_t)k * B + bb) * K4 + cc] = v;
+    }
+    __syncthreads();
+    // q1 = lrelu(pe0 x + b)   (waves 0,1)
+    if (wave < 2) {
+      int m0 = 16 * wave;
+      f32x4 acc = ld4(smem + L.bias + 2 * 32 + m0 + 4 * lg);
+      acc = tile_mm_rt(smem + L.pe0 + (m0 + ln) * L.ldp + 4 * lg, smem + L.x + ln * L.ldp + 4 * lg, (L.ldp - 4) / 16, acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu(acc[r]);
+      st4(smem + L.q1 + ln * LD32 + m0 + 4 * lg, acc);
+      if (dsave && live) st4(dsave + ds.q1 + ((size_t)k * B + b) * 32 + m0 + 4 * lg, acc);
+    }
+    __syncthreads();
+    // pred_code = pe1 q1 + b -> both[:, 32:64]   (waves 0,1)
+    if (wave < 2) {
+      int m0 = 16 * wave;
+      f32x4 acc = ld4(smem + L.bias + 3 * 32 + m0 + 4 * lg);
+      acc = tile_mm_rt(smem + L.pe1 + (m0 + ln) * LD32 + 4 * lg, smem + L.q1 + ln * LD32 + 4 * lg, 2, acc);
+      st4(smem + L.both + ln * LD64 + 32 + m0 + 4 * lg, acc);
+    }
+    __syncthreads();
+    if (dsave && live) {  // both codes (64) saved by all 4 waves, 16 floats each
+      st4(dsave + ds.both + ((size_t)k * B + b) * 64 + u0 + 4 * lg, ld4(smem + L.both + ln * LD64 + u0 + 4 * lg));
+    }
+    // c1 = lrelu(cl0 both + b) (waves 0,1) ; l1 = lrelu(la0 both + b) (waves 2,3)
+    {
+      int m0 = 16 * (wave & 1);
+      bool cls = wave < 2;
+      f32x4 acc = ld4(smem + L.bias + (cls ? 4 : 5) * 32 + m0 + 4 * lg);
+      acc = tile_mm_rt(smem + (cls ? L.cl0 : L.la0) + (m0 + ln) * LD64 + 4 * lg, smem + L.both + ln * LD64 + 4 * lg, 4, acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu(acc[r]);
+      st4(smem + (cls ? L.c1 : L.l1) + ln * LD32 + m0 + 4 * lg, acc);
+      if (dsave && live) st4(dsave + (cls ? ds.c1 : ds.l1) + ((size_t)k * B + b) * 32 + m0 + 4 * lg, acc);
+    }
+    __syncthreads();
+    // label = cl1 c1 + b (wave 0) ; code_hat = la1 l1 + b (wave 1)
+    if (wave < 2) {
+      bool cls = wave == 0;
+      f32x4 acc = ld4(smem + L.bias + (cls ? 6 : 7) * 32 + 4 * lg);
+      acc = tile_mm_rt(smem + (cls ? L.cl1 : L.la1) + ln * LD32 + 4 * lg, smem + (cls ? L.c1 : L.l1) + ln * LD32 + 4 * lg, 2, acc);
+      if (lg == 0 && live) {
+        if (cls) label[b] = acc[0];
+        else { code[(size_t)b * 2] = acc[0]; code[(size_t)b * 2 + 1] = acc[1]; }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct HeadLdsB {
+  int of0T, of1T, pe0T, pe1T, cl0T, la0T, cl1T, la1T, dlab, dcod, dc1, dl1, dboth, docode, dq1, do1, total, kp;
+};
+__host__ __device__ inline HeadLdsB head_lds_b(int Tp, int base) {
+  HeadLdsB L;
+  L.kp = ((4 * Tp + 15) / 16) * 16;
+  int o = base;
+  L.of0T = o; o += 64 * LD32;       // [64][36]   of0T[m][k] = of0[k][m]
+  L.of1T = o; o += 32 * LD32;
+  L.pe0T = o; o += L.kp * LD32;     // [kp][36]
+  L.pe1T = o; o += 32 * LD32;
+  L.cl0T = o; o += 64 * LD32;
+  L.la0T = o; o += 64 * LD32;
+  L.cl1T = o; o += 32 * LD16;       // [32][20]  (K = 1)
+  L.la1T = o; o += 32 * LD16;       // [32][20]  (K = 2)
+  L.dlab = o; o += 16 * LD16;
+  L.dcod = o; o += 16 * LD16;
+  L.dc1 = o; o += 16 * LD32;
+  L.dl1 = o; o += 16 * LD32;
+  L.dboth = o; o += 16 * LD64;
+  L.docode = o; o += 16 * LD32;
+  L.dq1 = o; o += 16 * LD32;
+  L.do1 = o; o += 16 * LD32;
+  L.total = o;
+  return L;
+}
+}  // namespace
+
+__global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
+    const float* __restrict__ d_w, const float* __restrict__ dsave, const float* __restrict__ dlabel_a,
+    const float* __restrict__ dlabel_b, const float* __restrict__ dcode_a, const float* __restrict__ dcode_b, int nb,
+    int B, int To, int Tp, int want_w, float* __restrict__ ddelta, float* __restrict__ dpred_a,
+    float* __restrict__ dpred_b) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* dgbuf = smem;  // [2][16][260]
+  const HeadLdsB L = head_lds_b(Tp, 2 * 16 * SW_GLD);
+  const swp::Disc O = swp::disc(Tp);
+  const DSave ds = dsave_layout(B, To, Tp, nb);
+  const DDelta dd = ddelta_layout(B, To, Tp, nb);
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  const int u0 = wave * 16;
+  const int a0 = blockIdx.x * SW_TILE;
+  const int b = min(a0 + ln, B - 1);
+  const bool live = (a0 + ln) < B;
+  const int K4 = 4 * Tp;
+
+  stage_wT(smem + L.of0T, LD32, 64, d_w + O.of0w, 64, 32, 64);
+  stage_wT(smem + L.of1T, LD32, 32, d_w + O.of1w, 32, 32, 32);
+  stage_wT(smem + L.pe0T, LD32, L.kp, d_w + O.pe0w, K4, 32, K4);
+  stage_wT(smem + L.pe1T, LD32, 32, d_w + O.pe1w, 32, 32, 32);
+  stage_wT(smem + L.cl0T, LD32, 64, d_w + O.cl0w, 64, 32, 64);
+  stage_wT(smem + L.la0T, LD32, 64, d_w + O.la0w, 64, 32, 64);
+  stage_wT(smem + L.cl1T, LD16, 32, d_w + O.cl1w, 32, 1, 32);
+  stage_wT(smem + L.la1T, LD16, 32, d_w + O.la1w, 32, 2, 32);
+  for (int i = threadIdx.x; i < 16 * LD32; i += blockDim.x) smem[L.docode + i] = 0.f;
+
+  for (int k = 0; k < nb; ++k) {
+    const float* dlabel = k == 0 ? dlabel_a : dlabel_b;
+    const float* dcode = k == 0 ? dcode_a : dcode_b;
+    float* dpred = k == 0 ? dpred_a : dpred_b;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * LD16; i += blockDim.x) {
+      int a = i / LD16, cc = i - a * LD16;
+      int bb = min(a0 + a, B - 1);
+      float vl = cc == 0 ? dlabel[bb] : 0.f;
+      float vc = cc < 2 ? dcode[(size_t)bb * 2 + cc] : 0.f;
+      smem[L.dlab + i] = vl;
+      smem[L.dcod + i] = vc;
+      if (want_w && a0 + a < B && cc < 4) {
+        ddelta[dd.dlab + ((size_t)k * B + bb) * 4 + cc] = vl;
+        ddelta[dd.dcod + ((size_t)k * B + bb) * 4 + cc] = vc;
+      }
+    }
+    __syncthreads();
+    // dc1 = (cl1^T dlabel) * lrelu'(c1)  (waves 0,1) ; dl1 = (la1^T dcode) * lrelu'(l1)  (waves 2,3)
+    {
+      int m0 = 16 * (wave & 1);
+      bool cls = wave < 2;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = tile_mm_rt(smem + (cls ? L.cl1T : L.la1T) + (m0 + ln) * LD16 + 4 * lg,
+                       smem + (cls ? L.dlab : L.dcod) + ln * LD16 + 4 * lg, 1, acc);
+      f32x4 a = ld4(dsave + (cls ? ds.c1 : ds.l1) + ((size_t)k * B + b) * 32 + m0 + 4 * lg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(a[r], acc[r]);
+      st4(smem + (cls ? L.dc1 : L.dl1) + ln * LD32 + m0 + 4 * lg, acc);
+      if (want_w && live) st4(ddelta + (cls ? dd.dc1 : dd.dl1) + ((size_t)k * B + b) * 32 + m0 + 4 * lg, acc);
+    }
+    __syncthreads();
+    // dboth = cl0^T dc1 + la0^T dl1   (wave w: rows 16w..)
+    {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = tile_mm_rt(smem + L.cl0T + (u0 + ln) * LD32 + 4 * lg, smem + L.dc1 + ln * LD32 + 4 * lg, 2, acc);
+      acc = tile_mm_rt(smem + L.la0T + (u0 + ln) * LD32 + 4 * lg, smem + L.dl1 + ln * LD32 + 4 * lg, 2, acc);
+      st4(smem + L.dboth + ln * LD64 + u0 + 4 * lg, acc);
+      if (wave < 2) {  // observation-code half: summed over branches
+        float* p = smem + L.docode + ln * LD32 + u0 + 4 * lg;
+        st4(p, ld4(p) + acc);
+      } else if (want_w && live) {
+        st4(ddelta + dd.dpcode + ((size_t)k * B + b) * 32 + (u0 - 32) + 4 * lg, acc);
+      }
+    }
+    __syncthreads();
+    // dq1 = (pe1^T dpcode) * lrelu'(q1)   (waves 0,1)
+    if (wave < 2) {
+      int m0 = 16 * wave;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = tile_mm_rt(smem + L.pe1T + (m0 + ln) * LD32 + 4 * lg, smem + L.dboth + ln * LD64 + 32 + 4 * lg, 2, acc);
+      f32x4 a = ld4(dsave + ds.q1 + ((size_t)k * B + b) * 32 + m0 + 4 * lg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(a[r], acc[r]);
+      st4(smem + L.dq1 + ln * LD32 + m0 + 4 * lg, acc);
+      if (want_w && live) st4(ddelta + dd.dq1 + ((size_t)k * B + b) * 32 + m0 + 4 * lg, acc);
+    }
+    __syncthreads();
+    // dpred = pe0^T dq1   (4Tp rows)
+    if (dpred) {
+      for (int mt = wave; mt * 16 < K4; mt += 4) {
+        int m0 = 16 * mt;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = tile_mm_rt(smem + L.pe0T + (m0 + ln) * LD32 + 4 * lg, smem + L.dq1 + ln * LD32 + 4 * lg, 2, acc);
+        if (live && m0 + 4 * lg < K4) st4(dpred + (size_t)b * K4 + m0 + 4 * lg, acc);
+      }
+    }
+  }
+  if (!want_w) return;
+  __syncthreads();
+  // ---- observation path: of1, of0, LSTM BPTT -------------------------------------------------
+  if (live && wave < 2) st4(ddelta + dd.docode + (size_t)b * 32 + u0 + 4 * lg, ld4(smem + L.docode + ln * LD32 + u0 + 4 * lg));
+  if (wave < 2) {
+    int m0 = 16 * wave;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = tile_mm_rt(smem + L.of1T + (m0 + ln) * LD32 + 4 * lg, smem + L.docode + ln * LD32 + 4 * lg, 2, acc);
+    f32x4 a = ld4(dsave + ds.o1 + (size_t)b * 32 + m0 + 4 * lg);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(a[r], acc[r]);
+    st4(smem + L.do1 + ln * LD32 + m0 + 4 * lg, acc);
+    if (live) st4(ddelta + dd.do1 + (size_t)b * 32 + m0 + 4 * lg, acc);
+  }
+  __syncthreads();
+  f32x4 dh = {0.f, 0.f, 0.f, 0.f}, dc = {0.f, 0.f, 0.f, 0.f};
+  dh = tile_mm_rt(smem + L.of0T + (u0 + ln) * LD32 + 4 * lg, smem + L.do1 + ln * LD32 + 4 * lg, 2, dh);
+  LstmWT WT;
+  lstm_load_wT(WT, d_w + O.whh, u0, ln, lg);
+  for (int t = To - 1; t >= 0; --t) {
+    const float* row = dsave + ds.act + ((size_t)t * B + b) * 384 + u0 + 4 * lg;
+    f32x4 gate[4], dgate[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gate[g] = ld4(row + g * 64);
+    f32x4 ct = ld4(row + 256);
+    f32x4 cprev = {0.f, 0.f, 0.f, 0.f};
+    if (t > 0) cprev = ld4(row - (size_t)B * 384 + 256);
+    lstm_cell_bwd(gate, ct, cprev, dh, dc, dgate);
+    float* dgl = &dgbuf[(t & 1) * 16 * SW_GLD + ln * SW_GLD + u0 + 4 * lg];
+    float* dgg = ddelta + dd.dgates + ((size_t)t * B + b) * 256 + u0 + 4 * lg;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      st4(dgl + g * 64, dgate[g]);
+      if (live) st4(dgg + g * 64, dgate[g]);
+    }
+    __syncthreads();
+    if (t > 0) dh = lstm_dh_prev(WT, &dgbuf[(t & 1) * 16 * SW_GLD + ln * SW_GLD + 4 * lg]);
+  }
+}
+
+static int set_lds(const void* fn, int bytes) {
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    sw_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e);
+    return SW_EHIP;
+  }
+  return SW_OK;
+}
+
+size_t sw_dsave_floats(int B, int To, int Tp, int nb) { return dsave_layout(B, To, Tp, nb).total; }
+size_t sw_ddelta_floats(int B, int To, int Tp, int nb) { return ddelta_layout(B, To, Tp, nb).total; }
+
+extern "C" int sw_disc_fwd(const float* obsv, int To, int x_mode, const float* const* pred4, int nb,
+                           const float* d_w, int B, int Tp, float* const* label, float* const* code, float* dsave,
+                           void* stream) {
+  if (!obsv || !pred4 || !d_w || !label || !code || nb < 1 || nb > SW_DISC_MAXB || B < 0 || To < 1 || Tp < 1 ||
+      (x_mode != 0 && x_mode != 1) || (x_mode == 0 && To < 2))
+    return SW_EARG;
+  for (int k = 0; k < nb; ++k)
+    if (!pred4[k] || !label[k] || !code[k]) return SW_EARG;
+  if (Tp > 64) return SW_ESHAPE;
+  if (B == 0) return SW_OK;
+  int lds = head_lds(Tp, 2 * 16 * SW_HLD + 1280).total * 4;
+  if (lds > 163840) return SW_ESHAPE;
+  static int attr = 0;
+  if (attr < lds) {
+    if (int rc = set_lds((const void*)disc_fwd_kernel, lds)) return rc;
+    attr = lds;
+  }
+  hipLaunchKernelGGL(disc_fwd_kernel, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS), lds, (hipStream_t)stream,
+                     obsv, To, x_mode, pred4[0], nb > 1 ? pred4[1] : nullptr, nb, d_w, B, Tp, label[0],
+                     nb > 1 ? label[1] : nullptr, code[0], nb > 1 ? code[1] : nullptr, dsave);
+  SW_CHECK_LAUNCH("disc_fwd_kernel");
+  return SW_OK;
+}
+
+extern "C" int sw_disc_bwd(const float* d_w, const float* dsave, const float* const* dlabel,
+                           const float* const* dcode, int nb, int B, int To, int Tp, float* ddelta, float* d_d_w,
+                           float* const* dpred4, float* wgrad_ws, void* stream) {
+  if (!d_w || !dsave || !dlabel || !dcode || nb < 1 || nb > SW_DISC_MAXB || B < 0 || To < 1 || Tp < 1) return SW_EARG;
+  for (int k = 0; k < nb; ++k)
+    if (!dlabel[k] || !dcode[k]) return SW_EARG;
+  if (d_d_w && (!ddelta || !wgrad_ws)) return SW_EARG;
+  if (Tp > 64) return SW_ESHAPE;
+  if (B == 0) return SW_OK;
+  int lds = head_lds_b(Tp, 2 * 16 * SW_GLD).total * 4;
+  if (lds > 163840) return SW_ESHAPE;
+  static int attr = 0;
+  if (attr < lds) {
+    if (int rc = set_lds((const void*)disc_bwd_kernel, lds)) return rc;
+    attr = lds;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(disc_bwd_kernel, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS), lds, st, d_w, dsave,
+                     dlabel[0], nb > 1 ? dlabel[1] : nullptr, dcode[0], nb > 1 ? dcode[1] : nullptr, nb, B, To, Tp,
+                     d_d_w ? 1 : 0, ddelta, dpred4 ? dpred4[0] : nullptr, (dpred4 && nb > 1) ? dpred4[1] : nullptr);
+  SW_CHECK_LAUNCH("disc_bwd_kernel");
+  if (!d_d_w) return SW_OK;
+  const swp::Disc O = swp::disc(Tp);
+  const DSave ds = dsave_layout(B, To, Tp, nb);
+  const DDelta dd = ddelta_layout(B, To, Tp, nb);
+  const int R = nb * B, K4 = 4 * Tp;
+  WgBatch wb;
+  // LSTM: dW_hh over rows t >= 1 against h_{t-1}; dW_ih / biases over all rows against x4
+  wg_add(wb, ddelta + dd.dgates + (size_t)B * 256, 256, dsave + ds.act + 320, 384, (To - 1) * B, 256, 64,
+         d_d_w + O.whh, 64, nullptr, nullptr, 0);
+  wg_add(wb, ddelta + dd.dgates, 256, dsave + ds.x4s, 4, To * B, 256, 4, d_d_w + O.wih, 4, d_d_w + O.bih,
+         d_d_w + O.bhh, 0);
+  wg_add(wb, ddelta + dd.do1, 32, dsave + ds.act + (size_t)(To - 1) * B * 384 + 320, 384, B, 32, 64, d_d_w + O.of0w,
+         64, d_d_w + O.of0b, nullptr, 0);
+  wg_add(wb, ddelta + dd.docode, 32, dsave + ds.o1, 32, B, 32, 32, d_d_w + O.of1w, 32, d_d_w + O.of1b, nullptr, 0);
+  wg_add(wb, ddelta + dd.dq1, 32, dsave + ds.px, K4, R, 32, K4, d_d_w + O.pe0w, K4, d_d_w + O.pe0b, nullptr, 0);
+  wg_add(wb, ddelta + dd.dpcode, 32, dsave + ds.q1, 32, R, 32, 32, d_d_w + O.pe1w, 32, d_d_w + O.pe1b, nullptr, 0);
+  wg_add(wb, ddelta + dd.dc1, 32, dsave + ds.both, 64, R, 32, 64, d_d_w + O.cl0w, 64, d_d_w + O.cl0b, nullptr, 0);
+  wg_add(wb, ddelta + dd.dlab, 4, dsave + ds.c1, 32, R, 1, 32, d_d_w + O.cl1w, 32, d_d_w + O.cl1b, nullptr, 0);
+  wg_add(wb, ddelta + dd.dl1, 32, dsave + ds.both, 64, R, 32, 64, d_d_w + O.la0w, 64, d_d_w + O.la0b, nullptr, 0);
+  wg_add(wb, ddelta + dd.dcod, 4, dsave + ds.l1, 32, R, 2, 32, d_d_w + O.la1w, 32, d_d_w + O.la1b, nullptr, 0);
+  return wg_launch(wb, wgrad_ws, st);
+}

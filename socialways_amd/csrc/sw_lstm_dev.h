@@ -1,0 +1,148 @@
+// sw_lstm_dev.h - the time-unrolled LSTM cell shared by the encoder, decode-loop and
+// discriminator kernels (reference: nn.LSTM in EncoderLstm train.py:254,268 and Discriminator
+// train.py:278,299; gate order i,f,g,o, c' = f c + i g, h' = o tanh(c')).
+//
+// A workgroup = 4 waves owns a tile of 16 agents.  Wave w owns hidden units [16w, 16w+16) of all
+// four gates, so the cell update is lane-local.  W_hh lives in registers for the whole kernel
+// (64 VGPRs/lane); the 4-d input goes through a 256x4 input matrix Wx which for the encoder is
+// the composition W_ih * W_embed (no non-linearity sits between embed and the LSTM,
+// train.py:266-268), for the discriminator W_ih itself.
+#pragma once
+#include "sw_common.h"
+
+#define SW_HLD 68    // LDS row stride of a 64-wide h tile
+#define SW_GLD 260   // LDS row stride of a 256-wide dgates tile
+
+struct LstmW {
+  f32x4 whh[4][4];  // [gate][j] = Whh[gate*64 + u0 + ln][16j + 4lg .. +3]
+  float wx[4];      // Wx[gate*64 + u0 + ln][lg]
+  f32x4 bias[4];    // rows gate*64 + u0 + 4lg + r
+};
+
+// Cooperative prologue: every thread computes one row of the input matrix / bias into LDS
+// (wx_lds[256][4], bx_lds[256]); caller must __syncthreads() afterwards.
+//   composed (encoder): Wx = Wih * We, bx = Wih * be + bih + bhh
+//   direct (discriminator): Wx = Wih (256x4), bx = bih + bhh
+__device__ __forceinline__ void lstm_prep_rows(const float* We, const float* be, const float* Wih,
+                                               const float* bih, const float* bhh, bool composed,
+                                               float* wx_lds, float* bx_lds) {
+  int row = threadIdx.x;  // 256 threads = 256 gate rows
+  if (composed) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, ab = 0.f;
+    const float* wr = Wih + (size_t)row * 64;
+    for (int e = 0; e < 64; e += 4) {
+      f32x4 w = ld4(wr + e);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 em = ld4(We + (e + q) * 4);
+        a0 = fmaf(w[q], em[0], a0);
+        a1 = fmaf(w[q], em[1], a1);
+        a2 = fmaf(w[q], em[2], a2);
+        a3 = fmaf(w[q], em[3], a3);
+        ab = fmaf(w[q], be[e + q], ab);
+      }
+    }
+    wx_lds[row * 4 + 0] = a0;
+    wx_lds[row * 4 + 1] = a1;
+    wx_lds[row * 4 + 2] = a2;
+    wx_lds[row * 4 + 3] = a3;
+    bx_lds[row] = ab + bih[row] + bhh[row];
+  } else {
+    f32x4 w = ld4(Wih + row * 4);
+    wx_lds[row * 4 + 0] = w[0];
+    wx_lds[row * 4 + 1] = w[1];
+    wx_lds[row * 4 + 2] = w[2];
+    wx_lds[row * 4 + 3] = w[3];
+    bx_lds[row] = bih[row] + bhh[row];
+  }
+}
+
+__device__ __forceinline__ void lstm_load_w(LstmW& W, const float* Whh, const float* wx_lds,
+                                            const float* bx_lds, int u0, int ln, int lg) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float* wr = Whh + (size_t)(g * 64 + u0 + ln) * 64 + 4 * lg;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) W.whh[g][j] = ld4(wr + 16 * j);
+    W.wx[g] = wx_lds[(g * 64 + u0 + ln) * 4 + lg];
+    W.bias[g] = ld4(bx_lds + g * 64 + u0 + 4 * lg);
+  }
+}
+
+// One cell step.  xb = x4[agent ln][component lg]; hrow = &h_lds[ln*SW_HLD + 4*lg] (previous h).
+// On return gate[] holds the post-activation gates i,f,g,o, c the new cell state, h the new h.
+__device__ __forceinline__ void lstm_cell(const LstmW& W, float xb, const float* hrow, f32x4 gate[4],
+                                          f32x4& c, f32x4& h) {
+  f32x4 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) acc[g] = SW_MFMA(W.wx[g], xb, W.bias[g]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f32x4 b = ld4(hrow + 16 * j);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = SW_MFMA(W.whh[g][j][r], b[r], acc[g]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float i = sw_sigmoid(acc[0][r]);
+    float f = sw_sigmoid(acc[1][r]);
+    float g = tanhf(acc[2][r]);
+    float o = sw_sigmoid(acc[3][r]);
+    float cn = fmaf(f, c[r], i * g);
+    gate[0][r] = i;
+    gate[1][r] = f;
+    gate[2][r] = g;
+    gate[3][r] = o;
+    c[r] = cn;
+    h[r] = o * tanhf(cn);
+  }
+}
+
+// Backward of one cell step (elementwise part).  In: dh, dc (gradients w.r.t. h_t, c_t), saved
+// gates/c_t/c_{t-1}.  Out: dgate[] = gradients w.r.t. the four PRE-activation gate rows, dc :=
+// gradient w.r.t. c_{t-1}.
+__device__ __forceinline__ void lstm_cell_bwd(const f32x4 gate[4], f32x4 ct, f32x4 cprev, f32x4 dh,
+                                              f32x4& dc, f32x4 dgate[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float i = gate[0][r], f = gate[1][r], g = gate[2][r], o = gate[3][r];
+    float tc = tanhf(ct[r]);
+    float d_o = dh[r] * tc;
+    float dct = fmaf(dh[r] * o, 1.0f - tc * tc, dc[r]);
+    dgate[0][r] = dct * g * i * (1.0f - i);
+    dgate[1][r] = dct * cprev[r] * f * (1.0f - f);
+    dgate[2][r] = dct * i * (1.0f - g * g);
+    dgate[3][r] = d_o * o * (1.0f - o);
+    dc[r] = dct * f;
+  }
+}
+
+// W_hh^T in registers for dh_{t-1} = W_hh^T dgates: whhT[j][r] = Whh[16j + 4lg + r][u0 + ln].
+struct LstmWT {
+  f32x4 whhT[16];
+};
+__device__ __forceinline__ void lstm_load_wT(LstmWT& W, const float* Whh, int u0, int ln, int lg) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) W.whhT[j][r] = Whh[(size_t)(16 * j + 4 * lg + r) * 64 + u0 + ln];
+  }
+}
+// dgrow = &dg_lds[ln*SW_GLD + 4*lg]
+__device__ __forceinline__ f32x4 lstm_dh_prev(const LstmWT& W, const float* dgrow) {
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 16; j += 2) {
+    f32x4 b0 = ld4(dgrow + 16 * j);
+    f32x4 b1 = ld4(dgrow + 16 * (j + 1));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      a0 = SW_MFMA(W.whhT[j][r], b0[r], a0);
+      a1 = SW_MFMA(W.whhT[j + 1][r], b1[r], a1);
+    }
+  }
+  return a0 + a1;
+}

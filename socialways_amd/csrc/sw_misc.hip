@@ -1,0 +1,236 @@
+// sw_misc.hip - ABI plumbing (errors, packed-weight layout, workspace sizes), the generator's
+// deferred weight-gradient batch, the LSGAN/InfoGAN loss kernel and the ADE/FDE reduction.
+#include "../../include/socialways_hip.h"
+#include "sw_common.h"
+#include "sw_wgrad.h"
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[256] = "";
+void sw_set_error(const char* what, hipError_t e) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+}
+extern "C" const char* sw_last_error(void) { return g_err; }
+extern "C" int sw_version(void) { return 1; }
+
+size_t sw_dsave_floats(int B, int To, int Tp, int nb);
+size_t sw_ddelta_floats(int B, int To, int Tp, int nb);
+
+// ---- packed-weight layout (state_dict order) ---------------------------------------------------
+static int group_offsets(int grp, int Tp, int* off, int* count) {
+  using namespace swp;
+  switch (grp) {
+    case SW_GRP_ENC: {
+      const int o[] = {ENC_EMB_W, ENC_EMB_B, ENC_WIH, ENC_WHH, ENC_BIH, ENC_BHH};
+      memcpy(off, o, sizeof(o));
+      *count = ENC_N;
+      return 6;
+    }
+    case SW_GRP_EMB: {
+      const int o[] = {EMB_W0, EMB_B0, EMB_W1, EMB_B1, EMB_W2, EMB_B2};
+      memcpy(off, o, sizeof(o));
+      *count = EMB_N;
+      return 6;
+    }
+    case SW_GRP_ATT: {
+      const int o[] = {ATT_W, ATT_B};
+      memcpy(off, o, sizeof(o));
+      *count = ATT_N;
+      return 2;
+    }
+    case SW_GRP_DEC: {
+      const int o[] = {DEC_W1, DEC_B1, DEC_W2, DEC_B2, DEC_W3, DEC_B3, DEC_W4, DEC_B4};
+      memcpy(off, o, sizeof(o));
+      *count = DEC_N;
+      return 8;
+    }
+    case SW_GRP_DISC: {
+      if (Tp < 1) return -1;
+      Disc d = disc(Tp);
+      const int o[] = {d.wih,  d.whh,  d.bih,  d.bhh,  d.of0w, d.of0b, d.of1w, d.of1b, d.pe0w, d.pe0b,
+                       d.pe1w, d.pe1b, d.cl0w, d.cl0b, d.cl1w, d.cl1b, d.la0w, d.la0b, d.la1w, d.la1b};
+      memcpy(off, o, sizeof(o));
+      *count = d.n;
+      return 20;
+    }
+  }
+  return -1;
+}
+extern "C" int sw_param_tensors(int grp) {
+  int off[32], n;
+  return group_offsets(grp, 1, off, &n);
+}
+extern "C" int sw_param_count(int grp, int Tp) {
+  int off[32], n = -1;
+  if (group_offsets(grp, Tp, off, &n) < 0) return SW_EARG;
+  return n;
+}
+extern "C" int sw_param_offset(int grp, int idx, int Tp) {
+  int off[32], n;
+  int k = group_offsets(grp, Tp, off, &n);
+  if (k < 0 || idx < 0 || idx >= k) return SW_EARG;
+  return off[idx];
+}
+
+extern "C" size_t sw_workspace_floats(int ws_id, int B, int To, int Tp, int nb, long long P) {
+  if (B < 0 || To < 1 || Tp < 1) return 0;
+  switch (ws_id) {
+    case SW_WS_GSAVE: return gsave_layout(B, To, Tp).total;
+    case SW_WS_GDELTA: return gdelta_layout(B, To, Tp).total;
+    case SW_WS_DSAVE: return sw_dsave_floats(B, To, Tp, nb < 1 ? 1 : nb);
+    case SW_WS_DDELTA: return sw_ddelta_floats(B, To, Tp, nb < 1 ? 1 : nb);
+    case SW_WS_WGRAD: return SW_WG_WS_FLOATS + 2048;
+    case SW_WS_PAIRS: return (size_t)B * 64 + (size_t)(P < 0 ? 0 : P) * 324;
+  }
+  return 0;
+}
+
+// ---- encoder: gradients of the composed input matrix back to embed / W_ih --------------------
+//   Wx = Wih We, bx = Wih be + bih + bhh   (sw_lstm_dev.h)
+__global__ void enc_compose_bwd_kernel(const float* __restrict__ enc_w, const float* __restrict__ dWx,
+                                       const float* __restrict__ dbx, float* __restrict__ d_enc_w) {
+  using namespace swp;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float* We = enc_w + ENC_EMB_W;
+  const float* be = enc_w + ENC_EMB_B;
+  const float* Wih = enc_w + ENC_WIH;
+  if (i < 256 * 64) {  // dWih[row][e] = sum_c dWx[row][c] We[e][c] + dbx[row] be[e]
+    int row = i >> 6, e = i & 63;
+    f32x4 g = ld4(dWx + row * 4), w = ld4(We + e * 4);
+    float v = dbx[row] * be[e];
+    v = fmaf(g[0], w[0], v); v = fmaf(g[1], w[1], v); v = fmaf(g[2], w[2], v); v = fmaf(g[3], w[3], v);
+    d_enc_w[ENC_WIH + i] = v;
+  } else if (i < 256 * 64 + 64 * 5) {  // dWe[e][c] = sum_row Wih[row][e] dWx[row][c]; dbe[e] = sum_row Wih[row][e] dbx[row]
+    int k = i - 256 * 64, e = k / 5, c = k - e * 5;
+    float v = 0.f;
+    for (int row = 0; row < 256; ++row) v = fmaf(Wih[row * 64 + e], c < 4 ? dWx[row * 4 + c] : dbx[row], v);
+    if (c < 4) d_enc_w[ENC_EMB_W + e * 4 + c] = v;
+    else d_enc_w[ENC_EMB_B + e] = v;
+  } else if (i < 256 * 64 + 64 * 5 + 256) {
+    int row = i - (256 * 64 + 64 * 5);
+    d_enc_w[ENC_BIH + row] = dbx[row];
+    d_enc_w[ENC_BHH + row] = dbx[row];
+  }
+}
+
+extern "C" int sw_gen_wgrad(const float* enc_w, const float* gsave, const float* gdelta, const float* z,
+                            const float* S_pool, int B, int To, int Tp, float* d_enc_w, float* d_dec_w,
+                            float* wgrad_ws, void* stream) {
+  if (!enc_w || !gsave || !gdelta || !z || !S_pool || !d_enc_w || !d_dec_w || !wgrad_ws || B < 1 || To < 2 || Tp < 1)
+    return SW_EARG;
+  using namespace swp;
+  const GSave gs = gsave_layout(B, To, Tp);
+  const GDelta gd = gdelta_layout(B, To, Tp);
+  const int Ta = To + Tp - 1;
+  float* dWx = wgrad_ws + SW_WG_WS_FLOATS;
+  float* dbx = dWx + 1024;
+  hipStream_t st = (hipStream_t)stream;
+  WgBatch wb;
+  // EncoderLstm: W_hh against h_{t-1} (rows t >= 1), composed input matrix against x4 (all rows)
+  wg_add(wb, gdelta + gd.dgates + (size_t)B * 256, 256, gsave + gs.act + 320, 384, (Ta - 1) * B, 256, 64,
+         d_enc_w + ENC_WHH, 64, nullptr, nullptr, 0);
+  wg_add(wb, gdelta + gd.dgates, 256, gsave + gs.x4s, 4, Ta * B, 256, 4, dWx, 4, dbx, nullptr, 0);
+  // DecoderFC: fc1.0 split in its h / S / z column blocks; h of decode step i is LSTM row To-1+i
+  wg_add(wb, gdelta + gd.dz1, 160, gsave + gs.act + (size_t)(To - 1) * B * 384 + 320, 384, Tp * B, 160, 64,
+         d_dec_w + DEC_W1, 160, nullptr, nullptr, 0);
+  wg_add(wb, gdelta + gd.du, 160, S_pool, 64, B, 160, 64, d_dec_w + DEC_W1 + 64, 160, nullptr, nullptr, 0);
+  wg_add(wb, gdelta + gd.du, 160, z, 32, B, 160, 32, d_dec_w + DEC_W1 + 128, 160, d_dec_w + DEC_B1, nullptr, 0);
+  wg_add(wb, gdelta + gd.dz2, 80, gsave + gs.a1, 160, Tp * B, 80, 160, d_dec_w + DEC_W2, 160, d_dec_w + DEC_B2,
+         nullptr, 0);
+  wg_add(wb, gdelta + gd.da3, 40, gsave + gs.a2, 80, Tp * B, 40, 80, d_dec_w + DEC_W3, 80, d_dec_w + DEC_B3, nullptr, 0);
+  wg_add(wb, gdelta + gd.dv, 4, gsave + gs.a3, 40, Tp * B, 2, 40, d_dec_w + DEC_W4, 40, d_dec_w + DEC_B4, nullptr, 0);
+  if (int rc = wg_launch(wb, wgrad_ws, st)) return rc;
+  int n = 256 * 64 + 64 * 5 + 256;
+  hipLaunchKernelGGL(enc_compose_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, enc_w, dWx, dbx, d_enc_w);
+  SW_CHECK_LAUNCH("enc_compose_bwd_kernel");
+  return SW_OK;
+}
+
+// ---- losses (train.py:484-494, 512-523) ---------------------------------------------------------
+__global__ void gan_loss_kernel(const float* __restrict__ label_a, float t_a, const float* __restrict__ code_a,
+                                const float* __restrict__ z, const float* __restrict__ label_b, float t_b, int B,
+                                float g_label, float g_code, float* __restrict__ out, float* __restrict__ dlabel_a,
+                                float* __restrict__ dcode_a, float* __restrict__ dlabel_b, float* __restrict__ dcode_b) {
+  __shared__ float red[3][256];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    float e = label_a[b] - t_a;
+    s0 = fmaf(e, e, s0);
+    if (dlabel_a) dlabel_a[b] = 2.0f * e * g_label;
+    float c0 = code_a[(size_t)b * 2] - z[(size_t)b * SW_Z], c1 = code_a[(size_t)b * 2 + 1] - z[(size_t)b * SW_Z + 1];
+    s1 += c0 * c0 + c1 * c1;
+    if (dcode_a) {
+      dcode_a[(size_t)b * 2] = 2.0f * c0 * g_code;
+      dcode_a[(size_t)b * 2 + 1] = 2.0f * c1 * g_code;
+    }
+    if (label_b) {
+      float f = label_b[b] - t_b;
+      s2 = fmaf(f, f, s2);
+      if (dlabel_b) dlabel_b[b] = 2.0f * f * g_label;
+    }
+    if (dcode_b) {
+      dcode_b[(size_t)b * 2] = 0.f;
+      dcode_b[(size_t)b * 2 + 1] = 0.f;
+    }
+  }
+  red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+      red[2][threadIdx.x] += red[2][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) out[threadIdx.x] = red[threadIdx.x][0];
+}
+
+extern "C" int sw_gan_loss(const float* label_a, float t_a, const float* code_a, const float* z, const float* label_b,
+                           float t_b, int B, float g_label, float g_code, float* out_sums, float* dlabel_a,
+                           float* dcode_a, float* dlabel_b, float* dcode_b, void* stream) {
+  if (!label_a || !code_a || !z || !out_sums || B < 1) return SW_EARG;
+  hipLaunchKernelGGL(gan_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, label_a, t_a, code_a, z, label_b, t_b,
+                     B, g_label, g_code, out_sums, dlabel_a, dcode_a, dlabel_b, dcode_b);
+  SW_CHECK_LAUNCH("gan_loss_kernel");
+  return SW_OK;
+}
+
+// ---- ADE/FDE partial sums (train.py:546-551) ----------------------------------------------------
+__global__ void ade_fde_kernel(const float* __restrict__ pred4, const float* __restrict__ gt, int B, int Tp,
+                               float inv_ss, float* __restrict__ out) {
+  __shared__ float red[3][256];
+  float sa = 0.f, sf = 0.f, sl = 0.f;
+  for (int i = threadIdx.x; i < B * Tp; i += blockDim.x) {
+    int t = i % Tp;
+    float dx = (pred4[(size_t)i * 4] - gt[(size_t)i * 2]) * inv_ss;
+    float dy = (pred4[(size_t)i * 4 + 1] - gt[(size_t)i * 2 + 1]) * inv_ss;
+    float q = dx * dx + dy * dy;
+    float e = sqrtf(q);
+    sa += e;
+    sl += q;
+    if (t == Tp - 1) sf += e;
+  }
+  red[0][threadIdx.x] = sa; red[1][threadIdx.x] = sf; red[2][threadIdx.x] = sl;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+      red[2][threadIdx.x] += red[2][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = red[0][0] / (float)Tp;
+    out[1] = red[1][0];
+    out[2] = red[2][0];  // sum of squared (scaled) displacement errors, for the L2 term
+  }
+}
+
+extern "C" int sw_ade_fde(const float* pred4, const float* gt, int B, int Tp, float inv_ss, float* out, void* stream) {
+  if (!pred4 || !gt || !out || B < 1 || Tp < 1) return SW_EARG;
+  hipLaunchKernelGGL(ade_fde_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred4, gt, B, Tp, inv_ss, out);
+  SW_CHECK_LAUNCH("ade_fde_kernel");
+  return SW_OK;
+}

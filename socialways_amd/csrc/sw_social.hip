@@ -1,0 +1,568 @@
+// sw_social.hip - the pairwise social block of predict() (reference train.py:408-411):
+//   SocialFeatures (train.py:208-241)  ->  EmbedSocialFeatures (train.py:178-189)
+//   ->  AttentionPooling (train.py:153-175), fused and BLOCK-DIAGONAL.
+//
+// The reference builds dense (B,B,3) / (B,B,64) tensors over all agents of the packed batch and
+// then reads only the in-scene blocks; here one workgroup owns one scene and only
+// its n^2 ordered pairs are ever formed.  Per 16-pair tile (one wave):
+//   features (VALU, per lane)  ->  3->32 ReLU (VALU, produced directly in MFMA B-operand layout)
+//   ->  32->64 ReLU  ->  64->64 on the matrix cores, the output registers of one layer being
+//   the B operands of the next (no LDS round trip: the K order of sw_common.h is chosen so that
+//   C/D layout == B layout)  ->  score = <f_ij, W h_j> by a 4-lane shuffle reduction.
+// Pair embeddings never touch HBM in the forward pass.
+#include "../../include/socialways_hip.h"
+#include "sw_common.h"
+#include "sw_wgrad.h"
+
+#define SW_AMAX 64  // max agents per scene handled by one workgroup (attn row stride)
+
+namespace {
+struct PairW {            // per-lane register-resident pair-MLP weights
+  f32x4 w1[4][2];         // fc.2.weight[16mt + ln][16j + 4lg ..]   (64 x 32)
+  f32x4 w2[4][4];         // fc.4.weight[16mt'+ ln][16mt + 4lg ..]  (64 x 64)
+};
+__device__ __forceinline__ void load_pair_w(PairW& W, const float* emb_w, int ln, int lg) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) W.w1[mt][j] = ld4(emb_w + swp::EMB_W1 + (16 * mt + ln) * 32 + 16 * j + 4 * lg);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) W.w2[mt][k] = ld4(emb_w + swp::EMB_W2 + (16 * mt + ln) * 64 + 16 * k + 4 * lg);
+  }
+}
+
+// [dist, bearing, dca] of the ordered pair (i, j): dp = p_i - p_j, dv = v_i - v_j (train.py:232-234);
+// eps placement as train.py:212,225.  The diagonal gives (0, 0, 0).
+__device__ __forceinline__ void pair_feat(f32x4 si, f32x4 sj, float& f0, float& f1, float& f2) {
+  float dpx = si[0] - sj[0], dpy = si[1] - sj[1];
+  float dvx = si[2] - sj[2], dvy = si[3] - sj[3];
+  float l2 = sqrtf(dpx * dpx + dpy * dpy);
+  float vn = sqrtf(si[2] * si[2] + si[3] * si[3]);
+  f0 = l2;
+  f1 = (dpx * si[2] + dpy * si[3]) / (l2 * vn + 1e-6f);
+  float ttca = -((dpx * dvx + dpy * dvy) / (dvx * dvx + dvy * dvy + 1e-6f));
+  float cx = dpx + ttca * dvx, cy = dpy + ttca * dvy;
+  f2 = sqrtf(cx * cx + cy * cy);
+}
+
+// layer 1 (3->32, ReLU) produced in B-operand layout: h1[j][r] = unit 16j + 4lg + r
+__device__ __forceinline__ void pair_l1(const float* w0b, int lg, float f0, float f1, float f2, f32x4 h1[2]) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      f32x4 w = ld4(w0b + (16 * j + 4 * lg + r) * 4);  // (w0, w1, w2, bias)
+      float v = fmaf(w[2], f2, fmaf(w[1], f1, fmaf(w[0], f0, w[3])));
+      h1[j][r] = fmaxf(v, 0.f);
+    }
+  }
+}
+// layers 2, 3 on the matrix cores; pre-activations of layer 2 are returned post-ReLU in h2
+__device__ __forceinline__ void pair_l23(const PairW& W, const float* b1, const float* b2, int lg,
+                                         const f32x4 h1[2], f32x4 h2[4], f32x4 f[4]) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    f32x4 acc = ld4(b1 + 16 * mt + 4 * lg);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = SW_MFMA(W.w1[mt][j][r], h1[j][r], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h2[mt][r] = fmaxf(acc[r], 0.f);
+  }
+#pragma unroll
+  for (int mo = 0; mo < 4; ++mo) f[mo] = ld4(b2 + 16 * mo + 4 * lg);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int mo = 0; mo < 4; ++mo) f[mo] = SW_MFMA(W.w2[mo][k][r], h2[k][r], f[mo]);
+    }
+  }
+}
+
+// LDS carve shared by forward and backward (floats)
+struct SocLds {
+  static constexpr int hs = 0;                          // [64][68]  h of the scene
+  static constexpr int wh = hs + SW_AMAX * 68;          // [64][68]  W h + b
+  static constexpr int x4 = wh + SW_AMAX * 68;          // [64][4]
+  static constexpr int sig = x4 + SW_AMAX * 4;          // [64][64]  scores -> attention weights
+  static constexpr int w0b = sig + SW_AMAX * SW_AMAX;   // [32][4]   fc.0 weight|bias
+  static constexpr int b12 = w0b + 128;                 // fc.2.bias[64] | fc.4.bias[64]
+  static constexpr int fwd_total = b12 + 128;
+  // backward only
+  static constexpr int ds = fwd_total;                  // [64][68]  dS of the scene
+  static constexpr int dsg = ds + SW_AMAX * 68;         // [64][64]  dsigma
+  static constexpr int dwh = dsg + SW_AMAX * SW_AMAX;   // [64][68]  dWh
+  static constexpr int bwd_total = dwh + SW_AMAX * 68;
+};
+static_assert(SocLds::bwd_total * 4 <= 163840, "LDS budget");
+
+// h rows of the scene into LDS (+ zero rows up to a multiple of 16) and Wh = W h + b (train.py:161)
+__device__ __forceinline__ void scene_load_h_wh(float* smem, const float* h, const float* att_w, int s0, int n) {
+  float* hs = smem + SocLds::hs;
+  float* wh = smem + SocLds::wh;
+  for (int i = threadIdx.x; i < n * 16; i += blockDim.x) {
+    int a = i >> 4, q = i & 15;
+    st4(&hs[a * 68 + 4 * q], ld4(h + (size_t)(s0 + a) * 64 + 4 * q));
+  }
+  int npad = ((n + 15) & ~15);
+  for (int i = threadIdx.x; i < (npad - n) * 16; i += blockDim.x) {
+    int a = n + (i >> 4), q = i & 15;
+    st4(&hs[a * 68 + 4 * q], f32x4{0.f, 0.f, 0.f, 0.f});
+  }
+  __syncthreads();
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  f32x4 wr[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wr[j] = ld4(att_w + swp::ATT_W + (16 * wave + ln) * 64 + 16 * j + 4 * lg);
+  f32x4 bias = ld4(att_w + swp::ATT_B + 16 * wave + 4 * lg);
+  for (int at = 0; at < npad / 16; ++at) {
+    f32x4 acc = tile_mm_reg<4>(wr, &hs[(16 * at + ln) * 68 + 4 * lg], bias);
+    st4(&wh[(16 * at + ln) * 68 + 16 * wave + 4 * lg], acc);
+  }
+  __syncthreads();
+}
+// fc.0 weight|bias and fc.2 / fc.4 biases into LDS
+__device__ __forceinline__ void stage_pair_consts(float* smem, const float* emb_w) {
+  float* w0b = smem + SocLds::w0b;
+  float* b12 = smem + SocLds::b12;
+  if (threadIdx.x < 32) {
+    int k = threadIdx.x;
+    f32x4 v = {emb_w[swp::EMB_W0 + k * 3], emb_w[swp::EMB_W0 + k * 3 + 1], emb_w[swp::EMB_W0 + k * 3 + 2],
+               emb_w[swp::EMB_B0 + k]};
+    st4(&w0b[k * 4], v);
+  }
+  if (threadIdx.x >= 64 && threadIdx.x < 192) {
+    int k = threadIdx.x - 64;
+    b12[k] = k < 64 ? emb_w[swp::EMB_B1 + k] : emb_w[swp::EMB_B2 + k - 64];
+  }
+}
+__device__ __forceinline__ void scene_prologue(float* smem, const float* obsv, int To, const float* h,
+                                               const float* emb_w, const float* att_w, int s0, int n) {
+  float* x4 = smem + SocLds::x4;
+  for (int a = threadIdx.x; a < n; a += blockDim.x) {
+    const float* p = obsv + ((size_t)(s0 + a) * To + To - 2) * 2;  // last two observed points
+    f32x4 v = {p[2], p[3], p[2] - p[0], p[3] - p[1]};
+    st4(&x4[a * 4], v);
+  }
+  stage_pair_consts(smem, emb_w);
+  scene_load_h_wh(smem, h, att_w, s0, n);
+}
+// softmax over the scene for every agent i (train.py:172, one wave per row) then
+// S_i = sum_j a_ij h_j (train.py:173: pools the raw hidden states)
+__device__ __forceinline__ void scene_softmax_pool(float* smem, int s0, int n, float* S_out, float* attn) {
+  float* hs = smem + SocLds::hs;
+  float* sig = smem + SocLds::sig;
+  const int lane = sw_lane(), wave = sw_wave();
+  for (int i = wave; i < n; i += 4) {
+    float v = lane < n ? sig[i * SW_AMAX + lane] : -INFINITY;
+    float m = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float e = lane < n ? expf(v - m) : 0.f;
+    float sum = e;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    float a = e / sum;
+    if (lane < n) {
+      sig[i * SW_AMAX + lane] = a;
+      if (attn) attn[(size_t)(s0 + i) * SW_AMAX + lane] = a;
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n * 64; e += blockDim.x) {
+    int i = e >> 6, u = e & 63;
+    float acc = 0.f;
+    for (int j = 0; j < n; ++j) acc = fmaf(sig[i * SW_AMAX + j], hs[j * 68 + u], acc);
+    S_out[(size_t)(s0 + i) * 64 + u] = acc;
+  }
+}
+}  // namespace
+
+__global__ __launch_bounds__(SW_THREADS) void social_pool_fwd_kernel(
+    const float* __restrict__ obsv, int To, const float* __restrict__ h, const int* __restrict__ scene_off,
+    const float* __restrict__ emb_w, const float* __restrict__ att_w, float* __restrict__ S_out,
+    float* __restrict__ attn) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* wh = smem + SocLds::wh;
+  float* x4 = smem + SocLds::x4;
+  float* sig = smem + SocLds::sig;
+  const float* w0b = smem + SocLds::w0b;
+  const float* b12 = smem + SocLds::b12;
+  const int s0 = scene_off[blockIdx.x], n = scene_off[blockIdx.x + 1] - s0;
+  if (n <= 0) return;
+  if (n == 1) {  // train.py:165: single-agent scenes keep S = 0
+    if (threadIdx.x < 16) st4(S_out + (size_t)s0 * 64 + 4 * threadIdx.x, f32x4{0.f, 0.f, 0.f, 0.f});
+    if (attn && threadIdx.x == 0) attn[(size_t)s0 * SW_AMAX] = 0.f;
+    return;
+  }
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  scene_prologue(smem, obsv, To, h, emb_w, att_w, s0, n);
+  PairW W;
+  load_pair_w(W, emb_w, ln, lg);
+  const int P = n * n;
+  for (int pt = wave; pt * 16 < P; pt += 4) {
+    int p = min(pt * 16 + ln, P - 1);
+    int i = p / n, j = p - i * n;
+    float f0, f1, f2;
+    pair_feat(ld4(&x4[i * 4]), ld4(&x4[j * 4]), f0, f1, f2);
+    f32x4 h1[2], h2[4], f[4];
+    pair_l1(w0b, lg, f0, f1, f2, h1);
+    pair_l23(W, b12, b12 + 64, lg, h1, h2, f);
+    float part = 0.f;
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) {
+      f32x4 w = ld4(&wh[j * 68 + 16 * mo + 4 * lg]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part = fmaf(f[mo][r], w[r], part);
+    }
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    if (lg == 0 && pt * 16 + ln < P) sig[i * SW_AMAX + j] = (i == j) ? -1000.0f : part;  // train.py:170
+  }
+  __syncthreads();
+  scene_softmax_pool(smem, s0, n, S_out, attn);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward.  Inputs carry no gradient (tracks are data); gradients flow to h (through the pooling
+// and through W h), to W/b of the attention and to the pair MLP.  The pair MLP forward is
+// recomputed per tile; its weight gradients are deferred GEMMs over per-pair rows.
+// pair rows (P_total = sum n_s^2, row index = pair_off[s] + i*n + j):
+//   f[64] dz3[64] h2[64] dh2[64] h1[32] dh1[32] feat[4]
+// ---------------------------------------------------------------------------------------------
+struct PairRows {
+  float *f, *dz3, *h2, *dh2, *h1, *dh1, *feat;
+};
+__host__ __device__ inline PairRows pair_rows(float* base, long long P) {
+  PairRows r;
+  r.f = base;
+  r.dz3 = r.f + 64 * P;
+  r.h2 = r.dz3 + 64 * P;
+  r.dh2 = r.h2 + 64 * P;
+  r.h1 = r.dh2 + 64 * P;
+  r.dh1 = r.h1 + 32 * P;
+  r.feat = r.dh1 + 32 * P;
+  return r;
+}
+#define SW_PAIR_ROW_FLOATS 324
+
+__global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
+    const float* __restrict__ obsv, int To, const float* __restrict__ h, const int* __restrict__ scene_off,
+    const long long* __restrict__ pair_off, const float* __restrict__ emb_w, const float* __restrict__ att_w,
+    const float* __restrict__ attn, const float* __restrict__ dS, float* __restrict__ dh,
+    float* __restrict__ dwh_rows, PairRows pr) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* hs = smem + SocLds::hs;
+  float* wh = smem + SocLds::wh;
+  float* x4 = smem + SocLds::x4;
+  float* sig = smem + SocLds::sig;  // attention weights a_ij
+  const float* w0b = smem + SocLds::w0b;
+  const float* b12 = smem + SocLds::b12;
+  float* dsl = smem + SocLds::ds;
+  float* dsg = smem + SocLds::dsg;
+  float* dwh = smem + SocLds::dwh;
+  const int s0 = scene_off[blockIdx.x], n = scene_off[blockIdx.x + 1] - s0;
+  if (n <= 0) return;
+  if (n == 1) {  // S = 0 constant: no gradient anywhere; dWh row is zero
+    if (threadIdx.x < 16) st4(dwh_rows + (size_t)s0 * 64 + 4 * threadIdx.x, f32x4{0.f, 0.f, 0.f, 0.f});
+    return;
+  }
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  const long long p0 = pair_off[blockIdx.x];
+  scene_prologue(smem, obsv, To, h, emb_w, att_w, s0, n);
+  for (int i = threadIdx.x; i < n * 16; i += blockDim.x) {
+    int a = i >> 4, q = i & 15;
+    st4(&dsl[a * 68 + 4 * q], ld4(dS + (size_t)(s0 + a) * 64 + 4 * q));
+  }
+  for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+    int i = e / n, j = e - i * n;
+    sig[i * SW_AMAX + j] = attn[(size_t)(s0 + i) * SW_AMAX + j];
+  }
+  __syncthreads();
+  // da_ij = <dS_i, h_j>;  dsigma_ij = a_ij (da_ij - sum_j' a_ij' da_ij')   (softmax backward)
+  for (int i = wave; i < n; i += 4) {
+    float da = 0.f, a = 0.f;
+    if (lane < n) {
+      a = sig[i * SW_AMAX + lane];
+      for (int u = 0; u < 64; u += 4) {
+        f32x4 x = ld4(&dsl[i * 68 + u]), y = ld4(&hs[lane * 68 + u]);
+        da = fmaf(x[0], y[0], da); da = fmaf(x[1], y[1], da); da = fmaf(x[2], y[2], da); da = fmaf(x[3], y[3], da);
+      }
+    }
+    float t = a * da;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (lane < n) dsg[i * SW_AMAX + lane] = a * (da - t);
+  }
+  __syncthreads();
+  // ---- pair tiles: recompute the MLP, back-propagate, leave rows for the deferred GEMMs --------
+  PairW W;
+  load_pair_w(W, emb_w, ln, lg);
+  f32x4 w2T[4][4];  // fc.4.weight^T: [mt][mo][r] = W2[16mo + 4lg + r][16mt + ln]
+  f32x4 w1T[2][4];  // fc.2.weight^T: [jt][mt][r] = W1[16mt + 4lg + r][16jt + ln]
+#pragma unroll
+  for (int mo = 0; mo < 4; ++mo) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* row2 = emb_w + swp::EMB_W2 + (16 * mo + 4 * lg + r) * 64 + ln;
+      const float* row1 = emb_w + swp::EMB_W1 + (16 * mo + 4 * lg + r) * 32 + ln;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) w2T[mt][mo][r] = row2[16 * mt];
+      w1T[0][mo][r] = row1[0];
+      w1T[1][mo][r] = row1[16];
+    }
+  }
+  const int P = n * n;
+  for (int pt = wave; pt * 16 < P; pt += 4) {
+    const bool valid = pt * 16 + ln < P;
+    int p = min(pt * 16 + ln, P - 1);
+    int i = p / n, j = p - i * n;
+    float f0, f1, f2;
+    pair_feat(ld4(&x4[i * 4]), ld4(&x4[j * 4]), f0, f1, f2);
+    f32x4 h1[2], h2[4], f[4];
+    pair_l1(w0b, lg, f0, f1, f2, h1);
+    pair_l23(W, b12, b12 + 64, lg, h1, h2, f);
+    const float dsv = valid ? dsg[i * SW_AMAX + j] : 0.f;
+    f32x4 dz3[4];
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) {
+      f32x4 w = ld4(&wh[j * 68 + 16 * mo + 4 * lg]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dz3[mo][r] = dsv * w[r];
+    }
+    f32x4 dh2[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) dh2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) dh2[mt] = SW_MFMA(w2T[mt][mo][r], dz3[mo][r], dh2[mt]);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh2[mt][r] = h2[mt][r] > 0.f ? dh2[mt][r] : 0.f;
+    }
+    f32x4 dh1[2];
+    dh1[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dh1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dh1[0] = SW_MFMA(w1T[0][mt][r], dh2[mt][r], dh1[0]);
+        dh1[1] = SW_MFMA(w1T[1][mt][r], dh2[mt][r], dh1[1]);
+      }
+    }
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh1[jt][r] = h1[jt][r] > 0.f ? dh1[jt][r] : 0.f;
+    }
+    if (valid) {
+      const size_t row = (size_t)(p0 + p);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        st4(pr.f + row * 64 + 16 * mt + 4 * lg, f[mt]);
+        st4(pr.dz3 + row * 64 + 16 * mt + 4 * lg, dz3[mt]);
+        st4(pr.h2 + row * 64 + 16 * mt + 4 * lg, h2[mt]);
+        st4(pr.dh2 + row * 64 + 16 * mt + 4 * lg, dh2[mt]);
+      }
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        st4(pr.h1 + row * 32 + 16 * jt + 4 * lg, h1[jt]);
+        st4(pr.dh1 + row * 32 + 16 * jt + 4 * lg, dh1[jt]);
+      }
+      if (lg == 0) st4(pr.feat + row * 4, f32x4{f0, f1, f2, 0.f});
+    }
+  }
+  __syncthreads();  // pair rows of this scene are visible to the whole workgroup (same CU)
+  // dWh_j = sum_i dsigma_ij f_ij
+  for (int e = threadIdx.x; e < n * 64; e += blockDim.x) {
+    int j = e >> 6, u = e & 63;
+    float acc = 0.f;
+    for (int i = 0; i < n; ++i) acc = fmaf(dsg[i * SW_AMAX + j], pr.f[(size_t)(p0 + i * n + j) * 64 + u], acc);
+    dwh[j * 68 + u] = acc;
+    dwh_rows[(size_t)(s0 + j) * 64 + u] = acc;
+  }
+  __syncthreads();
+  // dh_j += sum_i a_ij dS_i  +  W^T dWh_j
+  for (int e = threadIdx.x; e < n * 64; e += blockDim.x) {
+    int j = e >> 6, u = e & 63;
+    float acc = 0.f;
+    for (int i = 0; i < n; ++i) acc = fmaf(sig[i * SW_AMAX + j], dsl[i * 68 + u], acc);
+    const float* wc = att_w + swp::ATT_W + u;
+    for (int k = 0; k < 64; ++k) acc = fmaf(wc[k * 64], dwh[j * 68 + k], acc);
+    dh[(size_t)(s0 + j) * 64 + u] += acc;
+  }
+}
+
+// dense SocialFeatures for the module-level API (train.py:229-241): feat[i][j][0..2]
+__global__ void social_features_kernel(const float* __restrict__ x4, int B, float* __restrict__ feat) {
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)B * B) return;
+  int i = e / B, j = e - (size_t)i * B;
+  float f0, f1, f2;
+  pair_feat(ld4(x4 + (size_t)i * 4), ld4(x4 + (size_t)j * 4), f0, f1, f2);
+  feat[e * 3 + 0] = f0;
+  feat[e * 3 + 1] = f1;
+  feat[e * 3 + 2] = f2;
+}
+
+
+static int set_lds(const void* fn, int bytes) {
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    sw_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e);
+    return SW_EHIP;
+  }
+  return SW_OK;
+}
+
+// ---- module-level API helpers (dense layouts of the reference, small batches) -----------------
+// AttentionPooling.forward on a dense (B,B,64) embedding tensor: only in-scene blocks are read.
+__global__ __launch_bounds__(SW_THREADS) void attention_pool_dense_kernel(
+    const float* __restrict__ f, const float* __restrict__ h, const int* __restrict__ scene_off, int B,
+    const float* __restrict__ att_w, float* __restrict__ S_out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* wh = smem + SocLds::wh;
+  float* sig = smem + SocLds::sig;
+  const int s0 = scene_off[blockIdx.x], n = scene_off[blockIdx.x + 1] - s0;
+  if (n <= 0) return;
+  if (n == 1) {
+    if (threadIdx.x < 16) st4(S_out + (size_t)s0 * 64 + 4 * threadIdx.x, f32x4{0.f, 0.f, 0.f, 0.f});
+    return;
+  }
+  scene_load_h_wh(smem, h, att_w, s0, n);
+  for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+    int i = e / n, j = e - i * n;
+    const float* fr = f + ((size_t)(s0 + i) * B + (s0 + j)) * 64;
+    float acc = 0.f;
+    for (int u = 0; u < 64; u += 4) {
+      f32x4 x = ld4(fr + u), y = ld4(&wh[j * 68 + u]);
+      acc = fmaf(x[0], y[0], acc); acc = fmaf(x[1], y[1], acc); acc = fmaf(x[2], y[2], acc); acc = fmaf(x[3], y[3], acc);
+    }
+    sig[i * SW_AMAX + j] = (i == j) ? -1000.0f : acc;
+  }
+  __syncthreads();
+  scene_softmax_pool(smem, s0, n, S_out, nullptr);
+}
+
+// EmbedSocialFeatures.forward on R rows of 3 features (one wave per 16 rows).
+__global__ __launch_bounds__(SW_THREADS) void embed_features_kernel(const float* __restrict__ feat, long long R,
+                                                                    const float* __restrict__ emb_w,
+                                                                    float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const float* w0b = smem + SocLds::w0b;
+  const float* b12 = smem + SocLds::b12;
+  stage_pair_consts(smem, emb_w);
+  __syncthreads();
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  PairW W;
+  load_pair_w(W, emb_w, ln, lg);
+  long long r0 = ((long long)blockIdx.x * 4 + wave) * 16;
+  if (r0 >= R) return;
+  long long row = r0 + ln < R ? r0 + ln : R - 1;
+  float f0 = feat[row * 3], f1 = feat[row * 3 + 1], f2 = feat[row * 3 + 2];
+  f32x4 h1[2], h2[4], f[4];
+  pair_l1(w0b, lg, f0, f1, f2, h1);
+  pair_l23(W, b12, b12 + 64, lg, h1, h2, f);
+  if (r0 + ln < R) {
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) st4(out + row * 64 + 16 * mo + 4 * lg, f[mo]);
+  }
+}
+
+extern "C" int sw_attention_pool_dense(const float* f, const float* h, const int* scene_off, int S, int B,
+                                       const float* att_w, float* S_out, void* stream) {
+  if (!f || !h || !scene_off || !att_w || !S_out || S < 0 || B < 0) return SW_EARG;
+  if (S == 0 || B == 0) return SW_OK;
+  static bool attr = false;
+  if (!attr) {
+    if (int rc = set_lds((const void*)attention_pool_dense_kernel, SocLds::fwd_total * 4)) return rc;
+    attr = true;
+  }
+  hipLaunchKernelGGL(attention_pool_dense_kernel, dim3(S), dim3(SW_THREADS), SocLds::fwd_total * 4, (hipStream_t)stream,
+                     f, h, scene_off, B, att_w, S_out);
+  SW_CHECK_LAUNCH("attention_pool_dense_kernel");
+  return SW_OK;
+}
+
+extern "C" int sw_embed_features(const float* feat, long long R, const float* emb_w, float* out, void* stream) {
+  if (!feat || !emb_w || !out || R < 0) return SW_EARG;
+  if (R == 0) return SW_OK;
+  static bool attr = false;
+  if (!attr) {
+    if (int rc = set_lds((const void*)embed_features_kernel, SocLds::fwd_total * 4)) return rc;
+    attr = true;
+  }
+  hipLaunchKernelGGL(embed_features_kernel, dim3((unsigned)((R + 63) / 64)), dim3(SW_THREADS), SocLds::fwd_total * 4,
+                     (hipStream_t)stream, feat, R, emb_w, out);
+  SW_CHECK_LAUNCH("embed_features_kernel");
+  return SW_OK;
+}
+
+extern "C" int sw_social_features(const float* x4_last, int B, float* feat, void* stream) {
+  if (!x4_last || !feat || B < 0) return SW_EARG;
+  if (B == 0) return SW_OK;
+  size_t n = (size_t)B * B;
+  hipLaunchKernelGGL(social_features_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     x4_last, B, feat);
+  SW_CHECK_LAUNCH("social_features_kernel");
+  return SW_OK;
+}
+
+extern "C" int sw_social_pool_fwd(const float* obsv, int To, const float* h, const int* scene_off, int S, int B,
+                                  int Amax, const float* emb_w, const float* att_w, float* S_out, float* attn,
+                                  void* stream) {
+  if (!obsv || !h || !scene_off || !emb_w || !att_w || !S_out || S < 0 || B < 0 || To < 2) return SW_EARG;
+  if (Amax > SW_AMAX) return SW_ESHAPE;
+  if (S == 0 || B == 0) return SW_OK;
+  static bool attr = false;
+  if (!attr) {
+    if (int rc = set_lds((const void*)social_pool_fwd_kernel, SocLds::fwd_total * 4)) return rc;
+    attr = true;
+  }
+  hipLaunchKernelGGL(social_pool_fwd_kernel, dim3(S), dim3(SW_THREADS), SocLds::fwd_total * 4, (hipStream_t)stream,
+                     obsv, To, h, scene_off, emb_w, att_w, S_out, attn);
+  SW_CHECK_LAUNCH("social_pool_fwd_kernel");
+  return SW_OK;
+}
+
+extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, const int* scene_off,
+                                  const long long* pair_off, int S, int B, int Amax, long long P,
+                                  const float* emb_w, const float* att_w, const float* attn, const float* dS,
+                                  float* dh, float* d_emb_w, float* d_att_w, float* pair_ws, float* wgrad_ws,
+                                  void* stream) {
+  if (!obsv || !h || !scene_off || !pair_off || !emb_w || !att_w || !attn || !dS || !dh || !d_emb_w || !d_att_w ||
+      !pair_ws || !wgrad_ws || S < 0 || B < 0 || P < 0 || To < 2)
+    return SW_EARG;
+  if (Amax > SW_AMAX) return SW_ESHAPE;
+  if (S == 0 || B == 0) return SW_OK;
+  static bool attr = false;
+  if (!attr) {
+    if (int rc = set_lds((const void*)social_pool_bwd_kernel, SocLds::bwd_total * 4)) return rc;
+    attr = true;
+  }
+  // pair_ws: [B][64] dWh rows, then the per-pair rows
+  float* dwh_rows = pair_ws;
+  PairRows pr = pair_rows(pair_ws + (size_t)B * 64, P);
+  hipLaunchKernelGGL(social_pool_bwd_kernel, dim3(S), dim3(SW_THREADS), SocLds::bwd_total * 4, (hipStream_t)stream,
+                     obsv, To, h, scene_off, pair_off, emb_w, att_w, attn, dS, dh, dwh_rows, pr);
+  SW_CHECK_LAUNCH("social_pool_bwd_kernel");
+  WgBatch wb;
+  wg_add(wb, dwh_rows, 64, h, 64, B, 64, 64, d_att_w + swp::ATT_W, 64, d_att_w + swp::ATT_B, nullptr, 0);
+  if (P > 0) {
+    wg_add(wb, pr.dz3, 64, pr.h2, 64, (int)P, 64, 64, d_emb_w + swp::EMB_W2, 64, d_emb_w + swp::EMB_B2, nullptr, 0);
+    wg_add(wb, pr.dh2, 64, pr.h1, 32, (int)P, 64, 32, d_emb_w + swp::EMB_W1, 32, d_emb_w + swp::EMB_B1, nullptr, 0);
+    wg_add(wb, pr.dh1, 32, pr.feat, 4, (int)P, 32, 3, d_emb_w + swp::EMB_W0, 3, d_emb_w + swp::EMB_B0, nullptr, 0);
+  }
+  return wg_launch(wb, wgrad_ws, (hipStream_t)stream);
+}

@@ -1,0 +1,373 @@
+"""The reference's model surface (crowdbotp/socialways train.py) on MI355X.
+
+Same class / function names, constructor arguments, `forward` signatures and state_dict keys as
+the reference, so code written against train.py reads the same here:
+
+    get_traj_4d            train.py:130-138        SocialFeatures        train.py:229-241
+    AttentionPooling       train.py:153-175        EmbedSocialFeatures   train.py:178-189
+    EncoderLstm            train.py:245-269        DecoderFC             train.py:320-335
+    Discriminator          train.py:272-316        predict()             train.py:392-432
+
+The reference has no Generator class: `Generator` here only groups the four
+sub-modules `predict()` reads as module globals; its checkpoint still splits into the four
+reference dicts.  All compute is the HIP library (socialways_amd/_lib.py); parameters of each
+module live in ONE packed buffer (the layout the C ABI reads) and the nn.Parameters are views of
+it, so state_dict()/load_state_dict()/torch.optim work unchanged.
+
+Differentiable entry points are the two functions train() differentiates: `predict()` /
+`Generator.forward` and `Discriminator.forward`.  The stand-alone sub-module forwards
+(`EncoderLstm`, `DecoderFC`, `EmbedSocialFeatures`, `AttentionPooling`, `SocialFeatures`) run the
+same kernels for inference / inspection and do not record autograd graphs.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------------
+class _Packed(nn.Module):
+    """Parameters as views of one packed fp32 buffer (C-ABI layout) plus a packed grad buffer."""
+    _GRP = None
+
+    def _tp(self):
+        return 1
+
+    def _pack(self):
+        params = list(self.named_parameters())
+        lib = L.load()
+        tp = self._tp()
+        n = lib.sw_param_count(self._GRP, tp)
+        assert lib.sw_param_tensors(self._GRP) == len(params), (type(self).__name__, len(params))
+        dev = params[0][1].device
+        flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        gflat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._slices = []
+        for idx, (name, p) in enumerate(params):
+            off = lib.sw_param_offset(self._GRP, idx, tp)
+            k = p.numel()
+            flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + k].view(p.shape)
+            self._slices.append((off, k))
+        object.__setattr__(self, "_flat", flat)
+        object.__setattr__(self, "_gflat", gflat)
+        return self
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)      # .to()/.cuda() re-homes parameters: re-pack
+        if getattr(self, "_flat", None) is not None:
+            self._pack()
+        return out
+
+    def packed(self):
+        """The packed weight buffer the kernels read (re-packs if a parameter was re-pointed)."""
+        flat = self._flat
+        base = flat.data_ptr()
+        for (off, k), p in zip(self._slices, self.parameters()):
+            if p.data_ptr() != base + 4 * off:
+                self._pack()
+                return self._flat
+        return flat
+
+    def grad_views(self):
+        """Point every p.grad at its slice of the packed gradient buffer and return the buffer."""
+        g = self._gflat
+        for (off, k), p in zip(self._slices, self.parameters()):
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr() + 4 * off:
+                p.grad = g[off:off + k].view(p.shape)
+        return g
+
+    def split_grad(self, gflat):
+        return [gflat[off:off + k].view(p.shape) for (off, k), p in zip(self._slices, self.parameters())]
+
+
+def _scene_index(sub_batches, B, device):
+    return ops.SceneIndex.get(sub_batches if len(sub_batches) else np.zeros((0, 2), np.int64), B, device)
+
+
+# ------------------------------------------------------------------------------------------------
+def get_traj_4d(obsv_p, pred_p):
+    """(x,y) -> (x,y,vx,vy) (train.py:130-138); `pred_p=[]` returns the observation part only."""
+    L.require_gpu(obsv_p)
+    obsv_p = obsv_p.contiguous()
+    B, To = obsv_p.shape[0], obsv_p.shape[1]
+    o4 = torch.empty(B, To, 4, device=obsv_p.device)
+    if len(pred_p) == 0:
+        L.call("sw_traj_4d", L.ptr(obsv_p), None, B, To, 0, L.ptr(o4), None, L.stream())
+        return o4
+    pred_p = pred_p.contiguous()
+    Tp = pred_p.shape[1]
+    p4 = torch.empty(B, Tp, 4, device=obsv_p.device)
+    L.call("sw_traj_4d", L.ptr(obsv_p), L.ptr(pred_p), B, To, Tp, L.ptr(o4), L.ptr(p4), L.stream())
+    return o4, p4
+
+
+def SocialFeatures(x, sub_batches):
+    """Dense (B,B,3) [dist, bearing, dca] of the last observed state (train.py:229-241);
+    `sub_batches` is ignored, as in the reference."""
+    L.require_gpu(x)
+    last = x[:, -1].contiguous()
+    B = last.shape[0]
+    feat = torch.empty(B, B, 3, device=x.device)
+    L.call("sw_social_features", L.ptr(last), B, L.ptr(feat), L.stream())
+    return feat
+
+
+class AttentionPooling(_Packed):
+    _GRP = L.GRP_ATT
+
+    def __init__(self, h_dim, f_dim, device=None):
+        super().__init__()
+        if h_dim != 64 or f_dim != 64:
+            raise L.SocialWaysHipError("AttentionPooling kernels are built for h_dim = f_dim = 64")
+        self.f_dim, self.h_dim = f_dim, h_dim
+        self.W = nn.Linear(h_dim, f_dim, bias=True, device=device)
+        self._pack()
+
+    def forward(self, f, h, sub_batches):
+        """f: dense (B,B,F) pair embeddings (only in-scene blocks are read), h: (B,H).
+        sigma_ij=<f_ij, W h_j>, sigma_ii:=-1000, softmax over the scene, S_i = sum_j a_ij h_j."""
+        L.require_gpu(h)
+        B = h.shape[0]
+        sc = _scene_index(sub_batches, B, h.device)
+        S = torch.empty(B, 64, device=h.device)
+        L.call("sw_attention_pool_dense", L.ptr(f.contiguous()), L.ptr(h.contiguous()), L.ptr(sc.scene_off), sc.S, B,
+               L.ptr(self.packed()), L.ptr(S), L.stream())
+        return S
+
+
+class EmbedSocialFeatures(_Packed):
+    _GRP = L.GRP_EMB
+
+    def __init__(self, input_size, hidden_size, device=None):
+        super().__init__()
+        if input_size != 3 or hidden_size != 64:
+            raise L.SocialWaysHipError("EmbedSocialFeatures kernels are built for 3 -> 64")
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.fc = nn.Sequential(nn.Linear(input_size, 32, device=device), nn.ReLU(),
+                                nn.Linear(32, 64, device=device), nn.ReLU(),
+                                nn.Linear(64, hidden_size, device=device))
+        self._pack()
+
+    def forward(self, ftr_list, sub_batches):
+        L.require_gpu(ftr_list)
+        x = ftr_list.contiguous()
+        R = x.numel() // 3
+        out = torch.empty(*x.shape[:-1], 64, device=x.device)
+        L.call("sw_embed_features", L.ptr(x), R, L.ptr(self.packed()), L.ptr(out), L.stream())
+        return out
+
+
+class EncoderLstm(_Packed):
+    _GRP = L.GRP_ENC
+
+    def __init__(self, hidden_size, n_layers=2, device=None):
+        self.hidden_size = hidden_size
+        super().__init__()
+        if hidden_size != 64 or n_layers != 1:
+            raise L.SocialWaysHipError("EncoderLstm kernels are built for hidden_size=64, n_layers=1 "
+                                       "(train.py:77,82)")
+        self.embed = nn.Linear(4, hidden_size, device=device)
+        self.lstm = nn.LSTM(hidden_size, hidden_size, num_layers=n_layers, batch_first=True, device=device)
+        self.lstm_h = []
+        self._pack()
+
+    def init_lstm(self, h, c):
+        self.lstm_h = (h, c)
+
+    def forward(self, obsv):
+        """obsv (B,T,4) or (B,4): embed + LSTM from the stored state; returns y (B,T,H) and keeps
+        the new state in `self.lstm_h` (shape (1,B,H) each), like train.py:262-269."""
+        L.require_gpu(obsv)
+        bs = obsv.shape[0]
+        x = obsv.reshape(bs, -1, 4).contiguous()
+        T = x.shape[1]
+        h0 = self.lstm_h[0].reshape(bs, 64).contiguous()
+        c0 = self.lstm_h[1].reshape(bs, 64).contiguous()
+        hT, cT = torch.empty_like(h0), torch.empty_like(c0)
+        y = torch.empty(bs, T, 64, device=x.device)
+        L.call("sw_enc_lstm_fwd", L.ptr(x), 1, L.ptr(self.packed()), L.ptr(h0), L.ptr(c0), bs, T, L.ptr(hT), L.ptr(cT),
+               L.ptr(y), None, None, 0, L.stream())
+        self.lstm_h = (hT.view(1, bs, 64), cT.view(1, bs, 64))
+        return y
+
+
+class DecoderFC(_Packed):
+    _GRP = L.GRP_DEC
+
+    def __init__(self, hidden_dim, device=None):
+        super().__init__()
+        if hidden_dim != 160:
+            raise L.SocialWaysHipError("DecoderFC kernels are built for hidden_dim = 64+64+32 = 160")
+        self.fc1 = nn.Sequential(nn.Linear(hidden_dim, hidden_dim, device=device), nn.LeakyReLU(0.2),
+                                 nn.Linear(hidden_dim, hidden_dim // 2, device=device), nn.LeakyReLU(0.2),
+                                 nn.Linear(hidden_dim // 2, hidden_dim // 4, device=device),
+                                 nn.Linear(hidden_dim // 4, 2, device=device))
+        self._pack()
+
+    def forward(self, h, s, z, _encoder=None):
+        """cat[h,s,z] -> velocity (B,2) (train.py:330-335): one decode step of the rollout kernel."""
+        L.require_gpu(h)
+        B = h.shape[0]
+        dev = h.device
+        zero_obs = torch.zeros(B, 2, 2, device=dev)
+        c = torch.zeros(B, 64, device=dev)
+        pred4 = torch.empty(B, 1, 4, device=dev)
+        enc_w = _encoder.packed() if _encoder is not None else torch.zeros(L.load().sw_param_count(L.GRP_ENC, 1), device=dev)
+        L.call("sw_dec_rollout_fwd", L.ptr(zero_obs), 2, L.ptr(z.contiguous()), L.ptr(s.contiguous()),
+               L.ptr(h.contiguous()), L.ptr(c), L.ptr(enc_w), L.ptr(self.packed()), B, 1, L.ptr(pred4), None, None, None,
+               L.stream())
+        return pred4[:, 0, 2:4].contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+class _DiscFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, D, obsv, pred, *params):
+        labels, codes, dctx = ops.disc_forward(D.packed(), obsv, [pred], save=True)
+        ctx.D, ctx.dctx = D, dctx
+        ctx.need_pred = pred.requires_grad
+        ctx.need_w = any(p.requires_grad for p in params)
+        return labels[0], codes[0]
+
+    @staticmethod
+    def backward(ctx, dlabel, dcode):
+        D = ctx.D
+        dev = dlabel.device
+        B = ctx.dctx.B
+        dlabel = torch.zeros(B, 1, device=dev) if dlabel is None else dlabel
+        dcode = torch.zeros(B, 2, device=dev) if dcode is None else dcode
+        gflat = torch.empty_like(D._flat) if ctx.need_w else None
+        dpreds = ops.disc_backward(D.packed(), ctx.dctx, [dlabel], [dcode], gflat, [ctx.need_pred])
+        grads = D.split_grad(gflat) if ctx.need_w else [None] * len(D._slices)
+        return (None, None, dpreds[0]) + tuple(grads)
+
+
+class Discriminator(_Packed):
+    _GRP = L.GRP_DISC
+
+    def __init__(self, n_next, hidden_dim, n_latent_code, device=None):
+        super().__init__()
+        if hidden_dim != 64 or n_latent_code != 2:
+            raise L.SocialWaysHipError("Discriminator kernels are built for hidden_dim=64, n_latent_code=2")
+        self.lstm_dim = hidden_dim
+        self.n_next = n_next
+        self.obsv_encoder_lstm = nn.LSTM(4, hidden_dim, batch_first=True, device=device)
+        self.obsv_encoder_fc = nn.Sequential(nn.Linear(hidden_dim, hidden_dim // 2, device=device), nn.LeakyReLU(0.2),
+                                             nn.Linear(hidden_dim // 2, hidden_dim // 2, device=device))
+        self.pred_encoder = nn.Sequential(nn.Linear(n_next * 4, hidden_dim // 2, device=device), nn.LeakyReLU(0.2),
+                                          nn.Linear(hidden_dim // 2, hidden_dim // 2, device=device))
+        self.classifier = nn.Sequential(nn.Linear(hidden_dim, hidden_dim // 2, device=device), nn.LeakyReLU(0.2),
+                                        nn.Linear(hidden_dim // 2, 1, device=device))
+        self.latent_decoder = nn.Sequential(nn.Linear(hidden_dim, hidden_dim // 2, device=device), nn.LeakyReLU(0.2),
+                                            nn.Linear(self.lstm_dim // 2, n_latent_code, device=device))
+        self._pack()
+
+    def _tp(self):
+        return self.n_next
+
+    def forward(self, obsv, pred):
+        """obsv (B,To,4), pred (B,Tp,4) -> (label (B,1) raw LSGAN score, code_hat (B,2))."""
+        if torch.is_grad_enabled() and (pred.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return _DiscFn.apply(self, obsv, pred, *self.parameters())
+        labels, codes, _ = ops.disc_forward(self.packed(), obsv, [pred], save=False)
+        return labels[0], codes[0]
+
+    def load(self, backup):
+        """Restore nn.Linear weights/biases only; the LSTM keeps its update (train.py:311-316)."""
+        for m_from, m_to in zip(backup.modules(), self.modules()):
+            if isinstance(m_to, nn.Linear):
+                m_to.weight.data.copy_(m_from.weight.data)
+                if m_to.bias is not None:
+                    m_to.bias.data.copy_(m_from.bias.data)
+
+    def linear_mask(self):
+        """1.0 on the packed slots of nn.Linear parameters (what `load()` restores), else 0."""
+        m = torch.zeros_like(self._flat)
+        for (off, k), (name, _) in zip(self._slices, self.named_parameters()):
+            if "lstm" not in name:
+                m[off:off + k] = 1.0
+        return m
+
+
+# ------------------------------------------------------------------------------------------------
+class _PredictFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, G, obsv, noise, n_next, scenes, *params):
+        pred4, gctx = ops.gen_forward(G.encoder.packed(), G.feature_embedder.packed(), G.attention.packed(),
+                                      G.decoder.packed(), obsv, noise, scenes, n_next, G.use_social, save=True)
+        ctx.G, ctx.gctx = G, gctx
+        return pred4
+
+    @staticmethod
+    def backward(ctx, dpred4):
+        G = ctx.G
+        mods = (G.attention, G.feature_embedder, G.encoder, G.decoder)
+        gf = {m: torch.empty_like(m._flat) for m in mods}
+        ops.gen_backward(G.encoder.packed(), G.feature_embedder.packed(), G.attention.packed(), G.decoder.packed(),
+                         ctx.gctx, dpred4, gf[G.encoder], gf[G.feature_embedder], gf[G.attention], gf[G.decoder])
+        grads = []
+        for m in mods:
+            grads += m.split_grad(gf[m])
+        return (None, None, None, None, None) + tuple(grads)
+
+
+class Generator(nn.Module):
+    """encoder + feature_embedder + attention + decoder in the reference's construction order
+    (train.py:370-375: fixes the RNG -> init mapping) and `predict()` as forward."""
+
+    def __init__(self, hidden_size=64, n_lstm_layers=1, use_social=False, device=None):
+        super().__init__()
+        self.encoder = EncoderLstm(hidden_size, n_lstm_layers, device=device)
+        self.feature_embedder = EmbedSocialFeatures(3, hidden_size, device=device)
+        self.attention = AttentionPooling(hidden_size, hidden_size, device=device)
+        self.decoder = DecoderFC(hidden_size + hidden_size + hidden_size // 2, device=device)
+        self.use_social = use_social            # train.py:83 hard-codes False; the flag is explicit here
+        self.noise_len = hidden_size // 2
+
+    def predictor_params(self):
+        """Parameter order of the reference's generator optimizer (train.py:379-380)."""
+        from itertools import chain
+        return chain(self.attention.parameters(), self.feature_embedder.parameters(),
+                     self.encoder.parameters(), self.decoder.parameters())
+
+    def forward(self, obsv_p, noise, n_next, sub_batches=[]):
+        """predict(obsv_p (B,To,2), noise (B,32), n_next, sub_batches) -> pred_hat_4d (B,n_next,4)."""
+        L.require_gpu(obsv_p)
+        scenes = _scene_index(sub_batches, obsv_p.shape[0], obsv_p.device)
+        params = list(self.predictor_params())
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _PredictFn.apply(self, obsv_p, noise, n_next, scenes, *params)
+        pred4, _ = ops.gen_forward(self.encoder.packed(), self.feature_embedder.packed(), self.attention.packed(),
+                                   self.decoder.packed(), obsv_p, noise, scenes, n_next, self.use_social, save=False)
+        return pred4
+
+
+_default_generator = None
+
+
+def set_default_generator(g):
+    global _default_generator
+    _default_generator = g
+
+
+def predict(obsv_p, noise, n_next, sub_batches=[], generator=None):
+    """Module-level predict() with the reference's signature (train.py:392); the four sub-modules
+    it reads as globals in the reference are those of `generator` (or the default generator)."""
+    g = generator or _default_generator
+    if g is None:
+        raise RuntimeError("no generator: pass generator= or call set_default_generator()")
+    return g(obsv_p, noise, n_next, sub_batches)
+
+
+def predict_cv(obsv, n_next):
+    """Constant-velocity baseline of test() (utils/linear_models.py:9-20)."""
+    n_past = obsv.shape[1]
+    my_vel = (obsv[:, -1] - obsv[:, -3]) / 2. if n_past > 2 else (obsv[:, -1] - obsv[:, -2])
+    last, out = obsv[:, -1], []
+    for _ in range(n_next):                     # repeated addition, like the reference's loop
+        last = last + my_vel
+        out.append(last)
+    return torch.stack(out, dim=1)

@@ -1,0 +1,203 @@
+"""Kernel sequencing for the two differentiable functions of the reference's train():
+`predict()` (train.py:392-432) and `Discriminator.forward` (train.py:294-309).
+
+These are thin host wrappers: they own the workspaces (torch allocator), put the C-ABI calls of
+include/socialways_hip.h in order on the current stream and nothing else.  Both the autograd
+Functions of model.py and the fused training step of trainer.py go through them.
+"""
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+class SceneIndex:
+    """Device-side form of the reference's `sub_batches` ((S,2) [start,end) rows, train.py:446-461):
+    int32 prefix offsets, int64 pair offsets (n^2 per scene with n > 1), the largest scene."""
+
+    def __init__(self, sub_batches, B, device):
+        sb = np.asarray(sub_batches, dtype=np.int64).reshape(-1, 2)
+        if len(sb) == 0:                                   # predict() default: one scene (train.py:405-406)
+            sb = np.array([[0, B]], dtype=np.int64)
+        if sb[0, 0] != 0 or sb[-1, 1] != B or (sb[1:, 0] != sb[:-1, 1]).any():
+            raise ValueError("sub_batches must tile [0, B) contiguously")
+        n = sb[:, 1] - sb[:, 0]
+        if (n <= 0).any():
+            raise ValueError("empty scene in sub_batches")
+        self.S = len(sb)
+        self.B = int(B)
+        self.amax = int(n.max())
+        pairs = np.where(n > 1, n * n, 0)
+        poff = np.concatenate([[0], np.cumsum(pairs)]).astype(np.int64)
+        self.P = int(poff[-1])
+        off = np.concatenate([sb[:, 0], [B]]).astype(np.int32)
+        self.scene_off = torch.from_numpy(off).to(device)
+        self.pair_off = torch.from_numpy(poff).to(device)
+        self.sizes = n
+
+    _cache = {}
+
+    @classmethod
+    def get(cls, sub_batches, B, device):
+        sb = np.ascontiguousarray(np.asarray(sub_batches, dtype=np.int64))
+        key = (sb.tobytes(), int(B), str(device))
+        hit = cls._cache.get(key)
+        if hit is None:
+            if len(cls._cache) > 4096:
+                cls._cache.clear()
+            hit = cls._cache[key] = cls(sb, B, device)
+        return hit
+
+
+class Workspaces:
+    """Grow-only fp32 scratch buffers keyed by name (saves, deltas, split-K partials)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = {}
+
+    def get(self, name, nfloats):
+        t = self.buf.get(name)
+        if t is None or t.numel() < nfloats:
+            t = self.buf[name] = torch.empty(max(int(nfloats), 1), dtype=torch.float32, device=self.device)
+        return t
+
+
+_default_ws = {}
+
+
+def default_ws(device):
+    key = str(device)
+    if key not in _default_ws:
+        _default_ws[key] = Workspaces(device)
+    return _default_ws[key]
+
+
+class GenCtx:
+    __slots__ = ("obsv", "noise", "scenes", "hT", "cT", "S", "attn", "gsave", "B", "To", "Tp", "use_social")
+
+
+def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_social, save, ws=None, tag="g"):
+    """predict(): encode obs (train.py:397-404), social pooling (408-413), decode loop (415-432).
+    Returns pred_hat_4d (B, n_next, 4) and, if `save`, the context backward needs."""
+    L.require_gpu(obsv)
+    obsv = obsv.contiguous()
+    noise = noise.contiguous()
+    B, To = obsv.shape[0], obsv.shape[1]
+    if noise.shape != (B, 32):
+        raise ValueError("noise must be (B, 32)")
+    dev = obsv.device
+    st = L.stream()
+    hT = torch.empty(B, 64, device=dev)
+    cT = torch.empty(B, 64, device=dev)
+    pred4 = torch.empty(B, n_next, 4, device=dev)
+    gsave = None
+    if save:   # ws=None (autograd path): a private save buffer per call, several may be alive
+        nfl = L.workspace_floats(L.WS_GSAVE, B, To, n_next)
+        gsave = ws.get(tag + ".gsave", nfl) if ws is not None else torch.empty(nfl, device=dev)
+    # act rows live at offset 0 of gsave, x4s right behind (sw_common.h:gsave_layout)
+    x4s_off = (To + n_next - 1) * B * 384
+    L.call("sw_enc_lstm_fwd", L.ptr(obsv), 0, L.ptr(enc_w), None, None, B, To, L.ptr(hT), L.ptr(cT), None,
+           L.ptr(gsave), (gsave.data_ptr() + 4 * x4s_off) if save else None, 0, st)
+    attn = None
+    if use_social:
+        if scenes.amax > L.AMAX:
+            raise L.SocialWaysHipError("scene with %d agents > %d supported per scene" % (scenes.amax, L.AMAX))
+        S = torch.empty(B, 64, device=dev)
+        attn = torch.empty(B, L.AMAX, device=dev) if save else None
+        L.call("sw_social_pool_fwd", L.ptr(obsv), To, L.ptr(hT), L.ptr(scenes.scene_off), scenes.S, B, scenes.amax,
+               L.ptr(emb_w), L.ptr(att_w), L.ptr(S), L.ptr(attn), st)
+    else:
+        S = torch.zeros(B, 64, device=dev)                                   # train.py:413
+    L.call("sw_dec_rollout_fwd", L.ptr(obsv), To, L.ptr(noise), L.ptr(S), L.ptr(hT), L.ptr(cT), L.ptr(enc_w),
+           L.ptr(dec_w), B, n_next, L.ptr(pred4), None, None, L.ptr(gsave), st)
+    if not save:
+        return pred4, None
+    ctx = GenCtx()
+    ctx.obsv, ctx.noise, ctx.scenes, ctx.hT, ctx.cT, ctx.S, ctx.attn = obsv, noise, scenes, hT, cT, S, attn
+    ctx.gsave, ctx.B, ctx.To, ctx.Tp, ctx.use_social = gsave, B, To, n_next, use_social
+    return pred4, ctx
+
+
+def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d_dec, ws=None, tag="g"):
+    """Backward of predict(): decode BPTT -> social block -> obs BPTT -> deferred weight GEMMs.
+    d_* are the packed gradient buffers (overwritten)."""
+    dev = dpred4.device
+    ws = ws or default_ws(dev)
+    st = L.stream()
+    B, To, Tp = ctx.B, ctx.To, ctx.Tp
+    dpred4 = dpred4.contiguous()
+    gdelta = ws.get(tag + ".gdelta", L.workspace_floats(L.WS_GDELTA, B, To, Tp))
+    wgrad = ws.get("wgrad", L.workspace_floats(L.WS_WGRAD, B, To, Tp))
+    dhT = torch.empty(B, 64, device=dev)
+    dcT = torch.empty(B, 64, device=dev)
+    dS = torch.empty(B, 64, device=dev)
+    L.call("sw_dec_rollout_bwd", L.ptr(dpred4), L.ptr(enc_w), L.ptr(dec_w), L.ptr(ctx.gsave), B, To, Tp,
+           L.ptr(gdelta), L.ptr(dhT), L.ptr(dcT), L.ptr(dS), st)
+    if ctx.use_social and ctx.scenes.P > 0:
+        sc = ctx.scenes
+        pws = ws.get("pairs", L.workspace_floats(L.WS_PAIRS, B, To, Tp, 1, sc.P))
+        L.call("sw_social_pool_bwd", L.ptr(ctx.obsv), To, L.ptr(ctx.hT), L.ptr(sc.scene_off), L.ptr(sc.pair_off), sc.S,
+               B, sc.amax, sc.P, L.ptr(emb_w), L.ptr(att_w), L.ptr(ctx.attn), L.ptr(dS), L.ptr(dhT), L.ptr(d_emb),
+               L.ptr(d_att), L.ptr(pws), L.ptr(wgrad), st)
+    else:
+        d_emb.zero_()
+        d_att.zero_()
+    L.call("sw_enc_lstm_bwd", L.ptr(enc_w), L.ptr(ctx.gsave), None, L.ptr(dhT), L.ptr(dcT), None, B, To, 0,
+           L.ptr(gdelta), None, None, st)
+    L.call("sw_gen_wgrad", L.ptr(enc_w), L.ptr(ctx.gsave), L.ptr(gdelta), L.ptr(ctx.noise), L.ptr(ctx.S), B, To, Tp,
+           L.ptr(d_enc), L.ptr(d_dec), L.ptr(wgrad), st)
+
+
+class DiscCtx:
+    __slots__ = ("dsave", "B", "To", "Tp", "nb")
+
+
+def disc_forward(d_w, obsv, preds, save, ws=None, tag="d"):
+    """Discriminator.forward for 1 or 2 future branches sharing the observation encoding.
+    Returns ([label_k (B,1)], [code_k (B,2)], ctx)."""
+    L.require_gpu(obsv)
+    obsv = obsv.contiguous()
+    preds = [p.contiguous() for p in preds]
+    B, To = obsv.shape[0], obsv.shape[1]
+    x_mode = {2: 0, 4: 1}[obsv.shape[2]]        # positions (B,To,2) or obsv_4d (B,To,4)
+    Tp = preds[0].shape[1]
+    nb = len(preds)
+    dev = obsv.device
+    labels = [torch.empty(B, 1, device=dev) for _ in preds]
+    codes = [torch.empty(B, 2, device=dev) for _ in preds]
+    dsave = None
+    if save:
+        nfl = L.workspace_floats(L.WS_DSAVE, B, To, Tp, nb)
+        dsave = ws.get(tag + ".dsave", nfl) if ws is not None else torch.empty(nfl, device=dev)
+    pp, _k1 = L.ptr_array(preds)
+    lp, _k2 = L.ptr_array(labels)
+    cp, _k3 = L.ptr_array(codes)
+    L.call("sw_disc_fwd", L.ptr(obsv), To, x_mode, pp, nb, L.ptr(d_w), B, Tp, lp, cp, L.ptr(dsave), L.stream())
+    if not save:
+        return labels, codes, None
+    ctx = DiscCtx()
+    ctx.dsave, ctx.B, ctx.To, ctx.Tp, ctx.nb = dsave, B, To, Tp, nb
+    return labels, codes, ctx
+
+
+def disc_backward(d_w, ctx, dlabels, dcodes, d_d_w=None, want_dpred=(), ws=None, tag="d"):
+    """Backward of Discriminator.forward.  d_d_w (packed, overwritten) None = no weight gradients;
+    want_dpred[k] True = return d loss / d pred4 of branch k."""
+    dev = dlabels[0].device
+    ws = ws or default_ws(dev)
+    B, To, Tp, nb = ctx.B, ctx.To, ctx.Tp, ctx.nb
+    dlabels = [t.contiguous() for t in dlabels]
+    dcodes = [t.contiguous() for t in dcodes]
+    want = list(want_dpred) + [False] * (nb - len(want_dpred))
+    dpreds = [torch.empty(B, Tp, 4, device=dev) if w else None for w in want]
+    ddelta = wgrad = None
+    if d_d_w is not None:
+        ddelta = ws.get(tag + ".ddelta", L.workspace_floats(L.WS_DDELTA, B, To, Tp, nb))
+        wgrad = ws.get("wgrad", L.workspace_floats(L.WS_WGRAD, B, To, Tp))
+    lp, _k1 = L.ptr_array(dlabels)
+    cp, _k2 = L.ptr_array(dcodes)
+    dp, _k3 = L.ptr_array(dpreds)
+    L.call("sw_disc_bwd", L.ptr(d_w), L.ptr(ctx.dsave), lp, cp, nb, B, To, Tp, L.ptr(ddelta), L.ptr(d_d_w), dp,
+           L.ptr(wgrad), L.stream())
+    return dpreds

@@ -1,0 +1,151 @@
+"""GPU parity of every HIP kernel family against the golden vectors of the reference and against
+the CPU oracle, through the C ABI (socialways_amd/_lib.py).  fp32; tolerances are stated per check:
+the kernels use v_mfma_f32_16x16x4_f32 (an exact fp32 fmaf chain), so differences to MKL are
+summation-order only."""
+import numpy as np
+import pytest
+import torch
+
+import sw_oracle as O
+from _util import golden, state_from, as_checkpoint, dataset_from, assert_close
+
+pytestmark = pytest.mark.gpu
+RT, AT = 2e-5, 2e-6
+
+
+def _models(g, n_next, use_social):
+    import socialways_amd as sw
+    dev = torch.device("cuda:0")
+    G = sw.Generator(use_social=use_social, device=dev)
+    D = sw.Discriminator(n_next, 64, 2, device=dev)
+    st = state_from(g, "w0.")
+    G.attention.load_state_dict(st["attention"])
+    G.feature_embedder.load_state_dict(st["feature_embedder"])
+    G.encoder.load_state_dict(st["encoder"])
+    G.decoder.load_state_dict(st["decoder"])
+    D.load_state_dict(st["D"])
+    return G, D, dev
+
+
+def _step_inputs(g):
+    ds = dataset_from(g)
+    data = O.load_and_normalise(ds["obsvs"], ds["preds"], ds["batches"])
+    B = int(g["step_agents"][0])
+    sb = data["the_batches"][:data["train_size"]]
+    return data, data["obsv"][:B], data["pred"][:B], sb, torch.from_numpy(g["noise.0"])
+
+
+def cmp_grads(got, g, prefix, rtol, atol_rel):
+    for k, v in got.items():
+        ref = g[prefix + k]
+        assert_close(v.detach().cpu().numpy(), ref, rtol, atol_rel * max(np.abs(ref).max(), 1e-12), prefix + k)
+
+
+@pytest.mark.parametrize("case", ["syn_s16a8_off", "syn_s16a8_on", "syn_ragged_on"])
+def test_predict_forward(case):
+    g = golden(case)
+    G, D, dev = _models(g, 12, bool(g["use_social"]))
+    data, obsv, pred, sb, noise = _step_inputs(g)
+    with torch.no_grad():
+        out = G(obsv.to(dev), noise.to(dev), 12, sb)
+    assert_close(out.cpu(), g["pred_hat_4d"], RT, AT, "pred_hat_4d")
+
+
+@pytest.mark.parametrize("case", ["syn_s16a8_on", "syn_ragged_on"])
+def test_disc_forward(case):
+    import socialways_amd as sw
+    g = golden(case)
+    G, D, dev = _models(g, 12, True)
+    data, obsv, pred, sb, noise = _step_inputs(g)
+    o4, p4 = sw.get_traj_4d(obsv.to(dev), pred.to(dev))
+    assert_close(o4.cpu(), g["obsv_4d"], 0, 1e-7, "obsv_4d")
+    assert_close(p4.cpu(), g["pred_4d"], 0, 1e-7, "pred_4d")
+    with torch.no_grad():
+        lab_r, code_r = D(o4, p4)
+        lab_f, code_f = D(o4, torch.from_numpy(g["pred_hat_4d"]).to(dev))
+    assert_close(lab_r.cpu(), g["d0_real.label"], RT, AT, "real label")
+    assert_close(code_r.cpu(), g["d0_real.code"], RT, AT, "real code")
+    assert_close(lab_f.cpu(), g["d0_fake.label"], RT, AT, "fake label")
+    assert_close(code_f.cpu(), g["d0_fake.code"], RT, AT, "fake code")
+
+
+@pytest.mark.parametrize("case", ["syn_s16a8_off", "syn_s16a8_on", "syn_ragged_on"])
+def test_predict_backward(case):
+    """dL/dpred_hat of the reference's G phase pushed through the HIP backward: every generator
+    gradient must match the reference's autograd."""
+    g = golden(case)
+    G, D, dev = _models(g, 12, bool(g["use_social"]))
+    data, obsv, pred, sb, noise = _step_inputs(g)
+    out = G(obsv.to(dev), noise.to(dev), 12, sb)
+    out.backward(torch.from_numpy(g["dpred_hat_4d"]).to(dev))
+    got = {}
+    for name, mod in (("attention", G.attention), ("feature_embedder", G.feature_embedder),
+                      ("encoder", G.encoder), ("decoder", G.decoder)):
+        for k, p in mod.named_parameters():
+            got[name + "." + k] = p.grad
+    cmp_grads(got, g, "ggrad.", 2e-4, 2e-5)
+
+
+@pytest.mark.parametrize("case", ["syn_s16a8_on", "syn_ragged_on"])
+def test_disc_backward_first_update(case):
+    """D update u=0 of train.py:476-496 through autograd on the HIP Function: d_loss = fake + real +
+    0.5 info; gradients vs the reference's."""
+    import socialways_amd as sw
+    g = golden(case)
+    G, D, dev = _models(g, 12, True)
+    data, obsv, pred, sb, noise = _step_inputs(g)
+    o4, p4 = sw.get_traj_4d(obsv.to(dev), pred.to(dev))
+    B = obsv.shape[0]
+    zeros = torch.zeros(B, 1, device=dev) + float(g["uniform"][0, 0])
+    ones = torch.ones(B, 1, device=dev) * float(g["uniform"][0, 1])
+    z = noise.to(dev)
+    mse = torch.nn.MSELoss()
+    fake, code = D(o4, torch.from_numpy(g["pred_hat_4d"]).to(dev))
+    l_fake, l_info = mse(fake, zeros), mse(code.squeeze(), z[:, :2])
+    real, _ = D(o4, p4)
+    l_real = mse(real, ones)
+    assert_close([l_fake.item(), l_info.item(), l_real.item()], g["losses"][0][:3], 2e-5, 1e-6, "d losses")
+    (l_fake + l_real + 0.5 * l_info).backward()
+    cmp_grads({k: p.grad for k, p in D.named_parameters()}, g, "dgrad0.", 1e-4, 1e-5)
+
+
+def test_module_level_api_matches_reference_ops():
+    """SocialFeatures / EmbedSocialFeatures / AttentionPooling / EncoderLstm / DecoderFC called one by
+    one (the dense, small-batch module API of train.py) against the social_ops golden case."""
+    import socialways_amd as sw
+    g = golden("social_ops")
+    dev = torch.device("cuda:0")
+    st = state_from(g, "w0.")
+    fe = sw.EmbedSocialFeatures(3, 64, device=dev)
+    att = sw.AttentionPooling(64, 64, device=dev)
+    fe.load_state_dict(st["feature_embedder"])
+    att.load_state_dict(st["attention"])
+    obsv, h, sb = torch.from_numpy(g["obsv"]).to(dev), torch.from_numpy(g["h"]).to(dev), g["batches"]
+    x4 = sw.get_traj_4d(obsv, [])
+    feats = sw.SocialFeatures(x4, sb)
+    assert_close(feats.cpu(), g["features"], 1e-5, 1e-6, "dense features")
+    emb = fe(feats, sb)
+    for s, (a, b) in enumerate(sb):
+        assert_close(emb[a:b, a:b].cpu(), g["emb.%d" % s], 1e-5, 2e-6, "emb block %d" % s)
+    assert_close(att(emb, h, sb).cpu(), g["S"], 1e-5, 2e-6, "S")
+    # EncoderLstm stand-alone vs the oracle module, sequence then single step, state carried
+    enc = sw.EncoderLstm(64, 1, device=dev)
+    enc.load_state_dict(st["encoder"])
+    oenc = O.EncoderLstm(64, 1)
+    oenc.load_state_dict(st["encoder"])
+    B = obsv.shape[0]
+    enc.init_lstm(torch.zeros(1, B, 64, device=dev), torch.zeros(1, B, 64, device=dev))
+    oenc.init_lstm(torch.zeros(1, B, 64), torch.zeros(1, B, 64))
+    with torch.no_grad():
+        y, yo = enc(x4), oenc(x4.cpu())
+        assert_close(y.cpu(), yo, RT, AT, "encoder y (sequence)")
+        y1, yo1 = enc(x4[:, -1]), oenc(x4[:, -1].cpu())
+        assert_close(y1.cpu(), yo1, RT, AT, "encoder y (single step)")
+        assert_close(enc.lstm_h[1].cpu(), oenc.lstm_h[1], RT, AT, "encoder c")
+        dec = sw.DecoderFC(160, device=dev)
+        dec.load_state_dict(st["decoder"])
+        odec = O.DecoderFC(160)
+        odec.load_state_dict(st["decoder"])
+        torch.manual_seed(5)
+        s_, z_ = torch.randn(B, 64), torch.rand(B, 32)
+        assert_close(dec(h, s_.to(dev), z_.to(dev)).cpu(), odec(h.cpu(), s_, z_), RT, AT, "decoder")
