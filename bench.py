@@ -1,0 +1,174 @@
+"""bench.py - GAN train steps/s of the Social Ways inner loop on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload m1|c2|c4] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = the body of the reference's train() for one packed batch (train.py:458-554): generator
+rollout with the pairwise social block, 2 discriminator updates, 1 generator update (LSGAN + InfoGAN
+losses, n_unrolling_steps=1, use_social=True), the three Adam steps, D.load(backup) and the ADE/FDE
+sums, on synthetic tracks already resident in HBM (label noise and z are drawn on the host and
+copied each step, as the reference does).  Workload m1 (default, the metric's shape): 256 scenes x 8
+agents x (8 obs + 12 pred) = 2048 agents per step per GPU.  N > 1: one process per GPU, every rank
+trains on its own 256-scene shard of a 256*N-scene global batch, gradients all-reduced with RCCL
+three times per step (weak scaling); `value` counts 256-scene batches processed per second by the
+whole job.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {   # name -> (scenes per GPU step, agents per scene, To, Tp)
+    "m1": (256, 8, 8, 12),     # BASELINE metric shape: --batch-size 2048
+    "c2": (32, 8, 8, 12),      # BASELINE config 2: --batch-size 256
+    "c4": (512, 64, 8, 12),    # dense crowd: 32768 agents, 2.1M pairs
+}
+PEAK_FP32_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / VALU fp32 peak
+N_BATCHES = 8                  # distinct packed batches cycled through
+
+
+def alg_flops(B, P, To, Tp):
+    """Algorithmic work of SURVEY.md §8d (MAC = 2 FLOP, backward = 2 x forward)."""
+    G = B * ((To + Tp) * (256 + 32768) + Tp * 41680) + B * 4096 + P * 6368
+    Dd = B * (To * 17408 + 2048 + 1024 + 4 * Tp * 32 + 1024 + 4096 + 32 + 64)
+    return dict(step=2.0 * (3 * G + 15 * Dd),
+                # data-gradient pass of the decode loop: dX = W^T dY has the MAC count of the forward
+                sw_dec_rollout_bwd=2.0 * B * (Tp * 41680 + (Tp - 1) * 33024),
+                sw_dec_rollout_fwd=2.0 * B * (Tp * 41680 + (Tp - 1) * 33024),
+                sw_enc_lstm_fwd=2.0 * B * To * 33024,
+                sw_gen_wgrad=2.0 * B * ((To + Tp - 1) * 33024 + Tp * 41680))
+
+
+def cpu_baseline(tracks, S, A, To, Tp, budget_s=12.0):
+    """The CPU oracle (oracle/sw_oracle.py, block-diagonal social block, the reference's own call
+    structure incl. its three predict() calls) timed on this host's cores on the same batch shape."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import sw_oracle as O
+    torch.manual_seed(0)
+    data = O.load_and_normalise(tracks["obsvs"], tracks["preds"], tracks["batches"])
+    orc = O.SocialWaysOracle(Tp, use_social=True, social="blockdiag")
+    B = S * A
+    sb = data["the_batches"][:S]
+    obsv, pred = data["obsv"][:B], data["pred"][:B]
+    noise = torch.rand(B, 32)
+    orc.train_step(obsv, pred, sb, 0.05, 0.95, noise, data["ss"])       # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.train_step(obsv, pred, sb, 0.05, 0.95, noise, data["ss"])
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 50:
+            break
+    return {"value": n / dt, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d steps of one %dx%d-agent packed batch (To=%d, Tp=%d), torch CPU fp32, "
+                      "block-diagonal social block, reference call structure" % (n, S, A, To, Tp)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="m1", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dominant", default="sw_dec_rollout_bwd", help="C-ABI call timed with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                         % (args.gpus, args.gpus))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+        pg = torch.distributed.group.WORLD
+
+    import socialways_amd as sw
+    from socialways_amd import _lib as L
+    S, A, To, Tp = WORKLOADS[args.workload]
+    B = S * A
+    P = S * A * A if A > 1 else 0
+    torch.manual_seed(0)                      # identical replicas on every rank
+    np.random.seed(0)
+    tr = sw.SocialWaysTrainer(Tp, use_social=True, device=dev, process_group=pg)
+    tracks = sw.synth_tracks(S * N_BATCHES, A, To, Tp, seed=1234 + rank)
+    data = sw.SceneDataset(tracks["obsvs"], tracks["preds"], tracks["batches"], device=dev)
+    sb = np.stack([np.arange(S) * A, (np.arange(S) + 1) * A], axis=1).astype(np.int64)
+    Bg = B * world
+    out = torch.zeros(tr.n_unrolling_steps + 3, 3, device=dev)
+
+    def one_step(i):
+        a = (i % N_BATCHES) * B
+        zv = np.random.uniform(0, 0.1)                         # train.py:471-473, same host RNG use
+        ov = np.random.uniform(0.9, 1.0)
+        noise = torch.rand(B, tr.noise_len).to(dev, non_blocking=True)
+        tr.step(data.obsv[a:a + B], data.pred[a:a + B], sb, zv, ov, noise, data.ss, global_B=Bg, out=out)
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    fence()
+    L.TIMING = {"names": {args.dominant}, "events": []}
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    timing, L.TIMING = L.TIMING, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out).all(), "non-finite losses"
+
+    if rank == 0:
+        fl = alg_flops(B, P, To, Tp)
+        kern_ms = [e0.elapsed_time(e1) for _, e0, e1 in timing["events"]]
+        kern_s = float(np.mean(kern_ms)) * 1e-3 if kern_ms else float("nan")
+        achieved = fl.get(args.dominant, float("nan")) / kern_s / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_%s.json" % args.workload)
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get(args.dominant, {}).get("hbm_bytes_per_launch")
+        res = {
+            "metric": "GAN train steps/sec (256 scenes x 8 agents x 8+12 T per GPU step; fp32; social block on)",
+            "value": args.steps * world / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d scenes x %d agents x (%d obs + %d pred) per GPU step = reference "
+                                   "--batch-size %d; use_social=True, n_unrolling_steps=1, info loss on"
+                                   % (args.workload, S, A, To, Tp, B),
+                       "global_batch_scenes": S * world, "parallelism": "dp%d" % world,
+                       "step_alg_gflop": fl["step"] / 1e9,
+                       "step_frac_of_fp32_peak": fl["step"] / (dt / args.steps) / (PEAK_FP32_TFLOPS * 1e12)},
+            "roofline": {"bound": "mfma", "kernel": args.dominant.replace("sw_", "") + "_kernel", "achieved": achieved,
+                         "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
+                         "avg_launch_ms": kern_s * 1e3, "launches": len(kern_ms), "traffic": traffic},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(tracks, S if args.workload != "c4" else 16, A, To, Tp)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -81,9 +81,20 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+TIMING = None   # bench.py: {"names": {abi_call,...}, "events": [(name, start, end)]} -> HIP events around calls
+
+
 def call(name, *args):
     lib = load()
-    rc = getattr(lib, name)(*args)
+    t = TIMING
+    if t is not None and name in t["names"]:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()                      # on the current stream = the stream the kernel is launched on
+        rc = getattr(lib, name)(*args)
+        e1.record()
+        t["events"].append((name, e0, e1))
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = {-1: "bad argument", -2: "unsupported shape", -3: "HIP error: " + lib.sw_last_error().decode()}.get(rc, "?")
         raise SocialWaysHipError("%s failed (%d): %s" % (name, rc, msg))

@@ -1,0 +1,158 @@
+"""Host-side data glue of the training loop (reference train.py:86-124, 446-461 and the dataset
+schema of create_toy.py:187 / create_dataset.py:14): npz {obsvs (N,To,2), preds (N,Tp,2), times (N,),
+batches (S,2)} -> normalised device tensors + scene ranges, the greedy scene packing of train(),
+and synthetic generators for the benchmark shapes (no dataset ships with the reference).
+"""
+import numpy as np
+import torch
+
+
+class Scale(object):
+    """Min-max, keep-ratio normalisation (utils/parse_utils.py:11-76)."""
+
+    def __init__(self):
+        self.min_x, self.max_x = +np.inf, -np.inf
+        self.min_y, self.max_y = +np.inf, -np.inf
+        self.sx, self.sy = 1, 1
+
+    def calc_scale(self, keep_ratio=True):
+        self.sx = 1 / (self.max_x - self.min_x)
+        self.sy = 1 / (self.max_y - self.min_y)
+        if keep_ratio:
+            self.sx = self.sy = min(self.sx, self.sy)
+
+    def normalize(self, data, shift=True, inPlace=True):
+        out = data if inPlace else np.copy(data)
+        out[..., 0] = (data[..., 0] - self.min_x * shift) * self.sx
+        out[..., 1] = (data[..., 1] - self.min_y * shift) * self.sy
+        return out
+
+    def denormalize(self, data, shift=True, inPlace=False):
+        out = data if inPlace else np.copy(data)
+        out[..., 0] = data[..., 0] / self.sx + self.min_x * shift
+        out[..., 1] = data[..., 1] / self.sy + self.min_y * shift
+        return out
+
+
+class SceneDataset:
+    """train.py:89-124: 4/5 of the scenes train, the rest test; float32 keep-ratio normalisation;
+    tracks resident on the device for the whole run.  `batches` may be int16 on disk
+    (utils/parse_utils.py:490 overflows above 32767 rows): widened to int64 here."""
+
+    def __init__(self, obsvs, preds, batches, times=None, device="cuda"):
+        obsvs = np.array(obsvs, dtype=np.float32, copy=True)
+        preds = np.array(preds, dtype=np.float32, copy=True)
+        self.the_batches = np.asarray(batches).astype(np.int64)
+        self.times = None if times is None else np.asarray(times)
+        self.train_size = max(1, (len(self.the_batches) * 4) // 5)
+        self.n_past, self.n_next = obsvs.shape[1], preds.shape[1]
+        self.n_train_samples = int(self.the_batches[self.train_size - 1][1])
+        self.n_test_samples = obsvs.shape[0] - self.n_train_samples
+        if self.n_test_samples == 0:                                         # train.py:107-109
+            self.n_test_samples = 1
+            self.the_batches = np.array([self.the_batches[0], self.the_batches[0]])
+        sc = Scale()
+        sc.max_x = max(np.max(obsvs[:, :, 0]), np.max(preds[:, :, 0]))
+        sc.min_x = min(np.min(obsvs[:, :, 0]), np.min(preds[:, :, 0]))
+        sc.max_y = max(np.max(obsvs[:, :, 1]), np.max(preds[:, :, 1]))
+        sc.min_y = min(np.min(obsvs[:, :, 1]), np.min(preds[:, :, 1]))
+        sc.calc_scale(keep_ratio=True)
+        self.scale, self.ss = sc, sc.sx
+        self.obsv = torch.from_numpy(sc.normalize(obsvs)).to(device)
+        self.pred = torch.from_numpy(sc.normalize(preds)).to(device)
+
+    @classmethod
+    def from_npz(cls, path, device="cuda"):
+        d = np.load(path)
+        return cls(d["obsvs"], d["preds"], d["batches"], d["times"] if "times" in d.files else None, device)
+
+    @property
+    def train_batches(self):
+        return self.the_batches[:self.train_size]
+
+    @property
+    def test_batches(self):
+        return self.the_batches[self.train_size:]
+
+    def packed_steps(self, batch_size):
+        """Greedy scene packing of train() (train.py:446-456): scenes are appended until the next one
+        would exceed `batch_size` AGENTS.  Yields (row_start, row_end, sub_batches)
+        with sub_batches already relative to row_start (train.py:461)."""
+        tb, allb = self.train_batches, self.the_batches
+        acc, subs = 0, []
+        for ii, b in enumerate(tb):
+            acc += int(b[1] - b[0])
+            subs.append(b)
+            if ii >= self.train_size - 1 or acc + int(allb[ii + 1][1] - allb[ii + 1][0]) > batch_size:
+                a = int(subs[0][0])
+                yield a, int(subs[-1][1]), np.asarray(subs, dtype=np.int64) - a
+                acc, subs = 0, []
+
+
+def synth_tracks(n_scenes, agents, n_past=8, n_next=12, seed=1234):
+    """Synthetic crowd of SURVEY §8d: p0~U[0,10)^2, v = N(0,0.3^2) (per agent) + cumsum_t N(0,0.05^2),
+    track = p0 + cumsum_t v, float32, scenes contiguous.  `agents`: int or per-scene list."""
+    rng = np.random.default_rng(seed)
+    sizes = [int(agents)] * n_scenes if np.isscalar(agents) else [int(a) for a in agents]
+    N, T = int(np.sum(sizes)), n_past + n_next
+    p0 = rng.uniform(0, 10, size=(N, 1, 2))
+    v = rng.normal(0, 0.3, size=(N, 1, 2)) + np.cumsum(rng.normal(0, 0.05, size=(N, T, 2)), axis=1)
+    track = (p0 + np.cumsum(v, axis=1)).astype(np.float32)
+    ends = np.cumsum(sizes)
+    batches = np.stack([ends - np.asarray(sizes), ends], axis=1).astype(np.int64)
+    times = np.repeat(np.arange(len(sizes)), sizes).astype(np.int32)
+    return dict(obsvs=track[:, :n_past], preds=track[:, n_past:], times=times, batches=batches)
+
+
+def toy_tracks(n_samples=768, n_conditions=8, n_modes=3, n_per_batch=6, seed=30):
+    """The toy multi-modal set of create_toy.py:11-54 + its npz packing (:162-187): 4-point tracks
+    (2 observed + 2 to predict) approaching the origin from `n_conditions` directions and turning
+    by one of `n_modes` angles.  Draw order per sample: one uniform for the 3rd point, one for the
+    4th, numpy legacy seed 30 (create_toy.py:37-48,145)."""
+    rs = np.random.RandomState(seed)
+    samples, stamps = np.zeros((n_samples, 4, 2)), np.zeros(n_samples)
+    for ii in range(n_samples):
+        way = (ii * n_conditions) // n_samples
+        w_i = way % (n_conditions / n_per_batch)
+        t0 = ii % (n_samples // n_conditions) + w_i * (n_samples // n_conditions)
+        ang = way * (2.0 * np.pi / n_conditions)
+        turn = ((ii % n_modes) - n_modes // 2) * 16 * np.pi / 180
+        r2 = (rs.rand() - 0.5) * 4 * np.pi / 180
+        r3 = (rs.rand() - 0.5) * 6 * np.pi / 180
+        samples[ii] = [[np.cos(ang) * 4, np.sin(ang) * 4], [np.cos(ang) * 3, np.sin(ang) * 3],
+                       [np.cos(ang + turn + r2) * 2, np.sin(ang + turn + r2) * 2],
+                       [np.cos(ang + turn + r2 + r3), np.sin(ang + turn + r2 + r3)]]
+        stamps[ii] = t0 * 4
+    samples = samples / 4
+    groups = {}
+    for ii in range(n_samples):                                              # scene = identical first timestamp
+        groups.setdefault(stamps[ii], []).append(ii)
+    obsvs, preds, times, batches = [], [], [], []
+    for key, idx in groups.items():
+        batches.append([len(obsvs), len(obsvs) + len(idx)])
+        for k in idx:
+            obsvs.append(samples[k][:2])
+            preds.append(samples[k][2:])
+            times.append(stamps[k])
+    return dict(obsvs=np.array(obsvs).astype(np.float32), preds=np.array(preds).astype(np.float32),
+                times=np.array(times).astype(np.int32), batches=np.array(batches))
+
+
+def shard_scenes(sub_batches, world_size):
+    """Contiguous, scene-aligned split of one packed batch over `world_size` ranks (never splits a
+    scene), balanced by a per-scene cost of agents + pairs/8 (the social block is O(n^2), the LSTM
+    / decoder O(n)).  Returns [(scene_lo, scene_hi)] per rank; trailing ranks may get (k,k)."""
+    sb = np.asarray(sub_batches, dtype=np.int64).reshape(-1, 2)
+    n = sb[:, 1] - sb[:, 0]
+    cost = n + (n * n) / 8.0
+    csum = np.concatenate([[0.0], np.cumsum(cost)])
+    total = csum[-1]
+    cuts = [0]
+    for r in range(1, world_size):
+        target = total * r / world_size
+        k = int(np.searchsorted(csum, target, side="left"))
+        if k > 0 and abs(csum[k - 1] - target) <= abs(csum[min(k, len(csum) - 1)] - target):
+            k -= 1
+        cuts.append(min(max(k, cuts[-1]), len(sb)))
+    cuts.append(len(sb))
+    return [(cuts[r], cuts[r + 1]) for r in range(world_size)]

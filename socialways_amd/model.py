@@ -35,15 +35,25 @@ class _Packed(nn.Module):
     def _tp(self):
         return 1
 
-    def _pack(self):
+    def _move(self, device):
+        """Parameters are initialised on the CPU generator exactly like the reference (which builds
+        on the CPU and then calls .cuda(), train.py:370-384) and moved afterwards."""
+        if device is not None and torch.device(device).type != "cpu":
+            self.to(device)
+
+    def _pack(self, into=None):
         params = list(self.named_parameters())
         lib = L.load()
         tp = self._tp()
         n = lib.sw_param_count(self._GRP, tp)
         assert lib.sw_param_tensors(self._GRP) == len(params), (type(self).__name__, len(params))
         dev = params[0][1].device
-        flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        gflat = torch.zeros(n, dtype=torch.float32, device=dev)
+        if into is not None:                   # slices of a buffer shared with sibling modules
+            flat, gflat = into
+            assert flat.numel() == n and gflat.numel() == n
+        else:
+            flat = torch.zeros(n, dtype=torch.float32, device=dev)
+            gflat = torch.zeros(n, dtype=torch.float32, device=dev)
         self._slices = []
         for idx, (name, p) in enumerate(params):
             off = lib.sw_param_offset(self._GRP, idx, tp)
@@ -123,8 +133,9 @@ class AttentionPooling(_Packed):
         if h_dim != 64 or f_dim != 64:
             raise L.SocialWaysHipError("AttentionPooling kernels are built for h_dim = f_dim = 64")
         self.f_dim, self.h_dim = f_dim, h_dim
-        self.W = nn.Linear(h_dim, f_dim, bias=True, device=device)
+        self.W = nn.Linear(h_dim, f_dim, bias=True)
         self._pack()
+        self._move(device)
 
     def forward(self, f, h, sub_batches):
         """f: dense (B,B,F) pair embeddings (only in-scene blocks are read), h: (B,H).
@@ -146,10 +157,11 @@ class EmbedSocialFeatures(_Packed):
         if input_size != 3 or hidden_size != 64:
             raise L.SocialWaysHipError("EmbedSocialFeatures kernels are built for 3 -> 64")
         self.input_size, self.hidden_size = input_size, hidden_size
-        self.fc = nn.Sequential(nn.Linear(input_size, 32, device=device), nn.ReLU(),
-                                nn.Linear(32, 64, device=device), nn.ReLU(),
-                                nn.Linear(64, hidden_size, device=device))
+        self.fc = nn.Sequential(nn.Linear(input_size, 32), nn.ReLU(),
+                                nn.Linear(32, 64), nn.ReLU(),
+                                nn.Linear(64, hidden_size))
         self._pack()
+        self._move(device)
 
     def forward(self, ftr_list, sub_batches):
         L.require_gpu(ftr_list)
@@ -169,10 +181,11 @@ class EncoderLstm(_Packed):
         if hidden_size != 64 or n_layers != 1:
             raise L.SocialWaysHipError("EncoderLstm kernels are built for hidden_size=64, n_layers=1 "
                                        "(train.py:77,82)")
-        self.embed = nn.Linear(4, hidden_size, device=device)
-        self.lstm = nn.LSTM(hidden_size, hidden_size, num_layers=n_layers, batch_first=True, device=device)
+        self.embed = nn.Linear(4, hidden_size)
+        self.lstm = nn.LSTM(hidden_size, hidden_size, num_layers=n_layers, batch_first=True)
         self.lstm_h = []
         self._pack()
+        self._move(device)
 
     def init_lstm(self, h, c):
         self.lstm_h = (h, c)
@@ -201,11 +214,12 @@ class DecoderFC(_Packed):
         super().__init__()
         if hidden_dim != 160:
             raise L.SocialWaysHipError("DecoderFC kernels are built for hidden_dim = 64+64+32 = 160")
-        self.fc1 = nn.Sequential(nn.Linear(hidden_dim, hidden_dim, device=device), nn.LeakyReLU(0.2),
-                                 nn.Linear(hidden_dim, hidden_dim // 2, device=device), nn.LeakyReLU(0.2),
-                                 nn.Linear(hidden_dim // 2, hidden_dim // 4, device=device),
-                                 nn.Linear(hidden_dim // 4, 2, device=device))
+        self.fc1 = nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.LeakyReLU(0.2),
+                                 nn.Linear(hidden_dim, hidden_dim // 2), nn.LeakyReLU(0.2),
+                                 nn.Linear(hidden_dim // 2, hidden_dim // 4),
+                                 nn.Linear(hidden_dim // 4, 2))
         self._pack()
+        self._move(device)
 
     def forward(self, h, s, z, _encoder=None):
         """cat[h,s,z] -> velocity (B,2) (train.py:330-335): one decode step of the rollout kernel."""
@@ -254,16 +268,17 @@ class Discriminator(_Packed):
             raise L.SocialWaysHipError("Discriminator kernels are built for hidden_dim=64, n_latent_code=2")
         self.lstm_dim = hidden_dim
         self.n_next = n_next
-        self.obsv_encoder_lstm = nn.LSTM(4, hidden_dim, batch_first=True, device=device)
-        self.obsv_encoder_fc = nn.Sequential(nn.Linear(hidden_dim, hidden_dim // 2, device=device), nn.LeakyReLU(0.2),
-                                             nn.Linear(hidden_dim // 2, hidden_dim // 2, device=device))
-        self.pred_encoder = nn.Sequential(nn.Linear(n_next * 4, hidden_dim // 2, device=device), nn.LeakyReLU(0.2),
-                                          nn.Linear(hidden_dim // 2, hidden_dim // 2, device=device))
-        self.classifier = nn.Sequential(nn.Linear(hidden_dim, hidden_dim // 2, device=device), nn.LeakyReLU(0.2),
-                                        nn.Linear(hidden_dim // 2, 1, device=device))
-        self.latent_decoder = nn.Sequential(nn.Linear(hidden_dim, hidden_dim // 2, device=device), nn.LeakyReLU(0.2),
-                                            nn.Linear(self.lstm_dim // 2, n_latent_code, device=device))
+        self.obsv_encoder_lstm = nn.LSTM(4, hidden_dim, batch_first=True)
+        self.obsv_encoder_fc = nn.Sequential(nn.Linear(hidden_dim, hidden_dim // 2), nn.LeakyReLU(0.2),
+                                             nn.Linear(hidden_dim // 2, hidden_dim // 2))
+        self.pred_encoder = nn.Sequential(nn.Linear(n_next * 4, hidden_dim // 2), nn.LeakyReLU(0.2),
+                                          nn.Linear(hidden_dim // 2, hidden_dim // 2))
+        self.classifier = nn.Sequential(nn.Linear(hidden_dim, hidden_dim // 2), nn.LeakyReLU(0.2),
+                                        nn.Linear(hidden_dim // 2, 1))
+        self.latent_decoder = nn.Sequential(nn.Linear(hidden_dim, hidden_dim // 2), nn.LeakyReLU(0.2),
+                                            nn.Linear(self.lstm_dim // 2, n_latent_code))
         self._pack()
+        self._move(device)
 
     def _tp(self):
         return self.n_next
@@ -320,18 +335,48 @@ class Generator(nn.Module):
 
     def __init__(self, hidden_size=64, n_lstm_layers=1, use_social=False, device=None):
         super().__init__()
-        self.encoder = EncoderLstm(hidden_size, n_lstm_layers, device=device)
-        self.feature_embedder = EmbedSocialFeatures(3, hidden_size, device=device)
-        self.attention = AttentionPooling(hidden_size, hidden_size, device=device)
-        self.decoder = DecoderFC(hidden_size + hidden_size + hidden_size // 2, device=device)
+        self.encoder = EncoderLstm(hidden_size, n_lstm_layers)
+        self.feature_embedder = EmbedSocialFeatures(3, hidden_size)
+        self.attention = AttentionPooling(hidden_size, hidden_size)
+        self.decoder = DecoderFC(hidden_size + hidden_size + hidden_size // 2)
         self.use_social = use_social            # train.py:83 hard-codes False; the flag is explicit here
         self.noise_len = hidden_size // 2
+        if device is not None and torch.device(device).type != "cpu":
+            self.to(device)                     # built on the CPU generator first, like train.py:370-375
 
     def predictor_params(self):
         """Parameter order of the reference's generator optimizer (train.py:379-380)."""
         from itertools import chain
         return chain(self.attention.parameters(), self.feature_embedder.parameters(),
                      self.encoder.parameters(), self.decoder.parameters())
+
+    def unify(self):
+        """Re-home the four packed weight / gradient buffers into ONE buffer each (optimizer order,
+        16-byte aligned), so a data-parallel step all-reduces a single flat gradient."""
+        mods = (self.attention, self.feature_embedder, self.encoder, self.decoder)
+        sizes = [m._flat.numel() for m in mods]
+        offs, o = [], 0
+        for n in sizes:
+            offs.append(o)
+            o += (n + 3) // 4 * 4
+        dev = mods[0]._flat.device
+        flat_all = torch.zeros(o, dtype=torch.float32, device=dev)
+        gflat_all = torch.zeros(o, dtype=torch.float32, device=dev)
+        for m, off, n in zip(mods, offs, sizes):
+            m._pack(into=(flat_all[off:off + n], gflat_all[off:off + n]))
+        object.__setattr__(self, "_flat_all", flat_all)
+        object.__setattr__(self, "_gflat_all", gflat_all)
+        return self
+
+    def grad_views(self):
+        for m in (self.attention, self.feature_embedder, self.encoder, self.decoder):
+            m.grad_views()
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        if getattr(self, "_flat_all", None) is not None:
+            self.unify()
+        return out
 
     def forward(self, obsv_p, noise, n_next, sub_batches=[]):
         """predict(obsv_p (B,To,2), noise (B,32), n_next, sub_batches) -> pred_hat_4d (B,n_next,4)."""

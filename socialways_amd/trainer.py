@@ -1,0 +1,276 @@
+"""train() / test() / checkpoint of the reference (train.py:439-668) over the HIP hot path.
+
+`SocialWaysTrainer.step()` is the body of train.py:458-554 for one packed batch:
+two discriminator updates (`n_unrolling_steps`+1), one generator update, the Linear-only restore of
+the unrolled-GAN surrogate (train.py:498-499, 541-543) and the ADE/FDE partial sums.
+Differences to the reference's *formulation*, none to its results:
+  * the three `predict()` calls of a step use the same noise and the same generator weights
+    (train.py:473,480,507), so the rollout is computed ONCE and its saved
+    activations serve the generator backward;
+  * the fake and the real branch of a D update share one observation-LSTM pass;
+  * gradients are written by the kernels straight into packed buffers that are the `.grad`s of
+    the parameters; Adam stays torch.optim.Adam (same parameter order as train.py:379-385, so the
+    optimizer state_dicts interchange with the reference's checkpoint).
+Data parallelism (one process per GPU): every rank runs `step()` on a scene-aligned shard of the
+packed batch with the GLOBAL batch size in the loss normalisation and the packed gradient buffers
+are all-reduced (sum) before each optimizer step - 3 RCCL all-reduces per training step.
+"""
+import copy
+import os
+
+import numpy as np
+import torch
+import torch.optim as opt
+
+from . import _lib as L
+from . import ops
+from .data import shard_scenes
+from .model import Discriminator, Generator, predict_cv
+
+
+class SocialWaysTrainer:
+    def __init__(self, n_next, hidden_size=64, lr_g=1e-4, lr_d=1e-3, n_unrolling_steps=1, use_social=True,
+                 use_info_loss=True, loss_info_w=0.5, n_latent_codes=2, device="cuda", process_group=None,
+                 fused_adam=True):
+        self.device = torch.device(device)
+        self.n_next = n_next
+        self.noise_len = hidden_size // 2
+        self.n_unrolling_steps = n_unrolling_steps
+        self.use_info_loss = use_info_loss
+        self.loss_info_w = loss_info_w
+        # construction order = train.py:370-385 (RNG -> init mapping, optimizer parameter order)
+        self.G = Generator(hidden_size, 1, use_social=use_social, device=self.device)
+        self.G.unify()
+        adam_kw = dict(betas=(0.9, 0.999))
+        if fused_adam and self.device.type == "cuda":
+            adam_kw["fused"] = True
+        self.predictor_optimizer = opt.Adam(self.G.predictor_params(), lr=lr_g, **adam_kw)
+        self.D = Discriminator(n_next, hidden_size, n_latent_codes, device=self.device)
+        self.D_optimizer = opt.Adam(self.D.parameters(), lr=lr_d, **adam_kw)
+        self.pg = process_group
+        self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
+        self.rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
+        self.ws = ops.Workspaces(self.device)
+        self._lin_mask = None
+        self.epoch = 0
+
+    # ------------------------------------------------------------------------------------------
+    @property
+    def use_social(self):
+        return self.G.use_social
+
+    def _allreduce(self, flat):
+        if self.pg is not None and self.world > 1:
+            torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+
+    def step(self, obsv, pred, sub_batches, zeros_val, ones_val, noise, ss=1.0, global_B=None, out=None):
+        """One packed batch (train.py:458-554) on this rank's rows.  obsv (B,To,2), pred (B,Tp,2) and
+        noise (B,32) are device tensors; `global_B` = agents of the whole packed batch over all ranks.
+        Returns a (4,3) device tensor `out`: rows = D update 0, D update 1, G phase, ADE/FDE;
+        loss rows hold SUMS of squared errors over the local rows [label_a, code, label_b]."""
+        G, D = self.G, self.D
+        B, Tp = obsv.shape[0], self.n_next
+        Bg = float(global_B if global_B is not None else B)
+        dev = self.device
+        st = L.stream()
+        ws = self.ws
+        if out is None:
+            out = torch.zeros(self.n_unrolling_steps + 3, 3, device=dev)
+        g_label = 1.0 / Bg
+        g_code = (self.loss_info_w if self.use_info_loss else 0.0) / (2.0 * Bg)
+        scenes = ops.SceneIndex.get(sub_batches, B, dev)
+        noise = noise.contiguous()
+        # real future as 4-d (train.py:470); the observation stays 2-d: kernels form (p, v) on the fly
+        pred4 = torch.empty(B, Tp, 4, device=dev)
+        o4_scratch = ws.get("o4", B * obsv.shape[1] * 4)
+        L.call("sw_traj_4d", L.ptr(obsv), L.ptr(pred), B, obsv.shape[1], Tp, L.ptr(o4_scratch), L.ptr(pred4), st)
+        # ---- generator rollout, once (train.py:480/507 are identical) ---------------
+        enc, emb, att, dec = G.encoder, G.feature_embedder, G.attention, G.decoder
+        pred_hat, gctx = ops.gen_forward(enc._flat, emb._flat, att._flat, dec._flat, obsv, noise, scenes, Tp,
+                                         G.use_social, save=True, ws=ws)
+        dl_f = ws.get("dl_f", B)
+        dc_f = ws.get("dc_f", 2 * B)
+        dl_r = ws.get("dl_r", B)
+        dc_r = ws.get("dc_r", 2 * B)
+        d_gflat = D.grad_views()
+        backup = None
+        # ---- discriminator updates (train.py:476-499) ------------------------------------------------
+        for u in range(self.n_unrolling_steps + 1):
+            labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat, pred4], save=True, ws=ws)
+            L.call("sw_gan_loss", L.ptr(labels[0]), float(zeros_val), L.ptr(codes[0]), L.ptr(noise), L.ptr(labels[1]),
+                   float(ones_val), B, g_label, g_code, L.ptr(out[u]), L.ptr(dl_f), L.ptr(dc_f), L.ptr(dl_r),
+                   L.ptr(dc_r), st)
+            ops.disc_backward(D._flat, dctx, [dl_f, dl_r], [dc_f, dc_r], d_gflat, (), ws=ws)
+            self._allreduce(d_gflat)
+            self.D_optimizer.step()
+            if u == 0 and self.n_unrolling_steps > 0:
+                backup = ws.get("d_backup", D._flat.numel())
+                backup[:D._flat.numel()].copy_(D._flat)
+        # ---- generator update (train.py:503-539) ----------------------------------------------------
+        labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat], save=True, ws=ws)
+        L.call("sw_gan_loss", L.ptr(labels[0]), float(ones_val), L.ptr(codes[0]), L.ptr(noise), None, 0.0, B, g_label,
+               g_code, L.ptr(out[self.n_unrolling_steps + 1]), L.ptr(dl_f), L.ptr(dc_f), None, None, st)
+        dpred = ops.disc_backward(D._flat, dctx, [dl_f], [dc_f], None, (True,), ws=ws)[0]
+        G.grad_views()
+        ops.gen_backward(enc._flat, emb._flat, att._flat, dec._flat, gctx, dpred, enc._gflat, emb._gflat, att._gflat,
+                         dec._gflat, ws=ws)
+        self._allreduce(G._gflat_all)
+        self.predictor_optimizer.step()
+        if self.n_unrolling_steps > 0:                                       # D.load(backup), Linear only
+            if self._lin_mask is None:
+                self._lin_mask = D.linear_mask() > 0
+            D._flat.copy_(torch.where(self._lin_mask, backup[:D._flat.numel()], D._flat))
+        # ---- ADE/FDE partial sums of the G-phase prediction (train.py:546-551) ---------------------
+        L.call("sw_ade_fde", L.ptr(pred_hat), L.ptr(pred), B, Tp, 1.0 / float(ss), L.ptr(out[self.n_unrolling_steps + 2]),
+               st)
+        self.last_pred_hat = pred_hat
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def losses_from(self, out, B_global, Tp=None, ss=1.0):
+        """(n_steps, U+3, 3) sums -> the reference's MSE terms in its order
+        [d_fake, d_info, d_real] x (U+1), [g_l2, g_fool, g_info] per step (train.py:484-488,512-516)."""
+        o = out.detach().double().cpu().numpy()
+        if o.ndim == 2:
+            o = o[None]
+        Bg = np.asarray(B_global, dtype=np.float64).reshape(-1, 1)
+        U = self.n_unrolling_steps + 1
+        Tp = Tp or self.n_next
+        cols = []
+        for u in range(U):
+            cols += [o[:, u, 0:1] / Bg, o[:, u, 1:2] / (2 * Bg), o[:, u, 2:3] / Bg]
+        cols += [o[:, U + 1, 2:3] * (ss * ss) / (2 * Tp * Bg), o[:, U, 0:1] / Bg, o[:, U, 1:2] / (2 * Bg)]
+        return np.concatenate(cols, axis=1)
+
+    def train_epoch(self, data, batch_size, draw=None):
+        """train() (train.py:439-557).  `draw(bs)` -> (zeros_val, ones_val, noise_cpu) overrides the
+        RNG draws of train.py:471-473 (tests feed the reference's recorded values)."""
+        outs, sizes = [], []
+        for a, b, sb in data.packed_steps(batch_size):
+            bs = b - a
+            if draw is None:
+                zv = np.random.uniform(0, 0.1)                               # train.py:471
+                ov = np.random.uniform(0.9, 1.0)                             # train.py:472
+                noise = torch.rand(bs, self.noise_len)                       # train.py:473 (CPU generator)
+            else:
+                zv, ov, noise = draw(bs)
+            if self.world > 1:
+                lo, hi = shard_scenes(sb, self.world)[self.rank]
+                if hi > lo:
+                    r0, r1 = int(sb[lo, 0]), int(sb[hi - 1, 1])
+                    out = self.step(data.obsv[a + r0:a + r1], data.pred[a + r0:a + r1], sb[lo:hi] - r0, zv, ov,
+                                    noise[r0:r1].to(self.device), data.ss, global_B=bs)
+                else:
+                    out = self._empty_step()
+            else:
+                out = self.step(data.obsv[a:b], data.pred[a:b], sb, zv, ov, noise.to(self.device), data.ss)
+            outs.append(out)
+            sizes.append((bs, len(sb)))
+        allo = torch.stack(outs)
+        self._allreduce(allo)
+        o = allo.double().cpu().numpy()
+        ade = float(o[:, -1, 0].sum() / data.n_train_samples)
+        fde = float(o[:, -1, 1].sum() / data.n_train_samples)
+        losses = self.losses_from(allo, [s[0] for s in sizes], data.n_next, data.ss)
+        self.epoch += 1
+        return ade, fde, losses, sizes
+
+    def _empty_step(self):
+        """A rank without scenes in this packed batch still takes part in the 3 all-reduces."""
+        d_g = self.D.grad_views()
+        self.G.grad_views()
+        for u in range(self.n_unrolling_steps + 1):
+            d_g.zero_()
+            self._allreduce(d_g)
+            self.D_optimizer.step()
+            if u == 0 and self.n_unrolling_steps > 0:
+                backup = self.D._flat.clone()
+        self.G._gflat_all.zero_()
+        self._allreduce(self.G._gflat_all)
+        self.predictor_optimizer.step()
+        if self.n_unrolling_steps > 0:
+            if self._lin_mask is None:
+                self._lin_mask = self.D.linear_mask() > 0
+            self.D._flat.copy_(torch.where(self._lin_mask, backup, self.D._flat))
+        return torch.zeros(self.n_unrolling_steps + 3, 3, device=self.device)
+
+    # ------------------------------------------------------------------------------------------
+    def test(self, data, n_gen_samples=20, linear=False, write_to_file=None, just_one=False, collect=None):
+        """test() (train.py:563-616): K sampled futures per held-out scene, avg / min-over-K ADE & FDE,
+        optional prediction npz ('<epoch>-<t>.npz': timestamp, obsvs, preds_our, preds_gtt, preds_lnr,
+        all denormalised - the schema visualize.py / calc_statistics.py read).  The K rollouts of a
+        scene are independent given the noise, so they run as ONE batch of K*n agents with K copies
+        of the scene (identical results, K times fewer launches)."""
+        ss, dev, K = data.ss, self.device, n_gen_samples
+        ade_avg = fde_avg = ade_min = fde_min = 0.0
+        for ii, batch_i in enumerate(data.test_batches):
+            obsv = data.obsv[batch_i[0]:batch_i[1]]
+            pred = data.pred[batch_i[0]:batch_i[1]]
+            bs = int(batch_i[1] - batch_i[0])
+            with torch.no_grad():
+                linear_preds = predict_cv(obsv, self.n_next)
+                if linear and not write_to_file:
+                    preds_k = linear_preds.unsqueeze(0)
+                    errs = torch.pow((linear_preds[:, :, :2] - pred) / ss, 2).sum(dim=2, keepdim=True).sqrt().unsqueeze(0)
+                else:
+                    noise = torch.cat([torch.rand(bs, self.noise_len) for _ in range(K)]).to(dev)   # train.py:584
+                    sb = np.stack([np.arange(K) * bs, (np.arange(K) + 1) * bs], axis=1)
+                    ph = self.G(obsv.repeat(K, 1, 1), noise, self.n_next, sb).view(K, bs, self.n_next, 4)
+                    preds_k = ph
+                    errs = torch.pow((ph[:, :, :, :2] - pred.unsqueeze(0)) / ss, 2).sum(dim=3, keepdim=True).sqrt()
+                if write_to_file or collect is not None:
+                    sc = data.scale
+                    t = data.times[batch_i[0]] if data.times is not None else ii
+                    rec = dict(timestamp=t, obsvs=sc.denormalize(obsv[:, :, :2].cpu().numpy()),
+                               preds_our=sc.denormalize(preds_k[:, :, :, :2].cpu().numpy()),
+                               preds_gtt=sc.denormalize(pred[:, :, :2].cpu().numpy()),
+                               preds_lnr=sc.denormalize(linear_preds[:, :, :2].cpu().numpy()))
+                    if collect is not None:
+                        collect.append(rec)
+                    if write_to_file:
+                        os.makedirs(write_to_file, exist_ok=True)
+                        np.savez(os.path.join(write_to_file, str(self.epoch) + '-' + str(t) + '.npz'), **rec)
+                fde_min += errs[:, :, -1].min(0, keepdim=True)[0].sum().item()
+                ade_min += errs.mean(2).min(0, keepdim=True)[0].sum().item()
+                fde_avg += errs[:, :, -1].mean(0, keepdim=True).sum().item()
+                ade_avg += errs.mean(2).mean(0, keepdim=True).sum().item()
+            if just_one:
+                break
+        n = data.n_test_samples
+        return ade_avg / n, fde_avg / n, ade_min / n, fde_min / n
+
+    # ------------------------------------------------------------------------------------------
+    def checkpoint(self, epoch=None):
+        """The reference's checkpoint dict (train.py:653-663)."""
+        G = self.G
+        return {'epoch': self.epoch if epoch is None else epoch,
+                'attentioner_dict': G.attention.state_dict(),
+                'feature_embedder_dict': G.feature_embedder.state_dict(),
+                'encoder_dict': G.encoder.state_dict(),
+                'decoder_dict': G.decoder.state_dict(),
+                'pred_optimizer': self.predictor_optimizer.state_dict(),
+                'D_dict': self.D.state_dict(),
+                'D_optimizer': self.D_optimizer.state_dict()}
+
+    def save(self, path, epoch=None):
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save(self.checkpoint(epoch), path)
+
+    def load_checkpoint(self, ck):
+        """Resume (train.py:622-634); optimizer entries are optional (weights-only dicts load too)."""
+        if isinstance(ck, (str, os.PathLike)):
+            ck = torch.load(ck, map_location=self.device)
+        G = self.G
+        G.attention.load_state_dict(ck['attentioner_dict'])
+        G.feature_embedder.load_state_dict(ck['feature_embedder_dict'])
+        G.encoder.load_state_dict(ck['encoder_dict'])
+        G.decoder.load_state_dict(ck['decoder_dict'])
+        self.D.load_state_dict(ck['D_dict'])
+        for key, optim in (('pred_optimizer', self.predictor_optimizer), ('D_optimizer', self.D_optimizer)):
+            if key in ck:
+                keep = {k: optim.param_groups[0].get(k) for k in ('fused', 'foreach', 'capturable')}
+                optim.load_state_dict(copy.deepcopy(ck[key]))
+                for k, v in keep.items():
+                    optim.param_groups[0][k] = v
+        self.epoch = int(ck.get('epoch', 0))
+        return self.epoch + 1
