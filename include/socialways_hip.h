@@ -129,15 +129,16 @@ int sw_disc_bwd(const float* d_w, const float* dsave, const float* const* dlabel
                 float* d_d_w, float* const* dpred4, float* wgrad_ws, void* stream);
 
 /* ---- LSGAN + InfoGAN losses of train.py:484-494 / 512-523 and their gradients -------------- */
-/* out_sums[3] = { sum (label_a - t_a)^2, sum (code_a - z[:, :2])^2, sum (label_b - t_b)^2 } over the
+/* t_a = targets[ia], t_b = targets[ib] (read on the device, so a captured hipGraph sees new values).
+ * out_sums[3] = { sum (label_a - t_a)^2, sum (code_a - z[:, :2])^2, sum (label_b - t_b)^2 } over the
  * B local rows (label_b may be NULL).  Gradients (any may be NULL):
  *   dlabel_x = 2 (label_x - t_x) g_label,  dcode_a = 2 (code_a - z) g_code,  dcode_b = 0
  * with g_label = 1/B_global and g_code = loss_info_w / (2 B_global) for a mean over the global
  * batch (data-parallel ranks pass the GLOBAL batch size so summed gradients are exact).          */
-int sw_gan_loss(const float* label_a, float t_a, const float* code_a, const float* z /*[B,32]*/,
-                const float* label_b, float t_b, int B, float g_label, float g_code,
-                float* out_sums /*[3]*/, float* dlabel_a, float* dcode_a, float* dlabel_b,
-                float* dcode_b, void* stream);
+int sw_gan_loss(const float* label_a, const float* targets /*device [>=2]: label-noise scalars*/, int ia,
+                const float* code_a, const float* z /*[B,32]*/, const float* label_b, int ib, int B,
+                float g_label, float g_code, float* out_sums /*[3]*/, float* dlabel_a, float* dcode_a,
+                float* dlabel_b, float* dcode_b, void* stream);
 
 /* ---- ADE/FDE partial sums of train.py:546-551:
  *      out[3] = { sum_{b,t} err / Tp, sum_b err[:, -1], sum_{b,t} err^2 },  err = |(p_hat - p) / ss|   */

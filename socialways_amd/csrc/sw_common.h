@@ -29,7 +29,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int sw_lane() { return threadIdx.x & 63; }
 __device__ __forceinline__ int sw_wave() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 
+// Gate non-linearities.  SW_FAST_ACT=1 (default): v_exp_f32 / v_rcp_f32 forms (each ~1 ulp of its own
+// result; |abs err| of sigmoid/tanh <= ~2e-7), 5-7 VALU ops instead of the ~40-op ocml expf/tanhf -
+// the LSTM cell is latency-bound on exactly this chain.  SW_FAST_ACT=0 builds the ocml versions.
+#ifndef SW_FAST_ACT
+#define SW_FAST_ACT 1
+#endif
+#if SW_FAST_ACT
+__device__ __forceinline__ float sw_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float sw_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + sw_exp(-x)); }
+__device__ __forceinline__ float sw_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + sw_exp(2.0f * x)); }
+#else
 __device__ __forceinline__ float sw_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sw_tanh(float x) { return tanhf(x); }
+#endif
 __device__ __forceinline__ float sw_lrelu(float x) { return x > 0.0f ? x : 0.2f * x; }
 __device__ __forceinline__ float sw_lrelu_grad(float a, float g) { return a > 0.0f ? g : 0.2f * g; }
 

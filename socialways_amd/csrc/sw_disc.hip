@@ -479,19 +479,21 @@ extern "C" int sw_disc_bwd(const float* d_w, const float* dsave, const float* co
   const DDelta dd = ddelta_layout(B, To, Tp, nb);
   const int R = nb * B, K4 = 4 * Tp;
   WgBatch wb;
+  int rc_add = 0;
   // LSTM: dW_hh over rows t >= 1 against h_{t-1}; dW_ih / biases over all rows against x4
-  wg_add(wb, ddelta + dd.dgates + (size_t)B * 256, 256, dsave + ds.act + 320, 384, (To - 1) * B, 256, 64,
+  rc_add |= wg_add(wb, ddelta + dd.dgates + (size_t)B * 256, 256, dsave + ds.act + 320, 384, (To - 1) * B, 256, 64,
          d_d_w + O.whh, 64, nullptr, nullptr, 0);
-  wg_add(wb, ddelta + dd.dgates, 256, dsave + ds.x4s, 4, To * B, 256, 4, d_d_w + O.wih, 4, d_d_w + O.bih,
+  rc_add |= wg_add(wb, ddelta + dd.dgates, 256, dsave + ds.x4s, 4, To * B, 256, 4, d_d_w + O.wih, 4, d_d_w + O.bih,
          d_d_w + O.bhh, 0);
-  wg_add(wb, ddelta + dd.do1, 32, dsave + ds.act + (size_t)(To - 1) * B * 384 + 320, 384, B, 32, 64, d_d_w + O.of0w,
+  rc_add |= wg_add(wb, ddelta + dd.do1, 32, dsave + ds.act + (size_t)(To - 1) * B * 384 + 320, 384, B, 32, 64, d_d_w + O.of0w,
          64, d_d_w + O.of0b, nullptr, 0);
-  wg_add(wb, ddelta + dd.docode, 32, dsave + ds.o1, 32, B, 32, 32, d_d_w + O.of1w, 32, d_d_w + O.of1b, nullptr, 0);
-  wg_add(wb, ddelta + dd.dq1, 32, dsave + ds.px, K4, R, 32, K4, d_d_w + O.pe0w, K4, d_d_w + O.pe0b, nullptr, 0);
-  wg_add(wb, ddelta + dd.dpcode, 32, dsave + ds.q1, 32, R, 32, 32, d_d_w + O.pe1w, 32, d_d_w + O.pe1b, nullptr, 0);
-  wg_add(wb, ddelta + dd.dc1, 32, dsave + ds.both, 64, R, 32, 64, d_d_w + O.cl0w, 64, d_d_w + O.cl0b, nullptr, 0);
-  wg_add(wb, ddelta + dd.dlab, 4, dsave + ds.c1, 32, R, 1, 32, d_d_w + O.cl1w, 32, d_d_w + O.cl1b, nullptr, 0);
-  wg_add(wb, ddelta + dd.dl1, 32, dsave + ds.both, 64, R, 32, 64, d_d_w + O.la0w, 64, d_d_w + O.la0b, nullptr, 0);
-  wg_add(wb, ddelta + dd.dcod, 4, dsave + ds.l1, 32, R, 2, 32, d_d_w + O.la1w, 32, d_d_w + O.la1b, nullptr, 0);
+  rc_add |= wg_add(wb, ddelta + dd.docode, 32, dsave + ds.o1, 32, B, 32, 32, d_d_w + O.of1w, 32, d_d_w + O.of1b, nullptr, 0);
+  rc_add |= wg_add(wb, ddelta + dd.dq1, 32, dsave + ds.px, K4, R, 32, K4, d_d_w + O.pe0w, K4, d_d_w + O.pe0b, nullptr, 0);
+  rc_add |= wg_add(wb, ddelta + dd.dpcode, 32, dsave + ds.q1, 32, R, 32, 32, d_d_w + O.pe1w, 32, d_d_w + O.pe1b, nullptr, 0);
+  rc_add |= wg_add(wb, ddelta + dd.dc1, 32, dsave + ds.both, 64, R, 32, 64, d_d_w + O.cl0w, 64, d_d_w + O.cl0b, nullptr, 0);
+  rc_add |= wg_add(wb, ddelta + dd.dlab, 4, dsave + ds.c1, 32, R, 1, 32, d_d_w + O.cl1w, 32, d_d_w + O.cl1b, nullptr, 0);
+  rc_add |= wg_add(wb, ddelta + dd.dl1, 32, dsave + ds.both, 64, R, 32, 64, d_d_w + O.la0w, 64, d_d_w + O.la0b, nullptr, 0);
+  rc_add |= wg_add(wb, ddelta + dd.dcod, 4, dsave + ds.l1, 32, R, 2, 32, d_d_w + O.la1w, 32, d_d_w + O.la1b, nullptr, 0);
+  if (rc_add) return SW_ESHAPE;
   return wg_launch(wb, wgrad_ws, st);
 }

@@ -89,7 +89,7 @@ __device__ __forceinline__ void lstm_cell(const LstmW& W, float xb, const float*
   for (int r = 0; r < 4; ++r) {
     float i = sw_sigmoid(acc[0][r]);
     float f = sw_sigmoid(acc[1][r]);
-    float g = tanhf(acc[2][r]);
+    float g = sw_tanh(acc[2][r]);
     float o = sw_sigmoid(acc[3][r]);
     float cn = fmaf(f, c[r], i * g);
     gate[0][r] = i;
@@ -97,7 +97,7 @@ __device__ __forceinline__ void lstm_cell(const LstmW& W, float xb, const float*
     gate[2][r] = g;
     gate[3][r] = o;
     c[r] = cn;
-    h[r] = o * tanhf(cn);
+    h[r] = o * sw_tanh(cn);
   }
 }
 
@@ -109,7 +109,7 @@ __device__ __forceinline__ void lstm_cell_bwd(const f32x4 gate[4], f32x4 ct, f32
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     float i = gate[0][r], f = gate[1][r], g = gate[2][r], o = gate[3][r];
-    float tc = tanhf(ct[r]);
+    float tc = sw_tanh(ct[r]);
     float d_o = dh[r] * tc;
     float dct = fmaf(dh[r] * o, 1.0f - tc * tc, dc[r]);
     dgate[0][r] = dct * g * i * (1.0f - i);

@@ -87,30 +87,45 @@ extern "C" size_t sw_workspace_floats(int ws_id, int B, int To, int Tp, int nb, 
 
 // ---- encoder: gradients of the composed input matrix back to embed / W_ih --------------------
 //   Wx = Wih We, bx = Wih be + bih + bhh   (sw_lstm_dev.h)
-__global__ void enc_compose_bwd_kernel(const float* __restrict__ enc_w, const float* __restrict__ dWx,
-                                       const float* __restrict__ dbx, float* __restrict__ d_enc_w) {
+__global__ __launch_bounds__(256) void enc_compose_bwd_kernel(const float* __restrict__ enc_w,
+                                                              const float* __restrict__ dWx,
+                                                              const float* __restrict__ dbx,
+                                                              float* __restrict__ d_enc_w) {
   using namespace swp;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
   const float* We = enc_w + ENC_EMB_W;
   const float* be = enc_w + ENC_EMB_B;
   const float* Wih = enc_w + ENC_WIH;
-  if (i < 256 * 64) {  // dWih[row][e] = sum_c dWx[row][c] We[e][c] + dbx[row] be[e]
+  const int t = threadIdx.x;
+  if (blockIdx.x < 64) {  // dWih[row][e] = sum_c dWx[row][c] We[e][c] + dbx[row] be[e]; 256 elements per block
+    int i = blockIdx.x * 256 + t;
     int row = i >> 6, e = i & 63;
     f32x4 g = ld4(dWx + row * 4), w = ld4(We + e * 4);
     float v = dbx[row] * be[e];
     v = fmaf(g[0], w[0], v); v = fmaf(g[1], w[1], v); v = fmaf(g[2], w[2], v); v = fmaf(g[3], w[3], v);
     d_enc_w[ENC_WIH + i] = v;
-  } else if (i < 256 * 64 + 64 * 5) {  // dWe[e][c] = sum_row Wih[row][e] dWx[row][c]; dbe[e] = sum_row Wih[row][e] dbx[row]
-    int k = i - 256 * 64, e = k / 5, c = k - e * 5;
-    float v = 0.f;
-    for (int row = 0; row < 256; ++row) v = fmaf(Wih[row * 64 + e], c < 4 ? dWx[row * 4 + c] : dbx[row], v);
-    if (c < 4) d_enc_w[ENC_EMB_W + e * 4 + c] = v;
-    else d_enc_w[ENC_EMB_B + e] = v;
-  } else if (i < 256 * 64 + 64 * 5 + 256) {
-    int row = i - (256 * 64 + 64 * 5);
-    d_enc_w[ENC_BIH + row] = dbx[row];
-    d_enc_w[ENC_BHH + row] = dbx[row];
+    if (blockIdx.x == 0) {
+      d_enc_w[ENC_BIH + t] = dbx[t];
+      d_enc_w[ENC_BHH + t] = dbx[t];
+    }
+    return;
   }
+  // blocks 64..127: one embed unit e each; thread = gate row; dWe[e][c] = sum_row Wih[row][e] dWx[row][c],
+  // dbe[e] = sum_row Wih[row][e] dbx[row]
+  __shared__ float red[5][256];
+  const int e = blockIdx.x - 64;
+  float w = Wih[t * 64 + e];
+  f32x4 g = ld4(dWx + t * 4);
+  red[0][t] = w * g[0]; red[1][t] = w * g[1]; red[2][t] = w * g[2]; red[3][t] = w * g[3]; red[4][t] = w * dbx[t];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) {
+#pragma unroll
+      for (int c = 0; c < 5; ++c) red[c][t] += red[c][t + o];
+    }
+    __syncthreads();
+  }
+  if (t < 4) d_enc_w[ENC_EMB_W + e * 4 + t] = red[t][0];
+  if (t == 4) d_enc_w[ENC_EMB_B + e] = red[4][0];
 }
 
 extern "C" int sw_gen_wgrad(const float* enc_w, const float* gsave, const float* gdelta, const float* z,
@@ -126,32 +141,59 @@ extern "C" int sw_gen_wgrad(const float* enc_w, const float* gsave, const float*
   float* dbx = dWx + 1024;
   hipStream_t st = (hipStream_t)stream;
   WgBatch wb;
+  int rc_add = 0;
   // EncoderLstm: W_hh against h_{t-1} (rows t >= 1), composed input matrix against x4 (all rows)
-  wg_add(wb, gdelta + gd.dgates + (size_t)B * 256, 256, gsave + gs.act + 320, 384, (Ta - 1) * B, 256, 64,
+  rc_add |= wg_add(wb, gdelta + gd.dgates + (size_t)B * 256, 256, gsave + gs.act + 320, 384, (Ta - 1) * B, 256, 64,
          d_enc_w + ENC_WHH, 64, nullptr, nullptr, 0);
-  wg_add(wb, gdelta + gd.dgates, 256, gsave + gs.x4s, 4, Ta * B, 256, 4, dWx, 4, dbx, nullptr, 0);
+  rc_add |= wg_add(wb, gdelta + gd.dgates, 256, gsave + gs.x4s, 4, Ta * B, 256, 4, dWx, 4, dbx, nullptr, 0);
   // DecoderFC: fc1.0 split in its h / S / z column blocks; h of decode step i is LSTM row To-1+i
-  wg_add(wb, gdelta + gd.dz1, 160, gsave + gs.act + (size_t)(To - 1) * B * 384 + 320, 384, Tp * B, 160, 64,
+  rc_add |= wg_add(wb, gdelta + gd.dz1, 160, gsave + gs.act + (size_t)(To - 1) * B * 384 + 320, 384, Tp * B, 160, 64,
          d_dec_w + DEC_W1, 160, nullptr, nullptr, 0);
-  wg_add(wb, gdelta + gd.du, 160, S_pool, 64, B, 160, 64, d_dec_w + DEC_W1 + 64, 160, nullptr, nullptr, 0);
-  wg_add(wb, gdelta + gd.du, 160, z, 32, B, 160, 32, d_dec_w + DEC_W1 + 128, 160, d_dec_w + DEC_B1, nullptr, 0);
-  wg_add(wb, gdelta + gd.dz2, 80, gsave + gs.a1, 160, Tp * B, 80, 160, d_dec_w + DEC_W2, 160, d_dec_w + DEC_B2,
+  rc_add |= wg_add(wb, gdelta + gd.du, 160, S_pool, 64, B, 160, 64, d_dec_w + DEC_W1 + 64, 160, nullptr, nullptr, 0);
+  rc_add |= wg_add(wb, gdelta + gd.du, 160, z, 32, B, 160, 32, d_dec_w + DEC_W1 + 128, 160, d_dec_w + DEC_B1, nullptr, 0);
+  rc_add |= wg_add(wb, gdelta + gd.dz2, 80, gsave + gs.a1, 160, Tp * B, 80, 160, d_dec_w + DEC_W2, 160, d_dec_w + DEC_B2,
          nullptr, 0);
-  wg_add(wb, gdelta + gd.da3, 40, gsave + gs.a2, 80, Tp * B, 40, 80, d_dec_w + DEC_W3, 80, d_dec_w + DEC_B3, nullptr, 0);
-  wg_add(wb, gdelta + gd.dv, 4, gsave + gs.a3, 40, Tp * B, 2, 40, d_dec_w + DEC_W4, 40, d_dec_w + DEC_B4, nullptr, 0);
+  rc_add |= wg_add(wb, gdelta + gd.da3, 40, gsave + gs.a2, 80, Tp * B, 40, 80, d_dec_w + DEC_W3, 80, d_dec_w + DEC_B3, nullptr, 0);
+  rc_add |= wg_add(wb, gdelta + gd.dv, 4, gsave + gs.a3, 40, Tp * B, 2, 40, d_dec_w + DEC_W4, 40, d_dec_w + DEC_B4, nullptr, 0);
+  if (rc_add) return SW_ESHAPE;
   if (int rc = wg_launch(wb, wgrad_ws, st)) return rc;
-  int n = 256 * 64 + 64 * 5 + 256;
-  hipLaunchKernelGGL(enc_compose_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, enc_w, dWx, dbx, d_enc_w);
+  hipLaunchKernelGGL(enc_compose_bwd_kernel, dim3(128), dim3(256), 0, st, enc_w, dWx, dbx, d_enc_w);
   SW_CHECK_LAUNCH("enc_compose_bwd_kernel");
   return SW_OK;
 }
 
 // ---- losses (train.py:484-494, 512-523) ---------------------------------------------------------
-__global__ void gan_loss_kernel(const float* __restrict__ label_a, float t_a, const float* __restrict__ code_a,
-                                const float* __restrict__ z, const float* __restrict__ label_b, float t_b, int B,
-                                float g_label, float g_code, float* __restrict__ out, float* __restrict__ dlabel_a,
-                                float* __restrict__ dcode_a, float* __restrict__ dlabel_b, float* __restrict__ dcode_b) {
-  __shared__ float red[3][256];
+// block-wide sum of 3 values with 1024 threads: wave shuffles, then 16 partials through LDS
+__device__ __forceinline__ void block_sum3(float& a, float& b, float& c, float (*red)[16]) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o);
+    b += __shfl_xor(b, o);
+    c += __shfl_xor(c, o);
+  }
+  int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) { red[0][w] = a; red[1][w] = b; red[2][w] = c; }
+  __syncthreads();
+  if (w == 0) {
+    a = l < 16 ? red[0][l] : 0.f;
+    b = l < 16 ? red[1][l] : 0.f;
+    c = l < 16 ? red[2][l] : 0.f;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o);
+      b += __shfl_xor(b, o);
+      c += __shfl_xor(c, o);
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void gan_loss_kernel(
+    const float* __restrict__ label_a, const float* __restrict__ targets, int ia, const float* __restrict__ code_a,
+    const float* __restrict__ z, const float* __restrict__ label_b, int ib, int B, float g_label, float g_code,
+    float* __restrict__ out, float* __restrict__ dlabel_a, float* __restrict__ dcode_a, float* __restrict__ dlabel_b,
+    float* __restrict__ dcode_b) {
+  __shared__ float red[3][16];
+  const float t_a = targets[ia], t_b = targets[ib];
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
     float e = label_a[b] - t_a;
@@ -173,64 +215,58 @@ __global__ void gan_loss_kernel(const float* __restrict__ label_a, float t_a, co
       dcode_b[(size_t)b * 2 + 1] = 0.f;
     }
   }
-  red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) {
-      red[0][threadIdx.x] += red[0][threadIdx.x + o];
-      red[1][threadIdx.x] += red[1][threadIdx.x + o];
-      red[2][threadIdx.x] += red[2][threadIdx.x + o];
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x < 3) out[threadIdx.x] = red[threadIdx.x][0];
+  block_sum3(s0, s1, s2, red);
+  if (threadIdx.x == 0) { out[0] = s0; out[1] = s1; out[2] = s2; }
 }
 
-extern "C" int sw_gan_loss(const float* label_a, float t_a, const float* code_a, const float* z, const float* label_b,
-                           float t_b, int B, float g_label, float g_code, float* out_sums, float* dlabel_a,
-                           float* dcode_a, float* dlabel_b, float* dcode_b, void* stream) {
-  if (!label_a || !code_a || !z || !out_sums || B < 1) return SW_EARG;
-  hipLaunchKernelGGL(gan_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, label_a, t_a, code_a, z, label_b, t_b,
-                     B, g_label, g_code, out_sums, dlabel_a, dcode_a, dlabel_b, dcode_b);
+extern "C" int sw_gan_loss(const float* label_a, const float* targets, int ia, const float* code_a, const float* z,
+                           const float* label_b, int ib, int B, float g_label, float g_code, float* out_sums,
+                           float* dlabel_a, float* dcode_a, float* dlabel_b, float* dcode_b, void* stream) {
+  if (!label_a || !targets || !code_a || !z || !out_sums || B < 1 || ia < 0 || ib < 0) return SW_EARG;
+  hipLaunchKernelGGL(gan_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, label_a, targets, ia, code_a, z,
+                     label_b, ib, B, g_label, g_code, out_sums, dlabel_a, dcode_a, dlabel_b, dcode_b);
   SW_CHECK_LAUNCH("gan_loss_kernel");
   return SW_OK;
 }
 
 // ---- ADE/FDE partial sums (train.py:546-551) ----------------------------------------------------
-__global__ void ade_fde_kernel(const float* __restrict__ pred4, const float* __restrict__ gt, int B, int Tp,
-                               float inv_ss, float* __restrict__ out) {
-  __shared__ float red[3][256];
+__global__ __launch_bounds__(1024) void ade_fde_kernel(const float* __restrict__ pred4, const float* __restrict__ gt,
+                                                       int B, int Tp, float inv_ss, float* __restrict__ out) {
+  __shared__ float red[3][16];
   float sa = 0.f, sf = 0.f, sl = 0.f;
-  for (int i = threadIdx.x; i < B * Tp; i += blockDim.x) {
-    int t = i % Tp;
-    float dx = (pred4[(size_t)i * 4] - gt[(size_t)i * 2]) * inv_ss;
-    float dy = (pred4[(size_t)i * 4 + 1] - gt[(size_t)i * 2 + 1]) * inv_ss;
-    float q = dx * dx + dy * dy;
-    float e = sqrtf(q);
-    sa += e;
-    sl += q;
-    if (t == Tp - 1) sf += e;
-  }
-  red[0][threadIdx.x] = sa; red[1][threadIdx.x] = sf; red[2][threadIdx.x] = sl;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) {
-      red[0][threadIdx.x] += red[0][threadIdx.x + o];
-      red[1][threadIdx.x] += red[1][threadIdx.x + o];
-      red[2][threadIdx.x] += red[2][threadIdx.x + o];
+  const int n = B * Tp;
+  for (int base = 0; base < n; base += 1024 * 8) {  // 8 independent loads in flight per thread
+    f32x4 p[8];
+    float2 g[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int i = base + threadIdx.x + 1024 * u;
+      bool ok = i < n;
+      p[u] = ok ? ld4(pred4 + (size_t)i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      g[u] = ok ? *reinterpret_cast<const float2*>(gt + (size_t)i * 2) : float2{0.f, 0.f};
     }
-    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int i = base + threadIdx.x + 1024 * u;
+      float dx = (p[u][0] - g[u].x) * inv_ss, dy = (p[u][1] - g[u].y) * inv_ss;
+      float q = dx * dx + dy * dy;
+      float e = sqrtf(q);
+      sa += e;
+      sl += q;
+      if (i < n && i % Tp == Tp - 1) sf += e;
+    }
   }
+  block_sum3(sa, sf, sl, red);
   if (threadIdx.x == 0) {
-    out[0] = red[0][0] / (float)Tp;
-    out[1] = red[1][0];
-    out[2] = red[2][0];  // sum of squared (scaled) displacement errors, for the L2 term
+    out[0] = sa / (float)Tp;
+    out[1] = sf;
+    out[2] = sl;  // sum of squared (scaled) displacement errors, for the L2 term
   }
 }
 
 extern "C" int sw_ade_fde(const float* pred4, const float* gt, int B, int Tp, float inv_ss, float* out, void* stream) {
   if (!pred4 || !gt || !out || B < 1 || Tp < 1) return SW_EARG;
-  hipLaunchKernelGGL(ade_fde_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred4, gt, B, Tp, inv_ss, out);
+  hipLaunchKernelGGL(ade_fde_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred4, gt, B, Tp, inv_ss, out);
   SW_CHECK_LAUNCH("ade_fde_kernel");
   return SW_OK;
 }

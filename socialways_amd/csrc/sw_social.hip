@@ -558,11 +558,13 @@ extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, con
                      obsv, To, h, scene_off, pair_off, emb_w, att_w, attn, dS, dh, dwh_rows, pr);
   SW_CHECK_LAUNCH("social_pool_bwd_kernel");
   WgBatch wb;
-  wg_add(wb, dwh_rows, 64, h, 64, B, 64, 64, d_att_w + swp::ATT_W, 64, d_att_w + swp::ATT_B, nullptr, 0);
+  int rc_add = 0;
+  rc_add |= wg_add(wb, dwh_rows, 64, h, 64, B, 64, 64, d_att_w + swp::ATT_W, 64, d_att_w + swp::ATT_B, nullptr, 0);
   if (P > 0) {
-    wg_add(wb, pr.dz3, 64, pr.h2, 64, (int)P, 64, 64, d_emb_w + swp::EMB_W2, 64, d_emb_w + swp::EMB_B2, nullptr, 0);
-    wg_add(wb, pr.dh2, 64, pr.h1, 32, (int)P, 64, 32, d_emb_w + swp::EMB_W1, 32, d_emb_w + swp::EMB_B1, nullptr, 0);
-    wg_add(wb, pr.dh1, 32, pr.feat, 4, (int)P, 32, 3, d_emb_w + swp::EMB_W0, 3, d_emb_w + swp::EMB_B0, nullptr, 0);
+    rc_add |= wg_add(wb, pr.dz3, 64, pr.h2, 64, (int)P, 64, 64, d_emb_w + swp::EMB_W2, 64, d_emb_w + swp::EMB_B2, nullptr, 0);
+    rc_add |= wg_add(wb, pr.dh2, 64, pr.h1, 32, (int)P, 64, 32, d_emb_w + swp::EMB_W1, 32, d_emb_w + swp::EMB_B1, nullptr, 0);
+    rc_add |= wg_add(wb, pr.dh1, 32, pr.feat, 4, (int)P, 32, 3, d_emb_w + swp::EMB_W0, 3, d_emb_w + swp::EMB_B0, nullptr, 0);
   }
+  if (rc_add) return SW_ESHAPE;
   return wg_launch(wb, wgrad_ws, (hipStream_t)stream);
 }

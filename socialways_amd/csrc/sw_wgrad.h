@@ -3,20 +3,20 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
-#define SW_WG_MAXP 16
-#define SW_WG_MAXSPLIT 128
+#define SW_WG_MAXP 24
+#define SW_WG_MAXSPLIT 256
 // upper bound of the partial workspace one batch may need (floats): the largest batch (the
 // generator's) has < 64K output elements
 #define SW_WG_WS_FLOATS ((size_t)SW_WG_MAXSPLIT * 65536)
 
-struct WgProblem {
-  const float* delta;  // [R][ldd], N columns used
-  const float* act;    // [R][lda], K columns used
-  float* dW;           // [N][ldw]
-  float* db;           // [N] or null
-  float* db2;          // second copy of the bias gradient (LSTM b_ih / b_hh) or null
-  size_t ws_off, wsb_off;
-  int ldd, lda, ldw, R, N, K, accumulate;
+struct WgProblem {      // one column block (<= 64 act columns, optional trailing ones column) of a problem
+  const float* delta;   // [R][ldd], N columns used
+  const float* act;     // [R][lda], K columns used (already offset to the block's first column)
+  float* dW;            // [N][ldw], already offset to the block's first column
+  float* db;            // [N] or null: receives the ones column
+  float* db2;           // second copy of the bias gradient (LSTM b_ih / b_hh) or null
+  size_t ws_off;
+  int ldd, lda, ldw, R, N, K, ones, accumulate;
   int nbn, nbk, nsplit, job0, out0;
 };
 struct WgBatch {
@@ -24,8 +24,8 @@ struct WgBatch {
   int np = 0, total_jobs = 0, total_out = 0;
 };
 
-void wg_add(WgBatch& b, const float* delta, int ldd, const float* act, int lda, int R, int N, int K, float* dW,
-            int ldw, float* db, float* db2, int accumulate);
+int wg_add(WgBatch& b, const float* delta, int ldd, const float* act, int lda, int R, int N, int K, float* dW,
+           int ldw, float* db, float* db2, int accumulate);
 double wg_total_work(const WgBatch& b);
 size_t wg_finalize(WgBatch& b);
 int wg_launch(WgBatch& b, float* ws, hipStream_t stream);

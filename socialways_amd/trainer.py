@@ -80,6 +80,11 @@ class SocialWaysTrainer:
         g_code = (self.loss_info_w if self.use_info_loss else 0.0) / (2.0 * Bg)
         scenes = ops.SceneIndex.get(sub_batches, B, dev)
         noise = noise.contiguous()
+        # label-noise scalars of train.py:471-472 live in device memory: [zeros_val, ones_val]
+        if torch.is_tensor(zeros_val):
+            targets = zeros_val
+        else:
+            targets = torch.tensor([float(zeros_val), float(ones_val)], dtype=torch.float32).to(dev, non_blocking=True)
         # real future as 4-d (train.py:470); the observation stays 2-d: kernels form (p, v) on the fly
         pred4 = torch.empty(B, Tp, 4, device=dev)
         o4_scratch = ws.get("o4", B * obsv.shape[1] * 4)
@@ -97,9 +102,8 @@ class SocialWaysTrainer:
         # ---- discriminator updates (train.py:476-499) ------------------------------------------------
         for u in range(self.n_unrolling_steps + 1):
             labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat, pred4], save=True, ws=ws)
-            L.call("sw_gan_loss", L.ptr(labels[0]), float(zeros_val), L.ptr(codes[0]), L.ptr(noise), L.ptr(labels[1]),
-                   float(ones_val), B, g_label, g_code, L.ptr(out[u]), L.ptr(dl_f), L.ptr(dc_f), L.ptr(dl_r),
-                   L.ptr(dc_r), st)
+            L.call("sw_gan_loss", L.ptr(labels[0]), L.ptr(targets), 0, L.ptr(codes[0]), L.ptr(noise), L.ptr(labels[1]),
+                   1, B, g_label, g_code, L.ptr(out[u]), L.ptr(dl_f), L.ptr(dc_f), L.ptr(dl_r), L.ptr(dc_r), st)
             ops.disc_backward(D._flat, dctx, [dl_f, dl_r], [dc_f, dc_r], d_gflat, (), ws=ws)
             self._allreduce(d_gflat)
             self.D_optimizer.step()
@@ -108,7 +112,7 @@ class SocialWaysTrainer:
                 backup[:D._flat.numel()].copy_(D._flat)
         # ---- generator update (train.py:503-539) ----------------------------------------------------
         labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat], save=True, ws=ws)
-        L.call("sw_gan_loss", L.ptr(labels[0]), float(ones_val), L.ptr(codes[0]), L.ptr(noise), None, 0.0, B, g_label,
+        L.call("sw_gan_loss", L.ptr(labels[0]), L.ptr(targets), 1, L.ptr(codes[0]), L.ptr(noise), None, 1, B, g_label,
                g_code, L.ptr(out[self.n_unrolling_steps + 1]), L.ptr(dl_f), L.ptr(dc_f), None, None, st)
         dpred = ops.disc_backward(D._flat, dctx, [dl_f], [dc_f], None, (True,), ws=ws)[0]
         G.grad_views()
