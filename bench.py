@@ -115,7 +115,7 @@ def main():
         a = (i % N_BATCHES) * B
         zv = np.random.uniform(0, 0.1)                         # train.py:471-473, same host RNG use
         ov = np.random.uniform(0.9, 1.0)
-        noise = torch.rand(B, tr.noise_len).to(dev, non_blocking=True)
+        noise = torch.rand(B, tr.noise_len)                    # host generator, copied to HBM inside step()
         tr.step(data.obsv[a:a + B], data.pred[a:a + B], sb, zv, ov, noise, data.ss, global_B=Bg, out=out)
 
     def fence():

@@ -26,6 +26,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SW_TILE 16       // agents per workgroup tile
 #define SW_THREADS 256   // 4 waves: one per SIMD
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding
+// global load / store of the wave (s_waitcnt vmcnt(0)): the serial kernels keep save-stores and
+// prefetch-loads in flight across their per-layer barriers, and nothing they exchange between waves
+// goes through global memory, so only lgkmcnt is waited for.
+__device__ __forceinline__ void sw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ int sw_lane() { return threadIdx.x & 63; }
 __device__ __forceinline__ int sw_wave() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 
@@ -52,49 +58,95 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 // acc += W[row][16j+4lg+r] * X[agent][16j+4lg+r], j < KJ.  `wrow` / `xrow` already point at
 // column 4*lg of the lane's weight row / activation row.  Works for LDS and global pointers
 // (the compiler keeps the address space when the caller is inlined).
+//
+// All operand loads of a tile are issued before its first MFMA (one LDS round trip per tile, not
+// one per k-step: the compiler otherwise waits lgkmcnt(0) in front of every 4 MFMAs), and the
+// products alternate between two accumulators: a 16x16x4 f32 MFMA issues every 32 cycles but a
+// dependent one only every 40.
 template <int KJ>
 __device__ __forceinline__ f32x4 tile_mm(const float* wrow, const float* xrow, f32x4 acc) {
+  f32x4 a[KJ], b[KJ];
 #pragma unroll
   for (int j = 0; j < KJ; ++j) {
-    f32x4 a = ld4(wrow + 16 * j);
-    f32x4 b = ld4(xrow + 16 * j);
-    acc = SW_MFMA(a[0], b[0], acc);
-    acc = SW_MFMA(a[1], b[1], acc);
-    acc = SW_MFMA(a[2], b[2], acc);
-    acc = SW_MFMA(a[3], b[3], acc);
+    a[j] = ld4(wrow + 16 * j);
+    b[j] = ld4(xrow + 16 * j);
   }
-  return acc;
+  f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < KJ; ++j) {
+    acc = SW_MFMA(a[j][0], b[j][0], acc);
+    acc1 = SW_MFMA(a[j][1], b[j][1], acc1);
+    acc = SW_MFMA(a[j][2], b[j][2], acc);
+    acc1 = SW_MFMA(a[j][3], b[j][3], acc1);
+  }
+  return acc + acc1;
 }
 
 // Same with the weight operands held in registers (w[j] = float4 of the lane's row).
 template <int KJ>
 __device__ __forceinline__ f32x4 tile_mm_reg(const f32x4* w, const float* xrow, f32x4 acc) {
+  f32x4 b[KJ];
+#pragma unroll
+  for (int j = 0; j < KJ; ++j) b[j] = ld4(xrow + 16 * j);
+  f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < KJ; ++j) {
-    f32x4 b = ld4(xrow + 16 * j);
-    acc = SW_MFMA(w[j][0], b[0], acc);
-    acc = SW_MFMA(w[j][1], b[1], acc);
-    acc = SW_MFMA(w[j][2], b[2], acc);
-    acc = SW_MFMA(w[j][3], b[3], acc);
+    acc = SW_MFMA(w[j][0], b[j][0], acc);
+    acc1 = SW_MFMA(w[j][1], b[j][1], acc1);
+    acc = SW_MFMA(w[j][2], b[j][2], acc);
+    acc1 = SW_MFMA(w[j][3], b[j][3], acc1);
   }
-  return acc;
+  return acc + acc1;
 }
 
-// Stage a row-major [M][K] weight matrix (global, row stride lds_src) into LDS as [Mp][ld] with
-// zero padding up to Mp rows / ld columns (ld = roundup(K,16)+4).
+// Stage a row-major [M][K] weight matrix (global, row stride src_ld) into LDS as [Mp][ld] with zero
+// padding up to Mp rows / ld columns (ld = roundup(K,16)+4; ld, K, src_ld multiples of 4).  float4
+// granularity, 8 independent loads in flight per thread: the whole 115 KB decoder image is a handful
+// of L2 round trips instead of one per element.
 __device__ __forceinline__ void stage_w(float* dst, int ld, int Mp, const float* src, int src_ld,
                                         int M, int K) {
-  for (int i = threadIdx.x; i < Mp * ld; i += blockDim.x) {
-    int r = i / ld, c = i - r * ld;
-    dst[i] = (r < M && c < K) ? src[(size_t)r * src_ld + c] : 0.0f;
+  const int ldq = ld >> 2, n4 = Mp * ldq;
+  for (int base = 0; base < n4; base += SW_THREADS * 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int f = base + threadIdx.x + SW_THREADS * u;
+      int r = f / ldq, c = (f - r * ldq) * 4;
+      v[u] = (f < n4 && r < M && c < K) ? ld4(src + (size_t)r * src_ld + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int f = base + threadIdx.x + SW_THREADS * u;
+      if (f < n4) st4(dst + (size_t)f * 4, v[u]);
+    }
   }
 }
-// Transposed: dst[c][r] = src[r][c]; dst is [Kp][ld] (rows = source columns).
+// Transposed: dst[c][r] = src[r][c]; dst is [Kp][ld] (rows = source columns), zero padded.  Source
+// rows are read as float4s (coalesced), scattered to LDS as scalars.  The caller must have the
+// destination zero-filled by stage_zero() and a barrier in between.
+__device__ __forceinline__ void stage_zero(float* dst, int nfloats) {
+  for (int i = threadIdx.x * 4; i < nfloats; i += SW_THREADS * 4) st4(dst + i, f32x4{0.f, 0.f, 0.f, 0.f});
+}
 __device__ __forceinline__ void stage_wT(float* dst, int ld, int Kp, const float* src, int src_ld,
                                          int M, int K) {
-  for (int i = threadIdx.x; i < Kp * ld; i += blockDim.x) {
-    int c = i / ld, r = i - c * ld;  // c: source column (dst row), r: source row (dst column)
-    dst[i] = (r < M && c < K) ? src[(size_t)r * src_ld + c] : 0.0f;
+  const int k4 = K >> 2, n4 = M * k4;  // float4s of the live source block [M][K]
+  for (int base = 0; base < n4; base += SW_THREADS * 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int f = base + threadIdx.x + SW_THREADS * u;
+      int r = f / k4, c = (f - r * k4) * 4;
+      v[u] = f < n4 ? ld4(src + (size_t)r * src_ld + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int f = base + threadIdx.x + SW_THREADS * u;
+      int r = f / k4, c = (f - r * k4) * 4;
+      if (f < n4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[(size_t)(c + e) * ld + r] = v[u][e];
+      }
+    }
   }
 }
 

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
   f32x4 c = ld4(cT + (size_t)b * 64 + u0 + 4 * lg);
   f32x4 h = ld4(hT + (size_t)b * 64 + u0 + 4 * lg);
   st4(&hbuf[ln * LD64 + u0 + 4 * lg], h);
-  __syncthreads();
+  sw_barrier();
   LstmW W;
   lstm_load_w(W, enc_w + swp::ENC_WHH, wx_lds, bx_lds, u0, ln, lg);
   for (int mt = wave; mt < 10; mt += 4) {
@@ -116,13 +116,10 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
     acc = tile_mm<6>(dec_w + swp::DEC_W1 + (size_t)(m0 + ln) * 160 + 64 + 4 * lg, &szbuf[ln * LD96 + 4 * lg], acc);
     st4(&ubuf[ln * LD160 + m0 + 4 * lg], acc);
   }
-  // running position: lanes lg==0 of wave 0 own agent ln
-  float px = 0.f, py = 0.f;
-  if (wave == 0 && lg == 0) {
-    px = obsv[((size_t)b * To + To - 1) * 2 + 0];
-    py = obsv[((size_t)b * To + To - 1) * 2 + 1];
-  }
-  __syncthreads();  // szbuf / wx_lds aliases are dead from here on
+  // running position of agent ln (every lane keeps a copy)
+  float px = obsv[((size_t)b * To + To - 1) * 2 + 0];
+  float py = obsv[((size_t)b * To + To - 1) * 2 + 1];
+  sw_barrier();  // szbuf / wx_lds aliases are dead from here on
 
   int cur = 0;
   for (int i = 0; i < Tp; ++i) {
@@ -136,7 +133,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
       st4(&a1buf[ln * LD160 + m0 + 4 * lg], acc);
       if (gsave && live) st4(gsave + gs.a1 + ((size_t)i * B + b) * 160 + m0 + 4 * lg, acc);
     }
-    __syncthreads();
+    sw_barrier();
     // ---- layer 2: a2 = lrelu(W2 a1 + b2) ----------------------------------------------------
     for (int mt = wave; mt < 5; mt += 4) {
       int m0 = mt * 16;
@@ -147,7 +144,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
       st4(&a2buf[ln * LD80 + m0 + 4 * lg], acc);
       if (gsave && live) st4(gsave + gs.a2 + ((size_t)i * B + b) * 80 + m0 + 4 * lg, acc);
     }
-    __syncthreads();
+    sw_barrier();
     // ---- layer 3: a3 = W3 a2 + b3 (no activation, train.py:327-328) -------------------------
     if (wave < 3) {
       int m0 = wave * 16;
@@ -156,38 +153,37 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
       st4(&a3buf[ln * LD40 + m0 + 4 * lg], acc);
       if (gsave && live && m0 + 4 * lg < 40) st4(gsave + gs.a3 + ((size_t)i * B + b) * 40 + m0 + 4 * lg, acc);
     }
-    __syncthreads();
-    // ---- layer 4: v = W4 a3 + b4 ; p += v ---------------------------------------------------
-    if (wave == 0) {
+    sw_barrier();
+    // ---- layer 4 (v = W4 a3 + b4 ; p += v) and the re-fed encoder step (train.py:422-430) --------
+    // Every wave computes the 2-row layer 4 itself (12 MFMAs on otherwise idle SIMDs) and keeps its
+    // own copy of the running position, so the LSTM step needs no barrier / LDS hop for its input.
+    {
       f32x4 acc = ld4(&bbuf[128 + 4 * lg]);
       acc = tile_mm<3>(&W4[ln * LD40 + 4 * lg], &a3buf[ln * LD40 + 4 * lg], acc);
-      if (lg == 0) {
-        px += acc[0];
-        py += acc[1];
-        f32x4 x4 = {px, py, acc[0], acc[1]};
-        st4(&xbuf[ln * 4], x4);
-        if (live) {
-          st4(pred4 + ((size_t)b * Tp + i) * 4, x4);
-          if (gsave && i < Tp - 1) st4(gsave + gs.x4s + ((size_t)(To + i) * B + b) * 4, x4);
-        }
+      // rows 0,1 (= v_x, v_y of agent ln) sit in the lg == 0 lanes; every lane fetches its agent's pair
+      float vx = __shfl(acc[0], ln), vy = __shfl(acc[1], ln);
+      px += vx;
+      py += vy;
+      if (wave == 0 && lg == 0 && live) {
+        f32x4 x4 = {px, py, vx, vy};
+        st4(pred4 + ((size_t)b * Tp + i) * 4, x4);
+        if (gsave && i < Tp - 1) st4(gsave + gs.x4s + ((size_t)(To + i) * B + b) * 4, x4);
       }
-    }
-    __syncthreads();
-    // ---- re-fed encoder step (train.py:430); the one after the last decode is dead compute ---
-    if (i < Tp - 1 || h_end) {
-      float xb = xbuf[ln * 4 + lg];
-      f32x4 gate[4];
-      lstm_cell(W, xb, &hbuf[cur * 16 * LD64 + ln * LD64 + 4 * lg], gate, c, h);
-      st4(&hbuf[(cur ^ 1) * 16 * LD64 + ln * LD64 + u0 + 4 * lg], h);
-      if (gsave && live && i < Tp - 1) {
-        float* row = gsave + gs.act + ((size_t)(To + i) * B + b) * 384 + u0 + 4 * lg;
+      if (i < Tp - 1 || h_end) {  // the step after the last decode is dead compute (train.py:430)
+        float xb = lg == 0 ? px : (lg == 1 ? py : (lg == 2 ? vx : vy));
+        f32x4 gate[4];
+        lstm_cell(W, xb, &hbuf[cur * 16 * LD64 + ln * LD64 + 4 * lg], gate, c, h);
+        st4(&hbuf[(cur ^ 1) * 16 * LD64 + ln * LD64 + u0 + 4 * lg], h);
+        if (gsave && live && i < Tp - 1) {
+          float* row = gsave + gs.act + ((size_t)(To + i) * B + b) * 384 + u0 + 4 * lg;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) st4(row + g * 64, gate[g]);
-        st4(row + 256, c);
-        st4(row + 320, h);
+          for (int g = 0; g < 4; ++g) st4(row + g * 64, gate[g]);
+          st4(row + 256, c);
+          st4(row + 320, h);
+        }
+        cur ^= 1;
       }
-      cur ^= 1;
-      __syncthreads();
+      sw_barrier();
     }
   }
   if (h_end && live) {
@@ -227,6 +223,8 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
   const GDelta gd = gdelta_layout(B, To, Tp);
 
   // ---- prologue: transposed decoder weights into LDS, composed Wx^T, W_hh^T into registers ---
+  stage_zero(smem, BwdLds::dgbuf);  // transposed images are zero padded
+  sw_barrier();
   stage_wT(W1hT, LD160, 64, dec_w + swp::DEC_W1, 160, 160, 64);
   stage_wT(W2T, LD80, 160, dec_w + swp::DEC_W2, 160, 80, 160);
   stage_wT(W3T, LD40, 80, dec_w + swp::DEC_W3, 80, 40, 80);
@@ -234,7 +232,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
   lstm_prep_rows(enc_w + swp::ENC_EMB_W, enc_w + swp::ENC_EMB_B, enc_w + swp::ENC_WIH, enc_w + swp::ENC_BIH,
                  enc_w + swp::ENC_BHH, true, wx_lds, bx_lds);
   for (int i = threadIdx.x; i < 16 * LD2; i += blockDim.x) dvbuf[i] = 0.f;
-  __syncthreads();
+  sw_barrier();
   // Wx^T slice of this wave's K-quarter as A operands: row c = ln (< 4 live), k = 64*wave + 16j + 4lg + r
   f32x4 wxT[4];
 #pragma unroll
@@ -244,7 +242,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
   }
   LstmWT WT;
   lstm_load_wT(WT, enc_w + swp::ENC_WHH, u0, ln, lg);
-  __syncthreads();
+  sw_barrier();
 
   f32x4 dh = {0.f, 0.f, 0.f, 0.f}, dc = {0.f, 0.f, 0.f, 0.f};
   f32x4 du[3];
@@ -271,7 +269,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
         st4(&dgbuf[ln * SW_GLD + g * 64 + u0 + 4 * lg], dgate[g]);
         if (live) st4(dgg + g * 64, dgate[g]);
       }
-      __syncthreads();
+      sw_barrier();
       dh = lstm_dh_prev(WT, &dgbuf[ln * SW_GLD + 4 * lg]);
       // dx4 = Wx^T dgates: each wave reduces its own quarter of K, partials through LDS
       {
@@ -279,7 +277,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
         acc = tile_mm_reg<4>(wxT, &dgbuf[ln * SW_GLD + 64 * wave + 4 * lg], acc);
         if (lg == 0) st4(&dxpart[(wave * 16 + ln) * 4], acc);
       }
-      __syncthreads();
+      sw_barrier();
       if (wave == 0 && lg == 0) {
         f32x4 s = ld4(&dxpart[ln * 4]) + ld4(&dxpart[(16 + ln) * 4]) + ld4(&dxpart[(32 + ln) * 4]) +
                   ld4(&dxpart[(48 + ln) * 4]);
@@ -300,7 +298,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
         st4(gdelta + gd.dv + ((size_t)i * B + b) * 4, o);
       }
     }
-    __syncthreads();
+    sw_barrier();
     // da3 = W4^T dv  (40)
     if (wave < 3) {
       int m0 = wave * 16;
@@ -309,7 +307,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
       st4(&da3buf[ln * LD40 + m0 + 4 * lg], acc);
       if (live && m0 + 4 * lg < 40) st4(gdelta + gd.da3 + ((size_t)i * B + b) * 40 + m0 + 4 * lg, acc);
     }
-    __syncthreads();
+    sw_barrier();
     // dz2 = (W3^T da3) * lrelu'(a2)   (80)
     for (int mt = wave; mt < 5; mt += 4) {
       int m0 = mt * 16;
@@ -321,7 +319,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
       st4(&dz2buf[ln * LD80 + m0 + 4 * lg], acc);
       if (live) st4(gdelta + gd.dz2 + ((size_t)i * B + b) * 80 + m0 + 4 * lg, acc);
     }
-    __syncthreads();
+    sw_barrier();
     // dz1 = (W2^T dz2) * lrelu'(a1)   (160)
     {
       int q = 0;
@@ -339,7 +337,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
         else du[2] += acc;
       }
     }
-    __syncthreads();
+    sw_barrier();
     // dh_{To+i-1} += W1h^T dz1   (wave w owns units 16w.. : same layout as dh)
     {
       f32x4 acc = (i < Tp - 1) ? dh : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -353,7 +351,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
     st4(dhT + (size_t)b * 64 + u0 + 4 * lg, dh);
     st4(dcT + (size_t)b * 64 + u0 + 4 * lg, dc);
   }
-  __syncthreads();
+  sw_barrier();
   {
     int q = 0;
     for (int mt = wave; mt < 10; mt += 4, ++q) {
@@ -363,7 +361,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
       if (live) st4(gdelta + gd.du + (size_t)b * 160 + m0 + 4 * lg, v);
     }
   }
-  __syncthreads();
+  sw_barrier();
   if (dS_pool) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const float* w1 = dec_w + swp::DEC_W1 + 64 + u0 + ln;  // column 64+unit of fc1.0.weight

@@ -54,15 +54,27 @@ __host__ __device__ inline DDelta ddelta_layout(int B, int To, int Tp, int nb) {
 
 // runtime-K tile product (heads are tiny; KJ <= 4 normally)
 __device__ __forceinline__ f32x4 tile_mm_rt(const float* wrow, const float* xrow, int KJ, f32x4 acc) {
-  for (int j = 0; j < KJ; ++j) {
-    f32x4 a = ld4(wrow + 16 * j);
-    f32x4 b = ld4(xrow + 16 * j);
-    acc = SW_MFMA(a[0], b[0], acc);
-    acc = SW_MFMA(a[1], b[1], acc);
-    acc = SW_MFMA(a[2], b[2], acc);
-    acc = SW_MFMA(a[3], b[3], acc);
+  f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+  for (int j0 = 0; j0 < KJ; j0 += 4) {  // groups of <= 4 k-steps: loads first, then the MFMAs
+    f32x4 a[4], b[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (j0 + q < KJ) {
+        a[q] = ld4(wrow + 16 * (j0 + q));
+        b[q] = ld4(xrow + 16 * (j0 + q));
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (j0 + q < KJ) {
+        acc = SW_MFMA(a[q][0], b[q][0], acc);
+        acc1 = SW_MFMA(a[q][1], b[q][1], acc1);
+        acc = SW_MFMA(a[q][2], b[q][2], acc);
+        acc1 = SW_MFMA(a[q][3], b[q][3], acc1);
+      }
+    }
   }
-  return acc;
+  return acc + acc1;
 }
 
 struct HeadLds {  // forward LDS carve for a given padded pred width KP = roundup(4Tp,16)
@@ -139,7 +151,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
   lstm_prep_rows(nullptr, nullptr, d_w + O.wih, d_w + O.bih, d_w + O.bhh, false, wx_lds, bx_lds);
   f32x4 c = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};  // h0 = c0 = 0 (train.py:296-297)
   st4(&hbuf[ln * SW_HLD + u0 + 4 * lg], h);
-  __syncthreads();
+  sw_barrier();
   LstmW W;
   lstm_load_w(W, d_w + O.whh, wx_lds, bx_lds, u0, ln, lg);
 
@@ -164,7 +176,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
       st4(row + 320, h);
       if (wave == 0) dsave[ds.x4s + ((size_t)t * B + b) * 4 + lg] = xb;
     }
-    __syncthreads();
+    sw_barrier();
   }
   const float* hlast = &hbuf[(To & 1) * 16 * SW_HLD];
 
@@ -180,7 +192,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
     st4(smem + L.o1 + ln * LD32 + m0 + 4 * lg, acc);
     if (dsave && live) st4(dsave + ds.o1 + (size_t)b * 32 + m0 + 4 * lg, acc);
   }
-  __syncthreads();
+  sw_barrier();
   // phase B: obsv_code = of1 o1 + b  -> both[:, 0:32]  (waves 0,1)
   if (wave < 2) {
     int m0 = 16 * wave;
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
     const float* pred = k == 0 ? pred_a : pred_b;
     float* label = k == 0 ? label_a : label_b;
     float* code = k == 0 ? code_a : code_b;
-    __syncthreads();
+    sw_barrier();
     for (int i = threadIdx.x; i < 16 * L.ldp; i += blockDim.x) {
       int a = i / L.ldp, cc = i - a * L.ldp;
       int bb = min(a0 + a, B - 1);
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
       smem[L.x + i] = v;
       if (dsave && cc < K4 && a0 + a < B) dsave[ds.px + ((size_t)k * B + bb) * K4 + cc] = v;
     }
-    __syncthreads();
+    sw_barrier();
     // q1 = lrelu(pe0 x + b)   (waves 0,1)
     if (wave < 2) {
       int m0 = 16 * wave;
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
       st4(smem + L.q1 + ln * LD32 + m0 + 4 * lg, acc);
       if (dsave && live) st4(dsave + ds.q1 + ((size_t)k * B + b) * 32 + m0 + 4 * lg, acc);
     }
-    __syncthreads();
+    sw_barrier();
     // pred_code = pe1 q1 + b -> both[:, 32:64]   (waves 0,1)
     if (wave < 2) {
       int m0 = 16 * wave;
@@ -219,7 +231,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
       acc = tile_mm_rt(smem + L.pe1 + (m0 + ln) * LD32 + 4 * lg, smem + L.q1 + ln * LD32 + 4 * lg, 2, acc);
       st4(smem + L.both + ln * LD64 + 32 + m0 + 4 * lg, acc);
     }
-    __syncthreads();
+    sw_barrier();
     if (dsave && live) {  // both codes (64) saved by all 4 waves, 16 floats each
       st4(dsave + ds.both + ((size_t)k * B + b) * 64 + u0 + 4 * lg, ld4(smem + L.both + ln * LD64 + u0 + 4 * lg));
     }
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
       st4(smem + (cls ? L.c1 : L.l1) + ln * LD32 + m0 + 4 * lg, acc);
       if (dsave && live) st4(dsave + (cls ? ds.c1 : ds.l1) + ((size_t)k * B + b) * 32 + m0 + 4 * lg, acc);
     }
-    __syncthreads();
+    sw_barrier();
     // label = cl1 c1 + b (wave 0) ; code_hat = la1 l1 + b (wave 1)
     if (wave < 2) {
       bool cls = wave == 0;
@@ -298,6 +310,8 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
   const bool live = (a0 + ln) < B;
   const int K4 = 4 * Tp;
 
+  stage_zero(smem + L.of0T, L.dlab - L.of0T);  // transposed images are zero padded
+  sw_barrier();
   stage_wT(smem + L.of0T, LD32, 64, d_w + O.of0w, 64, 32, 64);
   stage_wT(smem + L.of1T, LD32, 32, d_w + O.of1w, 32, 32, 32);
   stage_wT(smem + L.pe0T, LD32, L.kp, d_w + O.pe0w, K4, 32, K4);
@@ -312,7 +326,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
     const float* dlabel = k == 0 ? dlabel_a : dlabel_b;
     const float* dcode = k == 0 ? dcode_a : dcode_b;
     float* dpred = k == 0 ? dpred_a : dpred_b;
-    __syncthreads();
+    sw_barrier();
     for (int i = threadIdx.x; i < 16 * LD16; i += blockDim.x) {
       int a = i / LD16, cc = i - a * LD16;
       int bb = min(a0 + a, B - 1);
@@ -325,7 +339,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
         ddelta[dd.dcod + ((size_t)k * B + bb) * 4 + cc] = vc;
       }
     }
-    __syncthreads();
+    sw_barrier();
     // dc1 = (cl1^T dlabel) * lrelu'(c1)  (waves 0,1) ; dl1 = (la1^T dcode) * lrelu'(l1)  (waves 2,3)
     {
       int m0 = 16 * (wave & 1);
@@ -339,7 +353,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
       st4(smem + (cls ? L.dc1 : L.dl1) + ln * LD32 + m0 + 4 * lg, acc);
       if (want_w && live) st4(ddelta + (cls ? dd.dc1 : dd.dl1) + ((size_t)k * B + b) * 32 + m0 + 4 * lg, acc);
     }
-    __syncthreads();
+    sw_barrier();
     // dboth = cl0^T dc1 + la0^T dl1   (wave w: rows 16w..)
     {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -353,7 +367,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
         st4(ddelta + dd.dpcode + ((size_t)k * B + b) * 32 + (u0 - 32) + 4 * lg, acc);
       }
     }
-    __syncthreads();
+    sw_barrier();
     // dq1 = (pe1^T dpcode) * lrelu'(q1)   (waves 0,1)
     if (wave < 2) {
       int m0 = 16 * wave;
@@ -365,7 +379,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
       st4(smem + L.dq1 + ln * LD32 + m0 + 4 * lg, acc);
       if (want_w && live) st4(ddelta + dd.dq1 + ((size_t)k * B + b) * 32 + m0 + 4 * lg, acc);
     }
-    __syncthreads();
+    sw_barrier();
     // dpred = pe0^T dq1   (4Tp rows)
     if (dpred) {
       for (int mt = wave; mt * 16 < K4; mt += 4) {
@@ -377,7 +391,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
     }
   }
   if (!want_w) return;
-  __syncthreads();
+  sw_barrier();
   // ---- observation path: of1, of0, LSTM BPTT -------------------------------------------------
   if (live && wave < 2) st4(ddelta + dd.docode + (size_t)b * 32 + u0 + 4 * lg, ld4(smem + L.docode + ln * LD32 + u0 + 4 * lg));
   if (wave < 2) {
@@ -390,7 +404,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
     st4(smem + L.do1 + ln * LD32 + m0 + 4 * lg, acc);
     if (live) st4(ddelta + dd.do1 + (size_t)b * 32 + m0 + 4 * lg, acc);
   }
-  __syncthreads();
+  sw_barrier();
   f32x4 dh = {0.f, 0.f, 0.f, 0.f}, dc = {0.f, 0.f, 0.f, 0.f};
   dh = tile_mm_rt(smem + L.of0T + (u0 + ln) * LD32 + 4 * lg, smem + L.do1 + ln * LD32 + 4 * lg, 2, dh);
   LstmWT WT;
@@ -411,7 +425,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
       st4(dgl + g * 64, dgate[g]);
       if (live) st4(dgg + g * 64, dgate[g]);
     }
-    __syncthreads();
+    sw_barrier();
     if (t > 0) dh = lstm_dh_prev(WT, &dgbuf[(t & 1) * 16 * SW_GLD + ln * SW_GLD + 4 * lg]);
   }
 }

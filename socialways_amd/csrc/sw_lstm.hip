@@ -33,7 +33,7 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
   if (h0) h = ld4(h0 + (size_t)b * 64 + u0 + 4 * lg);
   if (c0) c = ld4(c0 + (size_t)b * 64 + u0 + 4 * lg);
   st4(&hbuf[0][ln * SW_HLD + u0 + 4 * lg], h);
-  __syncthreads();
+  sw_barrier();
   LstmW W;
   lstm_load_w(W, enc_w + swp::ENC_WHH, wx_lds, bx_lds, u0, ln, lg);
 
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
       if (y) st4(y + ((size_t)b * T + t) * 64 + u0 + 4 * lg, h);
       if (x4s && wave == 0) x4s[((size_t)(t0 + t) * B + b) * 4 + lg] = xb;
     }
-    __syncthreads();
+    sw_barrier();
   }
   if (live) {
     st4(hT + (size_t)b * 64 + u0 + 4 * lg, h);
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_bwd_kernel(
       st4(dgl + g * 64, dgate[g]);
       if (live) st4(dgg + g * 64, dgate[g]);
     }
-    __syncthreads();
+    sw_barrier();
     dh = lstm_dh_prev(W, &dgbuf[t & 1][ln * SW_GLD + 4 * lg]);
   }
   if (live) {

@@ -73,16 +73,17 @@ __device__ __forceinline__ void lstm_load_w(LstmW& W, const float* Whh, const fl
 // On return gate[] holds the post-activation gates i,f,g,o, c the new cell state, h the new h.
 __device__ __forceinline__ void lstm_cell(const LstmW& W, float xb, const float* hrow, f32x4 gate[4],
                                           f32x4& c, f32x4& h) {
-  f32x4 acc[4];
+  f32x4 acc[4], b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b[j] = ld4(hrow + 16 * j);   // one LDS round trip for the whole step
 #pragma unroll
   for (int g = 0; g < 4; ++g) acc[g] = SW_MFMA(W.wx[g], xb, W.bias[g]);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    f32x4 b = ld4(hrow + 16 * j);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g] = SW_MFMA(W.whh[g][j][r], b[r], acc[g]);
+      for (int g = 0; g < 4; ++g) acc[g] = SW_MFMA(W.whh[g][j][r], b[j][r], acc[g]);
     }
   }
 #pragma unroll
@@ -134,14 +135,15 @@ __device__ __forceinline__ void lstm_load_wT(LstmWT& W, const float* Whh, int u0
 // dgrow = &dg_lds[ln*SW_GLD + 4*lg]
 __device__ __forceinline__ f32x4 lstm_dh_prev(const LstmWT& W, const float* dgrow) {
   f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 b[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) b[j] = ld4(dgrow + 16 * j);
 #pragma unroll
   for (int j = 0; j < 16; j += 2) {
-    f32x4 b0 = ld4(dgrow + 16 * j);
-    f32x4 b1 = ld4(dgrow + 16 * (j + 1));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      a0 = SW_MFMA(W.whhT[j][r], b0[r], a0);
-      a1 = SW_MFMA(W.whhT[j + 1][r], b1[r], a1);
+      a0 = SW_MFMA(W.whhT[j][r], b[j][r], a0);
+      a1 = SW_MFMA(W.whhT[j + 1][r], b[j + 1][r], a1);
     }
   }
   return a0 + a1;

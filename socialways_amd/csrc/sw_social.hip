@@ -113,7 +113,7 @@ __device__ __forceinline__ void scene_load_h_wh(float* smem, const float* h, con
     int a = n + (i >> 4), q = i & 15;
     st4(&hs[a * 68 + 4 * q], f32x4{0.f, 0.f, 0.f, 0.f});
   }
-  __syncthreads();
+  sw_barrier();
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
   f32x4 wr[4];
 #pragma unroll
@@ -123,7 +123,7 @@ __device__ __forceinline__ void scene_load_h_wh(float* smem, const float* h, con
     f32x4 acc = tile_mm_reg<4>(wr, &hs[(16 * at + ln) * 68 + 4 * lg], bias);
     st4(&wh[(16 * at + ln) * 68 + 16 * wave + 4 * lg], acc);
   }
-  __syncthreads();
+  sw_barrier();
 }
 // fc.0 weight|bias and fc.2 / fc.4 biases into LDS
 __device__ __forceinline__ void stage_pair_consts(float* smem, const float* emb_w) {
@@ -172,7 +172,7 @@ __device__ __forceinline__ void scene_softmax_pool(float* smem, int s0, int n, f
       if (attn) attn[(size_t)(s0 + i) * SW_AMAX + lane] = a;
     }
   }
-  __syncthreads();
+  sw_barrier();
   for (int e = threadIdx.x; e < n * 64; e += blockDim.x) {
     int i = e >> 6, u = e & 63;
     float acc = 0.f;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_fwd_kernel(
     part += __shfl_xor(part, 32);
     if (lg == 0 && pt * 16 + ln < P) sig[i * SW_AMAX + j] = (i == j) ? -1000.0f : part;  // train.py:170
   }
-  __syncthreads();
+  sw_barrier();
   scene_softmax_pool(smem, s0, n, S_out, attn);
 }
 
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
     int i = e / n, j = e - i * n;
     sig[i * SW_AMAX + j] = attn[(size_t)(s0 + i) * SW_AMAX + j];
   }
-  __syncthreads();
+  sw_barrier();
   // da_ij = <dS_i, h_j>;  dsigma_ij = a_ij (da_ij - sum_j' a_ij' da_ij')   (softmax backward)
   for (int i = wave; i < n; i += 4) {
     float da = 0.f, a = 0.f;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
     for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
     if (lane < n) dsg[i * SW_AMAX + lane] = a * (da - t);
   }
-  __syncthreads();
+  sw_barrier();
   // ---- pair tiles: recompute the MLP, back-propagate, leave rows for the deferred GEMMs --------
   PairW W;
   load_pair_w(W, emb_w, ln, lg);
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
     dwh[j * 68 + u] = acc;
     dwh_rows[(size_t)(s0 + j) * 64 + u] = acc;
   }
-  __syncthreads();
+  sw_barrier();
   // dh_j += sum_i a_ij dS_i  +  W^T dWh_j
   for (int e = threadIdx.x; e < n * 64; e += blockDim.x) {
     int j = e >> 6, u = e & 63;
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(SW_THREADS) void attention_pool_dense_kernel(
     }
     sig[i * SW_AMAX + j] = (i == j) ? -1000.0f : acc;
   }
-  __syncthreads();
+  sw_barrier();
   scene_softmax_pool(smem, s0, n, S_out, nullptr);
 }
 
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(SW_THREADS) void embed_features_kernel(const float*
   const float* w0b = smem + SocLds::w0b;
   const float* b12 = smem + SocLds::b12;
   stage_pair_consts(smem, emb_w);
-  __syncthreads();
+  sw_barrier();
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
   PairW W;
   load_pair_w(W, emb_w, ln, lg);

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(SW_THREADS) void wgrad_partial_kernel(WgBatch batch
   if (rbeg < rend) issue(rbeg);
   for (int r0 = rbeg; r0 < rend; r0 += Rc) {
     commit();
-    __syncthreads();
+    sw_barrier();
     if (r0 + Rc < rend) issue(r0 + Rc);
     const int gmax = min(Rc, (rend - r0 + 3) & ~3);
     for (int g = 0; g < gmax; g += 4) {
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(SW_THREADS) void wgrad_partial_kernel(WgBatch batch
         }
       }
     }
-    __syncthreads();
+    sw_barrier();
   }
   // partial of this slice: ws[ws_off + (s*N + n)*Kc + k]
   float* out = ws + P.ws_off + (size_t)s * N * Kc;

@@ -46,6 +46,7 @@ class SceneIndex:
             if len(cls._cache) > 4096:
                 cls._cache.clear()
             hit = cls._cache[key] = cls(sb, B, device)
+            hit.key = key
         return hit
 
 

@@ -31,7 +31,7 @@ from .model import Discriminator, Generator, predict_cv
 class SocialWaysTrainer:
     def __init__(self, n_next, hidden_size=64, lr_g=1e-4, lr_d=1e-3, n_unrolling_steps=1, use_social=True,
                  use_info_loss=True, loss_info_w=0.5, n_latent_codes=2, device="cuda", process_group=None,
-                 fused_adam=True):
+                 fused_adam=True, use_graph=None):
         self.device = torch.device(device)
         self.n_next = n_next
         self.noise_len = hidden_size // 2
@@ -41,14 +41,19 @@ class SocialWaysTrainer:
         # construction order = train.py:370-385 (RNG -> init mapping, optimizer parameter order)
         self.G = Generator(hidden_size, 1, use_social=use_social, device=self.device)
         self.G.unify()
+        self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
+        if use_graph is None:          # hipGraph replay of the step: single-GPU default
+            use_graph = self.device.type == "cuda" and self.world == 1 and fused_adam
+        self.use_graph = bool(use_graph)
+        self._graphs = {}
         adam_kw = dict(betas=(0.9, 0.999))
         if fused_adam and self.device.type == "cuda":
             adam_kw["fused"] = True
+            adam_kw["capturable"] = self.use_graph
         self.predictor_optimizer = opt.Adam(self.G.predictor_params(), lr=lr_g, **adam_kw)
         self.D = Discriminator(n_next, hidden_size, n_latent_codes, device=self.device)
         self.D_optimizer = opt.Adam(self.D.parameters(), lr=lr_d, **adam_kw)
         self.pg = process_group
-        self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
         self.rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
         self.ws = ops.Workspaces(self.device)
         self._lin_mask = None
@@ -65,26 +70,69 @@ class SocialWaysTrainer:
 
     def step(self, obsv, pred, sub_batches, zeros_val, ones_val, noise, ss=1.0, global_B=None, out=None):
         """One packed batch (train.py:458-554) on this rank's rows.  obsv (B,To,2), pred (B,Tp,2) and
-        noise (B,32) are device tensors; `global_B` = agents of the whole packed batch over all ranks.
+        noise (B,32) are tensors (noise may live on the host, like train.py:473); `global_B` = agents
+        of the whole packed batch over all ranks.
         Returns a (4,3) device tensor `out`: rows = D update 0, D update 1, G phase, ADE/FDE;
-        loss rows hold SUMS of squared errors over the local rows [label_a, code, label_b]."""
+        loss rows hold SUMS of squared errors over the local rows [label_a, code, label_b].
+        With `use_graph` (default on a single GPU) the whole step - ~45 kernels incl. the three Adam
+        updates - is captured once per batch shape into a hipGraph and replayed: the host then only
+        refreshes the inputs (tracks, z, the two label-noise scalars)."""
+        B = obsv.shape[0]
+        Bg = float(global_B if global_B is not None else B)
+        dev = self.device
+        if self.use_graph:
+            return self._step_graph(obsv, pred, sub_batches, zeros_val, ones_val, noise, float(ss), Bg, out)
+        if out is None:
+            out = torch.zeros(self.n_unrolling_steps + 3, 3, device=dev)
+        scenes = ops.SceneIndex.get(sub_batches, B, dev)
+        noise = noise.to(dev, non_blocking=True).contiguous()
+        # label-noise scalars of train.py:471-472 live in device memory: [zeros_val, ones_val]
+        targets = torch.tensor([float(zeros_val), float(ones_val)], dtype=torch.float32).to(dev, non_blocking=True)
+        return self._step_impl(obsv, pred, scenes, targets, noise, float(ss), Bg, out)
+
+    def _step_graph(self, obsv, pred, sub_batches, zeros_val, ones_val, noise, ss, Bg, out):
+        B, To = obsv.shape[0], obsv.shape[1]
+        dev = self.device
+        scenes = ops.SceneIndex.get(sub_batches, B, dev)
+        key = (scenes.key, To, ss, Bg)
+        st = self._graphs.get(key)
+        if st is None:
+            st = self._graphs[key] = dict(
+                n=0, graph=None, scenes=scenes, obsv=torch.empty(B, To, 2, device=dev),
+                pred=torch.empty(B, self.n_next, 2, device=dev), noise=torch.empty(B, self.noise_len, device=dev),
+                targets=torch.empty(2, device=dev), out=torch.zeros(self.n_unrolling_steps + 3, 3, device=dev),
+                host=torch.empty(2, dtype=torch.float32).pin_memory())
+        st["obsv"].copy_(obsv)
+        st["pred"].copy_(pred)
+        st["noise"].copy_(noise, non_blocking=True)
+        st["host"][0], st["host"][1] = float(zeros_val), float(ones_val)
+        st["targets"].copy_(st["host"], non_blocking=True)
+        if st["graph"] is not None:
+            st["graph"].replay()
+        elif st["n"] < 2:          # first steps of a shape run eagerly (lazy inits, workspace growth)
+            st["n"] += 1
+            self._step_impl(st["obsv"], st["pred"], scenes, st["targets"], st["noise"], ss, Bg, st["out"])
+        else:
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                self._step_impl(st["obsv"], st["pred"], scenes, st["targets"], st["noise"], ss, Bg, st["out"])
+            st["graph"] = g
+            g.replay()             # capture only records: this replay IS the step
+        if out is None:
+            return st["out"].clone()
+        out.copy_(st["out"])
+        return out
+
+    def _step_impl(self, obsv, pred, scenes, targets, noise, ss, Bg, out):
+        """Device-only body of the step (no host syncs, no host-dependent values: capturable)."""
         G, D = self.G, self.D
         B, Tp = obsv.shape[0], self.n_next
-        Bg = float(global_B if global_B is not None else B)
         dev = self.device
         st = L.stream()
         ws = self.ws
-        if out is None:
-            out = torch.zeros(self.n_unrolling_steps + 3, 3, device=dev)
         g_label = 1.0 / Bg
         g_code = (self.loss_info_w if self.use_info_loss else 0.0) / (2.0 * Bg)
-        scenes = ops.SceneIndex.get(sub_batches, B, dev)
-        noise = noise.contiguous()
-        # label-noise scalars of train.py:471-472 live in device memory: [zeros_val, ones_val]
-        if torch.is_tensor(zeros_val):
-            targets = zeros_val
-        else:
-            targets = torch.tensor([float(zeros_val), float(ones_val)], dtype=torch.float32).to(dev, non_blocking=True)
         # real future as 4-d (train.py:470); the observation stays 2-d: kernels form (p, v) on the fly
         pred4 = torch.empty(B, Tp, 4, device=dev)
         o4_scratch = ws.get("o4", B * obsv.shape[1] * 4)
