@@ -155,11 +155,11 @@ __global__ __launch_bounds__(SW_THREADS) void wgrad_partial_kernel(WgBatch batch
   }
 }
 
-// out element e of problem p = sum over slices, 8 lanes per element (slices q = lane&7, +8, ...),
+// out element e of problem p = sum over slices, 16 lanes per element (slices q = lane&15, +16, ...),
 // combined by a fixed shuffle tree.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgBatch batch, const float* __restrict__ ws) {
   int gid = blockIdx.x * 256 + threadIdx.x;
-  int i = gid >> 3, sub = gid & 7;
+  int i = gid >> 4, sub = gid & 15;
   bool live = i < batch.total_out;
   int ii = live ? i : batch.total_out - 1;
   int p = 0;
@@ -171,10 +171,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgBatch batch, const 
   const size_t stride = (size_t)P.N * Kc;
   const float* src = ws + P.ws_off + e;
   float s = 0.f;
-  for (int q = sub; q < P.nsplit; q += 8) s += src[(size_t)q * stride];
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int q = sub;
+  for (; q + 48 < P.nsplit; q += 64) {  // 4 independent loads in flight per lane, fixed combination order
+    s += src[(size_t)q * stride];
+    s1 += src[(size_t)(q + 16) * stride];
+    s2 += src[(size_t)(q + 32) * stride];
+    s3 += src[(size_t)(q + 48) * stride];
+  }
+  for (; q < P.nsplit; q += 16) s += src[(size_t)q * stride];
+  s = (s + s1) + (s2 + s3);
   s += __shfl_xor(s, 1);
   s += __shfl_xor(s, 2);
   s += __shfl_xor(s, 4);
+  s += __shfl_xor(s, 8);
   if (!live || sub != 0) return;
   int n = e / Kc, k = e - n * Kc;
   if (k < P.K) {
@@ -253,7 +263,7 @@ int wg_launch(WgBatch& b, float* ws, hipStream_t stream) {
   if (b.total_jobs == 0 || b.total_out == 0) return SW_OK;
   hipLaunchKernelGGL(wgrad_partial_kernel, dim3(b.total_jobs), dim3(SW_THREADS), WG_LDS_FLOATS * 4, stream, b, ws);
   SW_CHECK_LAUNCH("wgrad_partial_kernel");
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((b.total_out * 8 + 255) / 256), dim3(256), 0, stream, b, ws);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((b.total_out * 16 + 255) / 256), dim3(256), 0, stream, b, ws);
   SW_CHECK_LAUNCH("wgrad_reduce_kernel");
   return SW_OK;
 }

@@ -372,6 +372,15 @@ class Generator(nn.Module):
         for m in (self.attention, self.feature_embedder, self.encoder, self.decoder):
             m.grad_views()
 
+    def packed_slices(self):
+        """[(offset, numel, shape)] of every parameter inside the unified buffer, optimizer order."""
+        out = []
+        base = self._flat_all.data_ptr()
+        for m in (self.attention, self.feature_embedder, self.encoder, self.decoder):
+            moff = (m._flat.data_ptr() - base) // 4
+            out += [(moff + off, k, tuple(p.shape)) for (off, k), p in zip(m._slices, m.parameters())]
+        return out
+
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
         if getattr(self, "_flat_all", None) is not None:

@@ -28,6 +28,77 @@ from .data import shard_scenes
 from .model import Discriminator, Generator, predict_cv
 
 
+class PackedAdam:
+    """torch.optim.Adam over ONE packed parameter buffer - one fused multi-tensor kernel launch per
+    update instead of a 20-tensor list - that still reads and writes the reference's per-parameter
+    optimizer state_dict (train.py:659,662 / 631,634): `slices` = [(offset, numel, shape)] in the
+    reference's parameter order.  Padding floats have zero gradients and stay zero."""
+
+    CHUNK = 2048   # torch's multi-tensor Adam gives one workgroup per (tensor, 64K chunk): feed it many small views
+
+    def __init__(self, flat, gflat, slices, lr, betas=(0.9, 0.999), fused=True, capturable=False):
+        self.slices = slices
+        self.flat = flat
+        n, c = flat.numel(), self.CHUNK
+        self.ps = []
+        for o in range(0, n, c):
+            p = torch.nn.Parameter(flat[o:min(o + c, n)], requires_grad=True)   # shares storage with the packed buffer
+            p.grad = gflat[o:min(o + c, n)]
+            self.ps.append(p)
+        kw = dict(fused=True, capturable=capturable) if fused else {}
+        self.inner = opt.Adam(self.ps, lr=lr, betas=betas, **kw)
+
+    def step(self):
+        self.inner.step()
+
+    def zero_grad(self, set_to_none=False):
+        for p in self.ps:
+            p.grad.zero_()
+
+    @property
+    def param_groups(self):
+        return self.inner.param_groups
+
+    def _flat_state(self, key):
+        return torch.cat([self.inner.state[p][key].reshape(-1) for p in self.ps])
+
+    def state_dict(self):
+        g = {k: v for k, v in self.inner.param_groups[0].items() if k != "params"}
+        g["params"] = list(range(len(self.slices)))
+        state = {}
+        if self.inner.state.get(self.ps[0]):
+            m, v = self._flat_state("exp_avg"), self._flat_state("exp_avg_sq")
+            step = self.inner.state[self.ps[0]]["step"]
+            for i, (off, n, shape) in enumerate(self.slices):
+                state[i] = {"step": step.detach().clone(), "exp_avg": m[off:off + n].view(shape).clone(),
+                            "exp_avg_sq": v[off:off + n].view(shape).clone()}
+        return {"state": state, "param_groups": [g]}
+
+    def load_state_dict(self, sd):
+        grp = sd["param_groups"][0]
+        for k in ("lr", "betas", "eps", "weight_decay", "amsgrad", "maximize"):
+            if k in grp:
+                self.inner.param_groups[0][k] = grp[k]
+        state = sd.get("state", {})
+        if not state:
+            self.inner.state.clear()
+            return
+        dev = self.flat.device
+        m, v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        step = None
+        for i, (off, n, shape) in enumerate(self.slices):
+            e = state[i] if i in state else state[str(i)]
+            m[off:off + n] = e["exp_avg"].to(dev).reshape(-1)
+            v[off:off + n] = e["exp_avg_sq"].to(dev).reshape(-1)
+            step = e["step"]
+        capt = bool(self.inner.param_groups[0].get("capturable", False))
+        c = self.CHUNK
+        for k, p in enumerate(self.ps):
+            self.inner.state[p] = {"step": torch.as_tensor(float(step), dtype=torch.float32, device=dev if capt else "cpu"),
+                                   "exp_avg": m[k * c:k * c + p.numel()].clone(),
+                                   "exp_avg_sq": v[k * c:k * c + p.numel()].clone()}
+
+
 class SocialWaysTrainer:
     def __init__(self, n_next, hidden_size=64, lr_g=1e-4, lr_d=1e-3, n_unrolling_steps=1, use_social=True,
                  use_info_loss=True, loss_info_w=0.5, n_latent_codes=2, device="cuda", process_group=None,
@@ -46,13 +117,19 @@ class SocialWaysTrainer:
             use_graph = self.device.type == "cuda" and self.world == 1 and fused_adam
         self.use_graph = bool(use_graph)
         self._graphs = {}
-        adam_kw = dict(betas=(0.9, 0.999))
-        if fused_adam and self.device.type == "cuda":
-            adam_kw["fused"] = True
-            adam_kw["capturable"] = self.use_graph
-        self.predictor_optimizer = opt.Adam(self.G.predictor_params(), lr=lr_g, **adam_kw)
+        packed = fused_adam and self.device.type == "cuda"
+        if packed:
+            self.predictor_optimizer = PackedAdam(self.G._flat_all, self.G._gflat_all, self.G.packed_slices(), lr_g,
+                                                  capturable=self.use_graph)
+        else:       # per-parameter torch Adam (CPU tests, literal autograd formulation)
+            self.predictor_optimizer = opt.Adam(self.G.predictor_params(), lr=lr_g, betas=(0.9, 0.999))
         self.D = Discriminator(n_next, hidden_size, n_latent_codes, device=self.device)
-        self.D_optimizer = opt.Adam(self.D.parameters(), lr=lr_d, **adam_kw)
+        if packed:
+            self.D_optimizer = PackedAdam(self.D._flat, self.D._gflat,
+                                          [(off, k, tuple(p.shape)) for (off, k), p in
+                                           zip(self.D._slices, self.D.parameters())], lr_d, capturable=self.use_graph)
+        else:
+            self.D_optimizer = opt.Adam(self.D.parameters(), lr=lr_d, betas=(0.9, 0.999))
         self.pg = process_group
         self.rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
         self.ws = ops.Workspaces(self.device)
@@ -101,12 +178,34 @@ class SocialWaysTrainer:
                 n=0, graph=None, scenes=scenes, obsv=torch.empty(B, To, 2, device=dev),
                 pred=torch.empty(B, self.n_next, 2, device=dev), noise=torch.empty(B, self.noise_len, device=dev),
                 targets=torch.empty(2, device=dev), out=torch.zeros(self.n_unrolling_steps + 3, 3, device=dev),
-                host=torch.empty(2, dtype=torch.float32).pin_memory())
+                copy_stream=torch.cuda.Stream(device=dev),
+                ring=[(torch.empty(2 + B * self.noise_len, dtype=torch.float32).pin_memory(),
+                       torch.empty(2 + B * self.noise_len, dtype=torch.float32, device=dev),
+                       torch.cuda.Event(), torch.cuda.Event()) for _ in range(4)])
         st["obsv"].copy_(obsv)
         st["pred"].copy_(pred)
-        st["noise"].copy_(noise, non_blocking=True)
-        st["host"][0], st["host"][1] = float(zeros_val), float(ones_val)
-        st["targets"].copy_(st["host"], non_blocking=True)
+        # Host inputs (z, the two label-noise scalars): pinned slot -> device slot on a side COPY stream
+        # (overlaps the previous step's graph), then a device-to-device copy into the graph's static
+        # inputs on the main stream.  A host-to-device copy enqueued on the main stream behind a graph
+        # launch makes the host wait for that graph on ROCm, which would serialise host RNG and GPU.
+        if noise.is_cuda:
+            st["noise"].copy_(noise)
+            st["targets"].copy_(torch.tensor([float(zeros_val), float(ones_val)]), non_blocking=True)
+        else:
+            k = st["k"] = (st.get("k", -1) + 1) % len(st["ring"])
+            host, devslot, ready, consumed = st["ring"][k]
+            ready.synchronize()                                # the H2D copy that last read this pinned slot is done
+            host[0], host[1] = float(zeros_val), float(ones_val)
+            np.copyto(host[2:].view(B, self.noise_len).numpy(), noise.numpy())   # plain memcpy
+            main = torch.cuda.current_stream()
+            with torch.cuda.stream(st["copy_stream"]):
+                st["copy_stream"].wait_event(consumed)         # the main stream has read this device slot
+                devslot.copy_(host, non_blocking=True)
+                ready.record(st["copy_stream"])
+            main.wait_event(ready)
+            st["targets"].copy_(devslot[:2])
+            st["noise"].copy_(devslot[2:].view(B, self.noise_len))
+            consumed.record(main)
         if st["graph"] is not None:
             st["graph"].replay()
         elif st["n"] < 2:          # first steps of a shape run eagerly (lazy inits, workspace growth)
@@ -320,6 +419,9 @@ class SocialWaysTrainer:
         self.D.load_state_dict(ck['D_dict'])
         for key, optim in (('pred_optimizer', self.predictor_optimizer), ('D_optimizer', self.D_optimizer)):
             if key in ck:
+                if isinstance(optim, PackedAdam):
+                    optim.load_state_dict(ck[key])
+                    continue
                 keep = {k: optim.param_groups[0].get(k) for k in ('fused', 'foreach', 'capturable')}
                 optim.load_state_dict(copy.deepcopy(ck[key]))
                 for k, v in keep.items():
