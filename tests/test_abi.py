@@ -1,0 +1,128 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/socialways_hip.h declares;
+the packed-weight layout it reports is the one the Python modules pack their state_dicts into."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "socialways_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sw_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_header_symbol():
+    from socialways_amd import _lib as L
+    lib = L.load()
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for name in syms:
+        assert hasattr(lib, name), "include/socialways_hip.h declares %s but the library does not export it" % name
+    assert sorted(L.PROTOTYPES) == syms, "socialways_amd/_lib.py binds exactly the header's entry points"
+    assert lib.sw_version() >= 1
+    assert isinstance(lib.sw_last_error(), bytes)
+
+
+def test_argument_validation_without_gpu():
+    """Entry points reject bad arguments before touching the device (no compute call is made here)."""
+    from socialways_amd import _lib as L
+    lib = L.load()
+    assert lib.sw_traj_4d(None, None, 4, 8, 12, None, None, None) == -1
+    assert lib.sw_enc_lstm_fwd(None, 0, None, None, None, 4, 8, None, None, None, None, None, 0, None) == -1
+    assert lib.sw_param_count(99, 12) == -1 and lib.sw_param_offset(0, 99, 1) == -1
+    assert lib.sw_gan_loss(None, None, 0, None, None, None, 0, 8, 1.0, 1.0, None, None, None, None, None, None) == -1
+
+
+@pytest.mark.parametrize("tp", [2, 12])
+def test_packed_layout_matches_state_dicts(tp):
+    """Packed buffers = state_dict tensors in key order on 4-float boundaries (SURVEY.md §2.2 shapes)."""
+    import socialways_amd as sw
+    from socialways_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(0)
+    G = sw.Generator()
+    D = sw.Discriminator(tp, 64, 2)
+    for grp, mod, n_ref in ((L.GRP_ENC, G.encoder, 33600), (L.GRP_EMB, G.feature_embedder, 6400),
+                            (L.GRP_ATT, G.attention, 4160), (L.GRP_DEC, G.decoder, 41962),
+                            (L.GRP_DISC, D, 27939 if tp == 12 else 26659)):
+        sd = mod.state_dict()
+        assert sum(v.numel() for v in sd.values()) == n_ref
+        assert lib.sw_param_tensors(grp) == len(sd)
+        flat = mod._flat
+        assert flat.numel() == lib.sw_param_count(grp, tp)
+        end = 0
+        for i, (k, v) in enumerate(sd.items()):
+            off = lib.sw_param_offset(grp, i, tp)
+            assert off % 4 == 0 and off >= end, (k, off)
+            assert torch.equal(flat[off:off + v.numel()].view(v.shape), v), k
+            assert v.data_ptr() == flat.data_ptr() + 4 * off, "%s is a view of the packed buffer" % k
+            end = off + v.numel()
+    # load_state_dict writes through to the packed buffer
+    sd = {k: torch.randn_like(v) for k, v in D.state_dict().items()}
+    D.load_state_dict(sd)
+    off = lib.sw_param_offset(L.GRP_DISC, 19, tp)
+    assert torch.equal(D._flat[off:off + 2], sd["latent_decoder.2.bias"])
+
+
+def test_state_dict_keys_equal_reference_modules():
+    import socialways_amd as sw
+    import sw_oracle as O
+    G, D = sw.Generator(), sw.Discriminator(12, 64, 2)
+    o = O.SocialWaysOracle(12)
+    for a, b in ((G.encoder, o.encoder), (G.feature_embedder, o.feature_embedder), (G.attention, o.attention),
+                 (G.decoder, o.decoder), (D, o.D)):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        assert [tuple(v.shape) for v in sa.values()] == [tuple(v.shape) for v in sb.values()]
+
+
+def test_same_seed_same_initial_weights_as_reference_order():
+    """Construction order encoder, feature_embedder, attention, decoder, D on the CPU generator
+    (train.py:370-385): seed 0 reproduces the reference's initial weights bit for bit."""
+    import socialways_amd as sw
+    from _util import golden, state_from
+    g = golden("toy_b64_on")
+    torch.manual_seed(0)
+    G = sw.Generator()
+    D = sw.Discriminator(2, 64, 2)
+    w0 = state_from(g, "w0.")
+    for name, mod in (("encoder", G.encoder), ("feature_embedder", G.feature_embedder), ("attention", G.attention),
+                      ("decoder", G.decoder), ("D", D)):
+        for k, v in mod.state_dict().items():
+            assert torch.equal(v, w0[name][k]), (name, k)
+
+
+def test_workspace_sizes():
+    from socialways_amd import _lib as L
+    B, To, Tp = 2048, 8, 12
+    assert L.workspace_floats(L.WS_GSAVE, B, To, Tp) == B * ((To + Tp - 1) * 388 + Tp * 280)
+    assert L.workspace_floats(L.WS_GDELTA, B, To, Tp) == B * ((To + Tp - 1) * 256 + Tp * 284 + 160)
+    assert L.workspace_floats(L.WS_PAIRS, B, To, Tp, 1, 16384) == B * 64 + 16384 * 324
+    assert L.workspace_floats(L.WS_DSAVE, B, To, Tp, 2) > L.workspace_floats(L.WS_DSAVE, B, To, Tp, 1)
+
+
+def test_no_cpu_fallback():
+    """The product path fails loudly on CPU tensors / without the library; it never computes on the host."""
+    import socialways_amd as sw
+    G = sw.Generator(use_social=True)
+    with pytest.raises(sw.SocialWaysHipError):
+        G(torch.rand(4, 8, 2), torch.rand(4, 32), 12, [[0, 4]])
+    with pytest.raises(sw.SocialWaysHipError):
+        sw.get_traj_4d(torch.rand(4, 8, 2), [])
+    with pytest.raises(sw.SocialWaysHipError):
+        sw.Discriminator(12, 64, 2)(torch.rand(4, 8, 4), torch.rand(4, 12, 4))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "socialways_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "sw_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
