@@ -113,10 +113,11 @@ class SocialWaysTrainer:
         self.G = Generator(hidden_size, 1, use_social=use_social, device=self.device)
         self.G.unify()
         self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
-        if use_graph is None:          # hipGraph replay of the step: single-GPU default
-            use_graph = self.device.type == "cuda" and self.world == 1 and fused_adam
+        if use_graph is None:          # hipGraph replay of the step (segmented around the all-reduces when world > 1)
+            use_graph = self.device.type == "cuda" and fused_adam
         self.use_graph = bool(use_graph)
         self._graphs = {}
+        self._force_dist = os.environ.get("SW_FORCE_DIST", "") == "1"   # 1-rank group still runs the collectives (tests)
         packed = fused_adam and self.device.type == "cuda"
         if packed:
             self.predictor_optimizer = PackedAdam(self.G._flat_all, self.G._gflat_all, self.G.packed_slices(), lr_g,
@@ -142,7 +143,7 @@ class SocialWaysTrainer:
         return self.G.use_social
 
     def _allreduce(self, flat):
-        if self.pg is not None and self.world > 1:
+        if self.pg is not None and (self.world > 1 or self._force_dist):
             torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
     def step(self, obsv, pred, sub_batches, zeros_val, ones_val, noise, ss=1.0, global_B=None, out=None):
@@ -207,35 +208,62 @@ class SocialWaysTrainer:
             st["noise"].copy_(devslot[2:].view(B, self.noise_len))
             consumed.record(main)
         if st["graph"] is not None:
-            st["graph"].replay()
+            for g, buf in st["graph"]:
+                g.replay()
+                if buf is not None:
+                    self._allreduce(buf)
         elif st["n"] < 2:          # first steps of a shape run eagerly (lazy inits, workspace growth)
             st["n"] += 1
             self._step_impl(st["obsv"], st["pred"], scenes, st["targets"], st["noise"], ss, Bg, st["out"])
         else:
-            g = torch.cuda.CUDAGraph()
+            # Capture.  Single GPU: one graph for the whole step.  Data parallel: one graph per segment
+            # between the all-reduce points (the collectives themselves stay eager: no RCCL-in-graph
+            # dependency), all segments sharing one memory pool so intermediates stay alive.
             torch.cuda.synchronize()
-            with torch.cuda.graph(g):
-                self._step_impl(st["obsv"], st["pred"], scenes, st["targets"], st["noise"], ss, Bg, st["out"])
-            st["graph"] = g
-            g.replay()             # capture only records: this replay IS the step
+            gen = self._step_gen(st["obsv"], st["pred"], scenes, st["targets"], st["noise"], ss, Bg, st["out"])
+            graphs, pool, done = [], None, False
+            while not done:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    while True:
+                        try:
+                            buf = next(gen)
+                        except StopIteration:
+                            buf, done = None, True
+                        if done or self.world > 1 or self._force_dist:
+                            break
+                graphs.append((g, buf))
+                pool = g.pool()
+            st["graph"] = graphs
+            for g, buf in graphs:      # capture only records: this replay IS the step
+                g.replay()
+                if buf is not None:
+                    self._allreduce(buf)
         if out is None:
             return st["out"].clone()
         out.copy_(st["out"])
         return out
 
     def _step_impl(self, obsv, pred, scenes, targets, noise, ss, Bg, out):
-        """Device-only body of the step (no host syncs, no host-dependent values: capturable)."""
+        """Eager step: run the segments, all-reducing the packed gradient buffer each one hands back."""
+        for buf in self._step_gen(obsv, pred, scenes, targets, noise, ss, Bg, out):
+            self._allreduce(buf)
+        return out
+
+    def _step_gen(self, obsv, pred, scenes, targets, noise, ss, Bg, out):
+        """Device-only body of the step (no host syncs, no host-dependent values: capturable) as a
+        generator: it yields the packed gradient buffer at each of the 3 points where data-parallel
+        ranks must all-reduce before the optimizer step (D, D, G)."""
         G, D = self.G, self.D
         B, Tp = obsv.shape[0], self.n_next
         dev = self.device
-        st = L.stream()
         ws = self.ws
         g_label = 1.0 / Bg
         g_code = (self.loss_info_w if self.use_info_loss else 0.0) / (2.0 * Bg)
         # real future as 4-d (train.py:470); the observation stays 2-d: kernels form (p, v) on the fly
         pred4 = torch.empty(B, Tp, 4, device=dev)
         o4_scratch = ws.get("o4", B * obsv.shape[1] * 4)
-        L.call("sw_traj_4d", L.ptr(obsv), L.ptr(pred), B, obsv.shape[1], Tp, L.ptr(o4_scratch), L.ptr(pred4), st)
+        L.call("sw_traj_4d", L.ptr(obsv), L.ptr(pred), B, obsv.shape[1], Tp, L.ptr(o4_scratch), L.ptr(pred4), L.stream())
         # ---- generator rollout, once (train.py:480/507 are identical, SURVEY §0.11) ---------------
         enc, emb, att, dec = G.encoder, G.feature_embedder, G.attention, G.decoder
         pred_hat, gctx = ops.gen_forward(enc._flat, emb._flat, att._flat, dec._flat, obsv, noise, scenes, Tp,
@@ -250,9 +278,9 @@ class SocialWaysTrainer:
         for u in range(self.n_unrolling_steps + 1):
             labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat, pred4], save=True, ws=ws)
             L.call("sw_gan_loss", L.ptr(labels[0]), L.ptr(targets), 0, L.ptr(codes[0]), L.ptr(noise), L.ptr(labels[1]),
-                   1, B, g_label, g_code, L.ptr(out[u]), L.ptr(dl_f), L.ptr(dc_f), L.ptr(dl_r), L.ptr(dc_r), st)
+                   1, B, g_label, g_code, L.ptr(out[u]), L.ptr(dl_f), L.ptr(dc_f), L.ptr(dl_r), L.ptr(dc_r), L.stream())
             ops.disc_backward(D._flat, dctx, [dl_f, dl_r], [dc_f, dc_r], d_gflat, (), ws=ws)
-            self._allreduce(d_gflat)
+            yield d_gflat
             self.D_optimizer.step()
             if u == 0 and self.n_unrolling_steps > 0:
                 backup = ws.get("d_backup", D._flat.numel())
@@ -260,12 +288,12 @@ class SocialWaysTrainer:
         # ---- generator update (train.py:503-539) ----------------------------------------------------
         labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat], save=True, ws=ws)
         L.call("sw_gan_loss", L.ptr(labels[0]), L.ptr(targets), 1, L.ptr(codes[0]), L.ptr(noise), None, 1, B, g_label,
-               g_code, L.ptr(out[self.n_unrolling_steps + 1]), L.ptr(dl_f), L.ptr(dc_f), None, None, st)
+               g_code, L.ptr(out[self.n_unrolling_steps + 1]), L.ptr(dl_f), L.ptr(dc_f), None, None, L.stream())
         dpred = ops.disc_backward(D._flat, dctx, [dl_f], [dc_f], None, (True,), ws=ws)[0]
         G.grad_views()
         ops.gen_backward(enc._flat, emb._flat, att._flat, dec._flat, gctx, dpred, enc._gflat, emb._gflat, att._gflat,
                          dec._gflat, ws=ws)
-        self._allreduce(G._gflat_all)
+        yield G._gflat_all
         self.predictor_optimizer.step()
         if self.n_unrolling_steps > 0:                                       # D.load(backup), Linear only
             if self._lin_mask is None:
@@ -273,9 +301,8 @@ class SocialWaysTrainer:
             D._flat.copy_(torch.where(self._lin_mask, backup[:D._flat.numel()], D._flat))
         # ---- ADE/FDE partial sums of the G-phase prediction (train.py:546-551) ---------------------
         L.call("sw_ade_fde", L.ptr(pred_hat), L.ptr(pred), B, Tp, 1.0 / float(ss), L.ptr(out[self.n_unrolling_steps + 2]),
-               st)
+               L.stream())
         self.last_pred_hat = pred_hat
-        return out
 
     # ------------------------------------------------------------------------------------------
     def losses_from(self, out, B_global, Tp=None, ss=1.0):
