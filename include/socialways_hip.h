@@ -111,10 +111,13 @@ int sw_dec_rollout_fwd(const float* obsv /*[B,To,2]*/, int To, const float* z /*
 int sw_dec_rollout_bwd(const float* dpred4 /*[B,Tp,4]*/, const float* enc_w, const float* dec_w,
                        const float* gsave, int B, int To, int Tp, float* gdelta,
                        float* dhT, float* dcT, float* dS_pool /*[B,64]*/, void* stream);
-/* weight gradients of the whole generator rollout (encoder + decoder) from gsave/gdelta */
+/* weight gradients of the whole generator rollout (encoder + decoder) from gsave/gdelta.
+ * part 0 = all; 1 = what dec_rollout_bwd produced (decoder layers + LSTM rows t >= To); 2 = LSTM rows
+ * t < To (after enc_lstm_bwd) accumulated onto part 1, then the embed / W_ih split.  Parts 1 and 2
+ * may run on different streams with different `wgrad_ws`; `tmp` (2048 floats) links them.        */
 int sw_gen_wgrad(const float* enc_w, const float* gsave, const float* gdelta, const float* z,
-                 const float* S_pool, int B, int To, int Tp, float* d_enc_w, float* d_dec_w,
-                 float* wgrad_ws, void* stream);
+                 const float* S_pool, int B, int To, int Tp, float* d_enc_w, float* d_dec_w, int part,
+                 float* wgrad_ws, float* tmp /*[2048]*/, void* stream);
 
 /* ---- Discriminator.forward (train.py:294-309) for nb prediction branches sharing one
  *      observation encoding (fake / real of the same batch) ----------------------------------- */

@@ -252,16 +252,33 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
   float dpx = 0.f, dpy = 0.f;
 
   for (int i = Tp - 1; i >= 0; --i) {
-    float dxp0 = 0.f, dxp1 = 0.f, dxv0 = 0.f, dxv1 = 0.f;  // gradient through the LSTM input (p_i, v_i)
+    // ---- prefetch everything this iteration reads from HBM/L2 (saved activations, upstream grad):
+    //      the loads fly under the LSTM-step MFMAs instead of stalling each decoder layer ----------
+    f32x4 gate[4], ct, cprev;
+    if (i < Tp - 1) {
+      const float* row = gsave + gs.act + ((size_t)(To + i) * B + b) * 384 + u0 + 4 * lg;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gate[g] = ld4(row + g * 64);
+      ct = ld4(row + 256);
+      cprev = ld4(row - (size_t)B * 384 + 256);
+    }
+    f32x4 a2pre[2], a1pre[3];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      int mt = wave + 4 * q;
+      a2pre[q] = mt < 5 ? ld4(gsave + gs.a2 + ((size_t)i * B + b) * 80 + mt * 16 + 4 * lg) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      int mt = wave + 4 * q;
+      a1pre[q] = mt < 10 ? ld4(gsave + gs.a1 + ((size_t)i * B + b) * 160 + mt * 16 + 4 * lg) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const f32x4 g4 = ld4(dpred4 + ((size_t)b * Tp + i) * 4);  // every wave keeps its own copy of the p/v gradient state
+    f32x4 dx4 = {0.f, 0.f, 0.f, 0.f};  // gradient through the LSTM input (p_i, v_i)
     if (i < Tp - 1) {
       // ---- LSTM step t = To+i (consumed x4_i, produced h_t) --------------------------------
       const int t = To + i;
-      const float* row = gsave + gs.act + ((size_t)t * B + b) * 384 + u0 + 4 * lg;
-      f32x4 gate[4], dgate[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) gate[g] = ld4(row + g * 64);
-      f32x4 ct = ld4(row + 256);
-      f32x4 cprev = ld4(row - (size_t)B * 384 + 256);
+      f32x4 dgate[4];
       lstm_cell_bwd(gate, ct, cprev, dh, dc, dgate);
       float* dgg = gdelta + gd.dgates + ((size_t)t * B + b) * 256 + u0 + 4 * lg;
 #pragma unroll
@@ -278,42 +295,37 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
         if (lg == 0) st4(&dxpart[(wave * 16 + ln) * 4], acc);
       }
       sw_barrier();
-      if (wave == 0 && lg == 0) {
-        f32x4 s = ld4(&dxpart[ln * 4]) + ld4(&dxpart[(16 + ln) * 4]) + ld4(&dxpart[(32 + ln) * 4]) +
-                  ld4(&dxpart[(48 + ln) * 4]);
-        dxp0 = s[0]; dxp1 = s[1]; dxv0 = s[2]; dxv1 = s[3];
-      }
+      dx4 = ld4(&dxpart[ln * 4]) + ld4(&dxpart[(16 + ln) * 4]) + ld4(&dxpart[(32 + ln) * 4]) +
+            ld4(&dxpart[(48 + ln) * 4]);
     }
-    // ---- decoder step i ----------------------------------------------------------------------
-    if (wave == 0 && lg == 0) {
-      f32x4 g4 = ld4(dpred4 + ((size_t)b * Tp + i) * 4);
-      dpx += g4[0] + dxp0;  // dL/dp_i  (p_i also feeds p_{i+1}: carried in dpx)
-      dpy += g4[1] + dxp1;
-      float dvx = g4[2] + dxv0 + dpx;  // p_i = p_{i-1} + v_i
-      float dvy = g4[3] + dxv1 + dpy;
-      dvbuf[ln * LD2 + 0] = dvx;
-      dvbuf[ln * LD2 + 1] = dvy;
-      if (live) {
-        f32x4 o = {dvx, dvy, 0.f, 0.f};
-        st4(gdelta + gd.dv + ((size_t)i * B + b) * 4, o);
-      }
+    // ---- decoder step i: dv (registers, every wave) -> da3 = W4^T dv ---------------------------
+    dpx += g4[0] + dx4[0];  // dL/dp_i  (p_i also feeds p_{i+1}: carried in dpx)
+    dpy += g4[1] + dx4[1];
+    const float dvx = g4[2] + dx4[2] + dpx;  // p_i = p_{i-1} + v_i
+    const float dvy = g4[3] + dx4[3] + dpy;
+    if (wave == 0 && lg == 0 && live) {
+      f32x4 o = {dvx, dvy, 0.f, 0.f};
+      st4(gdelta + gd.dv + ((size_t)i * B + b) * 4, o);
     }
-    sw_barrier();
-    // da3 = W4^T dv  (40)
-    if (wave < 3) {
+    if (wave < 3) {  // B operand (k = 4lg + r, only k = 0,1 live) straight from registers
       int m0 = wave * 16;
+      f32x4 w = ld4(&W4T[(m0 + ln) * LD2 + 4 * lg]);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      acc = tile_mm<1>(&W4T[(m0 + ln) * LD2 + 4 * lg], &dvbuf[ln * LD2 + 4 * lg], acc);
+      acc = SW_MFMA(w[0], lg == 0 ? dvx : 0.f, acc);
+      acc = SW_MFMA(w[1], lg == 0 ? dvy : 0.f, acc);
       st4(&da3buf[ln * LD40 + m0 + 4 * lg], acc);
       if (live && m0 + 4 * lg < 40) st4(gdelta + gd.da3 + ((size_t)i * B + b) * 40 + m0 + 4 * lg, acc);
     }
     sw_barrier();
     // dz2 = (W3^T da3) * lrelu'(a2)   (80)
-    for (int mt = wave; mt < 5; mt += 4) {
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2) {
+      int mt = wave + 4 * q2;
+      if (mt >= 5) break;
       int m0 = mt * 16;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       acc = tile_mm<3>(&W3T[(m0 + ln) * LD40 + 4 * lg], &da3buf[ln * LD40 + 4 * lg], acc);
-      f32x4 a2 = ld4(gsave + gs.a2 + ((size_t)i * B + b) * 80 + m0 + 4 * lg);
+      f32x4 a2 = a2pre[q2];
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(a2[r], acc[r]);
       st4(&dz2buf[ln * LD80 + m0 + 4 * lg], acc);
@@ -322,12 +334,14 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
     sw_barrier();
     // dz1 = (W2^T dz2) * lrelu'(a1)   (160)
     {
-      int q = 0;
-      for (int mt = wave; mt < 10; mt += 4, ++q) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        int mt = wave + 4 * q;
+        if (mt >= 10) break;
         int m0 = mt * 16;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         acc = tile_mm<5>(&W2T[(m0 + ln) * LD80 + 4 * lg], &dz2buf[ln * LD80 + 4 * lg], acc);
-        f32x4 a1 = ld4(gsave + gs.a1 + ((size_t)i * B + b) * 160 + m0 + 4 * lg);
+        f32x4 a1 = a1pre[q];
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(a1[r], acc[r]);
         st4(&dz1buf[ln * LD160 + m0 + 4 * lg], acc);

@@ -409,14 +409,19 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
   dh = tile_mm_rt(smem + L.of0T + (u0 + ln) * LD32 + 4 * lg, smem + L.do1 + ln * LD32 + 4 * lg, 2, dh);
   LstmWT WT;
   lstm_load_wT(WT, d_w + O.whh, u0, ln, lg);
-  for (int t = To - 1; t >= 0; --t) {
+  auto load_row = [&](int t, f32x4 g[4], f32x4& ct_, f32x4& cp_) {
     const float* row = dsave + ds.act + ((size_t)t * B + b) * 384 + u0 + 4 * lg;
-    f32x4 gate[4], dgate[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) gate[g] = ld4(row + g * 64);
-    f32x4 ct = ld4(row + 256);
-    f32x4 cprev = {0.f, 0.f, 0.f, 0.f};
-    if (t > 0) cprev = ld4(row - (size_t)B * 384 + 256);
+    for (int q = 0; q < 4; ++q) g[q] = ld4(row + q * 64);
+    ct_ = ld4(row + 256);
+    cp_ = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t > 0) cp_ = ld4(row - (size_t)B * 384 + 256);
+  };
+  f32x4 gate[4], ct, cprev;
+  load_row(To - 1, gate, ct, cprev);
+  for (int t = To - 1; t >= 0; --t) {  // saved rows loaded one step ahead (latency under the MFMAs)
+    f32x4 ngate[4], nct, ncp, dgate[4];
+    if (t > 0) load_row(t - 1, ngate, nct, ncp);
     lstm_cell_bwd(gate, ct, cprev, dh, dc, dgate);
     float* dgl = &dgbuf[(t & 1) * 16 * SW_GLD + ln * SW_GLD + u0 + 4 * lg];
     float* dgg = ddelta + dd.dgates + ((size_t)t * B + b) * 256 + u0 + 4 * lg;
@@ -426,7 +431,13 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
       if (live) st4(dgg + g * 64, dgate[g]);
     }
     sw_barrier();
-    if (t > 0) dh = lstm_dh_prev(WT, &dgbuf[(t & 1) * 16 * SW_GLD + ln * SW_GLD + 4 * lg]);
+    if (t > 0) {
+      dh = lstm_dh_prev(WT, &dgbuf[(t & 1) * 16 * SW_GLD + ln * SW_GLD + 4 * lg]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gate[g] = ngate[g];
+      ct = nct;
+      cprev = ncp;
+    }
   }
 }
 

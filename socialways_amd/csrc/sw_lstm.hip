@@ -78,17 +78,21 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_bwd_kernel(
   f32x4 dh = {0.f, 0.f, 0.f, 0.f}, dc = {0.f, 0.f, 0.f, 0.f};
   if (dhT) dh = ld4(dhT + (size_t)b * 64 + u0 + 4 * lg);
   if (dcT) dc = ld4(dcT + (size_t)b * 64 + u0 + 4 * lg);
-  for (int t = T - 1; t >= 0; --t) {
+  // saved rows of step t are loaded one iteration ahead: their L2/HBM latency hides under the MFMAs
+  auto load_row = [&](int t, f32x4 g[4], f32x4& ct_, f32x4& cp_) {
     const float* row = act + ((size_t)(t0 + t) * B + b) * 384 + u0 + 4 * lg;
-    f32x4 gate[4], dgate[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) gate[g] = ld4(row + g * 64);
-    f32x4 ct = ld4(row + 256);
-    f32x4 cprev = {0.f, 0.f, 0.f, 0.f};
-    if (t0 + t > 0 && (t > 0 || t0 > 0))
-      cprev = ld4(row - (size_t)B * 384 + 256);
-    else if (c0)
-      cprev = ld4(c0 + (size_t)b * 64 + u0 + 4 * lg);
+    for (int q = 0; q < 4; ++q) g[q] = ld4(row + q * 64);
+    ct_ = ld4(row + 256);
+    cp_ = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t0 + t > 0) cp_ = ld4(row - (size_t)B * 384 + 256);
+    else if (c0) cp_ = ld4(c0 + (size_t)b * 64 + u0 + 4 * lg);
+  };
+  f32x4 gate[4], ct, cprev;
+  load_row(T - 1, gate, ct, cprev);
+  for (int t = T - 1; t >= 0; --t) {
+    f32x4 ngate[4], nct, ncp, dgate[4];
+    if (t > 0) load_row(t - 1, ngate, nct, ncp);
     if (dy) dh += ld4(dy + ((size_t)b * T + t) * 64 + u0 + 4 * lg);
     lstm_cell_bwd(gate, ct, cprev, dh, dc, dgate);
     float* dgl = &dgbuf[t & 1][ln * SW_GLD + u0 + 4 * lg];
@@ -100,6 +104,12 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_bwd_kernel(
     }
     sw_barrier();
     dh = lstm_dh_prev(W, &dgbuf[t & 1][ln * SW_GLD + 4 * lg]);
+    if (t > 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gate[g] = ngate[g];
+      ct = nct;
+      cprev = ncp;
+    }
   }
   if (live) {
     if (dh0) st4(dh0 + (size_t)b * 64 + u0 + 4 * lg, dh);

@@ -79,7 +79,7 @@ extern "C" size_t sw_workspace_floats(int ws_id, int B, int To, int Tp, int nb, 
     case SW_WS_GDELTA: return gdelta_layout(B, To, Tp).total;
     case SW_WS_DSAVE: return sw_dsave_floats(B, To, Tp, nb < 1 ? 1 : nb);
     case SW_WS_DDELTA: return sw_ddelta_floats(B, To, Tp, nb < 1 ? 1 : nb);
-    case SW_WS_WGRAD: return SW_WG_WS_FLOATS + 2048;
+    case SW_WS_WGRAD: return SW_WG_WS_FLOATS;
     case SW_WS_PAIRS: return (size_t)B * 64 + (size_t)(P < 0 ? 0 : P) * 324;
   }
   return 0;
@@ -128,37 +128,55 @@ __global__ __launch_bounds__(256) void enc_compose_bwd_kernel(const float* __res
   if (t == 4) d_enc_w[ENC_EMB_B + e] = red[4][0];
 }
 
+// part 0: everything.  part 1: what is available right after dec_rollout_bwd (all decoder problems +
+// the LSTM rows of the decode phase, t >= To).  part 2: the LSTM rows of the observation phase
+// (after enc_lstm_bwd), accumulated on top of part 1, then the composed-input-matrix back-propagation.
+// Parts 1 and 2 may run on different streams (different partial workspaces `wgrad_ws`); `tmp` holds
+// the 256x4 + 256 composed-matrix gradient between them.
 extern "C" int sw_gen_wgrad(const float* enc_w, const float* gsave, const float* gdelta, const float* z,
-                            const float* S_pool, int B, int To, int Tp, float* d_enc_w, float* d_dec_w,
-                            float* wgrad_ws, void* stream) {
-  if (!enc_w || !gsave || !gdelta || !z || !S_pool || !d_enc_w || !d_dec_w || !wgrad_ws || B < 1 || To < 2 || Tp < 1)
+                            const float* S_pool, int B, int To, int Tp, float* d_enc_w, float* d_dec_w, int part,
+                            float* wgrad_ws, float* tmp, void* stream) {
+  if (!enc_w || !gsave || !gdelta || !z || !S_pool || !d_enc_w || !d_dec_w || !wgrad_ws || !tmp || B < 1 || To < 2 ||
+      Tp < 1 || part < 0 || part > 2)
     return SW_EARG;
   using namespace swp;
   const GSave gs = gsave_layout(B, To, Tp);
   const GDelta gd = gdelta_layout(B, To, Tp);
   const int Ta = To + Tp - 1;
-  float* dWx = wgrad_ws + SW_WG_WS_FLOATS;
-  float* dbx = dWx + 1024;
+  float* dWx = tmp;
+  float* dbx = tmp + 1024;
   hipStream_t st = (hipStream_t)stream;
   WgBatch wb;
   int rc_add = 0;
   // EncoderLstm: W_hh against h_{t-1} (rows t >= 1), composed input matrix against x4 (all rows)
-  rc_add |= wg_add(wb, gdelta + gd.dgates + (size_t)B * 256, 256, gsave + gs.act + 320, 384, (Ta - 1) * B, 256, 64,
-         d_enc_w + ENC_WHH, 64, nullptr, nullptr, 0);
-  rc_add |= wg_add(wb, gdelta + gd.dgates, 256, gsave + gs.x4s, 4, Ta * B, 256, 4, dWx, 4, dbx, nullptr, 0);
-  // DecoderFC: fc1.0 split in its h / S / z column blocks; h of decode step i is LSTM row To-1+i
-  rc_add |= wg_add(wb, gdelta + gd.dz1, 160, gsave + gs.act + (size_t)(To - 1) * B * 384 + 320, 384, Tp * B, 160, 64,
-         d_dec_w + DEC_W1, 160, nullptr, nullptr, 0);
-  rc_add |= wg_add(wb, gdelta + gd.du, 160, S_pool, 64, B, 160, 64, d_dec_w + DEC_W1 + 64, 160, nullptr, nullptr, 0);
-  rc_add |= wg_add(wb, gdelta + gd.du, 160, z, 32, B, 160, 32, d_dec_w + DEC_W1 + 128, 160, d_dec_w + DEC_B1, nullptr, 0);
-  rc_add |= wg_add(wb, gdelta + gd.dz2, 80, gsave + gs.a1, 160, Tp * B, 80, 160, d_dec_w + DEC_W2, 160, d_dec_w + DEC_B2,
-         nullptr, 0);
-  rc_add |= wg_add(wb, gdelta + gd.da3, 40, gsave + gs.a2, 80, Tp * B, 40, 80, d_dec_w + DEC_W3, 80, d_dec_w + DEC_B3, nullptr, 0);
-  rc_add |= wg_add(wb, gdelta + gd.dv, 4, gsave + gs.a3, 40, Tp * B, 2, 40, d_dec_w + DEC_W4, 40, d_dec_w + DEC_B4, nullptr, 0);
+  const int t_lo = part == 1 ? To : 0, t_hi = part == 2 ? To : Ta;   // LSTM rows [t_lo, t_hi)
+  const int acc = part == 2 ? 1 : 0;
+  const int h_lo = t_lo < 1 ? 1 : t_lo;
+  if (t_hi > h_lo)
+    rc_add |= wg_add(wb, gdelta + gd.dgates + (size_t)h_lo * B * 256, 256, gsave + gs.act + (size_t)(h_lo - 1) * B * 384 + 320,
+                     384, (t_hi - h_lo) * B, 256, 64, d_enc_w + ENC_WHH, 64, nullptr, nullptr, acc);
+  if (t_hi > t_lo)
+    rc_add |= wg_add(wb, gdelta + gd.dgates + (size_t)t_lo * B * 256, 256, gsave + gs.x4s + (size_t)t_lo * B * 4, 4,
+                     (t_hi - t_lo) * B, 256, 4, dWx, 4, dbx, nullptr, acc);
+  if (part != 2) {
+    // DecoderFC: fc1.0 split in its h / S / z column blocks; h of decode step i is LSTM row To-1+i
+    rc_add |= wg_add(wb, gdelta + gd.dz1, 160, gsave + gs.act + (size_t)(To - 1) * B * 384 + 320, 384, Tp * B, 160, 64,
+                     d_dec_w + DEC_W1, 160, nullptr, nullptr, 0);
+    rc_add |= wg_add(wb, gdelta + gd.du, 160, S_pool, 64, B, 160, 64, d_dec_w + DEC_W1 + 64, 160, nullptr, nullptr, 0);
+    rc_add |= wg_add(wb, gdelta + gd.du, 160, z, 32, B, 160, 32, d_dec_w + DEC_W1 + 128, 160, d_dec_w + DEC_B1, nullptr, 0);
+    rc_add |= wg_add(wb, gdelta + gd.dz2, 80, gsave + gs.a1, 160, Tp * B, 80, 160, d_dec_w + DEC_W2, 160, d_dec_w + DEC_B2,
+                     nullptr, 0);
+    rc_add |= wg_add(wb, gdelta + gd.da3, 40, gsave + gs.a2, 80, Tp * B, 40, 80, d_dec_w + DEC_W3, 80, d_dec_w + DEC_B3,
+                     nullptr, 0);
+    rc_add |= wg_add(wb, gdelta + gd.dv, 4, gsave + gs.a3, 40, Tp * B, 2, 40, d_dec_w + DEC_W4, 40, d_dec_w + DEC_B4,
+                     nullptr, 0);
+  }
   if (rc_add) return SW_ESHAPE;
   if (int rc = wg_launch(wb, wgrad_ws, st)) return rc;
-  hipLaunchKernelGGL(enc_compose_bwd_kernel, dim3(128), dim3(256), 0, st, enc_w, dWx, dbx, d_enc_w);
-  SW_CHECK_LAUNCH("enc_compose_bwd_kernel");
+  if (part != 1) {
+    hipLaunchKernelGGL(enc_compose_bwd_kernel, dim3(128), dim3(256), 0, st, enc_w, dWx, dbx, d_enc_w);
+    SW_CHECK_LAUNCH("enc_compose_bwd_kernel");
+  }
   return SW_OK;
 }
 

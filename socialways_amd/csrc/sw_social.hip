@@ -83,27 +83,35 @@ __device__ __forceinline__ void pair_l23(const PairW& W, const float* b1, const 
   }
 }
 
-// LDS carve shared by forward and backward (floats)
-struct SocLds {
-  static constexpr int hs = 0;                          // [64][68]  h of the scene
-  static constexpr int wh = hs + SW_AMAX * 68;          // [64][68]  W h + b
-  static constexpr int x4 = wh + SW_AMAX * 68;          // [64][4]
-  static constexpr int sig = x4 + SW_AMAX * 4;          // [64][64]  scores -> attention weights
-  static constexpr int w0b = sig + SW_AMAX * SW_AMAX;   // [32][4]   fc.0 weight|bias
-  static constexpr int b12 = w0b + 128;                 // fc.2.bias[64] | fc.4.bias[64]
-  static constexpr int fwd_total = b12 + 128;
-  // backward only
-  static constexpr int ds = fwd_total;                  // [64][68]  dS of the scene
-  static constexpr int dsg = ds + SW_AMAX * 68;         // [64][64]  dsigma
-  static constexpr int dwh = dsg + SW_AMAX * SW_AMAX;   // [64][68]  dWh
-  static constexpr int bwd_total = dwh + SW_AMAX * 68;
+// LDS carve shared by forward and backward (floats), sized by the largest scene of the launch rounded
+// up to 16 agents (a16): 8-agent scenes need 9 KB, 64-agent scenes 127 KB - small scenes leave the CU's
+// LDS to co-resident workgroups.
+struct SocL {
+  int a16, sa;  // agents capacity, row stride of the n x n score matrices
+  int hs, wh, x4, sig, w0b, b12, fwd_total, ds, dsg, dwh, bwd_total;
 };
-static_assert(SocLds::bwd_total * 4 <= 163840, "LDS budget");
+__host__ __device__ inline SocL soc_lds(int a16) {
+  SocL L;
+  L.a16 = a16;
+  L.sa = a16;
+  L.hs = 0;                         // [a16][68]  h of the scene
+  L.wh = L.hs + a16 * 68;           // [a16][68]  W h + b
+  L.x4 = L.wh + a16 * 68;           // [a16][4]
+  L.sig = L.x4 + a16 * 4;           // [a16][a16] scores -> attention weights
+  L.w0b = L.sig + a16 * a16;        // [32][4]    fc.0 weight|bias
+  L.b12 = L.w0b + 128;              // fc.2.bias[64] | fc.4.bias[64]
+  L.fwd_total = L.b12 + 128;
+  L.ds = L.fwd_total;               // [a16][68]  dS of the scene          (backward only)
+  L.dsg = L.ds + a16 * 68;          // [a16][a16] dsigma
+  L.dwh = L.dsg + a16 * a16;        // [a16][68]  dWh
+  L.bwd_total = L.dwh + a16 * 68;
+  return L;
+}
 
 // h rows of the scene into LDS (+ zero rows up to a multiple of 16) and Wh = W h + b (train.py:161)
-__device__ __forceinline__ void scene_load_h_wh(float* smem, const float* h, const float* att_w, int s0, int n) {
-  float* hs = smem + SocLds::hs;
-  float* wh = smem + SocLds::wh;
+__device__ __forceinline__ void scene_load_h_wh(float* smem, const SocL& Ls, const float* h, const float* att_w, int s0, int n) {
+  float* hs = smem + Ls.hs;
+  float* wh = smem + Ls.wh;
   for (int i = threadIdx.x; i < n * 16; i += blockDim.x) {
     int a = i >> 4, q = i & 15;
     st4(&hs[a * 68 + 4 * q], ld4(h + (size_t)(s0 + a) * 64 + 4 * q));
@@ -126,9 +134,9 @@ __device__ __forceinline__ void scene_load_h_wh(float* smem, const float* h, con
   sw_barrier();
 }
 // fc.0 weight|bias and fc.2 / fc.4 biases into LDS
-__device__ __forceinline__ void stage_pair_consts(float* smem, const float* emb_w) {
-  float* w0b = smem + SocLds::w0b;
-  float* b12 = smem + SocLds::b12;
+__device__ __forceinline__ void stage_pair_consts(float* smem, const SocL& Ls, const float* emb_w) {
+  float* w0b = smem + Ls.w0b;
+  float* b12 = smem + Ls.b12;
   if (threadIdx.x < 32) {
     int k = threadIdx.x;
     f32x4 v = {emb_w[swp::EMB_W0 + k * 3], emb_w[swp::EMB_W0 + k * 3 + 1], emb_w[swp::EMB_W0 + k * 3 + 2],
@@ -140,25 +148,26 @@ __device__ __forceinline__ void stage_pair_consts(float* smem, const float* emb_
     b12[k] = k < 64 ? emb_w[swp::EMB_B1 + k] : emb_w[swp::EMB_B2 + k - 64];
   }
 }
-__device__ __forceinline__ void scene_prologue(float* smem, const float* obsv, int To, const float* h,
+__device__ __forceinline__ void scene_prologue(float* smem, const SocL& Ls, const float* obsv, int To, const float* h,
                                                const float* emb_w, const float* att_w, int s0, int n) {
-  float* x4 = smem + SocLds::x4;
+  float* x4 = smem + Ls.x4;
   for (int a = threadIdx.x; a < n; a += blockDim.x) {
     const float* p = obsv + ((size_t)(s0 + a) * To + To - 2) * 2;  // last two observed points
     f32x4 v = {p[2], p[3], p[2] - p[0], p[3] - p[1]};
     st4(&x4[a * 4], v);
   }
-  stage_pair_consts(smem, emb_w);
-  scene_load_h_wh(smem, h, att_w, s0, n);
+  stage_pair_consts(smem, Ls, emb_w);
+  scene_load_h_wh(smem, Ls, h, att_w, s0, n);
 }
 // softmax over the scene for every agent i (train.py:172, one wave per row) then
 // S_i = sum_j a_ij h_j (train.py:173: pools the raw hidden states)
-__device__ __forceinline__ void scene_softmax_pool(float* smem, int s0, int n, float* S_out, float* attn) {
-  float* hs = smem + SocLds::hs;
-  float* sig = smem + SocLds::sig;
+__device__ __forceinline__ void scene_softmax_pool(float* smem, const SocL& Ls, int s0, int n, float* S_out, float* attn) {
+  float* hs = smem + Ls.hs;
+  float* sig = smem + Ls.sig;
+  const int sa = Ls.sa;
   const int lane = sw_lane(), wave = sw_wave();
   for (int i = wave; i < n; i += 4) {
-    float v = lane < n ? sig[i * SW_AMAX + lane] : -INFINITY;
+    float v = lane < n ? sig[i * sa + lane] : -INFINITY;
     float m = v;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -168,7 +177,7 @@ __device__ __forceinline__ void scene_softmax_pool(float* smem, int s0, int n, f
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     float a = e / sum;
     if (lane < n) {
-      sig[i * SW_AMAX + lane] = a;
+      sig[i * sa + lane] = a;
       if (attn) attn[(size_t)(s0 + i) * SW_AMAX + lane] = a;
     }
   }
@@ -176,7 +185,7 @@ __device__ __forceinline__ void scene_softmax_pool(float* smem, int s0, int n, f
   for (int e = threadIdx.x; e < n * 64; e += blockDim.x) {
     int i = e >> 6, u = e & 63;
     float acc = 0.f;
-    for (int j = 0; j < n; ++j) acc = fmaf(sig[i * SW_AMAX + j], hs[j * 68 + u], acc);
+    for (int j = 0; j < n; ++j) acc = fmaf(sig[i * sa + j], hs[j * 68 + u], acc);
     S_out[(size_t)(s0 + i) * 64 + u] = acc;
   }
 }
@@ -185,13 +194,15 @@ __device__ __forceinline__ void scene_softmax_pool(float* smem, int s0, int n, f
 __global__ __launch_bounds__(SW_THREADS) void social_pool_fwd_kernel(
     const float* __restrict__ obsv, int To, const float* __restrict__ h, const int* __restrict__ scene_off,
     const float* __restrict__ emb_w, const float* __restrict__ att_w, float* __restrict__ S_out,
-    float* __restrict__ attn) {
+    float* __restrict__ attn, int a16) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* wh = smem + SocLds::wh;
-  float* x4 = smem + SocLds::x4;
-  float* sig = smem + SocLds::sig;
-  const float* w0b = smem + SocLds::w0b;
-  const float* b12 = smem + SocLds::b12;
+  const SocL Ls = soc_lds(a16);
+  const int sa = Ls.sa;
+  float* wh = smem + Ls.wh;
+  float* x4 = smem + Ls.x4;
+  float* sig = smem + Ls.sig;
+  const float* w0b = smem + Ls.w0b;
+  const float* b12 = smem + Ls.b12;
   const int s0 = scene_off[blockIdx.x], n = scene_off[blockIdx.x + 1] - s0;
   if (n <= 0) return;
   if (n == 1) {  // train.py:165: single-agent scenes keep S = 0
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_fwd_kernel(
     return;
   }
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
-  scene_prologue(smem, obsv, To, h, emb_w, att_w, s0, n);
+  scene_prologue(smem, Ls, obsv, To, h, emb_w, att_w, s0, n);
   PairW W;
   load_pair_w(W, emb_w, ln, lg);
   const int P = n * n;
@@ -221,10 +232,10 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_fwd_kernel(
     }
     part += __shfl_xor(part, 16);
     part += __shfl_xor(part, 32);
-    if (lg == 0 && pt * 16 + ln < P) sig[i * SW_AMAX + j] = (i == j) ? -1000.0f : part;  // train.py:170
+    if (lg == 0 && pt * 16 + ln < P) sig[i * sa + j] = (i == j) ? -1000.0f : part;  // train.py:170
   }
   sw_barrier();
-  scene_softmax_pool(smem, s0, n, S_out, attn);
+  scene_softmax_pool(smem, Ls, s0, n, S_out, attn);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -254,17 +265,19 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
     const float* __restrict__ obsv, int To, const float* __restrict__ h, const int* __restrict__ scene_off,
     const long long* __restrict__ pair_off, const float* __restrict__ emb_w, const float* __restrict__ att_w,
     const float* __restrict__ attn, const float* __restrict__ dS, float* __restrict__ dh,
-    float* __restrict__ dwh_rows, PairRows pr) {
+    float* __restrict__ dwh_rows, PairRows pr, int a16) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* hs = smem + SocLds::hs;
-  float* wh = smem + SocLds::wh;
-  float* x4 = smem + SocLds::x4;
-  float* sig = smem + SocLds::sig;  // attention weights a_ij
-  const float* w0b = smem + SocLds::w0b;
-  const float* b12 = smem + SocLds::b12;
-  float* dsl = smem + SocLds::ds;
-  float* dsg = smem + SocLds::dsg;
-  float* dwh = smem + SocLds::dwh;
+  const SocL Ls = soc_lds(a16);
+  const int sa = Ls.sa;
+  float* hs = smem + Ls.hs;
+  float* wh = smem + Ls.wh;
+  float* x4 = smem + Ls.x4;
+  float* sig = smem + Ls.sig;  // attention weights a_ij
+  const float* w0b = smem + Ls.w0b;
+  const float* b12 = smem + Ls.b12;
+  float* dsl = smem + Ls.ds;
+  float* dsg = smem + Ls.dsg;
+  float* dwh = smem + Ls.dwh;
   const int s0 = scene_off[blockIdx.x], n = scene_off[blockIdx.x + 1] - s0;
   if (n <= 0) return;
   if (n == 1) {  // S = 0 constant: no gradient anywhere; dWh row is zero
@@ -273,21 +286,21 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
   }
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
   const long long p0 = pair_off[blockIdx.x];
-  scene_prologue(smem, obsv, To, h, emb_w, att_w, s0, n);
+  scene_prologue(smem, Ls, obsv, To, h, emb_w, att_w, s0, n);
   for (int i = threadIdx.x; i < n * 16; i += blockDim.x) {
     int a = i >> 4, q = i & 15;
     st4(&dsl[a * 68 + 4 * q], ld4(dS + (size_t)(s0 + a) * 64 + 4 * q));
   }
   for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
     int i = e / n, j = e - i * n;
-    sig[i * SW_AMAX + j] = attn[(size_t)(s0 + i) * SW_AMAX + j];
+    sig[i * sa + j] = attn[(size_t)(s0 + i) * SW_AMAX + j];
   }
   sw_barrier();
   // da_ij = <dS_i, h_j>;  dsigma_ij = a_ij (da_ij - sum_j' a_ij' da_ij')   (softmax backward)
   for (int i = wave; i < n; i += 4) {
     float da = 0.f, a = 0.f;
     if (lane < n) {
-      a = sig[i * SW_AMAX + lane];
+      a = sig[i * sa + lane];
       for (int u = 0; u < 64; u += 4) {
         f32x4 x = ld4(&dsl[i * 68 + u]), y = ld4(&hs[lane * 68 + u]);
         da = fmaf(x[0], y[0], da); da = fmaf(x[1], y[1], da); da = fmaf(x[2], y[2], da); da = fmaf(x[3], y[3], da);
@@ -296,7 +309,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
     float t = a * da;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-    if (lane < n) dsg[i * SW_AMAX + lane] = a * (da - t);
+    if (lane < n) dsg[i * sa + lane] = a * (da - t);
   }
   sw_barrier();
   // ---- pair tiles: recompute the MLP, back-propagate, leave rows for the deferred GEMMs --------
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
     f32x4 h1[2], h2[4], f[4];
     pair_l1(w0b, lg, f0, f1, f2, h1);
     pair_l23(W, b12, b12 + 64, lg, h1, h2, f);
-    const float dsv = valid ? dsg[i * SW_AMAX + j] : 0.f;
+    const float dsv = valid ? dsg[i * sa + j] : 0.f;
     f32x4 dz3[4];
 #pragma unroll
     for (int mo = 0; mo < 4; ++mo) {
@@ -388,7 +401,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
   for (int e = threadIdx.x; e < n * 64; e += blockDim.x) {
     int j = e >> 6, u = e & 63;
     float acc = 0.f;
-    for (int i = 0; i < n; ++i) acc = fmaf(dsg[i * SW_AMAX + j], pr.f[(size_t)(p0 + i * n + j) * 64 + u], acc);
+    for (int i = 0; i < n; ++i) acc = fmaf(dsg[i * sa + j], pr.f[(size_t)(p0 + i * n + j) * 64 + u], acc);
     dwh[j * 68 + u] = acc;
     dwh_rows[(size_t)(s0 + j) * 64 + u] = acc;
   }
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
   for (int e = threadIdx.x; e < n * 64; e += blockDim.x) {
     int j = e >> 6, u = e & 63;
     float acc = 0.f;
-    for (int i = 0; i < n; ++i) acc = fmaf(sig[i * SW_AMAX + j], dsl[i * 68 + u], acc);
+    for (int i = 0; i < n; ++i) acc = fmaf(sig[i * sa + j], dsl[i * 68 + u], acc);
     const float* wc = att_w + swp::ATT_W + u;
     for (int k = 0; k < 64; ++k) acc = fmaf(wc[k * 64], dwh[j * 68 + k], acc);
     dh[(size_t)(s0 + j) * 64 + u] += acc;
@@ -430,17 +443,19 @@ static int set_lds(const void* fn, int bytes) {
 // AttentionPooling.forward on a dense (B,B,64) embedding tensor: only in-scene blocks are read.
 __global__ __launch_bounds__(SW_THREADS) void attention_pool_dense_kernel(
     const float* __restrict__ f, const float* __restrict__ h, const int* __restrict__ scene_off, int B,
-    const float* __restrict__ att_w, float* __restrict__ S_out) {
+    const float* __restrict__ att_w, float* __restrict__ S_out, int a16) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* wh = smem + SocLds::wh;
-  float* sig = smem + SocLds::sig;
+  const SocL Ls = soc_lds(a16);
+  const int sa = Ls.sa;
+  float* wh = smem + Ls.wh;
+  float* sig = smem + Ls.sig;
   const int s0 = scene_off[blockIdx.x], n = scene_off[blockIdx.x + 1] - s0;
   if (n <= 0) return;
   if (n == 1) {
     if (threadIdx.x < 16) st4(S_out + (size_t)s0 * 64 + 4 * threadIdx.x, f32x4{0.f, 0.f, 0.f, 0.f});
     return;
   }
-  scene_load_h_wh(smem, h, att_w, s0, n);
+  scene_load_h_wh(smem, Ls, h, att_w, s0, n);
   for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
     int i = e / n, j = e - i * n;
     const float* fr = f + ((size_t)(s0 + i) * B + (s0 + j)) * 64;
@@ -449,10 +464,10 @@ __global__ __launch_bounds__(SW_THREADS) void attention_pool_dense_kernel(
       f32x4 x = ld4(fr + u), y = ld4(&wh[j * 68 + u]);
       acc = fmaf(x[0], y[0], acc); acc = fmaf(x[1], y[1], acc); acc = fmaf(x[2], y[2], acc); acc = fmaf(x[3], y[3], acc);
     }
-    sig[i * SW_AMAX + j] = (i == j) ? -1000.0f : acc;
+    sig[i * sa + j] = (i == j) ? -1000.0f : acc;
   }
   sw_barrier();
-  scene_softmax_pool(smem, s0, n, S_out, nullptr);
+  scene_softmax_pool(smem, Ls, s0, n, S_out, nullptr);
 }
 
 // EmbedSocialFeatures.forward on R rows of 3 features (one wave per 16 rows).
@@ -460,9 +475,10 @@ __global__ __launch_bounds__(SW_THREADS) void embed_features_kernel(const float*
                                                                     const float* __restrict__ emb_w,
                                                                     float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const float* w0b = smem + SocLds::w0b;
-  const float* b12 = smem + SocLds::b12;
-  stage_pair_consts(smem, emb_w);
+  const SocL Ls = soc_lds(16);
+  const float* w0b = smem + Ls.w0b;
+  const float* b12 = smem + Ls.b12;
+  stage_pair_consts(smem, Ls, emb_w);
   sw_barrier();
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
   PairW W;
@@ -486,11 +502,11 @@ extern "C" int sw_attention_pool_dense(const float* f, const float* h, const int
   if (S == 0 || B == 0) return SW_OK;
   static bool attr = false;
   if (!attr) {
-    if (int rc = set_lds((const void*)attention_pool_dense_kernel, SocLds::fwd_total * 4)) return rc;
+    if (int rc = set_lds((const void*)attention_pool_dense_kernel, soc_lds(SW_AMAX).fwd_total * 4)) return rc;
     attr = true;
   }
-  hipLaunchKernelGGL(attention_pool_dense_kernel, dim3(S), dim3(SW_THREADS), SocLds::fwd_total * 4, (hipStream_t)stream,
-                     f, h, scene_off, B, att_w, S_out);
+  hipLaunchKernelGGL(attention_pool_dense_kernel, dim3(S), dim3(SW_THREADS), soc_lds(SW_AMAX).fwd_total * 4,
+                     (hipStream_t)stream, f, h, scene_off, B, att_w, S_out, SW_AMAX);
   SW_CHECK_LAUNCH("attention_pool_dense_kernel");
   return SW_OK;
 }
@@ -500,10 +516,10 @@ extern "C" int sw_embed_features(const float* feat, long long R, const float* em
   if (R == 0) return SW_OK;
   static bool attr = false;
   if (!attr) {
-    if (int rc = set_lds((const void*)embed_features_kernel, SocLds::fwd_total * 4)) return rc;
+    if (int rc = set_lds((const void*)embed_features_kernel, soc_lds(16).fwd_total * 4)) return rc;
     attr = true;
   }
-  hipLaunchKernelGGL(embed_features_kernel, dim3((unsigned)((R + 63) / 64)), dim3(SW_THREADS), SocLds::fwd_total * 4,
+  hipLaunchKernelGGL(embed_features_kernel, dim3((unsigned)((R + 63) / 64)), dim3(SW_THREADS), soc_lds(16).fwd_total * 4,
                      (hipStream_t)stream, feat, R, emb_w, out);
   SW_CHECK_LAUNCH("embed_features_kernel");
   return SW_OK;
@@ -527,11 +543,12 @@ extern "C" int sw_social_pool_fwd(const float* obsv, int To, const float* h, con
   if (S == 0 || B == 0) return SW_OK;
   static bool attr = false;
   if (!attr) {
-    if (int rc = set_lds((const void*)social_pool_fwd_kernel, SocLds::fwd_total * 4)) return rc;
+    if (int rc = set_lds((const void*)social_pool_fwd_kernel, soc_lds(SW_AMAX).fwd_total * 4)) return rc;
     attr = true;
   }
-  hipLaunchKernelGGL(social_pool_fwd_kernel, dim3(S), dim3(SW_THREADS), SocLds::fwd_total * 4, (hipStream_t)stream,
-                     obsv, To, h, scene_off, emb_w, att_w, S_out, attn);
+  const int a16 = Amax < 16 ? 16 : ((Amax + 15) & ~15);
+  hipLaunchKernelGGL(social_pool_fwd_kernel, dim3(S), dim3(SW_THREADS), soc_lds(a16).fwd_total * 4, (hipStream_t)stream,
+                     obsv, To, h, scene_off, emb_w, att_w, S_out, attn, a16);
   SW_CHECK_LAUNCH("social_pool_fwd_kernel");
   return SW_OK;
 }
@@ -548,14 +565,15 @@ extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, con
   if (S == 0 || B == 0) return SW_OK;
   static bool attr = false;
   if (!attr) {
-    if (int rc = set_lds((const void*)social_pool_bwd_kernel, SocLds::bwd_total * 4)) return rc;
+    if (int rc = set_lds((const void*)social_pool_bwd_kernel, soc_lds(SW_AMAX).bwd_total * 4)) return rc;
     attr = true;
   }
+  const int a16 = Amax < 16 ? 16 : ((Amax + 15) & ~15);
   // pair_ws: [B][64] dWh rows, then the per-pair rows
   float* dwh_rows = pair_ws;
   PairRows pr = pair_rows(pair_ws + (size_t)B * 64, P);
-  hipLaunchKernelGGL(social_pool_bwd_kernel, dim3(S), dim3(SW_THREADS), SocLds::bwd_total * 4, (hipStream_t)stream,
-                     obsv, To, h, scene_off, pair_off, emb_w, att_w, attn, dS, dh, dwh_rows, pr);
+  hipLaunchKernelGGL(social_pool_bwd_kernel, dim3(S), dim3(SW_THREADS), soc_lds(a16).bwd_total * 4, (hipStream_t)stream,
+                     obsv, To, h, scene_off, pair_off, emb_w, att_w, attn, dS, dh, dwh_rows, pr, a16);
   SW_CHECK_LAUNCH("social_pool_bwd_kernel");
   WgBatch wb;
   int rc_add = 0;

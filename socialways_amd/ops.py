@@ -120,34 +120,49 @@ def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_soc
     return pred4, ctx
 
 
-def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d_dec, ws=None, tag="g"):
+def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d_dec, ws=None, tag="g", side=None):
     """Backward of predict(): decode BPTT -> social block -> obs BPTT -> deferred weight GEMMs.
-    d_* are the packed gradient buffers (overwritten)."""
+    d_* are the packed gradient buffers (overwritten).  With a `side` stream the weight-gradient GEMMs
+    of the decode phase (all-CU, independent of the social / observation BPTT that follows on a
+    128-workgroup critical path) run concurrently with them."""
     dev = dpred4.device
     ws = ws or default_ws(dev)
-    st = L.stream()
     B, To, Tp = ctx.B, ctx.To, ctx.Tp
     dpred4 = dpred4.contiguous()
     gdelta = ws.get(tag + ".gdelta", L.workspace_floats(L.WS_GDELTA, B, To, Tp))
     wgrad = ws.get("wgrad", L.workspace_floats(L.WS_WGRAD, B, To, Tp))
+    tmp = ws.get(tag + ".dwx", 2048)
     dhT = torch.empty(B, 64, device=dev)
     dcT = torch.empty(B, 64, device=dev)
     dS = torch.empty(B, 64, device=dev)
     L.call("sw_dec_rollout_bwd", L.ptr(dpred4), L.ptr(enc_w), L.ptr(dec_w), L.ptr(ctx.gsave), B, To, Tp,
-           L.ptr(gdelta), L.ptr(dhT), L.ptr(dcT), L.ptr(dS), st)
+           L.ptr(gdelta), L.ptr(dhT), L.ptr(dcT), L.ptr(dS), L.stream())
+
+    def wgrad_part(part, wsbuf):
+        L.call("sw_gen_wgrad", L.ptr(enc_w), L.ptr(ctx.gsave), L.ptr(gdelta), L.ptr(ctx.noise), L.ptr(ctx.S), B, To, Tp,
+               L.ptr(d_enc), L.ptr(d_dec), part, L.ptr(wsbuf), L.ptr(tmp), L.stream())
+
+    if side is not None:
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            wgrad_part(1, ws.get("wgrad.side", L.workspace_floats(L.WS_WGRAD, B, To, Tp)))
     if ctx.use_social and ctx.scenes.P > 0:
         sc = ctx.scenes
         pws = ws.get("pairs", L.workspace_floats(L.WS_PAIRS, B, To, Tp, 1, sc.P))
         L.call("sw_social_pool_bwd", L.ptr(ctx.obsv), To, L.ptr(ctx.hT), L.ptr(sc.scene_off), L.ptr(sc.pair_off), sc.S,
                B, sc.amax, sc.P, L.ptr(emb_w), L.ptr(att_w), L.ptr(ctx.attn), L.ptr(dS), L.ptr(dhT), L.ptr(d_emb),
-               L.ptr(d_att), L.ptr(pws), L.ptr(wgrad), st)
+               L.ptr(d_att), L.ptr(pws), L.ptr(wgrad), L.stream())
     else:
         d_emb.zero_()
         d_att.zero_()
     L.call("sw_enc_lstm_bwd", L.ptr(enc_w), L.ptr(ctx.gsave), None, L.ptr(dhT), L.ptr(dcT), None, B, To, 0,
-           L.ptr(gdelta), None, None, st)
-    L.call("sw_gen_wgrad", L.ptr(enc_w), L.ptr(ctx.gsave), L.ptr(gdelta), L.ptr(ctx.noise), L.ptr(ctx.S), B, To, Tp,
-           L.ptr(d_enc), L.ptr(d_dec), L.ptr(wgrad), st)
+           L.ptr(gdelta), None, None, L.stream())
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)
+        wgrad_part(2, wgrad)
+    else:
+        wgrad_part(0, wgrad)
 
 
 class DiscCtx:

@@ -142,6 +142,11 @@ class SocialWaysTrainer:
     def use_social(self):
         return self.G.use_social
 
+    def _sides(self):
+        if getattr(self, "_side_streams", None) is None:
+            self._side_streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+        return self._side_streams
+
     def _allreduce(self, flat):
         if self.pg is not None and (self.world > 1 or self._force_dist):
             torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
@@ -208,7 +213,8 @@ class SocialWaysTrainer:
             st["noise"].copy_(devslot[2:].view(B, self.noise_len))
             consumed.record(main)
         if st["graph"] is not None:
-            for g, buf in st["graph"]:
+            st["flip"] ^= 1
+            for g, buf in st["graph"][st["flip"]]:
                 g.replay()
                 if buf is not None:
                     self._allreduce(buf)
@@ -219,23 +225,29 @@ class SocialWaysTrainer:
             # Capture.  Single GPU: one graph for the whole step.  Data parallel: one graph per segment
             # between the all-reduce points (the collectives themselves stay eager: no RCCL-in-graph
             # dependency), all segments sharing one memory pool so intermediates stay alive.
+            # The step is captured TWICE and the two executables alternate: launching an executable
+            # that is still running makes hipGraphLaunch wait for it, which would put the host-side
+            # launch cost (~150 us for ~50 nodes) on the critical path of every step.
             torch.cuda.synchronize()
-            gen = self._step_gen(st["obsv"], st["pred"], scenes, st["targets"], st["noise"], ss, Bg, st["out"])
-            graphs, pool, done = [], None, False
-            while not done:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
-                    while True:
-                        try:
-                            buf = next(gen)
-                        except StopIteration:
-                            buf, done = None, True
-                        if done or self.world > 1 or self._force_dist:
-                            break
-                graphs.append((g, buf))
-                pool = g.pool()
-            st["graph"] = graphs
-            for g, buf in graphs:      # capture only records: this replay IS the step
+            pool, sets = None, []
+            for _ in range(2):
+                gen = self._step_gen(st["obsv"], st["pred"], scenes, st["targets"], st["noise"], ss, Bg, st["out"])
+                graphs, done = [], False
+                while not done:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=pool):
+                        while True:
+                            try:
+                                buf = next(gen)
+                            except StopIteration:
+                                buf, done = None, True
+                            if done or self.world > 1 or self._force_dist:
+                                break
+                    graphs.append((g, buf))
+                    pool = g.pool()
+                sets.append(graphs)
+            st["graph"], st["flip"] = sets, 0
+            for g, buf in sets[0]:     # capture only records: this replay IS the step
                 g.replay()
                 if buf is not None:
                     self._allreduce(buf)
@@ -260,14 +272,26 @@ class SocialWaysTrainer:
         ws = self.ws
         g_label = 1.0 / Bg
         g_code = (self.loss_info_w if self.use_info_loss else 0.0) / (2.0 * Bg)
-        # real future as 4-d (train.py:470); the observation stays 2-d: kernels form (p, v) on the fly
+        main = torch.cuda.current_stream()
+        side_a, side_b = self._sides()
+        # real future as 4-d (train.py:470) on a side stream, concurrently with the observation encoder;
+        # the observation itself stays 2-d: kernels form (p, v) on the fly
         pred4 = torch.empty(B, Tp, 4, device=dev)
         o4_scratch = ws.get("o4", B * obsv.shape[1] * 4)
-        L.call("sw_traj_4d", L.ptr(obsv), L.ptr(pred), B, obsv.shape[1], Tp, L.ptr(o4_scratch), L.ptr(pred4), L.stream())
+        side_a.wait_stream(main)
+        with torch.cuda.stream(side_a):
+            L.call("sw_traj_4d", L.ptr(obsv), L.ptr(pred), B, obsv.shape[1], Tp, L.ptr(o4_scratch), L.ptr(pred4), L.stream())
         # ---- generator rollout, once (train.py:480/507 are identical) ---------------
         enc, emb, att, dec = G.encoder, G.feature_embedder, G.attention, G.decoder
         pred_hat, gctx = ops.gen_forward(enc._flat, emb._flat, att._flat, dec._flat, obsv, noise, scenes, Tp,
                                          G.use_social, save=True, ws=ws)
+        # ADE/FDE partial sums of the prediction (train.py:546-551) only need pred_hat: side stream,
+        # under the first discriminator pass
+        side_b.wait_stream(main)
+        with torch.cuda.stream(side_b):
+            L.call("sw_ade_fde", L.ptr(pred_hat), L.ptr(pred), B, Tp, 1.0 / float(ss),
+                   L.ptr(out[self.n_unrolling_steps + 2]), L.stream())
+        main.wait_stream(side_a)
         dl_f = ws.get("dl_f", B)
         dc_f = ws.get("dc_f", 2 * B)
         dl_r = ws.get("dl_r", B)
@@ -280,6 +304,8 @@ class SocialWaysTrainer:
             L.call("sw_gan_loss", L.ptr(labels[0]), L.ptr(targets), 0, L.ptr(codes[0]), L.ptr(noise), L.ptr(labels[1]),
                    1, B, g_label, g_code, L.ptr(out[u]), L.ptr(dl_f), L.ptr(dc_f), L.ptr(dl_r), L.ptr(dc_r), L.stream())
             ops.disc_backward(D._flat, dctx, [dl_f, dl_r], [dc_f, dc_r], d_gflat, (), ws=ws)
+            if u == 0:
+                main.wait_stream(side_b)
             yield d_gflat
             self.D_optimizer.step()
             if u == 0 and self.n_unrolling_steps > 0:
@@ -290,18 +316,18 @@ class SocialWaysTrainer:
         L.call("sw_gan_loss", L.ptr(labels[0]), L.ptr(targets), 1, L.ptr(codes[0]), L.ptr(noise), None, 1, B, g_label,
                g_code, L.ptr(out[self.n_unrolling_steps + 1]), L.ptr(dl_f), L.ptr(dc_f), None, None, L.stream())
         dpred = ops.disc_backward(D._flat, dctx, [dl_f], [dc_f], None, (True,), ws=ws)[0]
+        if self.n_unrolling_steps > 0:                                       # D.load(backup), Linear only: D is not
+            if self._lin_mask is None:                                      # read again in this step -> side stream
+                self._lin_mask = D.linear_mask() > 0
+            side_a.wait_stream(main)
+            with torch.cuda.stream(side_a):
+                D._flat.copy_(torch.where(self._lin_mask, backup[:D._flat.numel()], D._flat))
         G.grad_views()
         ops.gen_backward(enc._flat, emb._flat, att._flat, dec._flat, gctx, dpred, enc._gflat, emb._gflat, att._gflat,
-                         dec._gflat, ws=ws)
+                         dec._gflat, ws=ws, side=None)   # (side-stream wgrad starves the BPTT chain of CUs: measured slower)
+        main.wait_stream(side_a)
         yield G._gflat_all
         self.predictor_optimizer.step()
-        if self.n_unrolling_steps > 0:                                       # D.load(backup), Linear only
-            if self._lin_mask is None:
-                self._lin_mask = D.linear_mask() > 0
-            D._flat.copy_(torch.where(self._lin_mask, backup[:D._flat.numel()], D._flat))
-        # ---- ADE/FDE partial sums of the G-phase prediction (train.py:546-551) ---------------------
-        L.call("sw_ade_fde", L.ptr(pred_hat), L.ptr(pred), B, Tp, 1.0 / float(ss), L.ptr(out[self.n_unrolling_steps + 2]),
-               L.stream())
         self.last_pred_hat = pred_hat
 
     # ------------------------------------------------------------------------------------------
