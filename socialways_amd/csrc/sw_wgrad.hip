@@ -17,141 +17,119 @@
 #include "sw_common.h"
 #include "sw_wgrad.h"
 
-#define WG_LDS_FLOATS 12288  // 48 KB staging per workgroup -> 3 workgroups per CU
-
-__host__ __device__ inline int wg_ld(int tiles) {  // row stride = 16 (mod 32): the two rows a half-wave
-  int ld = tiles * 16;                             // reads never share an LDS bank
-  return (ld & 31) == 0 ? ld + 16 : ld;
+// One wave = one job: a 64 x 64 output block (4 x 4 MFMA tiles, 16 accumulators) of one column block
+// of one problem over one row slice.  Operands come straight from global memory in MFMA layout
+// (A: delta[r0+lg][n0+16i+ln], B: act[r0+lg][k0+16kt+ln], 64 B contiguous per 16 lanes), software
+// pipelined two 4-row groups ahead; no LDS, no barriers - every wave streams independently and the
+// SIMDs hold 4 such waves.  Each delta element is read once per column block, each act element once
+// per 64-row output block: L2 traffic, not HBM (the rows were written microseconds earlier).
+// Branch-free streaming body, specialised on the tile counts (NI output-row tiles x KT column tiles of
+// this wave's 64x64 block): loads are unconditional from clamped addresses and masked by a 0/1
+// factor, so the hot loop is NI+KT loads, a few multiplies and NI*KT MFMAs - no exec-mask branches,
+// no accumulator shuffling through control flow.
+template <int NI, int KT>
+__device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const float* __restrict__ abase, int ldd, int lda,
+                                       int rbeg, int rend, int rmax, const int* acol, const float* amask,
+                                       const int* bcol, const float* bmask, const float* bone, int lg, int ln,
+                                       float* __restrict__ mine) {
+  f32x4 acc[NI][KT];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) acc[i][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  constexpr int DEPTH = 6;  // groups in flight
+  float a[DEPTH][NI], b[DEPTH][KT];
+  auto load = [&](int r0, float* av, float* bv) {
+    const int r = r0 + lg;
+    const float rs = r < rend ? 1.0f : 0.0f;
+    const int rc = min(r, rmax);
+    const float* dr = dbase + (size_t)rc * ldd;
+    const float* ar = abase + (size_t)rc * lda;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) av[i] = dr[acol[i]] * (amask[i] * rs);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) bv[kt] = fmaf(ar[bcol[kt]], bmask[kt], bone[kt]) * rs;
+  };
+#pragma unroll
+  for (int q = 0; q < DEPTH - 1; ++q) load(rbeg + 4 * q, a[q], b[q]);
+  for (int r = rbeg; r < rend; r += 4 * DEPTH) {
+#pragma unroll
+    for (int q = 0; q < DEPTH; ++q) {
+      load(r + 4 * (q + DEPTH - 1), a[(q + DEPTH - 1) % DEPTH], b[(q + DEPTH - 1) % DEPTH]);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) acc[i][kt] = SW_MFMA(a[q][i], b[q][kt], acc[i][kt]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[(i * 16 + 4 * lg + r) * 65 + kt * 16 + ln] = acc[i][kt][r];
+    }
+  }
 }
-__host__ __device__ inline int wg_pow2(int x) {
-  int p = 4;
-  while (p < x) p <<= 1;
-  return p;
-}
 
+// One wave = one job: a 64 x 64 output block (NI x KT MFMA tiles) of one column block of one problem
+// over one row slice.  Operands come straight from global memory in MFMA layout (A: delta[r0+lg][n0+16i+ln],
+// B: act[r0+lg][16kt+ln], 64 B contiguous per 16 lanes), software pipelined 5 four-row groups ahead; no
+// LDS in the loop, no barriers - every wave streams independently, 3 waves per SIMD.  The 4 waves of a
+// workgroup take 4 consecutive row slices of the same block and sum them through LDS at the end.
 __global__ __launch_bounds__(SW_THREADS) void wgrad_partial_kernel(WgBatch batch, float* __restrict__ ws) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ __attribute__((aligned(16))) float red[4][64 * 65];   // per-wave 64x64 block (+1 pad), summed before the store
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
-  const int job = blockIdx.x;
+  const int job = blockIdx.x;            // one workgroup = 4 consecutive row slices of one output block
   int p = 0;
 #pragma unroll 1
   while (p + 1 < batch.np && job >= batch.p[p + 1].job0) ++p;
   const WgProblem& P = batch.p[p];
-  const int s = job - P.job0;
+  const int j = job - P.job0;
+  const int NB = (P.N + 63) >> 6;       // 64-row output blocks
+  const int sg = j / NB, nb = j - sg * NB;
+  const int s = sg * 4 + wave;          // this wave's row slice (may be empty)
   const int N = P.N, K = P.K, Kc = P.K + P.ones;
-  const int NT = (N + 15) >> 4, KT = (Kc + 15) >> 4;
-  const int ldn = wg_ld(NT), ldk = wg_ld(KT);
-  const int CW = wg_pow2(NT * 4), CWk = wg_pow2(KT * 4);  // float4 lanes per staged row
-  const int rpd = SW_THREADS / CW, rpa = SW_THREADS / CWk;  // rows per staging iteration
-  int Rc = WG_LDS_FLOATS / (ldn + ldk);
-  Rc = min(min(Rc, 64), min(8 * rpd, 4 * rpa)) & ~3;
-  float* dst = smem;
-  float* ast = smem + Rc * ldn;
-  const int rows_per = (((P.R + P.nsplit - 1) / P.nsplit) + 3) & ~3;
-  const int rbeg = s * rows_per;
+  const int n0 = nb * 64;
+  const int NI = min(4, (N - n0 + 15) >> 4), KT = (Kc + 15) >> 4;
+  const int nsub = P.nsplit * 4;
+  const int rows_per = (((P.R + nsub - 1) / nsub) + 3) & ~3;
+  const int rbeg = min(P.R, s * rows_per);
   const int rend = min(P.R, rbeg + rows_per);
-  const float* dptr = P.delta;
-  const float* aptr = P.act;
-  const int ldd = P.ldd, lda = P.lda;
-  const int ones = P.ones;
-  // this thread's staging coordinates
-  const int drow = threadIdx.x / CW, dcol = (threadIdx.x & (CW - 1)) * 4;
-  const int arow = threadIdx.x / CWk, acol = (threadIdx.x & (CWk - 1)) * 4;
-  const bool dlive = dcol < NT * 16, alive = acol < KT * 16;
-
-  f32x4 pd[8], pa[4];
-  auto issue = [&](int r0) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      int rr = drow + u * rpd, r = r0 + rr;
-      if (dlive && rr < Rc && r < rend) {
-        const float* q = dptr + (size_t)r * ldd + dcol;
-        if (dcol + 3 < N) v = ld4(q);
-        else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (dcol + e < N) v[e] = q[e];
-        }
-      }
-      pd[u] = v;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      int rr = arow + u * rpa, r = r0 + rr;
-      if (alive && rr < Rc && r < rend) {
-        const float* q = aptr + (size_t)r * lda + acol;
-        if (acol + 3 < K) v = ld4(q);
-        else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acol + e < K ? q[e] : ((ones && acol + e == K) ? 1.0f : 0.f);
-        }
-      }
-      pa[u] = v;
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      int rr = drow + u * rpd;
-      if (dlive && rr < Rc) st4(dst + rr * ldn + dcol, pd[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      int rr = arow + u * rpa;
-      if (alive && rr < Rc) st4(ast + rr * ldk + acol, pa[u]);
-    }
-  };
-
-  f32x4 acc[4][4];
+  int acol[4], bcol[4];
+  float amask[4], bmask[4], bone[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) acc[i][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int n = n0 + 16 * i + ln, k = 16 * i + ln;
+    acol[i] = min(n, N - 1);
+    amask[i] = n < N ? 1.0f : 0.0f;
+    bcol[i] = min(k, max(K - 1, 0));
+    bmask[i] = k < K ? 1.0f : 0.0f;
+    bone[i] = (P.ones && k == K) ? 1.0f : 0.0f;
   }
-  const float* abase = dst + lg * ldn + wave * 16 + ln;
-  const float* bbase = ast + lg * ldk + ln;
-  if (rbeg < rend) issue(rbeg);
-  for (int r0 = rbeg; r0 < rend; r0 += Rc) {
-    commit();
-    sw_barrier();
-    if (r0 + Rc < rend) issue(r0 + Rc);
-    const int gmax = min(Rc, (rend - r0 + 3) & ~3);
-    for (int g = 0; g < gmax; g += 4) {
-      float b[4];
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) b[kt] = kt < KT ? bbase[g * ldk + kt * 16] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (wave + 4 * i < NT) {
-          float a = abase[g * ldn + i * 64];
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt) {
-            if (kt < KT) acc[i][kt] = SW_MFMA(a, b[kt], acc[i][kt]);
-          }
-        }
-      }
-    }
-    sw_barrier();
+  float* mine = red[wave];
+#define WG_CASE(ni, kt)                                                                                          \
+  case ni * 4 + kt:                                                                                              \
+    wg_run<ni, kt>(P.delta, P.act, P.ldd, P.lda, rbeg, rend, P.R - 1, acol, amask, bcol, bmask, bone, lg, ln, mine); \
+    break;
+  switch (NI * 4 + KT) {
+    WG_CASE(1, 1) WG_CASE(1, 2) WG_CASE(1, 3) WG_CASE(1, 4)
+    WG_CASE(2, 1) WG_CASE(2, 2) WG_CASE(2, 3) WG_CASE(2, 4)
+    WG_CASE(3, 1) WG_CASE(3, 2) WG_CASE(3, 3) WG_CASE(3, 4)
+    WG_CASE(4, 1) WG_CASE(4, 2) WG_CASE(4, 3) WG_CASE(4, 4)
   }
-  // partial of this slice: ws[ws_off + (s*N + n)*Kc + k]
-  float* out = ws + P.ws_off + (size_t)s * N * Kc;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int nt = wave + 4 * i;
-    if (nt < NT) {
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        int k = kt * 16 + ln;
-        if (kt < KT && k < Kc) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            int n = nt * 16 + 4 * lg + r;
-            if (n < N) out[(size_t)n * Kc + k] = acc[i][kt][r];
-          }
-        }
-      }
-    }
+#undef WG_CASE
+  sw_barrier();
+  // one partial per workgroup (4 row slices summed): ws[ws_off + (sg*N + n)*Kc + k]
+  float* out = ws + P.ws_off + (size_t)sg * N * Kc;
+  const int rows = min(64, N - n0), cols = min(64, Kc);
+  for (int e = threadIdx.x; e < rows * cols; e += SW_THREADS) {
+    int rr = e / cols, cc = e - rr * cols;
+    int o = rr * 65 + cc;
+    float v = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+    out[(size_t)(n0 + rr) * Kc + cc] = v;
   }
 }
 
@@ -216,13 +194,18 @@ int wg_add(WgBatch& b, const float* delta, int ldd, const float* act, int lda, i
   return SW_OK;
 }
 
-// Cost model of one row slice: per 4-row group a wave issues NI x KT MFMAs (NI = its n-tiles) and the
-// workgroup pays a roughly constant staging / barrier price worth ~16 MFMAs.  Slices are sized so
-// that every workgroup of the launch carries the same cost: a narrow problem with many rows (bias-
-// like shapes, K = 4) is staging-bound and must be cut as finely as a wide one.
+// Cost of a problem in wave-cycles: per 4-row group a wave issues NI x KT MFMAs (32 cycles each) but
+// never less than the issue time of its ~8 operand loads; a problem has ceil(N/64) output blocks.
 static double wg_cost(const WgProblem& P) {
-  int ni = (P.nbn + 3) / 4;
-  return (double)P.R * (16.0 + ni * P.nbk);
+  double c = 0;
+  for (int n0 = 0; n0 < P.N; n0 += 64) {
+    int ni = (P.N - n0 + 15) / 16;
+    if (ni > 4) ni = 4;
+    double per_group = ni * P.nbk * 32.0;
+    if (per_group < 192.0) per_group = 192.0;
+    c += per_group;
+  }
+  return c * (P.R / 4.0 + 8.0);
 }
 double wg_total_work(const WgBatch& b) {
   double w = 0;
@@ -231,20 +214,21 @@ double wg_total_work(const WgBatch& b) {
 }
 
 size_t wg_finalize(WgBatch& b) {
-  // ~768 workgroups per launch (3 per CU by LDS and registers), equal cost each
+  // ~1024 workgroups = 4096 wave-jobs per launch (4 per SIMD), equal cost each
   const double total = wg_total_work(b) + 1.0;
   size_t ws = 0;
   int job = 0, out = 0;
   for (int i = 0; i < b.np; ++i) {
     WgProblem& P = b.p[i];
-    int ns = (int)(768.0 * wg_cost(P) / total + 0.5);
-    int cap = (P.R + 31) / 32;  // at least 32 rows per slice
+    const int NB = (P.N + 63) / 64;
+    int ns = (int)(1024.0 * wg_cost(P) / total / NB + 0.5);   // workgroups (4 row slices each) per output block
+    int cap = (P.R + 127) / 128;  // at least 32 rows per wave
     if (ns > cap) ns = cap;
     if (ns > SW_WG_MAXSPLIT) ns = SW_WG_MAXSPLIT;
     if (ns < 1) ns = 1;
     P.nsplit = ns;
     P.job0 = job;
-    job += ns;
+    job += ns * NB;
     P.out0 = out;
     const int Kc = P.K + P.ones;
     out += P.N * Kc;
@@ -261,7 +245,7 @@ int wg_launch(WgBatch& b, float* ws, hipStream_t stream) {
   size_t need = wg_finalize(b);
   if (need > SW_WG_WS_FLOATS) return SW_ESHAPE;
   if (b.total_jobs == 0 || b.total_out == 0) return SW_OK;
-  hipLaunchKernelGGL(wgrad_partial_kernel, dim3(b.total_jobs), dim3(SW_THREADS), WG_LDS_FLOATS * 4, stream, b, ws);
+  hipLaunchKernelGGL(wgrad_partial_kernel, dim3(b.total_jobs), dim3(SW_THREADS), 0, stream, b, ws);
   SW_CHECK_LAUNCH("wgrad_partial_kernel");
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((b.total_out * 16 + 255) / 256), dim3(256), 0, stream, b, ws);
   SW_CHECK_LAUNCH("wgrad_reduce_kernel");
