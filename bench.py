@@ -135,12 +135,22 @@ def main():
     for i in range(args.warmup):
         one_step(i)
     fence()
-    L.TIMING = {"names": {args.dominant}, "events": []}
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
+    # Roofline leg: the timed region replays hipGraphs, where no per-kernel event can be placed, so the
+    # dominant kernel is timed right here with HIP events around its C-ABI call (on the launch stream)
+    # over a few EAGER steps of the same workload; profiles/ holds the rocprofv3 trace of the graph run.
+    n_ev = max(4, min(args.steps, 20))
+    tr.use_graph = False
+    for i in range(2):
+        one_step(i)
+    L.TIMING = {"names": {args.dominant}, "events": []}
+    for i in range(n_ev):
+        one_step(i)
+    fence()
     timing, L.TIMING = L.TIMING, None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)

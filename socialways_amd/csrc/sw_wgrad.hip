@@ -184,7 +184,8 @@ int wg_add(WgBatch& b, const float* delta, int ldd, const float* act, int lda, i
     const int c1 = c0 + 64 < total ? c0 + 64 : total;
     const bool has_ones = db && c1 == total;
     WgProblem& P = b.p[b.np++];
-    P.delta = delta; P.ldd = ldd; P.act = act + c0; P.lda = lda;
+    // a block that holds only the ones column multiplies no act column: keep its (masked) loads in bounds
+    P.delta = delta; P.ldd = ldd; P.act = (has_ones && c1 - c0 == 1) ? act : act + c0; P.lda = lda;
     P.R = R; P.N = N; P.K = (c1 - c0) - (has_ones ? 1 : 0); P.ones = has_ones ? 1 : 0;
     P.dW = dW + c0; P.ldw = ldw; P.db = has_ones ? db : nullptr; P.db2 = has_ones ? db2 : nullptr;
     P.accumulate = accumulate;

@@ -1,0 +1,33 @@
+"""profiles/r01_pmc_<workload>.json from the FETCH_SIZE / WRITE_SIZE rocprofv3 passes (separate --pmc runs).
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB and, on gfx950,
+FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md §HBM) - validated here on
+dec_rollout_bwd, whose reads (saved LSTM rows + a1/a2) are 58 MB by construction vs 2 x 27.4 MB counted."""
+import json, sqlite3, sys
+from collections import defaultdict
+
+def mean_counter(db, name):
+    con = sqlite3.connect(db)
+    per, cnt = defaultdict(float), defaultdict(set)
+    for k, c, v, d in con.execute("select kernel_name, counter_name, value, dispatch_id from counters_collection"):
+        if c == name:
+            key = k.split("(")[0]
+            per[key] += v
+            cnt[key].add(d)
+    return {k: per[k] / len(cnt[k]) for k in per}
+
+fetch = mean_counter(sys.argv[1], "FETCH_SIZE")
+write = mean_counter(sys.argv[2], "WRITE_SIZE")
+abi = {"dec_rollout_bwd_kernel": "sw_dec_rollout_bwd", "dec_rollout_fwd_kernel": "sw_dec_rollout_fwd",
+       "enc_lstm_fwd_kernel": "sw_enc_lstm_fwd", "enc_lstm_bwd_kernel": "sw_enc_lstm_bwd",
+       "disc_fwd_kernel": "sw_disc_fwd", "disc_bwd_kernel": "sw_disc_bwd", "wgrad_partial_kernel": "wgrad_partial",
+       "social_pool_fwd_kernel": "sw_social_pool_fwd", "social_pool_bwd_kernel": "sw_social_pool_bwd"}
+out = {}
+for k in sorted(set(fetch) | set(write)):
+    name = abi.get(k.replace("void ", ""), None)
+    if name is None:
+        continue
+    f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+    out[name] = {"kernel": k, "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
+                 "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out, indent=1))
