@@ -168,7 +168,7 @@ def main():
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get(args.dominant, {}).get("hbm_bytes_per_launch")
         res = {
-            "metric": "GAN train steps/sec (256 scenes x 8 agents x 8+12 T per GPU step; fp32; social block on)",
+            "metric": "GAN train steps/sec (%d scenes x %d agents x %d+%d T per GPU step; fp32; social block on)" % (S, A, To, Tp),
             "value": args.steps * world / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

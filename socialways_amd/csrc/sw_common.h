@@ -106,16 +106,16 @@ __device__ __forceinline__ f32x4 tile_mm_reg(const f32x4* w, const float* xrow, 
 __device__ __forceinline__ void stage_w(float* dst, int ld, int Mp, const float* src, int src_ld,
                                         int M, int K) {
   const int ldq = ld >> 2, n4 = Mp * ldq;
-  for (int base = 0; base < n4; base += SW_THREADS * 8) {
-    f32x4 v[8];
+  for (int base = 0; base < n4; base += SW_THREADS * 16) {
+    f32x4 v[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       int f = base + threadIdx.x + SW_THREADS * u;
       int r = f / ldq, c = (f - r * ldq) * 4;
       v[u] = (f < n4 && r < M && c < K) ? ld4(src + (size_t)r * src_ld + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       int f = base + threadIdx.x + SW_THREADS * u;
       if (f < n4) st4(dst + (size_t)f * 4, v[u]);
     }
@@ -130,16 +130,16 @@ __device__ __forceinline__ void stage_zero(float* dst, int nfloats) {
 __device__ __forceinline__ void stage_wT(float* dst, int ld, int Kp, const float* src, int src_ld,
                                          int M, int K) {
   const int k4 = K >> 2, n4 = M * k4;  // float4s of the live source block [M][K]
-  for (int base = 0; base < n4; base += SW_THREADS * 8) {
-    f32x4 v[8];
+  for (int base = 0; base < n4; base += SW_THREADS * 16) {
+    f32x4 v[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       int f = base + threadIdx.x + SW_THREADS * u;
       int r = f / k4, c = (f - r * k4) * 4;
       v[u] = f < n4 ? ld4(src + (size_t)r * src_ld + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       int f = base + threadIdx.x + SW_THREADS * u;
       int r = f / k4, c = (f - r * k4) * 4;
       if (f < n4) {

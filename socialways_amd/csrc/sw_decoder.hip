@@ -85,6 +85,8 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
   const GSave gs = gsave_layout(B, To, Tp);
 
   // ---- prologue: stage decoder weights, compose the LSTM input matrix, build u ----------------
+  LstmW W;
+  lstm_load_whh(W, enc_w + swp::ENC_WHH, u0, ln, lg);   // global loads in flight during the LDS staging
   stage_w(W1h, LD64, 160, dec_w + swp::DEC_W1, 160, 160, 64);
   stage_w(W2, LD160, 80, dec_w + swp::DEC_W2, 160, 80, 160);
   stage_w(W3, LD80, 48, dec_w + swp::DEC_W3, 80, 40, 80);
@@ -108,8 +110,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
   f32x4 h = ld4(hT + (size_t)b * 64 + u0 + 4 * lg);
   st4(&hbuf[ln * LD64 + u0 + 4 * lg], h);
   sw_barrier();
-  LstmW W;
-  lstm_load_w(W, enc_w + swp::ENC_WHH, wx_lds, bx_lds, u0, ln, lg);
+  lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
   for (int mt = wave; mt < 10; mt += 4) {
     int m0 = mt * 16;
     f32x4 acc = ld4(dec_w + swp::DEC_B1 + m0 + 4 * lg);
@@ -223,6 +224,8 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
   const GDelta gd = gdelta_layout(B, To, Tp);
 
   // ---- prologue: transposed decoder weights into LDS, composed Wx^T, W_hh^T into registers ---
+  LstmWT WT;
+  lstm_load_wT(WT, enc_w + swp::ENC_WHH, u0, ln, lg);   // global loads in flight during the LDS staging
   stage_zero(smem, BwdLds::dgbuf);  // transposed images are zero padded
   sw_barrier();
   stage_wT(W1hT, LD160, 64, dec_w + swp::DEC_W1, 160, 160, 64);
@@ -240,8 +243,6 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
 #pragma unroll
     for (int r = 0; r < 4; ++r) wxT[j][r] = ln < 4 ? wx_lds[(64 * wave + 16 * j + 4 * lg + r) * 4 + ln] : 0.f;
   }
-  LstmWT WT;
-  lstm_load_wT(WT, enc_w + swp::ENC_WHH, u0, ln, lg);
   sw_barrier();
 
   f32x4 dh = {0.f, 0.f, 0.f, 0.f}, dc = {0.f, 0.f, 0.f, 0.f};

@@ -125,6 +125,8 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
   const bool live = (a0 + ln) < B;
   const int K4 = 4 * Tp;
 
+  LstmW W;
+  lstm_load_whh(W, d_w + O.whh, u0, ln, lg);   // global loads in flight during the LDS staging
   // ---- stage head weights / biases ------------------------------------------------------------
   stage_w(smem + L.of0, LD64, 32, d_w + O.of0w, 64, 32, 64);
   stage_w(smem + L.of1, LD32, 32, d_w + O.of1w, 32, 32, 32);
@@ -152,8 +154,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
   f32x4 c = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};  // h0 = c0 = 0 (train.py:296-297)
   st4(&hbuf[ln * SW_HLD + u0 + 4 * lg], h);
   sw_barrier();
-  LstmW W;
-  lstm_load_w(W, d_w + O.whh, wx_lds, bx_lds, u0, ln, lg);
+  lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
 
   // ---- LSTM over the observation (4-d state formed on the fly, train.py:130-133) ---------------
   for (int t = 0; t < To; ++t) {

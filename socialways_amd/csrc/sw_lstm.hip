@@ -25,6 +25,8 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
   const int a0 = blockIdx.x * SW_TILE;
   const int b = min(a0 + ln, B - 1);
   const bool live = (a0 + ln) < B;
+  LstmW W;
+  lstm_load_whh(W, enc_w + swp::ENC_WHH, u0, ln, lg);
 
   lstm_prep_rows(enc_w + swp::ENC_EMB_W, enc_w + swp::ENC_EMB_B, enc_w + swp::ENC_WIH, enc_w + swp::ENC_BIH,
                  enc_w + swp::ENC_BHH, true, wx_lds, bx_lds);
@@ -34,8 +36,7 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
   if (c0) c = ld4(c0 + (size_t)b * 64 + u0 + 4 * lg);
   st4(&hbuf[0][ln * SW_HLD + u0 + 4 * lg], h);
   sw_barrier();
-  LstmW W;
-  lstm_load_w(W, enc_w + swp::ENC_WHH, wx_lds, bx_lds, u0, ln, lg);
+  lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
 
   for (int t = 0; t < T; ++t) {
     float xb = x_mode == 0 ? obs_x4(x, b, t, T, lg) : x[((size_t)b * T + t) * 4 + lg];

@@ -28,18 +28,24 @@ __device__ __forceinline__ void lstm_prep_rows(const float* We, const float* be,
                                                float* wx_lds, float* bx_lds) {
   int row = threadIdx.x;  // 256 threads = 256 gate rows
   if (composed) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, ab = 0.f;
+    // the whole W_ih row first (16 independent float4 loads: ONE L2 round trip, not one per k-step),
+    // W_embed / b_embed are tiny and L1-resident after the first touch
+    f32x4 w[16];
     const float* wr = Wih + (size_t)row * 64;
-    for (int e = 0; e < 64; e += 4) {
-      f32x4 w = ld4(wr + e);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) w[e] = ld4(wr + 4 * e);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, ab = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      f32x4 bq = ld4(be + 4 * e);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        f32x4 em = ld4(We + (e + q) * 4);
-        a0 = fmaf(w[q], em[0], a0);
-        a1 = fmaf(w[q], em[1], a1);
-        a2 = fmaf(w[q], em[2], a2);
-        a3 = fmaf(w[q], em[3], a3);
-        ab = fmaf(w[q], be[e + q], ab);
+        f32x4 em = ld4(We + (4 * e + q) * 4);
+        a0 = fmaf(w[e][q], em[0], a0);
+        a1 = fmaf(w[e][q], em[1], a1);
+        a2 = fmaf(w[e][q], em[2], a2);
+        a3 = fmaf(w[e][q], em[3], a3);
+        ab = fmaf(w[e][q], bq[q], ab);
       }
     }
     wx_lds[row * 4 + 0] = a0;
@@ -57,13 +63,19 @@ __device__ __forceinline__ void lstm_prep_rows(const float* We, const float* be,
   }
 }
 
-__device__ __forceinline__ void lstm_load_w(LstmW& W, const float* Whh, const float* wx_lds,
-                                            const float* bx_lds, int u0, int ln, int lg) {
+// W_hh rows straight from global memory: issued at the very top of a kernel so the loads overlap the
+// LDS staging of the other weights; the composed input matrix / bias come from LDS after the barrier.
+__device__ __forceinline__ void lstm_load_whh(LstmW& W, const float* Whh, int u0, int ln, int lg) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const float* wr = Whh + (size_t)(g * 64 + u0 + ln) * 64 + 4 * lg;
 #pragma unroll
     for (int j = 0; j < 4; ++j) W.whh[g][j] = ld4(wr + 16 * j);
+  }
+}
+__device__ __forceinline__ void lstm_load_wx(LstmW& W, const float* wx_lds, const float* bx_lds, int u0, int ln, int lg) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
     W.wx[g] = wx_lds[(g * 64 + u0 + ln) * 4 + lg];
     W.bias[g] = ld4(bx_lds + g * 64 + u0 + 4 * lg);
   }

@@ -116,6 +116,7 @@ class SocialWaysTrainer:
         if use_graph is None:          # hipGraph replay of the step (segmented around the all-reduces when world > 1)
             use_graph = self.device.type == "cuda" and fused_adam
         self.use_graph = bool(use_graph)
+        self.max_graphs = 8
         self._graphs = {}
         self._force_dist = os.environ.get("SW_FORCE_DIST", "") == "1"   # 1-rank group still runs the collectives (tests)
         packed = fused_adam and self.device.type == "cuda"
@@ -164,7 +165,11 @@ class SocialWaysTrainer:
         Bg = float(global_B if global_B is not None else B)
         dev = self.device
         if self.use_graph:
-            return self._step_graph(obsv, pred, sub_batches, zeros_val, ones_val, noise, float(ss), Bg, out)
+            # one graph set per packed-batch layout; datasets with ragged scenes produce many layouts, so the
+            # number of captured layouts is capped and the rest of the steps run eagerly
+            scenes = ops.SceneIndex.get(sub_batches, B, dev)
+            if (scenes.key, obsv.shape[1], float(ss), Bg) in self._graphs or len(self._graphs) < self.max_graphs:
+                return self._step_graph(obsv, pred, sub_batches, zeros_val, ones_val, noise, float(ss), Bg, out)
         if out is None:
             out = torch.zeros(self.n_unrolling_steps + 3, 3, device=dev)
         scenes = ops.SceneIndex.get(sub_batches, B, dev)
