@@ -156,3 +156,113 @@ def shard_scenes(sub_batches, world_size):
         cuts.append(min(max(k, cuts[-1]), len(sb)))
     cuts.append(len(sb))
     return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
+
+
+# ------------------------------------------------------------------------------------------------
+# Dataset preparation: BIWI/ETH "obsmat.txt" -> sliding windows -> scenes.
+# Reference: utils/parse_utils.py:231-320 (BIWIParser.load), :457-508 (create_dataset),
+# create_dataset.py:1-15.  Offline, host-side, numpy.
+# ------------------------------------------------------------------------------------------------
+def write_biwi_obsmat(path, frames, ids, pos, vel=None):
+    """Write tracks in the BIWI column layout [frame, id, px, pz, py, vx, vz, vy] (the parser reads
+    columns 0,1,2,4,5,7; parse_utils.py:273-283).  Rows are written in the order given."""
+    frames, ids, pos = np.asarray(frames), np.asarray(ids), np.asarray(pos, dtype=np.float64)
+    vel = np.zeros_like(pos) if vel is None else np.asarray(vel, dtype=np.float64)
+    with open(path, "w") as f:
+        for t, i, p, v in zip(frames, ids, pos, vel):
+            f.write("%.7e %.7e %.7e %.7e %.7e %.7e %.7e %.7e\n" % (t, i, p[0], 0.0, p[1], v[0], 0.0, v[1]))
+
+
+def parse_biwi(path, down_sample=1):
+    """BIWIParser.load for a single file: per-pedestrian position / time arrays in first-appearance
+    order and the frame interval of the first pedestrian with two samples (parse_utils.py:300-305).
+    Returns (p_data, t_data, interval)."""
+    delim = "\t" if "zara" in path else " "
+    order, pos, tim = [], {}, {}
+    with open(path) as f:
+        for line in f:
+            row = [c for c in line.split(delim) if c != ""]
+            if len(row) < 8:
+                continue
+            ts = float(row[0])
+            pid = round(float(row[1]))
+            if ts % down_sample != 0:
+                continue
+            if pid not in pos:
+                order.append(pid)
+                pos[pid], tim[pid] = [], []
+            pos[pid].append((float(row[2]), float(row[4])))
+            tim[pid].append(ts)
+    interval = -1
+    for pid in order:
+        if len(tim[pid]) > 1:
+            d = int(round(tim[pid][1] - tim[pid][0]))
+            if d > 0:
+                interval = d
+                break
+    p_data = [np.array(pos[k]) for k in order]
+    t_data = [np.array(tim[k]).astype(np.int32) for k in order]
+    return p_data, t_data, interval
+
+
+def create_dataset(p_data, t_data, t_range, n_past=8, n_next=12):
+    """Sliding windows of n_past + n_next samples (parse_utils.py:457-508): for every integer t of
+    `t_range` (stepping by 1, like the reference) and every pedestrian that has samples at
+    t - step*n_past, t and t + step*(n_next-1): obs = the n_past samples before t, pred = the n_next
+    from t on.  A scene = the windows sharing t.  Returns (obsvs f32, preds f32, times list,
+    batches int64); the reference stores `batches` as int16 (overflow above 32767 rows)."""
+    step = t_range.step
+    index = [dict((int(t), k) for k, t in reversed(list(enumerate(td)))) for td in t_data]   # first occurrence wins
+    t0s, xs, ys = [], [], []
+    for t in range(t_range.start, t_range.stop, 1):
+        for i, ix in enumerate(index):
+            a, b, c = ix.get(t - step * n_past), ix.get(t), ix.get(t + step * (n_next - 1))
+            if a is None or b is None or c is None:
+                continue
+            t0s.append(t)
+            xs.append(p_data[i][a:b])
+            ys.append(p_data[i][b:c + 1])
+    batches, keep, last_t = [], [], -1000
+    for i, t in enumerate(t0s):          # min_interval = 1 (parse_utils.py:481-489)
+        if t > last_t + 1:
+            batches.append([i, i + 1])
+            last_t = t
+        if t == last_t:
+            batches[-1][1] = i + 1
+    out_b, last = [], 0
+    for a, b in batches:
+        keep += list(range(a, b))
+        out_b.append([last, last + (b - a)])
+        last += b - a
+    obsvs = np.array([xs[k] for k in keep]).astype(np.float32)
+    preds = np.array([ys[k] for k in keep]).astype(np.float32)
+    return obsvs, preds, t0s, np.array(out_b, dtype=np.int64)
+
+
+def biwi_to_npz(obsmat_path, npz_path, n_past=8, n_next=12):
+    """create_dataset.py:1-15: obsmat.txt -> npz {obsvs, preds, times, batches}."""
+    p_data, t_data, interval = parse_biwi(obsmat_path)
+    obsvs, preds, times, batches = create_dataset(p_data, t_data, range(int(t_data[0][0]), int(t_data[-1][-1]), interval),
+                                                  n_past, n_next)
+    np.savez(npz_path, obsvs=obsvs, preds=preds, times=times, batches=batches)
+    return obsvs, preds, times, batches
+
+
+def synth_crowd_frames(n_frames=60, n_ped=24, interval=6, seed=3, max_life=40):
+    """A synthetic ETH-like recording (no ETH/UCY data is available): pedestrians enter at
+    random frames, walk with slowly varying velocity for a random life span; returned frame-major
+    like obsmat.txt (frames, ids, positions, velocities)."""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for pid in range(1, n_ped + 1):
+        t_in = int(rng.integers(0, max(1, n_frames - 22)))
+        life = int(rng.integers(21, max_life))
+        p = rng.uniform(-5, 5, size=2)
+        v = rng.normal(0, 0.4, size=2)
+        for k in range(min(life, n_frames - t_in)):
+            rows.append(((t_in + k) * interval, pid, p.copy(), v.copy()))
+            v = v + rng.normal(0, 0.03, size=2)
+            p = p + v * 0.4
+    rows.sort(key=lambda r: (r[0], r[1]))
+    return (np.array([r[0] for r in rows], dtype=np.float64), np.array([r[1] for r in rows], dtype=np.float64),
+            np.array([r[2] for r in rows]), np.array([r[3] for r in rows]))

@@ -71,3 +71,21 @@ def test_synth_tracks_match_oracle_generator():
     a, b = sw.synth_tracks(5, [3, 1, 8, 2, 6], seed=7), O.synth_dataset(5, [3, 1, 8, 2, 6], seed=7)
     for k in ("obsvs", "preds", "batches", "times"):
         assert np.array_equal(a[k], b[k])
+
+
+def test_biwi_pipeline_matches_reference_parser(tmp_path):
+    """obsmat.txt -> windows -> scenes (create_dataset.py + utils/parse_utils.py:231-320,457-508): the
+    golden arrays were produced by the reference's BIWIParser + create_dataset on this synthetic file."""
+    import socialways_amd as sw
+    from socialways_amd import data as D
+    g = golden("biwi_synth")
+    path = str(tmp_path / "obsmat.txt")
+    D.write_biwi_obsmat(path, g["frames"], g["ids"], g["pos"], g["vel"])
+    p_data, t_data, interval = D.parse_biwi(path)
+    assert interval == int(g["interval"]) == 6
+    obsvs, preds, times, batches = D.biwi_to_npz(path, str(tmp_path / "data-8-12.npz"))
+    assert np.array_equal(obsvs, g["obsvs"]) and np.array_equal(preds, g["preds"])
+    assert list(times) == g["times"].tolist() and np.array_equal(batches, g["batches"])
+    assert obsvs.shape[1:] == (8, 2) and preds.shape[1:] == (12, 2) and np.diff(batches, axis=1).max() <= 8
+    d = sw.SceneDataset.from_npz(str(tmp_path / "data-8-12.npz"), device="cpu")     # train.py:89-124 on that file
+    assert d.n_past == 8 and d.n_next == 12 and d.train_size == (len(batches) * 4) // 5
