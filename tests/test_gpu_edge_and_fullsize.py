@@ -1,0 +1,145 @@
+"""Edge cases and full-size (BASELINE metric shape) properties of the HIP path.
+Small odd shapes are compared with the CPU oracle directly (no golden needed: the oracle is pinned
+to the reference by tests/test_oracle_golden.py); the full 256x8 shape is checked against the oracle
+once (forward + one training step) and through size-independent properties (determinism, scene
+locality, sub-batch equivalence)."""
+import numpy as np
+import pytest
+import torch
+
+import sw_oracle as O
+from _util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def pair(n_next, use_social=True, seed=0, **kw):
+    import socialways_amd as sw
+    torch.manual_seed(seed)
+    tr = sw.SocialWaysTrainer(n_next, use_social=use_social, device="cuda:0", **kw)
+    orc = O.SocialWaysOracle(n_next, use_social=use_social)
+    orc.load_state({k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in tr.checkpoint().items() if k.endswith("_dict")})
+    return tr, orc
+
+
+@pytest.mark.parametrize("sizes,To,Tp", [([1, 5, 16, 2, 13], 3, 5), ([7], 2, 1), ([1, 1, 1], 8, 12), ([64, 3], 8, 12),
+                                         ([2] * 9 + [3], 5, 7)])
+def test_step_matches_oracle_on_odd_shapes(sizes, To, Tp):
+    """B not a multiple of the 16-agent tile, single-agent scenes only, a 64-agent scene, To/Tp that are
+    not multiples of anything, Tp = 1: losses, rollout and ADE/FDE sums of one full step vs the oracle."""
+    import socialways_amd as sw
+    t = sw.synth_tracks(len(sizes) + 2, sizes + [2, 2], To, Tp, seed=11)
+    data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
+    tr, orc = pair(Tp)
+    B = int(np.sum(sizes))
+    sb = data.the_batches[:len(sizes)]
+    torch.manual_seed(3)
+    noise = torch.rand(B, 32)
+    out = tr.step(data.obsv[:B], data.pred[:B], sb, 0.07, 0.91, noise, data.ss)
+    got = tr.losses_from(out, [B], Tp, data.ss)[0]
+    want, ade, fde = orc.train_step(data.obsv[:B].cpu(), data.pred[:B].cpu(), sb, 0.07, 0.91, noise, data.ss)
+    assert_close(got, np.asarray(want), 5e-5, 2e-6, "9 MSE terms")
+    o = out.double().cpu().numpy()
+    assert abs(o[-1, 0] - ade) < 1e-4 * max(1.0, abs(ade)) and abs(o[-1, 1] - fde) < 1e-4 * max(1.0, abs(fde))
+    for name, mod in (("encoder", tr.G.encoder), ("decoder", tr.G.decoder), ("D", tr.D)):
+        ref = getattr(orc, name).state_dict()
+        for k, v in mod.state_dict().items():      # after Adam: elementwise agreement bounded by ~lr (see check_weights)
+            bad = (v.cpu() - ref[k]).abs() > 2e-3 * 1.01
+            assert bad.float().mean().item() == 0.0, (name, k)
+
+
+def test_scene_larger_than_64_agents_is_refused_loudly():
+    import socialways_amd as sw
+    t = sw.synth_tracks(1, 65)
+    G = sw.Generator(use_social=True, device="cuda:0")
+    obsv = torch.from_numpy(t["obsvs"]).cuda()
+    with pytest.raises(sw.SocialWaysHipError):
+        G(obsv, torch.rand(65, 32).cuda(), 12, [[0, 65]])
+    G.use_social = False                      # without the social block any batch size is fine
+    assert G(obsv, torch.rand(65, 32).cuda(), 12, [[0, 65]]).shape == (65, 12, 4)
+
+
+def test_empty_sub_batches_means_one_scene():
+    """predict(..., sub_batches=[]) treats the whole batch as one scene (train.py:405-406)."""
+    import socialways_amd as sw
+    t = sw.synth_tracks(1, 9, seed=2)
+    G = sw.Generator(use_social=True, device="cuda:0")
+    obsv, z = torch.from_numpy(t["obsvs"]).cuda(), torch.rand(9, 32).cuda()
+    with torch.no_grad():
+        assert torch.equal(G(obsv, z, 12), G(obsv, z, 12, [[0, 9]]))
+
+
+def _m1():
+    import socialways_amd as sw
+    S, A = 256, 8
+    t = sw.synth_tracks(S + 64, A, seed=1234)
+    data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
+    sb = data.the_batches[:S]
+    return data, sb, S * A
+
+
+def test_full_size_forward_matches_oracle_and_is_deterministic():
+    data, sb, B = _m1()
+    tr, orc = pair(12)
+    torch.manual_seed(1)
+    noise = torch.rand(B, 32)
+    with torch.no_grad():
+        a = tr.G(data.obsv[:B], noise.cuda(), 12, sb)
+        b = tr.G(data.obsv[:B], noise.cuda(), 12, sb)
+        ref = orc.predict(data.obsv[:B].cpu(), noise, 12, sb)
+    assert torch.equal(a, b), "same inputs -> bitwise identical rollout"
+    assert_close(a.cpu(), ref, 3e-5, 3e-6, "M1 rollout vs oracle")
+
+
+def test_full_size_scene_locality_and_sub_batch_equivalence():
+    """The social block is block-diagonal: (a) perturbing scene 0 leaves every other scene's rollout
+    bitwise unchanged, (b) running scenes 64..128 alone reproduces their rows of the full batch."""
+    data, sb, B = _m1()
+    tr, _ = pair(12)
+    torch.manual_seed(2)
+    z = torch.rand(B, 32).cuda()
+    obsv = data.obsv[:B].clone()
+    with torch.no_grad():
+        full = tr.G(obsv, z, 12, sb)
+        obsv2 = obsv.clone()
+        obsv2[:8] += 0.05
+        pert = tr.G(obsv2, z, 12, sb)
+        assert not torch.equal(full[:8], pert[:8]) and torch.equal(full[8:], pert[8:])
+        lo, hi = int(sb[64, 0]), int(sb[127, 1])
+        part = tr.G(obsv[lo:hi], z[lo:hi], 12, sb[64:128] - lo)
+        assert torch.equal(part, full[lo:hi])
+
+
+def test_full_size_training_step_matches_oracle():
+    """One whole GAN step at the BASELINE metric shape (2048 agents, 16384 pairs) vs the oracle."""
+    data, sb, B = _m1()
+    tr, orc = pair(12)
+    torch.manual_seed(4)
+    noise = torch.rand(B, 32)
+    out = tr.step(data.obsv[:B], data.pred[:B], sb, 0.02, 0.96, noise, data.ss)
+    got = tr.losses_from(out, [B], 12, data.ss)[0]
+    want, ade, fde = orc.train_step(data.obsv[:B].cpu(), data.pred[:B].cpu(), sb, 0.02, 0.96, noise, data.ss)
+    assert_close(got, np.asarray(want), 5e-5, 2e-6, "9 MSE terms at M1")
+    o = out.double().cpu().numpy()
+    assert abs(o[-1, 0] - ade) / ade < 1e-5 and abs(o[-1, 1] - fde) / fde < 1e-5
+
+
+def test_graph_replay_equals_eager():
+    """The hipGraph-replayed step (captured after two eager steps of a layout) continues the exact same
+    trajectory as a purely eager trainer."""
+    import socialways_amd as sw
+    t = sw.synth_tracks(24, 8, seed=9)
+    data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
+    B = data.n_train_samples
+    sb = data.train_batches
+    res = []
+    for use_graph in (True, False):
+        torch.manual_seed(0)
+        tr = sw.SocialWaysTrainer(12, use_social=True, device="cuda:0", use_graph=use_graph)
+        gen = torch.Generator().manual_seed(5)
+        outs = []
+        for i in range(6):
+            noise = torch.rand(B, 32, generator=gen)
+            outs.append(tr.step(data.obsv[:B], data.pred[:B], sb, 0.01 * i, 0.9 + 0.01 * i, noise, data.ss).clone())
+        res.append((torch.stack(outs).cpu(), tr.D._flat.clone().cpu(), tr.G._flat_all.clone().cpu()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
