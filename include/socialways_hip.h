@@ -131,6 +131,14 @@ int sw_disc_bwd(const float* d_w, const float* dsave, const float* const* dlabel
                 const float* const* dcode, int nb, int B, int To, int Tp, float* ddelta,
                 float* d_d_w, float* const* dpred4, float* wgrad_ws, void* stream);
 
+/* Same backward with the LSGAN / InfoGAN loss gradients formed inside the kernel from the forward
+ * outputs: dlabel_k = 2 (label_k - targets[t_k]) g_label, dcode_0 = 2 (code_0 - z[:, :2]) g_code,
+ * dcode_1 = 0 (train.py:484-494, 512-523) - no separate loss kernel on the critical path.          */
+int sw_disc_bwd_gan(const float* d_w, const float* dsave, const float* const* label,
+                    const float* const* code, const float* targets, int t0, int t1, const float* z /*[B,32]*/,
+                    float g_label, float g_code, int nb, int B, int To, int Tp, float* ddelta,
+                    float* d_d_w, float* const* dpred4, float* wgrad_ws, void* stream);
+
 /* ---- LSGAN + InfoGAN losses of train.py:484-494 / 512-523 and their gradients -------------- */
 /* t_a = targets[ia], t_b = targets[ib] (read on the device, so a captured hipGraph sees new values).
  * out_sums[3] = { sum (label_a - t_a)^2, sum (code_a - z[:, :2])^2, sum (label_b - t_b)^2 } over the
@@ -142,6 +150,10 @@ int sw_gan_loss(const float* label_a, const float* targets /*device [>=2]: label
                 const float* code_a, const float* z /*[B,32]*/, const float* label_b, int ib, int B,
                 float g_label, float g_code, float* out_sums /*[3]*/, float* dlabel_a, float* dcode_a,
                 float* dlabel_b, float* dcode_b, void* stream);
+
+/* ---- staging copy by a device kernel: `src` may be host-pinned (device-mapped) memory; used to feed
+ *      z / label-noise scalars to hipGraph-replayed steps without a blocking hipMemcpyAsync ---------- */
+int sw_copy_f32(float* dst, const float* src, long long n, void* stream);
 
 /* ---- ADE/FDE partial sums of train.py:546-551:
  *      out[3] = { sum_{b,t} err / Tp, sum_b err[:, -1], sum_{b,t} err^2 },  err = |(p_hat - p) / ss|   */

@@ -293,11 +293,21 @@ __host__ __device__ inline HeadLdsB head_lds_b(int Tp, int base) {
 }
 }  // namespace
 
+// GAN mode of the backward kernel: dlabel_* / dcode_* then carry the forward OUTPUTS (label, code) and
+// the loss gradients are formed in the kernel, so no separate loss kernel sits on the critical path.
+struct DiscLoss {
+  const float* targets;  // device: label-noise scalars
+  const float* z;        // [B][32] latent
+  int t0, t1;            // target index of branch 0 / 1
+  float g_label, g_code;
+  int on;
+};
+
 __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
     const float* __restrict__ d_w, const float* __restrict__ dsave, const float* __restrict__ dlabel_a,
     const float* __restrict__ dlabel_b, const float* __restrict__ dcode_a, const float* __restrict__ dcode_b, int nb,
     int B, int To, int Tp, int want_w, float* __restrict__ ddelta, float* __restrict__ dpred_a,
-    float* __restrict__ dpred_b) {
+    float* __restrict__ dpred_b, DiscLoss gl) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* dgbuf = smem;  // [2][16][260]
   const HeadLdsB L = head_lds_b(Tp, 2 * 16 * SW_GLD);
@@ -331,8 +341,15 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
     for (int i = threadIdx.x; i < 16 * LD16; i += blockDim.x) {
       int a = i / LD16, cc = i - a * LD16;
       int bb = min(a0 + a, B - 1);
-      float vl = cc == 0 ? dlabel[bb] : 0.f;
-      float vc = cc < 2 ? dcode[(size_t)bb * 2 + cc] : 0.f;
+      float vl, vc;
+      if (gl.on) {  // LSGAN / InfoGAN loss gradients formed here from the forward outputs (train.py:484-494, 512-523)
+        const float tgt = gl.targets[k == 0 ? gl.t0 : gl.t1];
+        vl = cc == 0 ? 2.0f * (dlabel[bb] - tgt) * gl.g_label : 0.f;
+        vc = (k == 0 && cc < 2) ? 2.0f * (dcode[(size_t)bb * 2 + cc] - gl.z[(size_t)bb * SW_Z + cc]) * gl.g_code : 0.f;
+      } else {
+        vl = cc == 0 ? dlabel[bb] : 0.f;
+        vc = cc < 2 ? dcode[(size_t)bb * 2 + cc] : 0.f;
+      }
       smem[L.dlab + i] = vl;
       smem[L.dcod + i] = vc;
       if (want_w && a0 + a < B && cc < 4) {
@@ -478,9 +495,9 @@ extern "C" int sw_disc_fwd(const float* obsv, int To, int x_mode, const float* c
   return SW_OK;
 }
 
-extern "C" int sw_disc_bwd(const float* d_w, const float* dsave, const float* const* dlabel,
-                           const float* const* dcode, int nb, int B, int To, int Tp, float* ddelta, float* d_d_w,
-                           float* const* dpred4, float* wgrad_ws, void* stream) {
+static int disc_bwd_impl(const float* d_w, const float* dsave, const float* const* dlabel, const float* const* dcode,
+                         int nb, int B, int To, int Tp, float* ddelta, float* d_d_w, float* const* dpred4,
+                         float* wgrad_ws, void* stream, DiscLoss gl) {
   if (!d_w || !dsave || !dlabel || !dcode || nb < 1 || nb > SW_DISC_MAXB || B < 0 || To < 1 || Tp < 1) return SW_EARG;
   for (int k = 0; k < nb; ++k)
     if (!dlabel[k] || !dcode[k]) return SW_EARG;
@@ -497,7 +514,7 @@ extern "C" int sw_disc_bwd(const float* d_w, const float* dsave, const float* co
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(disc_bwd_kernel, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS), lds, st, d_w, dsave,
                      dlabel[0], nb > 1 ? dlabel[1] : nullptr, dcode[0], nb > 1 ? dcode[1] : nullptr, nb, B, To, Tp,
-                     d_d_w ? 1 : 0, ddelta, dpred4 ? dpred4[0] : nullptr, (dpred4 && nb > 1) ? dpred4[1] : nullptr);
+                     d_d_w ? 1 : 0, ddelta, dpred4 ? dpred4[0] : nullptr, (dpred4 && nb > 1) ? dpred4[1] : nullptr, gl);
   SW_CHECK_LAUNCH("disc_bwd_kernel");
   if (!d_d_w) return SW_OK;
   const swp::Disc O = swp::disc(Tp);
@@ -522,4 +539,21 @@ extern "C" int sw_disc_bwd(const float* d_w, const float* dsave, const float* co
   rc_add |= wg_add(wb, ddelta + dd.dcod, 4, dsave + ds.l1, 32, R, 2, 32, d_d_w + O.la1w, 32, d_d_w + O.la1b, nullptr, 0);
   if (rc_add) return SW_ESHAPE;
   return wg_launch(wb, wgrad_ws, st);
+}
+
+extern "C" int sw_disc_bwd(const float* d_w, const float* dsave, const float* const* dlabel,
+                           const float* const* dcode, int nb, int B, int To, int Tp, float* ddelta, float* d_d_w,
+                           float* const* dpred4, float* wgrad_ws, void* stream) {
+  DiscLoss gl{};
+  gl.on = 0;
+  return disc_bwd_impl(d_w, dsave, dlabel, dcode, nb, B, To, Tp, ddelta, d_d_w, dpred4, wgrad_ws, stream, gl);
+}
+
+extern "C" int sw_disc_bwd_gan(const float* d_w, const float* dsave, const float* const* label,
+                               const float* const* code, const float* targets, int t0, int t1, const float* z,
+                               float g_label, float g_code, int nb, int B, int To, int Tp, float* ddelta,
+                               float* d_d_w, float* const* dpred4, float* wgrad_ws, void* stream) {
+  if (!targets || !z || t0 < 0 || t1 < 0) return SW_EARG;
+  DiscLoss gl{targets, z, t0, t1, g_label, g_code, 1};
+  return disc_bwd_impl(d_w, dsave, label, code, nb, B, To, Tp, ddelta, d_d_w, dpred4, wgrad_ws, stream, gl);
 }

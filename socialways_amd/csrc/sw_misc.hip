@@ -288,3 +288,22 @@ extern "C" int sw_ade_fde(const float* pred4, const float* gt, int B, int Tp, fl
   SW_CHECK_LAUNCH("ade_fde_kernel");
   return SW_OK;
 }
+
+// ---- staging copy: device kernel that reads a (host-pinned, device-mapped) source -----------------
+// A hipMemcpyAsync host-to-device enqueued behind hipGraph launches blocks the calling host thread
+// until the stream drains on this runtime; a kernel launch never does.  256 KB of z per step over
+// PCIe is ~5 us.
+__global__ void copy_f32_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = src[i];
+}
+extern "C" int sw_copy_f32(float* dst, const float* src, long long n, void* stream) {
+  if (!dst || !src || n < 0) return SW_EARG;
+  if (n == 0) return SW_OK;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(copy_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dst, src, n);
+  SW_CHECK_LAUNCH("copy_f32_kernel");
+  return SW_OK;
+}

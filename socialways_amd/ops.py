@@ -217,3 +217,25 @@ def disc_backward(d_w, ctx, dlabels, dcodes, d_d_w=None, want_dpred=(), ws=None,
     L.call("sw_disc_bwd", L.ptr(d_w), L.ptr(ctx.dsave), lp, cp, nb, B, To, Tp, L.ptr(ddelta), L.ptr(d_d_w), dp,
            L.ptr(wgrad), L.stream())
     return dpreds
+
+
+def disc_backward_gan(d_w, ctx, labels, codes, targets, t_idx, z, g_label, g_code, d_d_w=None, want_dpred=(), ws=None,
+                      tag="d"):
+    """disc_backward with the LSGAN / InfoGAN loss gradients formed inside the kernel from the forward
+    outputs `labels` / `codes` (targets = device [2] label-noise scalars, t_idx = target index per branch)."""
+    dev = labels[0].device
+    ws = ws or default_ws(dev)
+    B, To, Tp, nb = ctx.B, ctx.To, ctx.Tp, ctx.nb
+    want = list(want_dpred) + [False] * (nb - len(want_dpred))
+    dpreds = [torch.empty(B, Tp, 4, device=dev) if w else None for w in want]
+    ddelta = wgrad = None
+    if d_d_w is not None:
+        ddelta = ws.get(tag + ".ddelta", L.workspace_floats(L.WS_DDELTA, B, To, Tp, nb))
+        wgrad = ws.get("wgrad", L.workspace_floats(L.WS_WGRAD, B, To, Tp))
+    lp, _k1 = L.ptr_array(labels)
+    cp, _k2 = L.ptr_array(codes)
+    dp, _k3 = L.ptr_array(dpreds)
+    t0, t1 = (list(t_idx) + [0])[:2]
+    L.call("sw_disc_bwd_gan", L.ptr(d_w), L.ptr(ctx.dsave), lp, cp, L.ptr(targets), t0, t1, L.ptr(z), g_label, g_code, nb,
+           B, To, Tp, L.ptr(ddelta), L.ptr(d_d_w), dp, L.ptr(wgrad), L.stream())
+    return dpreds

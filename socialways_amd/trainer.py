@@ -187,36 +187,28 @@ class SocialWaysTrainer:
         if st is None:
             st = self._graphs[key] = dict(
                 n=0, graph=None, scenes=scenes, obsv=torch.empty(B, To, 2, device=dev),
-                pred=torch.empty(B, self.n_next, 2, device=dev), noise=torch.empty(B, self.noise_len, device=dev),
-                targets=torch.empty(2, device=dev), out=torch.zeros(self.n_unrolling_steps + 3, 3, device=dev),
-                copy_stream=torch.cuda.Stream(device=dev),
-                ring=[(torch.empty(2 + B * self.noise_len, dtype=torch.float32).pin_memory(),
-                       torch.empty(2 + B * self.noise_len, dtype=torch.float32, device=dev),
-                       torch.cuda.Event(), torch.cuda.Event()) for _ in range(4)])
+                pred=torch.empty(B, self.n_next, 2, device=dev), stage=torch.empty(4 + B * self.noise_len, device=dev),
+                out=torch.zeros(self.n_unrolling_steps + 3, 3, device=dev),
+                ring=[(torch.empty(4 + B * self.noise_len, dtype=torch.float32).pin_memory(), torch.cuda.Event())
+                      for _ in range(4)])
+            st["targets"] = st["stage"][:2]                     # [zeros_val, ones_val]
+            st["noise"] = st["stage"][4:].view(B, self.noise_len)   # 16-byte aligned
         st["obsv"].copy_(obsv)
         st["pred"].copy_(pred)
-        # Host inputs (z, the two label-noise scalars): pinned slot -> device slot on a side COPY stream
-        # (overlaps the previous step's graph), then a device-to-device copy into the graph's static
-        # inputs on the main stream.  A host-to-device copy enqueued on the main stream behind a graph
-        # launch makes the host wait for that graph on ROCm, which would serialise host RNG and GPU.
+        # Host inputs (z, the two label-noise scalars): ring of pinned slots, copied into the graph's static
+        # inputs by a device KERNEL reading the pinned (device-mapped) memory: a hipMemcpyAsync enqueued
+        # behind graph launches blocks the host until the stream drains, a kernel launch does not.
         if noise.is_cuda:
             st["noise"].copy_(noise)
             st["targets"].copy_(torch.tensor([float(zeros_val), float(ones_val)]), non_blocking=True)
         else:
             k = st["k"] = (st.get("k", -1) + 1) % len(st["ring"])
-            host, devslot, ready, consumed = st["ring"][k]
-            ready.synchronize()                                # the H2D copy that last read this pinned slot is done
+            host, done = st["ring"][k]
+            done.synchronize()                                 # the copy kernel that last read this pinned slot is done
             host[0], host[1] = float(zeros_val), float(ones_val)
-            np.copyto(host[2:].view(B, self.noise_len).numpy(), noise.numpy())   # plain memcpy
-            main = torch.cuda.current_stream()
-            with torch.cuda.stream(st["copy_stream"]):
-                st["copy_stream"].wait_event(consumed)         # the main stream has read this device slot
-                devslot.copy_(host, non_blocking=True)
-                ready.record(st["copy_stream"])
-            main.wait_event(ready)
-            st["targets"].copy_(devslot[:2])
-            st["noise"].copy_(devslot[2:].view(B, self.noise_len))
-            consumed.record(main)
+            np.copyto(host[4:].view(B, self.noise_len).numpy(), noise.numpy())   # plain memcpy
+            L.call("sw_copy_f32", L.ptr(st["stage"]), host.data_ptr(), host.numel(), L.stream())
+            done.record()
         if st["graph"] is not None:
             st["flip"] ^= 1
             for g, buf in st["graph"][st["flip"]]:
@@ -306,9 +298,13 @@ class SocialWaysTrainer:
         # ---- discriminator updates (train.py:476-499) ------------------------------------------------
         for u in range(self.n_unrolling_steps + 1):
             labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat, pred4], save=True, ws=ws)
-            L.call("sw_gan_loss", L.ptr(labels[0]), L.ptr(targets), 0, L.ptr(codes[0]), L.ptr(noise), L.ptr(labels[1]),
-                   1, B, g_label, g_code, L.ptr(out[u]), L.ptr(dl_f), L.ptr(dc_f), L.ptr(dl_r), L.ptr(dc_r), L.stream())
-            ops.disc_backward(D._flat, dctx, [dl_f, dl_r], [dc_f, dc_r], d_gflat, (), ws=ws)
+            # loss SUMS (reporting only) on a side stream; the loss gradients are formed inside the backward kernel
+            side_a.wait_stream(main)
+            with torch.cuda.stream(side_a):
+                L.call("sw_gan_loss", L.ptr(labels[0]), L.ptr(targets), 0, L.ptr(codes[0]), L.ptr(noise), L.ptr(labels[1]),
+                       1, B, g_label, g_code, L.ptr(out[u]), None, None, None, None, L.stream())
+            ops.disc_backward_gan(D._flat, dctx, labels, codes, targets, (0, 1), noise, g_label, g_code, d_gflat, (), ws=ws)
+            main.wait_stream(side_a)
             if u == 0:
                 main.wait_stream(side_b)
             yield d_gflat
@@ -318,9 +314,13 @@ class SocialWaysTrainer:
                 backup[:D._flat.numel()].copy_(D._flat)
         # ---- generator update (train.py:503-539) ----------------------------------------------------
         labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat], save=True, ws=ws)
-        L.call("sw_gan_loss", L.ptr(labels[0]), L.ptr(targets), 1, L.ptr(codes[0]), L.ptr(noise), None, 1, B, g_label,
-               g_code, L.ptr(out[self.n_unrolling_steps + 1]), L.ptr(dl_f), L.ptr(dc_f), None, None, L.stream())
-        dpred = ops.disc_backward(D._flat, dctx, [dl_f], [dc_f], None, (True,), ws=ws)[0]
+        side_a.wait_stream(main)
+        with torch.cuda.stream(side_a):
+            L.call("sw_gan_loss", L.ptr(labels[0]), L.ptr(targets), 1, L.ptr(codes[0]), L.ptr(noise), None, 1, B, g_label,
+                   g_code, L.ptr(out[self.n_unrolling_steps + 1]), None, None, None, None, L.stream())
+        dpred = ops.disc_backward_gan(D._flat, dctx, labels, codes, targets, (1, 1), noise, g_label, g_code, None, (True,),
+                                      ws=ws)[0]
+        main.wait_stream(side_a)
         if self.n_unrolling_steps > 0:                                       # D.load(backup), Linear only: D is not
             if self._lin_mask is None:                                      # read again in this step -> side stream
                 self._lin_mask = D.linear_mask() > 0
