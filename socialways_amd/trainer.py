@@ -269,26 +269,20 @@ class SocialWaysTrainer:
         ws = self.ws
         g_label = 1.0 / Bg
         g_code = (self.loss_info_w if self.use_info_loss else 0.0) / (2.0 * Bg)
-        main = torch.cuda.current_stream()
-        side_a, side_b = self._sides()
-        # real future as 4-d (train.py:470) on a side stream, concurrently with the observation encoder;
-        # the observation itself stays 2-d: kernels form (p, v) on the fly
+        # One stream: inside a hipGraph every cross-stream edge costs 5-10 us of queue synchronisation on
+        # this runtime - more than any of the small kernels that could be overlapped (measured).
+        # real future as 4-d (train.py:470); the observation itself stays 2-d: kernels form (p, v) on the fly
         pred4 = torch.empty(B, Tp, 4, device=dev)
         o4_scratch = ws.get("o4", B * obsv.shape[1] * 4)
-        side_a.wait_stream(main)
-        with torch.cuda.stream(side_a):
-            L.call("sw_traj_4d", L.ptr(obsv), L.ptr(pred), B, obsv.shape[1], Tp, L.ptr(o4_scratch), L.ptr(pred4), L.stream())
+        L.call("sw_traj_4d", L.ptr(obsv), L.ptr(pred), B, obsv.shape[1], Tp, L.ptr(o4_scratch), L.ptr(pred4), L.stream())
         # ---- generator rollout, once (train.py:480/507 are identical) ---------------
         enc, emb, att, dec = G.encoder, G.feature_embedder, G.attention, G.decoder
         pred_hat, gctx = ops.gen_forward(enc._flat, emb._flat, att._flat, dec._flat, obsv, noise, scenes, Tp,
                                          G.use_social, save=True, ws=ws)
         # ADE/FDE partial sums of the prediction (train.py:546-551) only need pred_hat: side stream,
         # under the first discriminator pass
-        side_b.wait_stream(main)
-        with torch.cuda.stream(side_b):
-            L.call("sw_ade_fde", L.ptr(pred_hat), L.ptr(pred), B, Tp, 1.0 / float(ss),
-                   L.ptr(out[self.n_unrolling_steps + 2]), L.stream())
-        main.wait_stream(side_a)
+        L.call("sw_ade_fde", L.ptr(pred_hat), L.ptr(pred), B, Tp, 1.0 / float(ss),
+               L.ptr(out[self.n_unrolling_steps + 2]), L.stream())
         dl_f = ws.get("dl_f", B)
         dc_f = ws.get("dc_f", 2 * B)
         dl_r = ws.get("dl_r", B)
@@ -299,14 +293,9 @@ class SocialWaysTrainer:
         for u in range(self.n_unrolling_steps + 1):
             labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat, pred4], save=True, ws=ws)
             # loss SUMS (reporting only) on a side stream; the loss gradients are formed inside the backward kernel
-            side_a.wait_stream(main)
-            with torch.cuda.stream(side_a):
-                L.call("sw_gan_loss", L.ptr(labels[0]), L.ptr(targets), 0, L.ptr(codes[0]), L.ptr(noise), L.ptr(labels[1]),
-                       1, B, g_label, g_code, L.ptr(out[u]), None, None, None, None, L.stream())
             ops.disc_backward_gan(D._flat, dctx, labels, codes, targets, (0, 1), noise, g_label, g_code, d_gflat, (), ws=ws)
-            main.wait_stream(side_a)
-            if u == 0:
-                main.wait_stream(side_b)
+            L.call("sw_gan_loss", L.ptr(labels[0]), L.ptr(targets), 0, L.ptr(codes[0]), L.ptr(noise), L.ptr(labels[1]),
+                   1, B, g_label, g_code, L.ptr(out[u]), None, None, None, None, L.stream())
             yield d_gflat
             self.D_optimizer.step()
             if u == 0 and self.n_unrolling_steps > 0:
@@ -314,23 +303,17 @@ class SocialWaysTrainer:
                 backup[:D._flat.numel()].copy_(D._flat)
         # ---- generator update (train.py:503-539) ----------------------------------------------------
         labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat], save=True, ws=ws)
-        side_a.wait_stream(main)
-        with torch.cuda.stream(side_a):
-            L.call("sw_gan_loss", L.ptr(labels[0]), L.ptr(targets), 1, L.ptr(codes[0]), L.ptr(noise), None, 1, B, g_label,
-                   g_code, L.ptr(out[self.n_unrolling_steps + 1]), None, None, None, None, L.stream())
         dpred = ops.disc_backward_gan(D._flat, dctx, labels, codes, targets, (1, 1), noise, g_label, g_code, None, (True,),
                                       ws=ws)[0]
-        main.wait_stream(side_a)
+        L.call("sw_gan_loss", L.ptr(labels[0]), L.ptr(targets), 1, L.ptr(codes[0]), L.ptr(noise), None, 1, B, g_label,
+               g_code, L.ptr(out[self.n_unrolling_steps + 1]), None, None, None, None, L.stream())
         if self.n_unrolling_steps > 0:                                       # D.load(backup), Linear only: D is not
             if self._lin_mask is None:                                      # read again in this step -> side stream
                 self._lin_mask = D.linear_mask() > 0
-            side_a.wait_stream(main)
-            with torch.cuda.stream(side_a):
-                D._flat.copy_(torch.where(self._lin_mask, backup[:D._flat.numel()], D._flat))
+            D._flat.copy_(torch.where(self._lin_mask, backup[:D._flat.numel()], D._flat))
         G.grad_views()
         ops.gen_backward(enc._flat, emb._flat, att._flat, dec._flat, gctx, dpred, enc._gflat, emb._gflat, att._gflat,
                          dec._gflat, ws=ws, side=None)   # (side-stream wgrad starves the BPTT chain of CUs: measured slower)
-        main.wait_stream(side_a)
         yield G._gflat_all
         self.predictor_optimizer.step()
         self.last_pred_hat = pred_hat
