@@ -154,6 +154,8 @@ int sw_gan_loss(const float* label_a, const float* targets /*device [>=2]: label
 /* ---- staging copy by a device kernel: `src` may be host-pinned (device-mapped) memory; used to feed
  *      z / label-noise scalars to hipGraph-replayed steps without a blocking hipMemcpyAsync ---------- */
 int sw_copy_f32(float* dst, const float* src, long long n, void* stream);
+int sw_copy3_f32(float* d0, const float* s0, long long n0, float* d1, const float* s1, long long n1,
+                 float* d2, const float* s2, long long n2, void* stream);
 
 /* ---- ADE/FDE partial sums of train.py:546-551:
  *      out[3] = { sum_{b,t} err / Tp, sum_b err[:, -1], sum_{b,t} err^2 },  err = |(p_hat - p) / ss|   */

@@ -307,3 +307,27 @@ extern "C" int sw_copy_f32(float* dst, const float* src, long long n, void* stre
   SW_CHECK_LAUNCH("copy_f32_kernel");
   return SW_OK;
 }
+
+// Three staging copies in one launch (tracks of the packed batch + host-pinned z / scalars).
+__global__ void copy3_f32_kernel(float* __restrict__ d0, const float* __restrict__ s0, long long n0,
+                                 float* __restrict__ d1, const float* __restrict__ s1, long long n1,
+                                 float* __restrict__ d2, const float* __restrict__ s2, long long n2) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long k = i; k < n0; k += stride) d0[k] = s0[k];
+  for (long long k = i; k < n1; k += stride) d1[k] = s1[k];
+  for (long long k = i; k < n2; k += stride) d2[k] = s2[k];
+}
+extern "C" int sw_copy3_f32(float* d0, const float* s0, long long n0, float* d1, const float* s1, long long n1,
+                            float* d2, const float* s2, long long n2, void* stream) {
+  if ((n0 > 0 && (!d0 || !s0)) || (n1 > 0 && (!d1 || !s1)) || (n2 > 0 && (!d2 || !s2)) || n0 < 0 || n1 < 0 || n2 < 0)
+    return SW_EARG;
+  long long n = n0 > n1 ? n0 : n1;
+  n = n > n2 ? n : n2;
+  if (n == 0) return SW_OK;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(copy3_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d0, s0, n0, d1, s1, n1, d2, s2, n2);
+  SW_CHECK_LAUNCH("copy3_f32_kernel");
+  return SW_OK;
+}

@@ -170,7 +170,7 @@ class SocialWaysTrainer:
             scenes = ops.SceneIndex.get(sub_batches, B, dev)
             if (scenes.key, obsv.shape[1], float(ss), Bg) in self._graphs or len(self._graphs) < self.max_graphs:
                 return self._step_graph(obsv, pred, sub_batches, zeros_val, ones_val, noise, float(ss), Bg, out)
-        if out is None:
+        if out is None or out is False:
             out = torch.zeros(self.n_unrolling_steps + 3, 3, device=dev)
         scenes = ops.SceneIndex.get(sub_batches, B, dev)
         noise = noise.to(dev, non_blocking=True).contiguous()
@@ -193,21 +193,24 @@ class SocialWaysTrainer:
                       for _ in range(4)])
             st["targets"] = st["stage"][:2]                     # [zeros_val, ones_val]
             st["noise"] = st["stage"][4:].view(B, self.noise_len)   # 16-byte aligned
-        st["obsv"].copy_(obsv)
-        st["pred"].copy_(pred)
-        # Host inputs (z, the two label-noise scalars): ring of pinned slots, copied into the graph's static
-        # inputs by a device KERNEL reading the pinned (device-mapped) memory: a hipMemcpyAsync enqueued
-        # behind graph launches blocks the host until the stream drains, a kernel launch does not.
+        # Inputs of the step -> the graph's static buffers, ONE kernel: the tracks of this packed batch
+        # (device) and z + the two label-noise scalars from a ring of pinned host slots.  The kernel reads
+        # the pinned (device-mapped) memory itself: a hipMemcpyAsync enqueued behind graph launches blocks
+        # the host until the stream drains, a kernel launch does not.
+        obsv, pred = obsv.contiguous(), pred.contiguous()
         if noise.is_cuda:
             st["noise"].copy_(noise)
             st["targets"].copy_(torch.tensor([float(zeros_val), float(ones_val)]), non_blocking=True)
+            L.call("sw_copy3_f32", L.ptr(st["obsv"]), L.ptr(obsv), obsv.numel(), L.ptr(st["pred"]), L.ptr(pred), pred.numel(),
+                   None, None, 0, L.stream())
         else:
             k = st["k"] = (st.get("k", -1) + 1) % len(st["ring"])
             host, done = st["ring"][k]
             done.synchronize()                                 # the copy kernel that last read this pinned slot is done
             host[0], host[1] = float(zeros_val), float(ones_val)
             np.copyto(host[4:].view(B, self.noise_len).numpy(), noise.numpy())   # plain memcpy
-            L.call("sw_copy_f32", L.ptr(st["stage"]), host.data_ptr(), host.numel(), L.stream())
+            L.call("sw_copy3_f32", L.ptr(st["obsv"]), L.ptr(obsv), obsv.numel(), L.ptr(st["pred"]), L.ptr(pred), pred.numel(),
+                   L.ptr(st["stage"]), host.data_ptr(), host.numel(), L.stream())
             done.record()
         if st["graph"] is not None:
             st["flip"] ^= 1
@@ -248,6 +251,8 @@ class SocialWaysTrainer:
                 g.replay()
                 if buf is not None:
                     self._allreduce(buf)
+        if out is False:           # caller reads the static result tensor before the next step overwrites it
+            return st["out"]
         if out is None:
             return st["out"].clone()
         out.copy_(st["out"])
@@ -310,7 +315,7 @@ class SocialWaysTrainer:
         if self.n_unrolling_steps > 0:                                       # D.load(backup), Linear only: D is not
             if self._lin_mask is None:                                      # read again in this step -> side stream
                 self._lin_mask = D.linear_mask() > 0
-            D._flat.copy_(torch.where(self._lin_mask, backup[:D._flat.numel()], D._flat))
+            torch.where(self._lin_mask, backup[:D._flat.numel()], D._flat, out=D._flat)
         G.grad_views()
         ops.gen_backward(enc._flat, emb._flat, att._flat, dec._flat, gctx, dpred, enc._gflat, emb._gflat, att._gflat,
                          dec._gflat, ws=ws, side=None)   # (side-stream wgrad starves the BPTT chain of CUs: measured slower)
