@@ -124,7 +124,9 @@ int sw_gen_wgrad(const float* enc_w, const float* gsave, const float* gdelta, co
 /* x_mode 0: obsv = positions [B,To,2] (4-d state formed on the fly); 1: obsv = obsv_4d [B,To,4].   */
 int sw_disc_fwd(const float* obsv, int To, int x_mode, const float* const* pred4 /*nb x [B,Tp,4]*/,
                 int nb, const float* d_w, int B, int Tp, float* const* label /*nb x [B,1]*/,
-                float* const* code /*nb x [B,2]*/, float* dsave /*or NULL*/, void* stream);
+                float* const* code /*nb x [B,2]*/, float* dsave /*or NULL*/,
+                int save_lstm /*0: head activations only - enough for a backward that wants d/dpred only*/,
+                void* stream);
 /* dlabel/dcode: nb x gradients of the loss w.r.t. label / code.  d_d_w NULL = skip weight grads
  * (generator phase), dpred4[k] NULL = skip input grad of branch k.                              */
 int sw_disc_bwd(const float* d_w, const float* dsave, const float* const* dlabel,

@@ -37,7 +37,7 @@ PROTOTYPES = {
     "sw_dec_rollout_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sw_dec_rollout_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sw_gen_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
-    "sw_disc_fwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "sw_disc_fwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "sw_disc_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sw_disc_bwd_gan": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sw_gan_loss": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -109,7 +109,7 @@ __host__ __device__ inline HeadLds head_lds(int Tp, int base) {
 __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
     const float* __restrict__ obsv, int To, int x_mode, const float* __restrict__ pred_a,
     const float* __restrict__ pred_b, int nb, const float* __restrict__ d_w, int B, int Tp, float* __restrict__ label_a, float* __restrict__ label_b,
-    float* __restrict__ code_a, float* __restrict__ code_b, float* __restrict__ dsave) {
+    float* __restrict__ code_a, float* __restrict__ code_b, float* __restrict__ dsave, int save_lstm) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // LSTM part
   float* hbuf = smem;                        // [2][16][68]
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
     f32x4 gate[4];
     lstm_cell(W, xb, &hbuf[(t & 1) * 16 * SW_HLD + ln * SW_HLD + 4 * lg], gate, c, h);
     st4(&hbuf[((t + 1) & 1) * 16 * SW_HLD + ln * SW_HLD + u0 + 4 * lg], h);
-    if (dsave && live) {
+    if (dsave && save_lstm && live) {
       float* row = dsave + ds.act + ((size_t)t * B + b) * 384 + u0 + 4 * lg;
 #pragma unroll
       for (int g = 0; g < 4; ++g) st4(row + g * 64, gate[g]);
@@ -473,7 +473,7 @@ size_t sw_ddelta_floats(int B, int To, int Tp, int nb) { return ddelta_layout(B,
 
 extern "C" int sw_disc_fwd(const float* obsv, int To, int x_mode, const float* const* pred4, int nb,
                            const float* d_w, int B, int Tp, float* const* label, float* const* code, float* dsave,
-                           void* stream) {
+                           int save_lstm, void* stream) {
   if (!obsv || !pred4 || !d_w || !label || !code || nb < 1 || nb > SW_DISC_MAXB || B < 0 || To < 1 || Tp < 1 ||
       (x_mode != 0 && x_mode != 1) || (x_mode == 0 && To < 2))
     return SW_EARG;
@@ -490,7 +490,7 @@ extern "C" int sw_disc_fwd(const float* obsv, int To, int x_mode, const float* c
   }
   hipLaunchKernelGGL(disc_fwd_kernel, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS), lds, (hipStream_t)stream,
                      obsv, To, x_mode, pred4[0], nb > 1 ? pred4[1] : nullptr, nb, d_w, B, Tp, label[0],
-                     nb > 1 ? label[1] : nullptr, code[0], nb > 1 ? code[1] : nullptr, dsave);
+                     nb > 1 ? label[1] : nullptr, code[0], nb > 1 ? code[1] : nullptr, dsave, save_lstm);
   SW_CHECK_LAUNCH("disc_fwd_kernel");
   return SW_OK;
 }

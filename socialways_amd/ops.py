@@ -169,7 +169,7 @@ class DiscCtx:
     __slots__ = ("dsave", "B", "To", "Tp", "nb")
 
 
-def disc_forward(d_w, obsv, preds, save, ws=None, tag="d"):
+def disc_forward(d_w, obsv, preds, save, ws=None, tag="d", save_lstm=True):
     """Discriminator.forward for 1 or 2 future branches sharing the observation encoding.
     Returns ([label_k (B,1)], [code_k (B,2)], ctx)."""
     L.require_gpu(obsv)
@@ -189,7 +189,8 @@ def disc_forward(d_w, obsv, preds, save, ws=None, tag="d"):
     pp, _k1 = L.ptr_array(preds)
     lp, _k2 = L.ptr_array(labels)
     cp, _k3 = L.ptr_array(codes)
-    L.call("sw_disc_fwd", L.ptr(obsv), To, x_mode, pp, nb, L.ptr(d_w), B, Tp, lp, cp, L.ptr(dsave), L.stream())
+    L.call("sw_disc_fwd", L.ptr(obsv), To, x_mode, pp, nb, L.ptr(d_w), B, Tp, lp, cp, L.ptr(dsave), 1 if save_lstm else 0,
+           L.stream())
     if not save:
         return labels, codes, None
     ctx = DiscCtx()

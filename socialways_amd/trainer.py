@@ -307,7 +307,7 @@ class SocialWaysTrainer:
                 backup = ws.get("d_backup", D._flat.numel())
                 backup[:D._flat.numel()].copy_(D._flat)
         # ---- generator update (train.py:503-539) ----------------------------------------------------
-        labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat], save=True, ws=ws)
+        labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat], save=True, ws=ws, save_lstm=False)   # only d/dpred is needed
         dpred = ops.disc_backward_gan(D._flat, dctx, labels, codes, targets, (1, 1), noise, g_label, g_code, None, (True,),
                                       ws=ws)[0]
         L.call("sw_gan_loss", L.ptr(labels[0]), L.ptr(targets), 1, L.ptr(codes[0]), L.ptr(noise), None, 1, B, g_label,
