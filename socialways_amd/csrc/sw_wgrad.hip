@@ -217,12 +217,17 @@ double wg_total_work(const WgBatch& b) {
 size_t wg_finalize(WgBatch& b) {
   // ~1024 workgroups = 4096 wave-jobs per launch (4 per SIMD), equal cost each
   const double total = wg_total_work(b) + 1.0;
+  // workgroups per launch: every wave should carry >= ~16K cycles of work (fixed per-workgroup costs -
+  // pipeline fill, LDS reduction, partial store - are ~8 us), at most 1024 (two rounds of residency)
+  double target = total / 16384.0 / 4.0;
+  if (target < 64.0) target = 64.0;
+  if (target > 1024.0) target = 1024.0;
   size_t ws = 0;
   int job = 0, out = 0;
   for (int i = 0; i < b.np; ++i) {
     WgProblem& P = b.p[i];
     const int NB = (P.N + 63) / 64;
-    int ns = (int)(1024.0 * wg_cost(P) / total / NB + 0.5);   // workgroups (4 row slices each) per output block
+    int ns = (int)(target * wg_cost(P) / total / NB + 0.5);   // workgroups (4 row slices each) per output block
     int cap = (P.R + 127) / 128;  // at least 32 rows per wave
     if (ns > cap) ns = cap;
     if (ns > SW_WG_MAXSPLIT) ns = SW_WG_MAXSPLIT;
