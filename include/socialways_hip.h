@@ -147,11 +147,14 @@ int sw_disc_bwd_gan(const float* d_w, const float* dsave, const float* const* la
  * B local rows (label_b may be NULL).  Gradients (any may be NULL):
  *   dlabel_x = 2 (label_x - t_x) g_label,  dcode_a = 2 (code_a - z) g_code,  dcode_b = 0
  * with g_label = 1/B_global and g_code = loss_info_w / (2 B_global) for a mean over the global
- * batch (data-parallel ranks pass the GLOBAL batch size so summed gradients are exact).          */
+ * batch (data-parallel ranks pass the GLOBAL batch size so summed gradients are exact).
+ * `scratch` (3*SW_RED_BLOCKS floats, optional): with it, large batches are reduced by up to
+ * SW_RED_BLOCKS workgroups and a fixed-order second stage; NULL keeps the one-workgroup path.   */
+#define SW_RED_BLOCKS 64
 int sw_gan_loss(const float* label_a, const float* targets /*device [>=2]: label-noise scalars*/, int ia,
                 const float* code_a, const float* z /*[B,32]*/, const float* label_b, int ib, int B,
                 float g_label, float g_code, float* out_sums /*[3]*/, float* dlabel_a, float* dcode_a,
-                float* dlabel_b, float* dcode_b, void* stream);
+                float* dlabel_b, float* dcode_b, float* scratch /*[3*SW_RED_BLOCKS] or NULL*/, void* stream);
 
 /* ---- staging copy by a device kernel: `src` may be host-pinned (device-mapped) memory; used to feed
  *      z / label-noise scalars to hipGraph-replayed steps without a blocking hipMemcpyAsync ---------- */
@@ -162,7 +165,7 @@ int sw_copy3_f32(float* d0, const float* s0, long long n0, float* d1, const floa
 /* ---- ADE/FDE partial sums of train.py:546-551:
  *      out[3] = { sum_{b,t} err / Tp, sum_b err[:, -1], sum_{b,t} err^2 },  err = |(p_hat - p) / ss|   */
 int sw_ade_fde(const float* pred4 /*[B,Tp,4]*/, const float* gt /*[B,Tp,2]*/, int B, int Tp, float inv_ss,
-               float* out /*[3]*/, void* stream);
+               float* out /*[3]*/, float* scratch /*[3*SW_RED_BLOCKS] or NULL*/, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libsocialways_hip.so")
 GRP_ENC, GRP_EMB, GRP_ATT, GRP_DEC, GRP_DISC = 0, 1, 2, 3, 4
 WS_GSAVE, WS_GDELTA, WS_DSAVE, WS_DDELTA, WS_WGRAD, WS_PAIRS = 0, 1, 2, 3, 4, 5
 AMAX = 64
+RED_BLOCKS = 64
 
 _vp, _i, _f, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 
@@ -40,10 +41,10 @@ PROTOTYPES = {
     "sw_disc_fwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "sw_disc_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sw_disc_bwd_gan": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "sw_gan_loss": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sw_gan_loss": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sw_copy_f32": (_i, [_vp, _vp, _ll, _vp]),
     "sw_copy3_f32": (_i, [_vp, _vp, _ll, _vp, _vp, _ll, _vp, _vp, _ll, _vp]),
-    "sw_ade_fde": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp]),
+    "sw_ade_fde": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(1024) void gan_loss_kernel(
   __shared__ float red[3][16];
   const float t_a = targets[ia], t_b = targets[ib];
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
     float e = label_a[b] - t_a;
     s0 = fmaf(e, e, s0);
     if (dlabel_a) dlabel_a[b] = 2.0f * e * g_label;
@@ -234,26 +234,53 @@ __global__ __launch_bounds__(1024) void gan_loss_kernel(
     }
   }
   block_sum3(s0, s1, s2, red);
-  if (threadIdx.x == 0) { out[0] = s0; out[1] = s1; out[2] = s2; }
+  if (threadIdx.x == 0) { out[3 * blockIdx.x] = s0; out[3 * blockIdx.x + 1] = s1; out[3 * blockIdx.x + 2] = s2; }
+}
+
+// second stage of the large-batch reductions: G per-block partial triples -> out[3], fixed order
+__global__ __launch_bounds__(64) void sum3_kernel(const float* __restrict__ part, int G, float s_a, float* __restrict__ out) {
+  float a = 0.f, b = 0.f, c = 0.f;
+  for (int g = threadIdx.x; g < G; g += 64) { a += part[3 * g]; b += part[3 * g + 1]; c += part[3 * g + 2]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o);
+    b += __shfl_xor(b, o);
+    c += __shfl_xor(c, o);
+  }
+  if (threadIdx.x == 0) { out[0] = a * s_a; out[1] = b; out[2] = c; }
+}
+// one 1024-thread block up to SW_RED_SINGLE items (launch-latency bound there), else up to 64 blocks
+#define SW_RED_SINGLE 32768
+static inline int red_blocks(long long n, const float* scratch) {
+  if (!scratch || n <= SW_RED_SINGLE) return 1;
+  long long g = (n + 8191) / 8192;
+  return (int)(g > SW_RED_BLOCKS ? SW_RED_BLOCKS : g);
 }
 
 extern "C" int sw_gan_loss(const float* label_a, const float* targets, int ia, const float* code_a, const float* z,
                            const float* label_b, int ib, int B, float g_label, float g_code, float* out_sums,
-                           float* dlabel_a, float* dcode_a, float* dlabel_b, float* dcode_b, void* stream) {
+                           float* dlabel_a, float* dcode_a, float* dlabel_b, float* dcode_b, float* scratch,
+                           void* stream) {
   if (!label_a || !targets || !code_a || !z || !out_sums || B < 1 || ia < 0 || ib < 0) return SW_EARG;
-  hipLaunchKernelGGL(gan_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, label_a, targets, ia, code_a, z,
-                     label_b, ib, B, g_label, g_code, out_sums, dlabel_a, dcode_a, dlabel_b, dcode_b);
+  const int G = red_blocks((long long)B * 4, scratch);
+  hipLaunchKernelGGL(gan_loss_kernel, dim3(G), dim3(1024), 0, (hipStream_t)stream, label_a, targets, ia, code_a, z,
+                     label_b, ib, B, g_label, g_code, G > 1 ? scratch : out_sums, dlabel_a, dcode_a, dlabel_b, dcode_b);
   SW_CHECK_LAUNCH("gan_loss_kernel");
+  if (G > 1) {
+    hipLaunchKernelGGL(sum3_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, G, 1.0f, out_sums);
+    SW_CHECK_LAUNCH("sum3_kernel");
+  }
   return SW_OK;
 }
 
 // ---- ADE/FDE partial sums (train.py:546-551) ----------------------------------------------------
 __global__ __launch_bounds__(1024) void ade_fde_kernel(const float* __restrict__ pred4, const float* __restrict__ gt,
-                                                       int B, int Tp, float inv_ss, float* __restrict__ out) {
+                                                       int B, int Tp, float inv_ss, float* __restrict__ out,
+                                                       int single) {
   __shared__ float red[3][16];
   float sa = 0.f, sf = 0.f, sl = 0.f;
   const int n = B * Tp;
-  for (int base = 0; base < n; base += 1024 * 8) {  // 8 independent loads in flight per thread
+  for (int base = blockIdx.x * 1024 * 8; base < n; base += gridDim.x * 1024 * 8) {  // 8 independent loads in flight per thread
     f32x4 p[8];
     float2 g[8];
 #pragma unroll
@@ -276,16 +303,23 @@ __global__ __launch_bounds__(1024) void ade_fde_kernel(const float* __restrict__
   }
   block_sum3(sa, sf, sl, red);
   if (threadIdx.x == 0) {
-    out[0] = sa / (float)Tp;
-    out[1] = sf;
-    out[2] = sl;  // sum of squared (scaled) displacement errors, for the L2 term
+    out[3 * blockIdx.x] = single ? sa / (float)Tp : sa;
+    out[3 * blockIdx.x + 1] = sf;
+    out[3 * blockIdx.x + 2] = sl;  // sum of squared (scaled) displacement errors, for the L2 term
   }
 }
 
-extern "C" int sw_ade_fde(const float* pred4, const float* gt, int B, int Tp, float inv_ss, float* out, void* stream) {
+extern "C" int sw_ade_fde(const float* pred4, const float* gt, int B, int Tp, float inv_ss, float* out, float* scratch,
+                          void* stream) {
   if (!pred4 || !gt || !out || B < 1 || Tp < 1) return SW_EARG;
-  hipLaunchKernelGGL(ade_fde_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred4, gt, B, Tp, inv_ss, out);
+  const int G = red_blocks((long long)B * Tp, scratch);
+  hipLaunchKernelGGL(ade_fde_kernel, dim3(G), dim3(1024), 0, (hipStream_t)stream, pred4, gt, B, Tp, inv_ss,
+                     G > 1 ? scratch : out, G == 1 ? 1 : 0);
   SW_CHECK_LAUNCH("ade_fde_kernel");
+  if (G > 1) {
+    hipLaunchKernelGGL(sum3_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, G, 1.0f / (float)Tp, out);
+    SW_CHECK_LAUNCH("sum3_kernel");
+  }
   return SW_OK;
 }
 

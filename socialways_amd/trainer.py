@@ -286,8 +286,9 @@ class SocialWaysTrainer:
                                          G.use_social, save=True, ws=ws)
         # ADE/FDE partial sums of the prediction (train.py:546-551) only need pred_hat: side stream,
         # under the first discriminator pass
+        red = L.ptr(ws.get("red_scratch", 3 * L.RED_BLOCKS))   # partials of the large-batch reductions
         L.call("sw_ade_fde", L.ptr(pred_hat), L.ptr(pred), B, Tp, 1.0 / float(ss),
-               L.ptr(out[self.n_unrolling_steps + 2]), L.stream())
+               L.ptr(out[self.n_unrolling_steps + 2]), red, L.stream())
         dl_f = ws.get("dl_f", B)
         dc_f = ws.get("dc_f", 2 * B)
         dl_r = ws.get("dl_r", B)
@@ -300,7 +301,7 @@ class SocialWaysTrainer:
             # loss SUMS (reporting only) on a side stream; the loss gradients are formed inside the backward kernel
             ops.disc_backward_gan(D._flat, dctx, labels, codes, targets, (0, 1), noise, g_label, g_code, d_gflat, (), ws=ws)
             L.call("sw_gan_loss", L.ptr(labels[0]), L.ptr(targets), 0, L.ptr(codes[0]), L.ptr(noise), L.ptr(labels[1]),
-                   1, B, g_label, g_code, L.ptr(out[u]), None, None, None, None, L.stream())
+                   1, B, g_label, g_code, L.ptr(out[u]), None, None, None, None, red, L.stream())
             yield d_gflat
             self.D_optimizer.step()
             if u == 0 and self.n_unrolling_steps > 0:
@@ -311,7 +312,7 @@ class SocialWaysTrainer:
         dpred = ops.disc_backward_gan(D._flat, dctx, labels, codes, targets, (1, 1), noise, g_label, g_code, None, (True,),
                                       ws=ws)[0]
         L.call("sw_gan_loss", L.ptr(labels[0]), L.ptr(targets), 1, L.ptr(codes[0]), L.ptr(noise), None, 1, B, g_label,
-               g_code, L.ptr(out[self.n_unrolling_steps + 1]), None, None, None, None, L.stream())
+               g_code, L.ptr(out[self.n_unrolling_steps + 1]), None, None, None, None, red, L.stream())
         if self.n_unrolling_steps > 0:                                       # D.load(backup), Linear only: D is not
             if self._lin_mask is None:                                      # read again in this step -> side stream
                 self._lin_mask = D.linear_mask() > 0

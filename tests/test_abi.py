@@ -36,7 +36,7 @@ def test_argument_validation_without_gpu():
     assert lib.sw_traj_4d(None, None, 4, 8, 12, None, None, None) == -1
     assert lib.sw_enc_lstm_fwd(None, 0, None, None, None, 4, 8, None, None, None, None, None, 0, None) == -1
     assert lib.sw_param_count(99, 12) == -1 and lib.sw_param_offset(0, 99, 1) == -1
-    assert lib.sw_gan_loss(None, None, 0, None, None, None, 0, 8, 1.0, 1.0, None, None, None, None, None, None) == -1
+    assert lib.sw_gan_loss(None, None, 0, None, None, None, 0, 8, 1.0, 1.0, None, None, None, None, None, None, None) == -1
 
 
 @pytest.mark.parametrize("tp", [2, 12])

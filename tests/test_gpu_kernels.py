@@ -149,3 +149,37 @@ def test_module_level_api_matches_reference_ops():
         torch.manual_seed(5)
         s_, z_ = torch.randn(B, 64), torch.rand(B, 32)
         assert_close(dec(h, s_.to(dev), z_.to(dev)).cpu(), odec(h.cpu(), s_, z_), RT, AT, "decoder")
+
+
+@pytest.mark.parametrize("B", [37, 2048, 40000])
+def test_loss_and_ade_reductions_any_batch_size(B):
+    """sw_gan_loss / sw_ade_fde (train.py:484-494, 546-551) against float64 torch sums: the one-workgroup
+    path (small B, or no scratch) and the multi-workgroup two-stage path (large B with scratch) agree
+    and the multi-workgroup path is run-to-run deterministic."""
+    from socialways_amd import _lib as L
+    g = torch.Generator().manual_seed(B)
+    Tp = 12
+    la, lb = torch.rand(B, generator=g).cuda(), torch.rand(B, generator=g).cuda()
+    code, z = torch.rand(B, 2, generator=g).cuda(), torch.rand(B, 32, generator=g).cuda()
+    tg = torch.tensor([0.05, 0.93]).cuda()
+    p4, gt = torch.randn(B, Tp, 4, generator=g).cuda(), torch.randn(B, Tp, 2, generator=g).cuda()
+    scratch = torch.zeros(3 * L.RED_BLOCKS).cuda()
+    res = []
+    for sc in (None, scratch, scratch):
+        out = torch.zeros(2, 3).cuda()
+        dla, dca, dlb, dcb = torch.zeros(B).cuda(), torch.zeros(B, 2).cuda(), torch.zeros(B).cuda(), torch.ones(B, 2).cuda()
+        L.call("sw_gan_loss", L.ptr(la), L.ptr(tg), 0, L.ptr(code), L.ptr(z), L.ptr(lb), 1, B, 0.5, 0.25, L.ptr(out[0]),
+               L.ptr(dla), L.ptr(dca), L.ptr(dlb), L.ptr(dcb), L.ptr(sc), L.stream())
+        L.call("sw_ade_fde", L.ptr(p4), L.ptr(gt), B, Tp, 0.5, L.ptr(out[1]), L.ptr(sc), L.stream())
+        res.append((out.cpu(), dla.cpu(), dca.cpu(), dlb.cpu(), dcb.cpu()))
+    d = lambda t: t.double().cpu()
+    err = ((d(p4)[..., :2] - d(gt)) * 0.5).norm(dim=-1)
+    want = torch.tensor([[((d(la) - 0.05) ** 2).sum(), ((d(code) - d(z)[:, :2]) ** 2).sum(), ((d(lb) - 0.93) ** 2).sum()],
+                         [err.sum() / Tp, err[:, -1].sum(), (err ** 2).sum()]])
+    for out, dla, dca, dlb, dcb in res:
+        assert_close(out.double(), want, 2e-5, 1e-6, "sums")
+        assert_close(dla, (la.cpu() - 0.05), 1e-6, 1e-7, "dlabel_a")
+        assert_close(dca, 0.5 * (code.cpu() - z.cpu()[:, :2]), 1e-6, 1e-7, "dcode_a")
+        assert_close(dlb, (lb.cpu() - 0.93), 1e-6, 1e-7, "dlabel_b")
+        assert float(dcb.abs().max()) == 0.0
+    assert torch.equal(res[1][0], res[2][0])
