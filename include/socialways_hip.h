@@ -156,6 +156,13 @@ int sw_gan_loss(const float* label_a, const float* targets /*device [>=2]: label
                 float g_label, float g_code, float* out_sums /*[3]*/, float* dlabel_a, float* dcode_a,
                 float* dlabel_b, float* dcode_b, float* scratch /*[3*SW_RED_BLOCKS] or NULL*/, void* stream);
 
+/* ---- optional L2 term of the generator loss (train.py:512,525-526; the "variety" term as written in
+ *      train.py:527-536 is the same expression restricted to one agent row):
+ *      dpred4[b][t][0:2] += scale * (pred4_hat[b][t][0:2] - gt[b][t][:]) for rows b in [row0,row1).
+ *      L2: rows [0,B), scale = loss_l2_w / (B_global * Tp).  Called after sw_disc_bwd_gan wrote dpred4. */
+int sw_l2_grad(const float* pred4_hat /*[B,Tp,4]*/, const float* gt /*[B,Tp,2]*/, int B, int Tp, int row0, int row1,
+               float scale, float* dpred4 /*[B,Tp,4]*/, void* stream);
+
 /* ---- staging copy by a device kernel: `src` may be host-pinned (device-mapped) memory; used to feed
  *      z / label-noise scalars to hipGraph-replayed steps without a blocking hipMemcpyAsync ---------- */
 int sw_copy_f32(float* dst, const float* src, long long n, void* stream);

@@ -27,6 +27,14 @@ Cases (all fp32, torch CPU; `threads` recorded in every file)
   test_eval
         test(n_gen_samples=4, write_to_file=...) on 2 held-out scenes: K predictions, the four
         metrics and the prediction-npz arrays (schema of train.py:598-599).
+  syn_variants
+        the syn_s16a8_on step again with the reference's loss / unrolling switches flipped (module
+        globals of train.py:61-69): use_l2_loss, use_variety_loss (as written in train.py:527-536),
+        n_unrolling_steps 0 and 2, use_info_loss off.  Per variant: every MSE value train() computed,
+        the D gradients of the last D update, the G gradients, D's weights after the step.
+  biwi_synth
+        a synthetic BIWI-format obsmat.txt (no ETH/UCY data exists here) through the
+        reference's BIWIParser + create_dataset (utils/parse_utils.py): windows, times, scene batches.
 """
 import contextlib
 import glob
@@ -154,7 +162,9 @@ class Recorder:
         real_dstep, real_gstep = m.D_optimizer.step, m.predictor_optimizer.step
 
         def dstep(*a, **k):
-            self.d_grads.append({k_: p.grad.detach().clone().numpy() for k_, p in m.D.named_parameters()})
+            self.d_grads.append({k_: (np.zeros(tuple(p.shape), np.float32) if p.grad is None     # info loss off: the
+                                      else p.grad.detach().clone().numpy())                       # code head gets none
+                                 for k_, p in m.D.named_parameters()})
             return real_dstep(*a, **k)
 
         def gstep(*a, **k):
@@ -189,8 +199,11 @@ class Recorder:
         np.random.uniform, torch.rand = self._real_uniform, self._real_rand
 
 
-def run_epoch(dataset, batch_size, use_social, seed=0):
+def run_epoch(dataset, batch_size, use_social, seed=0, overrides=None):
     m = import_reference(dataset, batch_size, seed, use_social)
+    for k, v in (overrides or {}).items():      # loss / unrolling switches are module globals read by train()
+        assert hasattr(m, k), k
+        setattr(m, k, v)
     w0 = flat_state(m, "w0.")
     rec = Recorder(m)
     buf = io.StringIO()
@@ -200,7 +213,7 @@ def run_epoch(dataset, batch_size, use_social, seed=0):
     rec.close()
     w1 = flat_state(m, "w1.")
     n_steps = len(rec.g_grads)
-    per = 3 * (m.n_unrolling_steps + 1) + 3
+    per = 3 * (m.n_unrolling_steps + 1) + 3 + (20 if m.use_variety_loss else 0)
     losses = np.asarray(rec.mse, np.float64).reshape(n_steps, per)
     # ADE/FDE: same expressions as train.py:546-557 on the recorded G-phase prediction of each step
     ade = fde = 0.0
@@ -329,6 +342,70 @@ def test_eval_case():
     return out
 
 
+VARIANTS = {
+    "l2": dict(use_l2_loss=True),
+    "variety": dict(use_variety_loss=True),
+    "unroll0": dict(n_unrolling_steps=0),
+    "unroll2": dict(n_unrolling_steps=2),
+    "noinfo": dict(use_info_loss=False),
+}
+
+
+def variants_case(dataset):
+    """One packed step of `dataset` (social on, seed 0: same initial weights and RNG draws as
+    syn_s16a8_on) per switch setting."""
+    batches = np.asarray(dataset["batches"])
+    train_size = max(1, (len(batches) * 4) // 5)
+    B = int(batches[train_size - 1][1])
+    out = dict(names=np.array(sorted(VARIANTS)), threads=torch.get_num_threads())
+    for name, ov in sorted(VARIANTS.items()):
+        m, rec, o = run_epoch(dataset, B, True, 0, overrides=ov)
+        assert len(rec.g_grads) == 1
+        if "w0.D.lstm.weight_ih_l0" not in out:
+            out.update({k: v for k, v in o.items() if k.startswith("w0.")})
+            out["noise"], out["uniform"], out["ss"] = o["noise.0"], o["uniform"], o["ss"]
+        else:
+            assert all(np.array_equal(out[k], v) for k, v in o.items() if k.startswith("w0."))
+            assert np.array_equal(out["noise"], o["noise.0"]) and np.array_equal(out["uniform"], o["uniform"])
+        out[name + ".losses"] = o["losses"][0]
+        out[name + ".ade_fde"] = np.asarray([o["ade"], o["fde"]])
+        out[name + ".n_d_updates"] = len(rec.d_grads)
+        for k, v in rec.d_grads[-1].items():
+            out["%s.dgrad_last.%s" % (name, k)] = v
+        for k, v in rec.g_grads[0].items():
+            out["%s.ggrad.%s" % (name, k)] = v
+        for k, v in o.items():
+            if k.startswith("w1.D."):
+                out[name + "." + k] = v
+        m._cleanup()
+    return out
+
+
+def biwi_case():
+    """Inputs from socialways_amd.data.synth_crowd_frames (pure numpy), expected outputs from the
+    reference's own parser and window extraction."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from socialways_amd import data as D
+    fr, ids, pos, vel = D.synth_crowd_frames()
+    d = tempfile.mkdtemp(prefix="swbiwi_")
+    path = os.path.join(d, "obsmat.txt")
+    D.write_biwi_obsmat(path, fr, ids, pos, vel)
+    old_path = list(sys.path)
+    sys.path.insert(0, REF)
+    for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
+        del sys.modules[k]
+    try:
+        from utils.parse_utils import BIWIParser, create_dataset
+        p = BIWIParser()
+        p.load(path)
+        ob, pr, ti, ba = create_dataset(p.p_data, p.t_data, range(p.t_data[0][0], p.t_data[-1][-1], p.interval), 8, 12)
+    finally:
+        sys.path[:] = old_path
+        shutil.rmtree(d, ignore_errors=True)
+    return dict(frames=fr, ids=ids, pos=pos, vel=vel, obsvs=ob, preds=pr, times=np.asarray(ti),
+                batches=ba.astype(np.int64), interval=p.interval)
+
+
 def save(name, d):
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + ".npz")
@@ -339,6 +416,15 @@ def save(name, d):
 def main():
     t0 = time.time()
     torch.set_num_threads(8)
+    only = set(sys.argv[1].split(",")) if len(sys.argv) > 1 else None      # e.g. `make_golden.py syn_variants,biwi_synth`
+    syn = sw_oracle.synth_dataset(20, 8, seed=1234)                  # 16 train scenes x 8
+    if only is None or "syn_variants" in only:
+        save("syn_variants", variants_case(syn))
+    if only is None or "biwi_synth" in only:
+        save("biwi_synth", biwi_case())
+    if only is not None:
+        print("done in %.1fs" % (time.time() - t0))
+        return
     toy8 = toy_dataset(768, 8, 3)
     toy6 = toy_dataset(768, 6, 3)
     save("toy_768_8_3", toy8)
@@ -348,7 +434,6 @@ def main():
         m._cleanup()
         print("  toy epoch social=%s  ADE/FDE=%.6f/%.6f  printed=%s" % (flag, out["ade"], out["fde"], str(out["printed"]).strip()))
         save("toy_b64_" + tag, out)
-    syn = sw_oracle.synth_dataset(20, 8, seed=1234)                  # 16 train scenes x 8
     for flag, tag in ((False, "off"), (True, "on")):
         out = run_one_step(syn, flag)
         for k in ("obsvs", "preds", "batches"):

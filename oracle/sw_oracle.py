@@ -308,7 +308,7 @@ class SocialWaysOracle:
 
     def __init__(self, n_next, hidden_size=64, lr_g=1e-4, lr_d=1e-3, n_unrolling_steps=1,
                  use_social=True, social="blockdiag", use_info_loss=True, loss_info_w=0.5,
-                 n_latent_codes=2):
+                 n_latent_codes=2, use_l2_loss=False, use_variety_loss=False, loss_l2_w=0.5):
         self.n_next = n_next
         self.hidden_size = hidden_size
         self.noise_len = hidden_size // 2                                    # train.py:81
@@ -319,6 +319,9 @@ class SocialWaysOracle:
         self.use_info_loss = use_info_loss
         self.loss_info_w = loss_info_w
         self.n_latent_codes = n_latent_codes
+        self.use_l2_loss = use_l2_loss                                       # train.py:67-69
+        self.use_variety_loss = use_variety_loss
+        self.loss_l2_w = loss_l2_w
         # construction order fixes the RNG -> init mapping (train.py:370-385)
         self.encoder = EncoderLstm(hidden_size, self.n_lstm_layers)
         self.feature_embedder = EmbedSocialFeatures(3, hidden_size)
@@ -393,7 +396,8 @@ class SocialWaysOracle:
             d_loss.backward()
             if record is not None:
                 record.setdefault("d_grads", []).append(
-                    {k: p.grad.detach().clone() for k, p in D.named_parameters()})
+                    {k: (torch.zeros_like(p) if p.grad is None else p.grad.detach().clone())
+                     for k, p in D.named_parameters()})
                 if u == 0:
                     record["fake_labels0"] = fake_labels.detach().clone()
                     record["code_hat_real0"] = code_hat.detach().clone()
@@ -412,6 +416,17 @@ class SocialWaysOracle:
         g_loss = g_loss_fooling
         if self.use_info_loss:
             g_loss = g_loss + self.loss_info_w * g_loss_info
+        if self.use_l2_loss:                                                 # train.py:525-526
+            g_loss = g_loss + self.loss_l2_w * g_loss_l2
+        variety = None
+        if self.use_variety_loss:
+            # train.py:527-536 AS WRITTEN: KV=20 predict() calls with the SAME noise (identical values,
+            # SURVEY §0.11), loss k compares AGENT k (not sample k) with its ground truth, and only the
+            # last one (k = 19) is appended -> the "variety" term is the L2 of agent 19 alone.
+            KV = 20
+            pred_hat_k = self.predict(obsv, noise, n_next, sub_batches)      # the k = KV-1 call; the other 19 are dead
+            variety = mse(pred_hat_k[KV - 1, :, :2], pred[KV - 1])
+            g_loss = g_loss + self.loss_l2_w * variety
         if record is not None:
             pred_hat_4d.retain_grad()
         g_loss.backward()
@@ -422,6 +437,8 @@ class SocialWaysOracle:
             record["gen_code_hat"] = code_hat.detach().clone()
             record["hT"] = self.last["hT"].detach().clone()
             record["S"] = self.last["S"].detach().clone()
+            if variety is not None:
+                record["variety"] = float(variety.item())
             record["g_grads"] = {}
             for name, mod in (("attention", self.attention), ("feature_embedder", self.feature_embedder),
                               ("encoder", self.encoder), ("decoder", self.decoder)):

@@ -323,6 +323,34 @@ extern "C" int sw_ade_fde(const float* pred4, const float* gt, int B, int Tp, fl
   return SW_OK;
 }
 
+// ---- optional L2 term of the generator loss (train.py:512, 525-526; variety as written :527-536) ----
+//   dpred4[b][t][0:2] += scale * (p_hat - p)   for rows b in [row0, row1)
+__global__ __launch_bounds__(256) void l2_grad_kernel(const float* __restrict__ pred4, const float* __restrict__ gt,
+                                                       int Tp, int row0, int row1, float scale,
+                                                       float* __restrict__ dpred4) {
+  const long long n = (long long)(row1 - row0) * Tp;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const size_t e = (size_t)row0 * Tp + i;
+    f32x4 p = ld4(pred4 + e * 4), d = ld4(dpred4 + e * 4);
+    float2 g = *reinterpret_cast<const float2*>(gt + e * 2);
+    d[0] = fmaf(scale, p[0] - g.x, d[0]);
+    d[1] = fmaf(scale, p[1] - g.y, d[1]);
+    st4(dpred4 + e * 4, d);
+  }
+}
+extern "C" int sw_l2_grad(const float* pred4, const float* gt, int B, int Tp, int row0, int row1, float scale,
+                          float* dpred4, void* stream) {
+  if (!pred4 || !gt || !dpred4 || B < 1 || Tp < 1 || row0 < 0 || row1 > B || row0 > row1) return SW_EARG;
+  if (row0 == row1) return SW_OK;
+  long long n = (long long)(row1 - row0) * Tp;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(l2_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred4, gt, Tp, row0, row1, scale,
+                     dpred4);
+  SW_CHECK_LAUNCH("l2_grad_kernel");
+  return SW_OK;
+}
+
 // ---- staging copy: device kernel that reads a (host-pinned, device-mapped) source -----------------
 // A hipMemcpyAsync host-to-device enqueued behind hipGraph launches blocks the calling host thread
 // until the stream drains on this runtime; a kernel launch never does.  256 KB of z per step over

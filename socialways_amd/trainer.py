@@ -102,13 +102,17 @@ class PackedAdam:
 class SocialWaysTrainer:
     def __init__(self, n_next, hidden_size=64, lr_g=1e-4, lr_d=1e-3, n_unrolling_steps=1, use_social=True,
                  use_info_loss=True, loss_info_w=0.5, n_latent_codes=2, device="cuda", process_group=None,
-                 fused_adam=True, use_graph=None):
+                 fused_adam=True, use_graph=None, use_l2_loss=False, use_variety_loss=False, loss_l2_w=0.5):
         self.device = torch.device(device)
         self.n_next = n_next
         self.noise_len = hidden_size // 2
         self.n_unrolling_steps = n_unrolling_steps
         self.use_info_loss = use_info_loss
         self.loss_info_w = loss_info_w
+        # train.py:67-69.  `use_variety_loss` reproduces train.py:527-536 AS WRITTEN: its 20 predict()
+        # calls reuse the same noise (identical values) and only the k = 19 term - the L2 of AGENT 19 of
+        # the packed batch - enters the loss; the 20 redundant rollouts are not executed.
+        self.use_l2_loss, self.use_variety_loss, self.loss_l2_w = use_l2_loss, use_variety_loss, loss_l2_w
         # construction order = train.py:370-385 (RNG -> init mapping, optimizer parameter order)
         self.G = Generator(hidden_size, 1, use_social=use_social, device=self.device)
         self.G.unify()
@@ -152,7 +156,7 @@ class SocialWaysTrainer:
         if self.pg is not None and (self.world > 1 or self._force_dist):
             torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
-    def step(self, obsv, pred, sub_batches, zeros_val, ones_val, noise, ss=1.0, global_B=None, out=None):
+    def step(self, obsv, pred, sub_batches, zeros_val, ones_val, noise, ss=1.0, global_B=None, out=None, global_row0=0):
         """One packed batch (train.py:458-554) on this rank's rows.  obsv (B,To,2), pred (B,Tp,2) and
         noise (B,32) are tensors (noise may live on the host, like train.py:473); `global_B` = agents
         of the whole packed batch over all ranks.
@@ -164,11 +168,14 @@ class SocialWaysTrainer:
         B = obsv.shape[0]
         Bg = float(global_B if global_B is not None else B)
         dev = self.device
+        self._row0 = int(global_row0)       # first row of this rank's shard in the packed batch (variety term only)
+        if self.use_variety_loss and Bg < 20:
+            raise ValueError("use_variety_loss indexes agent 19 of the packed batch (train.py:531): batch of %d" % Bg)
         if self.use_graph:
             # one graph set per packed-batch layout; datasets with ragged scenes produce many layouts, so the
             # number of captured layouts is capped and the rest of the steps run eagerly
             scenes = ops.SceneIndex.get(sub_batches, B, dev)
-            if (scenes.key, obsv.shape[1], float(ss), Bg) in self._graphs or len(self._graphs) < self.max_graphs:
+            if (scenes.key, obsv.shape[1], float(ss), Bg, self._row0) in self._graphs or len(self._graphs) < self.max_graphs:
                 return self._step_graph(obsv, pred, sub_batches, zeros_val, ones_val, noise, float(ss), Bg, out)
         if out is None or out is False:
             out = torch.zeros(self.n_unrolling_steps + 3, 3, device=dev)
@@ -182,7 +189,7 @@ class SocialWaysTrainer:
         B, To = obsv.shape[0], obsv.shape[1]
         dev = self.device
         scenes = ops.SceneIndex.get(sub_batches, B, dev)
-        key = (scenes.key, To, ss, Bg)
+        key = (scenes.key, To, ss, Bg, self._row0)
         st = self._graphs.get(key)
         if st is None:
             st = self._graphs[key] = dict(
@@ -313,6 +320,12 @@ class SocialWaysTrainer:
                                       ws=ws)[0]
         L.call("sw_gan_loss", L.ptr(labels[0]), L.ptr(targets), 1, L.ptr(codes[0]), L.ptr(noise), None, 1, B, g_label,
                g_code, L.ptr(out[self.n_unrolling_steps + 1]), None, None, None, None, red, L.stream())
+        if self.use_l2_loss:                                                 # train.py:525-526
+            L.call("sw_l2_grad", L.ptr(pred_hat), L.ptr(pred), B, Tp, 0, B, self.loss_l2_w / (Bg * Tp), L.ptr(dpred), L.stream())
+        if self.use_variety_loss:                                            # train.py:527-536 as written
+            r = 19 - self._row0
+            if 0 <= r < B:
+                L.call("sw_l2_grad", L.ptr(pred_hat), L.ptr(pred), B, Tp, r, r + 1, self.loss_l2_w / Tp, L.ptr(dpred), L.stream())
         if self.n_unrolling_steps > 0:                                       # D.load(backup), Linear only: D is not
             if self._lin_mask is None:                                      # read again in this step -> side stream
                 self._lin_mask = D.linear_mask() > 0
@@ -357,7 +370,7 @@ class SocialWaysTrainer:
                 if hi > lo:
                     r0, r1 = int(sb[lo, 0]), int(sb[hi - 1, 1])
                     out = self.step(data.obsv[a + r0:a + r1], data.pred[a + r0:a + r1], sb[lo:hi] - r0, zv, ov,
-                                    noise[r0:r1].to(self.device), data.ss, global_B=bs)
+                                    noise[r0:r1].to(self.device), data.ss, global_B=bs, global_row0=r0)
                 else:
                     out = self._empty_step()
             else:

@@ -41,3 +41,20 @@ def assert_close(a, b, rtol, atol, what=""):
         i = np.unravel_index(np.argmax(err - tol), err.shape)
         raise AssertionError("%s: max|err|=%.3e at %s (got %.8g want %.8g), rtol=%g atol=%g"
                              % (what, err.max(), i, a[i], b[i], rtol, atol))
+
+
+VARIANT_KW = {          # tests/golden/syn_variants.npz: the reference's module-global switches (train.py:61-69)
+    "l2": dict(use_l2_loss=True),
+    "variety": dict(use_variety_loss=True),
+    "unroll0": dict(n_unrolling_steps=0),
+    "unroll2": dict(n_unrolling_steps=2),
+    "noinfo": dict(use_info_loss=False),
+}
+
+
+def variant_expected_losses(g, name):
+    """The standard 3(U+1)+3 MSE terms of a variant (the variety case recorded 20 extra values - the
+    per-k L2 terms of train.py:531 - after them); returns (standard, extras)."""
+    v = np.asarray(g[name + ".losses"])
+    n = 3 * int(g[name + ".n_d_updates"]) + 3
+    return v[:n], v[n:]

@@ -223,3 +223,36 @@ def test_two_rank_data_parallel_step_equals_reference():
         assert_close(np.asarray(ret[r][0]), g["losses"][0], 5e-5, 1e-6, "rank %d losses" % r)
         assert abs(ret[r][1] - float(g["ade"])) < 1e-5
     assert ret[0][2] == ret[1][2] and ret[0][3] == ret[1][3], "replicas diverged"
+
+
+@pytest.mark.parametrize("name", ["l2", "variety", "unroll0", "unroll2", "noinfo"])
+def test_loss_and_unrolling_switches(name):
+    """The reference's module-global switches (train.py:61-69): L2 term, variety term as written
+    (train.py:527-536), n_unrolling_steps 0 / 2, info loss off - losses, the gradients of the last D update,
+    all G gradients and D's weights after the step (incl. the Linear-only restore) vs the reference."""
+    import socialways_amd as sw
+    from _util import VARIANT_KW, variant_expected_losses
+    g, base = golden("syn_variants"), golden("syn_s16a8_on")
+    ds = dataset_from(base)
+    data = sw.SceneDataset(ds["obsvs"], ds["preds"], ds["batches"], device="cuda:0")
+    tr = make_trainer(g, 12, True, **VARIANT_KW[name])
+    B = int(base["step_agents"][0])
+    out = tr.step(data.obsv[:B], data.pred[:B], data.train_batches, float(g["uniform"][0, 0]), float(g["uniform"][0, 1]),
+                  torch.from_numpy(g["noise"]).cuda(), data.ss)
+    want, _ = variant_expected_losses(g, name)
+    assert_close(tr.losses_from(out, [B], 12, data.ss)[0], want, 3e-5, 1e-6, "MSE terms")
+    for k, p in tr.D.named_parameters():
+        ref = g["%s.dgrad_last.%s" % (name, k)]
+        assert_close(p.grad.cpu(), ref, 2e-4, 2e-5 * max(np.abs(ref).max(), 1e-12), "dgrad_last." + k)
+    for mname, mod in (("attention", tr.G.attention), ("feature_embedder", tr.G.feature_embedder),
+                       ("encoder", tr.G.encoder), ("decoder", tr.G.decoder)):
+        for k, p in mod.named_parameters():
+            ref = g["%s.ggrad.%s.%s" % (name, mname, k)]
+            assert_close(p.grad.cpu(), ref, 3e-4, 3e-5 * max(np.abs(ref).max(), 1e-12), "ggrad.%s.%s" % (mname, k))
+    for k, v in tr.D.state_dict().items():
+        a, b = v.cpu().numpy().astype(np.float64), g["%s.w1.D.%s" % (name, k)].astype(np.float64)
+        bad = np.abs(a - b) > 5e-6 + 1e-4 * np.abs(b)
+        assert bad.mean() <= 0.001, "w1.D.%s: %.4f%% off" % (k, 100 * bad.mean())
+    o = out.double().cpu().numpy()
+    af = g[name + ".ade_fde"]
+    assert abs(o[-1, 0] / data.n_train_samples - af[0]) < 1e-5 and abs(o[-1, 1] / data.n_train_samples - af[1]) < 1e-5

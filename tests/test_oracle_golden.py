@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import sw_oracle as O
-from _util import golden, state_from, as_checkpoint, dataset_from, assert_close
+from _util import golden, state_from, as_checkpoint, dataset_from, assert_close, VARIANT_KW, variant_expected_losses
 
 # The golden vectors were produced with 8 MKL threads; another thread count moves last ulps
 # (SURVEY.md §8c), so comparisons are toleranced, not bitwise.
@@ -105,6 +105,37 @@ def test_one_step_all_intermediates(case, social):
         for k, v in sd.items():
             assert_close(cur[k].numpy(), v.numpy(), 1e-4, 2e-6, "w1.%s.%s" % (mod, k))
     assert abs(ade / data["n_train_samples"] - float(g["ade"])) < 1e-5
+
+
+@pytest.mark.parametrize("name", sorted(VARIANT_KW))
+def test_loss_and_unrolling_switches(name):
+    """use_l2_loss / use_variety_loss (as written, train.py:527-536) / n_unrolling_steps 0,2 / info loss
+    off: one step of the syn_s16a8_on case with the reference's module globals flipped."""
+    g, base = golden("syn_variants"), golden("syn_s16a8_on")
+    ds = dataset_from(base)
+    data = O.load_and_normalise(ds["obsvs"], ds["preds"], ds["batches"])
+    o = O.SocialWaysOracle(12, use_social=True, **VARIANT_KW[name])
+    o.load_state(as_checkpoint(state_from(g, "w0.")))
+    B = int(base["step_agents"][0])
+    sb = data["the_batches"][:data["train_size"]]
+    rec = {}
+    losses, ade, fde = o.train_step(data["obsv"][:B], data["pred"][:B], sb, float(g["uniform"][0, 0]),
+                                    float(g["uniform"][0, 1]), torch.from_numpy(g["noise"]), data["ss"], rec)
+    want, extra = variant_expected_losses(g, name)
+    assert_close(np.asarray(losses), want, 2e-5, 1e-6, "losses")
+    if name == "variety":
+        assert len(extra) == 20 and abs(rec["variety"] - extra[-1]) < 1e-6    # only k = 19 enters the loss
+    assert len(rec["d_grads"]) == int(g[name + ".n_d_updates"])
+    for k, v in rec["d_grads"][-1].items():
+        ref = g["%s.dgrad_last.%s" % (name, k)]
+        assert_close(v, ref, 1e-4, 1e-5 * max(np.abs(ref).max(), 1e-12), "dgrad_last." + k)
+    for k, v in rec["g_grads"].items():
+        ref = g["%s.ggrad.%s" % (name, k)]
+        assert_close(v, ref, 2e-4, 2e-5 * max(np.abs(ref).max(), 1e-12), "ggrad." + k)
+    for k, v in o.D.state_dict().items():
+        assert_close(v.numpy(), g["%s.w1.D.%s" % (name, k)], 1e-4, 2e-6, "w1.D." + k)
+    want_af = g[name + ".ade_fde"] * data["n_train_samples"]
+    assert abs(ade / want_af[0] - 1) < 1e-6 and abs(fde / want_af[1] - 1) < 1e-6
 
 
 def test_social_ops_dense_and_blockdiag():
