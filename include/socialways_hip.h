@@ -163,6 +163,11 @@ int sw_gan_loss(const float* label_a, const float* targets /*device [>=2]: label
 int sw_l2_grad(const float* pred4_hat /*[B,Tp,4]*/, const float* gt /*[B,Tp,2]*/, int B, int Tp, int row0, int row1,
                float scale, float* dpred4 /*[B,Tp,4]*/, void* stream);
 
+/* ---- toy statistics (calc_statistics.py:7-66): the O(K^2) distance loops of compute_1nn /
+ *      compute_wasserstein.  D[k][i][j] = mean over t in [t0,T) of ||a[i][k][t] - b[j][k][t]||.        */
+int sw_traj_dist(const float* a /*[Na,nPed,T,2]*/, const float* b /*[Nb,nPed,T,2]*/, int Na, int Nb, int nPed, int T,
+                 int t0, float* D /*[nPed,Na,Nb]*/, void* stream);
+
 /* ---- staging copy by a device kernel: `src` may be host-pinned (device-mapped) memory; used to feed
  *      z / label-noise scalars to hipGraph-replayed steps without a blocking hipMemcpyAsync ---------- */
 int sw_copy_f32(float* dst, const float* src, long long n, void* stream);

@@ -32,6 +32,10 @@ Cases (all fp32, torch CPU; `threads` recorded in every file)
         globals of train.py:61-69): use_l2_loss, use_variety_loss (as written in train.py:527-536),
         n_unrolling_steps 0 and 2, use_info_loss off.  Per variant: every MSE value train() computed,
         the D gradients of the last D update, the G gradients, D's weights after the step.
+  toy_stats
+        compute_1nn / compute_wasserstein of calc_statistics.py (the script's module body - dataset load,
+        plotting - is not run: only its import statements and these two function definitions are compiled,
+        from the file where it lies) on K=20 real toy samples vs perturbed copies, several noise levels.
   biwi_synth
         a synthetic BIWI-format obsmat.txt (no ETH/UCY data exists here) through the
         reference's BIWIParser + create_dataset (utils/parse_utils.py): windows, times, scene batches.
@@ -381,6 +385,43 @@ def variants_case(dataset):
     return out
 
 
+def reference_stat_functions():
+    """compute_1nn / compute_wasserstein from /root/reference/calc_statistics.py without running the script
+    body (it loads ../data/toy/toy-768.npz and plots at import time)."""
+    import ast
+    path = os.path.join(REF, "calc_statistics.py")
+    tree = ast.parse(open(path).read(), path)
+    keep = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom)) or
+            (isinstance(n, ast.FunctionDef) and n.name in ("compute_1nn", "compute_wasserstein"))]
+    ns = {}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return ns["compute_1nn"], ns["compute_wasserstein"]
+
+
+def toy_stats_case(toy6):
+    """real_samples as calc_statistics.py:167-176 builds them (obs+pred concatenated, (-1,6,4,2)[:20]);
+    fakes = the same conditions with K different perturbations of the futures (what preds_our holds)."""
+    one_nn, emd = reference_stat_functions()
+    real = np.concatenate((toy6["obsvs"], toy6["preds"]), axis=1).reshape((-1, 6, 4, 2))[:20]
+    rng = np.random.default_rng(5)
+    out = dict(real=real.astype(np.float32), sigmas=np.asarray([0.0, 0.01, 0.05, 0.3]))
+    for i, sg in enumerate(out["sigmas"]):
+        fake = real.copy()
+        perm = rng.permutation(20)                      # sample order of a generator is arbitrary
+        fake[:, :, 2:] = real[perm][:, :, 2:] + rng.normal(0, sg, size=real[:, :, 2:].shape).astype(np.float32)
+        fake = fake.astype(np.float32)
+        out["fake.%d" % i] = fake
+        out["one_nn.%d" % i] = np.asarray(one_nn(out["real"], fake), np.float64)
+        out["emd.%d" % i] = np.float64(emd(out["real"], fake))
+    # a ragged case: fewer pedestrians / longer tracks / obsv_len 3 (the functions are shape-generic)
+    a = rng.normal(0, 1, size=(7, 3, 9, 2)).astype(np.float32)
+    b = (a[rng.permutation(7)] + rng.normal(0, 0.2, size=a.shape)).astype(np.float32)
+    out["g.real"], out["g.fake"] = a, b
+    out["g.one_nn"] = np.asarray(one_nn(a, b, 3), np.float64)
+    out["g.emd"] = np.float64(emd(a, b, 3))
+    return out
+
+
 def biwi_case():
     """Inputs from socialways_amd.data.synth_crowd_frames (pure numpy), expected outputs from the
     reference's own parser and window extraction."""
@@ -422,6 +463,8 @@ def main():
         save("syn_variants", variants_case(syn))
     if only is None or "biwi_synth" in only:
         save("biwi_synth", biwi_case())
+    if only is None or "toy_stats" in only:
+        save("toy_stats", toy_stats_case(toy_dataset(768, 6, 3)))
     if only is not None:
         print("done in %.1fs" % (time.time() - t0))
         return

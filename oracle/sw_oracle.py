@@ -557,3 +557,55 @@ def synth_dataset(n_scenes, agents, n_past=8, n_next=12, seed=1234):
     batches = np.stack([ends - np.asarray(sizes), ends], axis=1).astype(np.int64)
     times = np.repeat(np.arange(len(sizes)), sizes).astype(np.int32)
     return dict(obsvs=track[:, :n_past], preds=track[:, n_past:], times=times, batches=batches)
+
+
+# ----------------------------------------------------------------------------- calc_statistics.py:7-66
+def _mean_l2(a, b, obsv_len):
+    """D[k][i][j] = mean_t ||a[i,k,t] - b[j,k,t]|| over t >= obsv_len, in fp32 like the reference's
+    numpy expression on fp32 inputs (calc_statistics.py:30-31, 58-59)."""
+    diff = a[:, None, :, obsv_len:, :] - b[None, :, :, obsv_len:, :]           # (Na, Nb, nPed, T', 2)
+    d = np.sqrt(np.sum(np.power(diff, 2), axis=-1)).mean(axis=-1)              # (Na, Nb, nPed)
+    return np.transpose(d, (2, 0, 1)).astype(np.float64)
+
+
+def compute_1nn(reals, fakes, obsv_len=2):
+    """Leave-one-out 1-NN two-sample test per pedestrian (calc_statistics.py:7-44): returns
+    [overall accuracy, real recall, fake recall].  Self-distance is 1000 (the matrix initial value)."""
+    n_r, n_f, n_ped = reals.shape[0], fakes.shape[0], reals.shape[1]
+    mixed = np.concatenate([reals, fakes], axis=0)
+    D = _mean_l2(mixed, mixed, obsv_len)
+    labels = np.concatenate([np.ones(n_r), -np.ones(n_f)])
+    real_pos = fake_pos = 0
+    for k in range(n_ped):
+        Dk = D[k].copy()
+        iu = np.triu_indices(n_r + n_f, 1)
+        Dk[(iu[1], iu[0])] = Dk[iu]              # the reference fills (i<j) and mirrors it
+        np.fill_diagonal(Dk, 1000.0)
+        nn_ind = np.argmin(Dk, axis=1)
+        same = labels[nn_ind] == labels
+        real_pos += int(np.sum(same & (labels == 1)))
+        fake_pos += int(np.sum(same & (labels == -1)))
+    return np.array([(real_pos + fake_pos) / ((n_r + n_f) * n_ped), real_pos / (n_r * n_ped), fake_pos / (n_f * n_ped)])
+
+
+def emd_cost_matrix(D):
+    """calc_statistics.py:56-60 writes `D[ii, jj], D[jj, ii] = dij, dij` for EVERY (ii, jj) of a
+    real x fake matrix, so later iterations overwrite earlier ones: the matrix that reaches the
+    assignment solver is the LOWER triangle of the true distances mirrored to the upper one.
+    Kept as is (needs n_reals == n_fakes, as in the reference's use)."""
+    L = np.tril(D)
+    return L + np.tril(D, -1).T
+
+
+def compute_wasserstein(reals, fakes, obsv_len=2):
+    """Per-pedestrian optimal assignment cost between real and generated futures, averaged
+    (calc_statistics.py:47-66)."""
+    import scipy.optimize as sopt
+    n_r, n_ped = reals.shape[0], reals.shape[1]
+    D = _mean_l2(reals, fakes, obsv_len)
+    cost = 0.0
+    for k in range(n_ped):
+        Dk = emd_cost_matrix(D[k])
+        r, c = sopt.linear_sum_assignment(Dk)
+        cost += Dk[r, c].sum()
+    return cost / (n_r * n_ped)

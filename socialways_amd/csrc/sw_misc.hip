@@ -351,6 +351,35 @@ extern "C" int sw_l2_grad(const float* pred4, const float* gt, int B, int Tp, in
   return SW_OK;
 }
 
+// ---- toy statistics: pairwise mean displacement between sample sets (calc_statistics.py:28-32, 56-60) ----
+//   D[k][i][j] = mean_{t >= t0} || a[i][k][t] - b[j][k][t] ||
+__global__ __launch_bounds__(256) void traj_dist_kernel(const float* __restrict__ a, const float* __restrict__ b, int Na,
+                                                         int Nb, int nPed, int T, int t0, float* __restrict__ D) {
+  const long long n = (long long)nPed * Na * Nb;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const int j = (int)(e % Nb), i = (int)((e / Nb) % Na), k = (int)(e / ((long long)Nb * Na));
+    const float2* pa = reinterpret_cast<const float2*>(a) + ((size_t)i * nPed + k) * T;
+    const float2* pb = reinterpret_cast<const float2*>(b) + ((size_t)j * nPed + k) * T;
+    float s = 0.f;
+    for (int t = t0; t < T; ++t) {
+      float2 x = pa[t], y = pb[t];
+      float dx = x.x - y.x, dy = x.y - y.y;
+      s += sqrtf(dx * dx + dy * dy);
+    }
+    D[e] = s / (float)(T - t0);
+  }
+}
+extern "C" int sw_traj_dist(const float* a, const float* b, int Na, int Nb, int nPed, int T, int t0, float* D,
+                            void* stream) {
+  if (!a || !b || !D || Na < 1 || Nb < 1 || nPed < 1 || T < 1 || t0 < 0 || t0 >= T) return SW_EARG;
+  long long n = (long long)nPed * Na * Nb;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(traj_dist_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, Na, Nb, nPed, T, t0, D);
+  SW_CHECK_LAUNCH("traj_dist_kernel");
+  return SW_OK;
+}
+
 // ---- staging copy: device kernel that reads a (host-pinned, device-mapped) source -----------------
 // A hipMemcpyAsync host-to-device enqueued behind hipGraph launches blocks the calling host thread
 // until the stream drains on this runtime; a kernel launch never does.  256 KB of z per step over

@@ -181,3 +181,13 @@ def test_test_eval_and_prediction_npz():
         for k in ("obsvs", "preds_our", "preds_gtt", "preds_lnr"):
             assert_close(c[k], g["npz.%s.%s" % (tag, k)], 1e-5, 1e-5, k)
         assert c["preds_our"].shape[0] == 4
+
+
+def test_toy_statistics_1nn_and_emd():
+    """calc_statistics.py compute_1nn / compute_wasserstein (incl. the cost-matrix mirroring quirk)."""
+    g = golden("toy_stats")
+    for i in range(len(g["sigmas"])):
+        assert_close(O.compute_1nn(g["real"], g["fake.%d" % i]), g["one_nn.%d" % i], 0, 1e-12, "1nn %d" % i)
+        assert abs(O.compute_wasserstein(g["real"], g["fake.%d" % i]) - float(g["emd.%d" % i])) < 1e-7
+    assert_close(O.compute_1nn(g["g.real"], g["g.fake"], 3), g["g.one_nn"], 0, 1e-12, "1nn generic")
+    assert abs(O.compute_wasserstein(g["g.real"], g["g.fake"], 3) - float(g["g.emd"])) < 1e-7
