@@ -107,7 +107,12 @@ int sw_dec_rollout_fwd(const float* obsv /*[B,To,2]*/, int To, const float* z /*
                        const float* S_pool /*[B,64] or NULL = zeros*/, const float* hT, const float* cT,
                        const float* enc_w, const float* dec_w, int B, int Tp,
                        float* pred4 /*[B,Tp,4]*/, float* h_end, float* c_end /*[B,64] or NULL*/,
-                       float* gsave /*or NULL*/, void* stream);
+                       float* gsave /*or NULL*/,
+                       /* optional ADE/FDE partial sums of train.py:546-551, one triple per 16-agent tile
+                        * (summed by the caller): { sum err / Tp, sum err[:, -1], sum err^2 },
+                        * err = |(p_hat - gt) * inv_ss|; NULL to skip */
+                       const float* gt /*[B,Tp,2]*/, float inv_ss, float* ade_part /*[ceil(B/16)][3]*/,
+                       void* stream);
 int sw_dec_rollout_bwd(const float* dpred4 /*[B,Tp,4]*/, const float* enc_w, const float* dec_w,
                        const float* gsave, int B, int To, int Tp, float* gdelta,
                        float* dhT, float* dcT, float* dS_pool /*[B,64]*/, void* stream);
@@ -139,7 +144,10 @@ int sw_disc_bwd(const float* d_w, const float* dsave, const float* const* dlabel
 int sw_disc_bwd_gan(const float* d_w, const float* dsave, const float* const* label,
                     const float* const* code, const float* targets, int t0, int t1, const float* z /*[B,32]*/,
                     float g_label, float g_code, int nb, int B, int To, int Tp, float* ddelta,
-                    float* d_d_w, float* const* dpred4, float* wgrad_ws, void* stream);
+                    float* d_d_w, float* const* dpred4, float* wgrad_ws,
+                    float* loss_part /*[ceil(B/16)][3] or NULL: per-tile sums {(label_0-t0)^2, (code_0-z)^2,
+                                       (label_1-t1)^2}, the reported MSE terms; column 2 untouched if nb == 1*/,
+                    void* stream);
 
 /* ---- LSGAN + InfoGAN losses of train.py:484-494 / 512-523 and their gradients -------------- */
 /* t_a = targets[ia], t_b = targets[ib] (read on the device, so a captured hipGraph sees new values).
@@ -173,6 +181,15 @@ int sw_traj_dist(const float* a /*[Na,nPed,T,2]*/, const float* b /*[Nb,nPed,T,2
 int sw_copy_f32(float* dst, const float* src, long long n, void* stream);
 int sw_copy3_f32(float* d0, const float* s0, long long n0, float* d1, const float* s1, long long n1,
                  float* d2, const float* s2, long long n2, void* stream);
+
+/* ---- input staging of a hipGraph-replayed step, one kernel with fixed arguments.  `slot` = host-pinned
+ *      (device-mapped) words the host rewrites before each replay: [0,1] device pointer of obsv (B,To,2),
+ *      [2,3] device pointer of pred (B,Tp,2), [4] zeros_val, [5] ones_val, [6,7] reserved, [8..] z (B*32).
+ *      Writes the static buffers of the graph: tracks, real future as (p,v) rows (train.py:135-137),
+ *      label-noise scalars and z. ------------------------------------------------------------------- */
+#define SW_STAGE_HEADER 8
+int sw_stage_step(const float* slot, int B, int To, int Tp, float* obsv_dst /*[B,To,2]*/, float* pred_dst /*[B,Tp,2]*/,
+                  float* pred4_dst /*[B,Tp,4]*/, float* targets_dst /*[2]*/, float* z_dst /*[B,32]*/, void* stream);
 
 /* ---- ADE/FDE partial sums of train.py:546-551:
  *      out[3] = { sum_{b,t} err / Tp, sum_b err[:, -1], sum_{b,t} err^2 },  err = |(p_hat - p) / ss|   */

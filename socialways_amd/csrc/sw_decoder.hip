@@ -60,7 +60,8 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
     const float* __restrict__ obsv, int To, const float* __restrict__ z, const float* __restrict__ S_pool,
     const float* __restrict__ hT, const float* __restrict__ cT, const float* __restrict__ enc_w,
     const float* __restrict__ dec_w, int B, int Tp, float* __restrict__ pred4, float* __restrict__ h_end,
-    float* __restrict__ c_end, float* __restrict__ gsave) {
+    float* __restrict__ c_end, float* __restrict__ gsave, const float* __restrict__ gt, float inv_ss,
+    float* __restrict__ ade_part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W1h = smem + FwdLds::W1h;
   float* W2 = smem + FwdLds::W2;
@@ -122,8 +123,13 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
   float py = obsv[((size_t)b * To + To - 1) * 2 + 1];
   sw_barrier();  // szbuf / wx_lds aliases are dead from here on
 
+  // displacement-error sums of this tile (train.py:546-551), lanes lg == 0 of wave 0
+  float e_sum = 0.f, e_last = 0.f, e_sq = 0.f;
+  const bool ade_lane = ade_part && wave == 0 && lg == 0;
   int cur = 0;
   for (int i = 0; i < Tp; ++i) {
+    float2 gti = {0.f, 0.f};
+    if (ade_lane) gti = *reinterpret_cast<const float2*>(gt + ((size_t)b * Tp + i) * 2);   // in flight under the layers
     // ---- layer 1: a1 = lrelu(W1h h + u) -----------------------------------------------------
     for (int mt = wave; mt < 10; mt += 4) {
       int m0 = mt * 16;
@@ -165,6 +171,14 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
       float vx = __shfl(acc[0], ln), vy = __shfl(acc[1], ln);
       px += vx;
       py += vy;
+      if (ade_lane && live) {
+        float dx = (px - gti.x) * inv_ss, dy = (py - gti.y) * inv_ss;
+        float q = dx * dx + dy * dy;
+        float e = sqrtf(q);
+        e_sum += e;
+        e_sq += q;
+        if (i == Tp - 1) e_last = e;
+      }
       if (wave == 0 && lg == 0 && live) {
         f32x4 x4 = {px, py, vx, vy};
         st4(pred4 + ((size_t)b * Tp + i) * 4, x4);
@@ -190,6 +204,19 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
   if (h_end && live) {
     st4(h_end + (size_t)b * 64 + u0 + 4 * lg, h);
     if (c_end) st4(c_end + (size_t)b * 64 + u0 + 4 * lg, c);
+  }
+  if (ade_part && wave == 0) {   // fixed shuffle tree over the tile's 16 agents -> one partial triple per workgroup
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      e_sum += __shfl_xor(e_sum, o);
+      e_last += __shfl_xor(e_last, o);
+      e_sq += __shfl_xor(e_sq, o);
+    }
+    if (lane == 0) {
+      ade_part[(size_t)blockIdx.x * 3 + 0] = e_sum / (float)Tp;
+      ade_part[(size_t)blockIdx.x * 3 + 1] = e_last;
+      ade_part[(size_t)blockIdx.x * 3 + 2] = e_sq;
+    }
   }
 }
 
@@ -402,8 +429,9 @@ static int set_lds(const void* fn, int bytes) {
 extern "C" int sw_dec_rollout_fwd(const float* obsv, int To, const float* z, const float* S_pool,
                                   const float* hT, const float* cT, const float* enc_w, const float* dec_w,
                                   int B, int Tp, float* pred4, float* h_end, float* c_end, float* gsave,
-                                  void* stream) {
+                                  const float* gt, float inv_ss, float* ade_part, void* stream) {
   if (!obsv || !z || !hT || !cT || !enc_w || !dec_w || !pred4 || B < 0 || To < 2 || Tp < 1) return SW_EARG;
+  if (ade_part && !gt) return SW_EARG;
   if (B == 0) return SW_OK;
   static bool attr = false;
   if (!attr) {
@@ -412,7 +440,7 @@ extern "C" int sw_dec_rollout_fwd(const float* obsv, int To, const float* z, con
   }
   hipLaunchKernelGGL(dec_rollout_fwd_kernel, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS),
                      FwdLds::total * 4, (hipStream_t)stream, obsv, To, z, S_pool, hT, cT, enc_w, dec_w, B, Tp,
-                     pred4, h_end, c_end, gsave);
+                     pred4, h_end, c_end, gsave, gt, inv_ss, ade_part);
   SW_CHECK_LAUNCH("dec_rollout_fwd_kernel");
   return SW_OK;
 }

@@ -301,6 +301,7 @@ struct DiscLoss {
   int t0, t1;            // target index of branch 0 / 1
   float g_label, g_code;
   int on;
+  float* loss_part;      // [tiles][3] per-tile sums of the squared errors (reporting), or null
 };
 
 __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
@@ -355,6 +356,25 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
       if (want_w && a0 + a < B && cc < 4) {
         ddelta[dd.dlab + ((size_t)k * B + bb) * 4 + cc] = vl;
         ddelta[dd.dcod + ((size_t)k * B + bb) * 4 + cc] = vc;
+      }
+    }
+    if (gl.on && gl.loss_part && wave == 3 && k < 2) {  // the reported MSE sums of this tile (train.py:484-488, 512-516)
+      const bool lv = lane < 16 && a0 + lane < B;
+      const int bb = min(a0 + (lane & 15), B - 1);
+      const float e = dlabel[bb] - gl.targets[k == 0 ? gl.t0 : gl.t1];
+      float sl = lv ? e * e : 0.f, sc = 0.f;
+      if (k == 0 && lv) {
+        const float c0 = dcode[(size_t)bb * 2] - gl.z[(size_t)bb * SW_Z], c1 = dcode[(size_t)bb * 2 + 1] - gl.z[(size_t)bb * SW_Z + 1];
+        sc = c0 * c0 + c1 * c1;
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        sl += __shfl_xor(sl, o);
+        sc += __shfl_xor(sc, o);
+      }
+      if (lane == 0) {
+        gl.loss_part[(size_t)blockIdx.x * 3 + (k == 0 ? 0 : 2)] = sl;
+        if (k == 0) gl.loss_part[(size_t)blockIdx.x * 3 + 1] = sc;
       }
     }
     sw_barrier();
@@ -546,14 +566,15 @@ extern "C" int sw_disc_bwd(const float* d_w, const float* dsave, const float* co
                            float* const* dpred4, float* wgrad_ws, void* stream) {
   DiscLoss gl{};
   gl.on = 0;
+  gl.loss_part = nullptr;
   return disc_bwd_impl(d_w, dsave, dlabel, dcode, nb, B, To, Tp, ddelta, d_d_w, dpred4, wgrad_ws, stream, gl);
 }
 
 extern "C" int sw_disc_bwd_gan(const float* d_w, const float* dsave, const float* const* label,
                                const float* const* code, const float* targets, int t0, int t1, const float* z,
                                float g_label, float g_code, int nb, int B, int To, int Tp, float* ddelta,
-                               float* d_d_w, float* const* dpred4, float* wgrad_ws, void* stream) {
+                               float* d_d_w, float* const* dpred4, float* wgrad_ws, float* loss_part, void* stream) {
   if (!targets || !z || t0 < 0 || t1 < 0) return SW_EARG;
-  DiscLoss gl{targets, z, t0, t1, g_label, g_code, 1};
+  DiscLoss gl{targets, z, t0, t1, g_label, g_code, 1, loss_part};
   return disc_bwd_impl(d_w, dsave, label, code, nb, B, To, Tp, ddelta, d_d_w, dpred4, wgrad_ws, stream, gl);
 }

@@ -232,7 +232,7 @@ class DecoderFC(_Packed):
         enc_w = _encoder.packed() if _encoder is not None else torch.zeros(L.load().sw_param_count(L.GRP_ENC, 1), device=dev)
         L.call("sw_dec_rollout_fwd", L.ptr(zero_obs), 2, L.ptr(z.contiguous()), L.ptr(s.contiguous()),
                L.ptr(h.contiguous()), L.ptr(c), L.ptr(enc_w), L.ptr(self.packed()), B, 1, L.ptr(pred4), None, None, None,
-               L.stream())
+               None, 0.0, None, L.stream())
         return pred4[:, 0, 2:4].contiguous()
 
 

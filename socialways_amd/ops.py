@@ -78,9 +78,11 @@ class GenCtx:
     __slots__ = ("obsv", "noise", "scenes", "hT", "cT", "S", "attn", "gsave", "B", "To", "Tp", "use_social")
 
 
-def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_social, save, ws=None, tag="g"):
+def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_social, save, ws=None, tag="g", ade=None):
     """predict(): encode obs (train.py:397-404), social pooling (408-413), decode loop (415-432).
-    Returns pred_hat_4d (B, n_next, 4) and, if `save`, the context backward needs."""
+    Returns pred_hat_4d (B, n_next, 4) and, if `save`, the context backward needs.
+    ade = (gt (B,n_next,2), 1/ss, out (ceil(B/16),3)): the decode kernel also leaves the per-tile ADE/FDE
+    partial sums of train.py:546-551 in `out`."""
     L.require_gpu(obsv)
     obsv = obsv.contiguous()
     noise = noise.contiguous()
@@ -111,7 +113,8 @@ def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_soc
     else:
         S = torch.zeros(B, 64, device=dev)                                   # train.py:413
     L.call("sw_dec_rollout_fwd", L.ptr(obsv), To, L.ptr(noise), L.ptr(S), L.ptr(hT), L.ptr(cT), L.ptr(enc_w),
-           L.ptr(dec_w), B, n_next, L.ptr(pred4), None, None, L.ptr(gsave), st)
+           L.ptr(dec_w), B, n_next, L.ptr(pred4), None, None, L.ptr(gsave),
+           L.ptr(ade[0]) if ade else None, float(ade[1]) if ade else 0.0, L.ptr(ade[2]) if ade else None, st)
     if not save:
         return pred4, None
     ctx = GenCtx()
@@ -221,9 +224,10 @@ def disc_backward(d_w, ctx, dlabels, dcodes, d_d_w=None, want_dpred=(), ws=None,
 
 
 def disc_backward_gan(d_w, ctx, labels, codes, targets, t_idx, z, g_label, g_code, d_d_w=None, want_dpred=(), ws=None,
-                      tag="d"):
+                      tag="d", loss_part=None):
     """disc_backward with the LSGAN / InfoGAN loss gradients formed inside the kernel from the forward
-    outputs `labels` / `codes` (targets = device [2] label-noise scalars, t_idx = target index per branch)."""
+    outputs `labels` / `codes` (targets = device [2] label-noise scalars, t_idx = target index per branch).
+    loss_part (ceil(B/16),3): receives the per-tile sums of the squared errors (the reported MSE terms)."""
     dev = labels[0].device
     ws = ws or default_ws(dev)
     B, To, Tp, nb = ctx.B, ctx.To, ctx.Tp, ctx.nb
@@ -238,5 +242,5 @@ def disc_backward_gan(d_w, ctx, labels, codes, targets, t_idx, z, g_label, g_cod
     dp, _k3 = L.ptr_array(dpreds)
     t0, t1 = (list(t_idx) + [0])[:2]
     L.call("sw_disc_bwd_gan", L.ptr(d_w), L.ptr(ctx.dsave), lp, cp, L.ptr(targets), t0, t1, L.ptr(z), g_label, g_code, nb,
-           B, To, Tp, L.ptr(ddelta), L.ptr(d_d_w), dp, L.ptr(wgrad), L.stream())
+           B, To, Tp, L.ptr(ddelta), L.ptr(d_d_w), dp, L.ptr(wgrad), L.ptr(loss_part), L.stream())
     return dpreds

@@ -158,97 +158,105 @@ class SocialWaysTrainer:
 
     def step(self, obsv, pred, sub_batches, zeros_val, ones_val, noise, ss=1.0, global_B=None, out=None, global_row0=0):
         """One packed batch (train.py:458-554) on this rank's rows.  obsv (B,To,2), pred (B,Tp,2) and
-        noise (B,32) are tensors (noise may live on the host, like train.py:473); `global_B` = agents
+        noise (B,32) are tensors (noise normally lives on the host, like train.py:473); `global_B` = agents
         of the whole packed batch over all ranks.
-        Returns a (4,3) device tensor `out`: rows = D update 0, D update 1, G phase, ADE/FDE;
-        loss rows hold SUMS of squared errors over the local rows [label_a, code, label_b].
-        With `use_graph` (default on a single GPU) the whole step - ~45 kernels incl. the three Adam
-        updates - is captured once per batch shape into a hipGraph and replayed: the host then only
-        refreshes the inputs (tracks, z, the two label-noise scalars)."""
+        Returns a (U+3, 3) float64 device tensor: rows = the U+1 D updates, the G phase, ADE/FDE; loss rows
+        hold SUMS of squared errors over the local rows [label_a, code, label_b], the last row
+        [sum err / Tp, sum err[:, -1], sum err^2].  The kernels leave one partial triple per 16-agent tile
+        (no reduction kernels on the critical path); they are summed here in float64.  `out=False` returns
+        the raw (U+3, tiles, 3) partials without that extra reduction (bench loop).
+        With `use_graph` the whole step - ~35 kernels incl. the input staging and the Adam updates - is
+        captured once per batch layout into a hipGraph and replayed: per step the host only fills a pinned
+        slot (pointers of the track slices, z, the two label-noise scalars) and launches the graph."""
         B = obsv.shape[0]
         Bg = float(global_B if global_B is not None else B)
         dev = self.device
         self._row0 = int(global_row0)       # first row of this rank's shard in the packed batch (variety term only)
         if self.use_variety_loss and Bg < 20:
             raise ValueError("use_variety_loss indexes agent 19 of the packed batch (train.py:531): batch of %d" % Bg)
+        part = None
         if self.use_graph:
             # one graph set per packed-batch layout; datasets with ragged scenes produce many layouts, so the
             # number of captured layouts is capped and the rest of the steps run eagerly
             scenes = ops.SceneIndex.get(sub_batches, B, dev)
             if (scenes.key, obsv.shape[1], float(ss), Bg, self._row0) in self._graphs or len(self._graphs) < self.max_graphs:
-                return self._step_graph(obsv, pred, sub_batches, zeros_val, ones_val, noise, float(ss), Bg, out)
-        if out is None or out is False:
-            out = torch.zeros(self.n_unrolling_steps + 3, 3, device=dev)
-        scenes = ops.SceneIndex.get(sub_batches, B, dev)
-        noise = noise.to(dev, non_blocking=True).contiguous()
-        # label-noise scalars of train.py:471-472 live in device memory: [zeros_val, ones_val]
-        targets = torch.tensor([float(zeros_val), float(ones_val)], dtype=torch.float32).to(dev, non_blocking=True)
-        return self._step_impl(obsv, pred, scenes, targets, noise, float(ss), Bg, out)
+                part = self._step_graph(obsv, pred, sub_batches, zeros_val, ones_val, noise, float(ss), Bg)
+        if part is None:
+            part = torch.zeros(self.n_unrolling_steps + 3, (B + 15) // 16, 3, device=dev)
+            scenes = ops.SceneIndex.get(sub_batches, B, dev)
+            noise = noise.to(dev, non_blocking=True).contiguous()
+            # label-noise scalars of train.py:471-472 live in device memory: [zeros_val, ones_val]
+            targets = torch.tensor([float(zeros_val), float(ones_val)], dtype=torch.float32).to(dev, non_blocking=True)
+            self._step_impl(obsv.contiguous(), pred.contiguous(), None, scenes, targets, noise, float(ss), Bg, part)
+        if out is False:           # caller reads the static partials before the next step overwrites them
+            return part
+        return part.sum(1, dtype=torch.float64)
 
-    def _step_graph(self, obsv, pred, sub_batches, zeros_val, ones_val, noise, ss, Bg, out):
-        B, To = obsv.shape[0], obsv.shape[1]
+    def _step_graph(self, obsv, pred, sub_batches, zeros_val, ones_val, noise, ss, Bg):
+        B, To, Tp = obsv.shape[0], obsv.shape[1], self.n_next
         dev = self.device
         scenes = ops.SceneIndex.get(sub_batches, B, dev)
         key = (scenes.key, To, ss, Bg, self._row0)
         st = self._graphs.get(key)
+        HDR = 8                                                   # SW_STAGE_HEADER words in front of z
         if st is None:
             st = self._graphs[key] = dict(
-                n=0, graph=None, scenes=scenes, obsv=torch.empty(B, To, 2, device=dev),
-                pred=torch.empty(B, self.n_next, 2, device=dev), stage=torch.empty(4 + B * self.noise_len, device=dev),
-                out=torch.zeros(self.n_unrolling_steps + 3, 3, device=dev),
-                ring=[(torch.empty(4 + B * self.noise_len, dtype=torch.float32).pin_memory(), torch.cuda.Event())
-                      for _ in range(4)])
-            st["targets"] = st["stage"][:2]                     # [zeros_val, ones_val]
-            st["noise"] = st["stage"][4:].view(B, self.noise_len)   # 16-byte aligned
-        # Inputs of the step -> the graph's static buffers, ONE kernel: the tracks of this packed batch
-        # (device) and z + the two label-noise scalars from a ring of pinned host slots.  The kernel reads
-        # the pinned (device-mapped) memory itself: a hipMemcpyAsync enqueued behind graph launches blocks
-        # the host until the stream drains, a kernel launch does not.
+                n=0, graph=None, flip=0, scenes=scenes, obsv=torch.empty(B, To, 2, device=dev),
+                pred=torch.empty(B, Tp, 2, device=dev), pred4=torch.empty(B, Tp, 4, device=dev),
+                targets=torch.empty(4, device=dev), noise=torch.empty(B, self.noise_len, device=dev),
+                out=torch.zeros(self.n_unrolling_steps + 3, (B + 15) // 16, 3, device=dev),
+                slots=[(torch.zeros(HDR + B * self.noise_len, dtype=torch.float32).pin_memory(), torch.cuda.Event())
+                       for _ in range(2)], keep=[None, None])
+        # Inputs of the step travel through a pinned host slot that the graph's first node (sw_stage_step)
+        # reads itself: the device pointers of this batch's track slices, the two label-noise scalars and z.
+        # A hipMemcpyAsync enqueued behind graph launches would block the host until the stream drains; a
+        # kernel reading device-mapped host memory does not.  One slot per graph executable.
+        k = (st["flip"] ^ 1) if st["graph"] is not None else 0
+        host, done = st["slots"][k]
+        done.synchronize()                                     # the replay that last read this slot has finished
         obsv, pred = obsv.contiguous(), pred.contiguous()
-        if noise.is_cuda:
-            st["noise"].copy_(noise)
-            st["targets"].copy_(torch.tensor([float(zeros_val), float(ones_val)]), non_blocking=True)
-            L.call("sw_copy3_f32", L.ptr(st["obsv"]), L.ptr(obsv), obsv.numel(), L.ptr(st["pred"]), L.ptr(pred), pred.numel(),
-                   None, None, 0, L.stream())
-        else:
-            k = st["k"] = (st.get("k", -1) + 1) % len(st["ring"])
-            host, done = st["ring"][k]
-            done.synchronize()                                 # the copy kernel that last read this pinned slot is done
-            host[0], host[1] = float(zeros_val), float(ones_val)
-            np.copyto(host[4:].view(B, self.noise_len).numpy(), noise.numpy())   # plain memcpy
-            L.call("sw_copy3_f32", L.ptr(st["obsv"]), L.ptr(obsv), obsv.numel(), L.ptr(st["pred"]), L.ptr(pred), pred.numel(),
-                   L.ptr(st["stage"]), host.data_ptr(), host.numel(), L.stream())
-            done.record()
+        st["keep"][k] = (obsv, pred)                           # alive until the slot is rewritten
+        hn = host.numpy()
+        hn[:4].view(np.uint64)[:] = (obsv.data_ptr(), pred.data_ptr())
+        hn[4], hn[5] = float(zeros_val), float(ones_val)
+        np.copyto(hn[HDR:].reshape(B, self.noise_len), (noise.cpu() if noise.is_cuda else noise).numpy())   # plain memcpy
+
+        def stage(kk):
+            L.call("sw_stage_step", st["slots"][kk][0].data_ptr(), B, To, Tp, L.ptr(st["obsv"]), L.ptr(st["pred"]),
+                   L.ptr(st["pred4"]), L.ptr(st["targets"]), L.ptr(st["noise"]), L.stream())
+        args = (st["obsv"], st["pred"], st["pred4"], scenes, st["targets"], st["noise"], ss, Bg, st["out"])
         if st["graph"] is not None:
-            st["flip"] ^= 1
-            for g, buf in st["graph"][st["flip"]]:
+            st["flip"] = k
+            for g, buf in st["graph"][k]:
                 g.replay()
                 if buf is not None:
                     self._allreduce(buf)
-        elif st["n"] < 2:          # first steps of a shape run eagerly (lazy inits, workspace growth)
+        elif st["n"] < 2:          # first steps of a layout run eagerly (lazy inits, workspace growth)
             st["n"] += 1
-            self._step_impl(st["obsv"], st["pred"], scenes, st["targets"], st["noise"], ss, Bg, st["out"])
+            stage(0)
+            self._step_impl(*args)
         else:
             # Capture.  Single GPU: one graph for the whole step.  Data parallel: one graph per segment
             # between the all-reduce points (the collectives themselves stay eager: no RCCL-in-graph
             # dependency), all segments sharing one memory pool so intermediates stay alive.
             # The step is captured TWICE and the two executables alternate: launching an executable
             # that is still running makes hipGraphLaunch wait for it, which would put the host-side
-            # launch cost (~150 us for ~50 nodes) on the critical path of every step.
+            # launch cost (~150 us for ~40 nodes) on the critical path of every step.
             torch.cuda.synchronize()
             pool, sets = None, []
-            for _ in range(2):
-                gen = self._step_gen(st["obsv"], st["pred"], scenes, st["targets"], st["noise"], ss, Bg, st["out"])
-                graphs, done = [], False
-                while not done:
+            for kk in range(2):
+                gen = self._step_gen(*args, pre=lambda kk=kk: stage(kk))
+                graphs, fin = [], False
+                while not fin:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=pool):
+                    # thread_local: other threads (the RCCL watchdog) may touch the runtime during capture
+                    with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                         while True:
                             try:
                                 buf = next(gen)
                             except StopIteration:
-                                buf, done = None, True
-                            if done or self.world > 1 or self._force_dist:
+                                buf, fin = None, True
+                            if fin or self.world > 1 or self._force_dist:
                                 break
                     graphs.append((g, buf))
                     pool = g.pool()
@@ -258,57 +266,48 @@ class SocialWaysTrainer:
                 g.replay()
                 if buf is not None:
                     self._allreduce(buf)
-        if out is False:           # caller reads the static result tensor before the next step overwrites it
-            return st["out"]
-        if out is None:
-            return st["out"].clone()
-        out.copy_(st["out"])
-        return out
+        done.record()
+        return st["out"]
 
-    def _step_impl(self, obsv, pred, scenes, targets, noise, ss, Bg, out):
+    def _step_impl(self, obsv, pred, pred4, scenes, targets, noise, ss, Bg, out):
         """Eager step: run the segments, all-reducing the packed gradient buffer each one hands back."""
-        for buf in self._step_gen(obsv, pred, scenes, targets, noise, ss, Bg, out):
+        for buf in self._step_gen(obsv, pred, pred4, scenes, targets, noise, ss, Bg, out):
             self._allreduce(buf)
         return out
 
-    def _step_gen(self, obsv, pred, scenes, targets, noise, ss, Bg, out):
+    def _step_gen(self, obsv, pred, pred4, scenes, targets, noise, ss, Bg, out, pre=None):
         """Device-only body of the step (no host syncs, no host-dependent values: capturable) as a
         generator: it yields the packed gradient buffer at each of the 3 points where data-parallel
-        ranks must all-reduce before the optimizer step (D, D, G)."""
+        ranks must all-reduce before the optimizer step (D, D, G).  `out` (U+3, tiles, 3) receives the
+        per-tile loss / ADE partial sums; `pre` = the input staging of a captured step."""
         G, D = self.G, self.D
         B, Tp = obsv.shape[0], self.n_next
         dev = self.device
         ws = self.ws
+        U = self.n_unrolling_steps
         g_label = 1.0 / Bg
         g_code = (self.loss_info_w if self.use_info_loss else 0.0) / (2.0 * Bg)
         # One stream: inside a hipGraph every cross-stream edge costs 5-10 us of queue synchronisation on
         # this runtime - more than any of the small kernels that could be overlapped (measured).
-        # real future as 4-d (train.py:470); the observation itself stays 2-d: kernels form (p, v) on the fly
-        pred4 = torch.empty(B, Tp, 4, device=dev)
-        o4_scratch = ws.get("o4", B * obsv.shape[1] * 4)
-        L.call("sw_traj_4d", L.ptr(obsv), L.ptr(pred), B, obsv.shape[1], Tp, L.ptr(o4_scratch), L.ptr(pred4), L.stream())
+        if pre is not None:
+            pre()
+        if pred4 is None:          # real future as 4-d (train.py:470); the observation stays 2-d: kernels form (p, v) on the fly
+            pred4 = torch.empty(B, Tp, 4, device=dev)
+            o4_scratch = ws.get("o4", B * obsv.shape[1] * 4)
+            L.call("sw_traj_4d", L.ptr(obsv), L.ptr(pred), B, obsv.shape[1], Tp, L.ptr(o4_scratch), L.ptr(pred4), L.stream())
         # ---- generator rollout, once (train.py:480/507 are identical, SURVEY §0.11) ---------------
         enc, emb, att, dec = G.encoder, G.feature_embedder, G.attention, G.decoder
+        # the decode kernel also leaves the ADE/FDE partial sums of the prediction (train.py:546-551)
         pred_hat, gctx = ops.gen_forward(enc._flat, emb._flat, att._flat, dec._flat, obsv, noise, scenes, Tp,
-                                         G.use_social, save=True, ws=ws)
-        # ADE/FDE partial sums of the prediction (train.py:546-551) only need pred_hat: side stream,
-        # under the first discriminator pass
-        red = L.ptr(ws.get("red_scratch", 3 * L.RED_BLOCKS))   # partials of the large-batch reductions
-        L.call("sw_ade_fde", L.ptr(pred_hat), L.ptr(pred), B, Tp, 1.0 / float(ss),
-               L.ptr(out[self.n_unrolling_steps + 2]), red, L.stream())
-        dl_f = ws.get("dl_f", B)
-        dc_f = ws.get("dc_f", 2 * B)
-        dl_r = ws.get("dl_r", B)
-        dc_r = ws.get("dc_r", 2 * B)
+                                         G.use_social, save=True, ws=ws, ade=(pred, 1.0 / float(ss), out[U + 2]))
         d_gflat = D.grad_views()
         backup = None
         # ---- discriminator updates (train.py:476-499) ------------------------------------------------
         for u in range(self.n_unrolling_steps + 1):
             labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat, pred4], save=True, ws=ws)
-            # loss SUMS (reporting only) on a side stream; the loss gradients are formed inside the backward kernel
-            ops.disc_backward_gan(D._flat, dctx, labels, codes, targets, (0, 1), noise, g_label, g_code, d_gflat, (), ws=ws)
-            L.call("sw_gan_loss", L.ptr(labels[0]), L.ptr(targets), 0, L.ptr(codes[0]), L.ptr(noise), L.ptr(labels[1]),
-                   1, B, g_label, g_code, L.ptr(out[u]), None, None, None, None, red, L.stream())
+            # the loss gradients AND the reported loss sums (per-tile partials) are formed inside the backward kernel
+            ops.disc_backward_gan(D._flat, dctx, labels, codes, targets, (0, 1), noise, g_label, g_code, d_gflat, (), ws=ws,
+                                  loss_part=out[u])
             yield d_gflat
             self.D_optimizer.step()
             if u == 0 and self.n_unrolling_steps > 0:
@@ -317,9 +316,7 @@ class SocialWaysTrainer:
         # ---- generator update (train.py:503-539) ----------------------------------------------------
         labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat], save=True, ws=ws, save_lstm=False)   # only d/dpred is needed
         dpred = ops.disc_backward_gan(D._flat, dctx, labels, codes, targets, (1, 1), noise, g_label, g_code, None, (True,),
-                                      ws=ws)[0]
-        L.call("sw_gan_loss", L.ptr(labels[0]), L.ptr(targets), 1, L.ptr(codes[0]), L.ptr(noise), None, 1, B, g_label,
-               g_code, L.ptr(out[self.n_unrolling_steps + 1]), None, None, None, None, red, L.stream())
+                                      ws=ws, loss_part=out[U + 1])[0]
         if self.use_l2_loss:                                                 # train.py:525-526
             L.call("sw_l2_grad", L.ptr(pred_hat), L.ptr(pred), B, Tp, 0, B, self.loss_l2_w / (Bg * Tp), L.ptr(dpred), L.stream())
         if self.use_variety_loss:                                            # train.py:527-536 as written
@@ -403,7 +400,7 @@ class SocialWaysTrainer:
             if self._lin_mask is None:
                 self._lin_mask = self.D.linear_mask() > 0
             self.D._flat.copy_(torch.where(self._lin_mask, backup, self.D._flat))
-        return torch.zeros(self.n_unrolling_steps + 3, 3, device=self.device)
+        return torch.zeros(self.n_unrolling_steps + 3, 3, device=self.device, dtype=torch.float64)
 
     # ------------------------------------------------------------------------------------------
     def test(self, data, n_gen_samples=20, linear=False, write_to_file=None, just_one=False, collect=None):
