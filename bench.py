@@ -31,6 +31,7 @@ WORKLOADS = {   # name -> (scenes per GPU step, agents per scene, To, Tp)
     "c2": (32, 8, 8, 12),      # BASELINE config 2: --batch-size 256
     "c4": (512, 64, 8, 12),    # dense crowd: 32768 agents, 2.1M pairs
 }
+PEAK_HBM_BPS = 8.0e12          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_FP32_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / VALU fp32 peak
 N_BATCHES = 8                  # distinct packed batches cycled through
 
@@ -181,7 +182,10 @@ def main():
                        "step_frac_of_fp32_peak": fl["step"] / (dt / args.steps) / (PEAK_FP32_TFLOPS * 1e12)},
             "roofline": {"bound": "mfma", "kernel": args.dominant.replace("sw_", "") + "_kernel", "achieved": achieved,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
-                         "avg_launch_ms": kern_s * 1e3, "launches": len(kern_ms), "traffic": traffic},
+                         "avg_launch_ms": kern_s * 1e3, "launches": len(kern_ms), "traffic": traffic,
+                         # north_star also asks for the HBM view: measured bytes / launch time vs 8 TB/s
+                         "hbm_GBps": (traffic / kern_s / 1e9) if traffic else None,
+                         "hbm_frac": (traffic / kern_s / PEAK_HBM_BPS) if traffic else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(tracks, S if args.workload != "c4" else 16, A, To, Tp)

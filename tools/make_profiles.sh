@@ -4,7 +4,7 @@
 D=$1; O=$2; R=$3
 mkdir -p $O
 python tools/rocpd_stats.py $D/trace_results.db > $O/${R}_m1_kernel_stats.txt
-python tools/rocpd_timeline.py $D/trace_results.db 140 | head -64 > $O/${R}_m1_step_timeline.txt
+python tools/rocpd_step.py $D/trace_results.db > $O/${R}_m1_step_timeline.txt
 python tools/rocpd_stats.py $D/trace_c4_results.db > $O/${R}_c4_kernel_stats.txt
 python tools/pmc_traffic.py $D/fetch_results.db $D/write_results.db $O/${R}_pmc_m1.json > /dev/null
 { python tools/rocpd_pmc.py $D/fetch_results.db; python tools/rocpd_pmc.py $D/write_results.db; } > $O/${R}_m1_hbm_pmc.txt
