@@ -241,10 +241,340 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_fwd_kernel(
 // ---------------------------------------------------------------------------------------------
 // Backward.  Inputs carry no gradient (tracks are data); gradients flow to h (through the pooling
 // and through W h), to W/b of the attention and to the pair MLP.  The pair MLP forward is
-// recomputed per tile; its weight gradients are deferred GEMMs over per-pair rows.
-// pair rows (P_total = sum n_s^2, row index = pair_off[s] + i*n + j):
-//   f[64] dz3[64] h2[64] dh2[64] h1[32] dh1[32] feat[4]
+// recomputed per 16-pair tile and its WEIGHT GRADIENTS ARE ACCUMULATED IN REGISTERS across all tiles
+// (and scenes) a wave processes: per tile the operands (dz3, h2, dh2, h1) are transposed through a
+// small per-wave LDS scratch into "k = pair" MFMA layout and 96 more MFMAs update the 64x64 / 64x32
+// accumulators.  Writing per-pair rows for a deferred GEMM instead costs 324 floats per pair - 2.7 GB
+// per step at 512 x 64-agent scenes.  One partial (6400 floats) per workgroup goes to the wgrad
+// workspace and is reduced in fixed order by wgrad_reduce_kernel.  Only f_ij (64 floats per pair) is
+// still written: dWh_j = sum_i dsigma_ij f_ij needs it after all pairs of the scene are done.
 // ---------------------------------------------------------------------------------------------
+#define SW_SOC_W2LD 68   // LDS row strides of the row-major fc.4 / fc.2 weight images (conflict-free
+#define SW_SOC_W1LD 36   //   transposed reads, see below)
+#define SW_SOC_TLD 20    // row stride of a 16x16 transposition tile
+#define SW_SOC_SCR (4 * 16 * SW_SOC_TLD)   // per-wave scratch: 4 tiles
+#define SW_SOC_FUSE_MIN_PAIRS 256   // mean pairs per scene from which the in-register weight gradients pay (>= 4 tiles per wave)
+#define SW_SOC_PART (64 * 65 + 64 * 33 + 32 * 4)   // floats per workgroup partial: dW3|db3, dW2|db2, dW1|db1
+
+struct SocPart {   // where workgroup g leaves its partial (wgrad workspace, [g][N][Kc] per problem)
+  float *p3, *p2, *p1;
+};
+
+// V (C layout: lane holds V[unit 4lg+r][pair ln]) -> T[r] = V[unit ln][pair 4lg+r] through a per-wave tile
+__device__ __forceinline__ void tr_put(float* tile, f32x4 v, int ln, int lg) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tile[(4 * lg + r) * SW_SOC_TLD + ln] = v[r];
+}
+__device__ __forceinline__ f32x4 tr_get(const float* tile, int ln, int lg) { return ld4(tile + ln * SW_SOC_TLD + 4 * lg); }
+// The LDS unit executes one wave's DS instructions in order, so a wave re-reading what its own lanes just
+// wrote needs no hardware wait - only the compiler must not move the accesses across each other.  (A real
+// fence would also drain the wave's outstanding GLOBAL stores - the f rows - at every transposition.)
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("" ::: "memory"); }
+
+__global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
+    const float* __restrict__ obsv, int To, const float* __restrict__ h, const int* __restrict__ scene_off,
+    const long long* __restrict__ pair_off, int S, const float* __restrict__ emb_w, const float* __restrict__ att_w,
+    const float* __restrict__ attn, const float* __restrict__ dS, float* __restrict__ dh,
+    float* __restrict__ dwh_rows, float* __restrict__ f_rows, SocPart part, int a16) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const SocL Ls = soc_lds(a16);
+  const int sa = Ls.sa;
+  float* hs = smem + Ls.hs;
+  float* wh = smem + Ls.wh;
+  float* x4 = smem + Ls.x4;
+  float* sig = smem + Ls.sig;  // attention weights a_ij
+  const float* w0b = smem + Ls.w0b;
+  const float* b12 = smem + Ls.b12;
+  float* dsl = smem + Ls.ds;
+  float* dsg = smem + Ls.dsg;
+  float* dwh = smem + Ls.dwh;
+  float* w2s = smem + Ls.bwd_total;                   // fc.4.weight [64][68]
+  float* w1s = w2s + 64 * SW_SOC_W2LD;                // fc.2.weight [64][36]
+  float* scr_all = w1s + 64 * SW_SOC_W1LD;            // [4 waves][4 tiles][16][20]
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  float* scr = scr_all + wave * SW_SOC_SCR;
+
+  // ---- once per workgroup: weights ------------------------------------------------------------
+  for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {
+    int r = i >> 4, q = i & 15;
+    st4(&w2s[r * SW_SOC_W2LD + 4 * q], ld4(emb_w + swp::EMB_W2 + r * 64 + 4 * q));
+    if (q < 8) st4(&w1s[r * SW_SOC_W1LD + 4 * q], ld4(emb_w + swp::EMB_W1 + r * 32 + 4 * q));
+  }
+  PairW W;
+  load_pair_w(W, emb_w, ln, lg);
+  // accumulators of this wave (C layout: [out unit 4lg+r][in unit ln] per tile)
+  f32x4 acc3[4][4], acc2[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc3[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc2[a][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc2[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float b3s[4] = {0.f, 0.f, 0.f, 0.f}, b2s[4] = {0.f, 0.f, 0.f, 0.f};   // bias sums: unit 16t + ln, partial over (lg, r)
+  float b1s[2] = {0.f, 0.f};
+  float w0s[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};                 // dW1[unit 16jt + ln][c], partial over (lg, r)
+
+  for (int sc = blockIdx.x; sc < S; sc += gridDim.x) {
+    const int s0 = scene_off[sc], n = scene_off[sc + 1] - s0;
+    if (n <= 0) continue;
+    if (n == 1) {  // S = 0 constant: no gradient anywhere; dWh row is zero
+      if (threadIdx.x < 16) st4(dwh_rows + (size_t)s0 * 64 + 4 * threadIdx.x, f32x4{0.f, 0.f, 0.f, 0.f});
+      continue;
+    }
+    const long long p0 = pair_off[sc];
+    __syncthreads();   // previous scene's LDS (and its global f rows) are done with
+    scene_prologue(smem, Ls, obsv, To, h, emb_w, att_w, s0, n);
+    for (int i = threadIdx.x; i < n * 16; i += blockDim.x) {
+      int a = i >> 4, q = i & 15;
+      st4(&dsl[a * 68 + 4 * q], ld4(dS + (size_t)(s0 + a) * 64 + 4 * q));
+    }
+    for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+      int i = e / n, j = e - i * n;
+      sig[i * sa + j] = attn[(size_t)(s0 + i) * SW_AMAX + j];
+    }
+    sw_barrier();
+    // da_ij = <dS_i, h_j>;  dsigma_ij = a_ij (da_ij - sum_j' a_ij' da_ij')   (softmax backward)
+    for (int i = wave; i < n; i += 4) {
+      float da = 0.f, a = 0.f;
+      if (lane < n) {
+        a = sig[i * sa + lane];
+        for (int u = 0; u < 64; u += 4) {
+          f32x4 x = ld4(&dsl[i * 68 + u]), y = ld4(&hs[lane * 68 + u]);
+          da = fmaf(x[0], y[0], da); da = fmaf(x[1], y[1], da); da = fmaf(x[2], y[2], da); da = fmaf(x[3], y[3], da);
+        }
+      }
+      float t = a * da;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+      if (lane < n) dsg[i * sa + lane] = a * (da - t);
+    }
+    sw_barrier();
+    // ---- pair tiles: recompute the MLP, back-propagate, accumulate the weight gradients ----------
+    const int P = n * n;
+    for (int pt = wave; pt * 16 < P; pt += 4) {
+      const bool valid = pt * 16 + ln < P;
+      int p = min(pt * 16 + ln, P - 1);
+      int i = p / n, j = p - i * n;
+      float f0, f1, f2;
+      pair_feat(ld4(&x4[i * 4]), ld4(&x4[j * 4]), f0, f1, f2);
+      f32x4 h1[2], h2[4], f[4];
+      pair_l1(w0b, lg, f0, f1, f2, h1);
+      pair_l23(W, b12, b12 + 64, lg, h1, h2, f);
+      const float dsv = valid ? dsg[i * sa + j] : 0.f;   // invalid lanes contribute exact zeros everywhere below
+      if (valid) {
+        const size_t row = (size_t)(p0 + p);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) st4(f_rows + row * 64 + 16 * mt + 4 * lg, f[mt]);
+      }
+      f32x4 dz3[4];
+#pragma unroll
+      for (int mo = 0; mo < 4; ++mo) {
+        f32x4 w = ld4(&wh[j * 68 + 16 * mo + 4 * lg]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dz3[mo][r] = dsv * w[r];
+      }
+      // dW3 += dz3 h2^T (k = pairs): both operands through the transposition scratch
+      f32x4 ta[4], tb[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) tr_put(scr + t * 16 * SW_SOC_TLD, dz3[t], ln, lg);
+      wave_lds_fence();
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ta[t] = tr_get(scr + t * 16 * SW_SOC_TLD, ln, lg);
+      wave_lds_fence();
+#pragma unroll
+      for (int t = 0; t < 4; ++t) tr_put(scr + t * 16 * SW_SOC_TLD, h2[t], ln, lg);
+      wave_lds_fence();
+#pragma unroll
+      for (int t = 0; t < 4; ++t) tb[t] = tr_get(scr + t * 16 * SW_SOC_TLD, ln, lg);
+      wave_lds_fence();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int mo = 0; mo < 4; ++mo) {
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) acc3[mo][kt] = SW_MFMA(ta[mo][r], tb[kt][r], acc3[mo][kt]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) b3s[t] += (ta[t][0] + ta[t][1]) + (ta[t][2] + ta[t][3]);
+      // dh2 = (W2^T dz3) * relu'(h2): A operand = W2[16mo+4lg+r][16mt+ln] read transposed from the LDS image
+      f32x4 dh2[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) dh2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mo = 0; mo < 4; ++mo) {
+        float wt[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) wt[r][mt] = w2s[(16 * mo + 4 * lg + r) * SW_SOC_W2LD + 16 * mt + ln];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) dh2[mt] = SW_MFMA(wt[r][mt], dz3[mo][r], dh2[mt]);
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh2[mt][r] = h2[mt][r] > 0.f ? dh2[mt][r] : 0.f;
+      }
+      // dW2 += dh2 h1^T
+#pragma unroll
+      for (int t = 0; t < 4; ++t) tr_put(scr + t * 16 * SW_SOC_TLD, dh2[t], ln, lg);
+      wave_lds_fence();
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ta[t] = tr_get(scr + t * 16 * SW_SOC_TLD, ln, lg);
+      wave_lds_fence();
+      tr_put(scr, h1[0], ln, lg);
+      tr_put(scr + 16 * SW_SOC_TLD, h1[1], ln, lg);
+      wave_lds_fence();
+      tb[0] = tr_get(scr, ln, lg);
+      tb[1] = tr_get(scr + 16 * SW_SOC_TLD, ln, lg);
+      wave_lds_fence();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          acc2[mt][0] = SW_MFMA(ta[mt][r], tb[0][r], acc2[mt][0]);
+          acc2[mt][1] = SW_MFMA(ta[mt][r], tb[1][r], acc2[mt][1]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) b2s[t] += (ta[t][0] + ta[t][1]) + (ta[t][2] + ta[t][3]);
+      // dh1 = (W1^T dh2) * relu'(h1)
+      f32x4 dh1[2];
+      dh1[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dh1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        float wt[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          wt[r][0] = w1s[(16 * mt + 4 * lg + r) * SW_SOC_W1LD + ln];
+          wt[r][1] = w1s[(16 * mt + 4 * lg + r) * SW_SOC_W1LD + 16 + ln];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dh1[0] = SW_MFMA(wt[r][0], dh2[mt][r], dh1[0]);
+          dh1[1] = SW_MFMA(wt[r][1], dh2[mt][r], dh1[1]);
+        }
+      }
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh1[jt][r] = h1[jt][r] > 0.f ? dh1[jt][r] : 0.f;
+      }
+      // dW1 += dh1 feat^T, db1 += dh1 (VALU): transposed dh1 against the features of pairs 4lg + r
+      tr_put(scr, dh1[0], ln, lg);
+      tr_put(scr + 16 * SW_SOC_TLD, dh1[1], ln, lg);
+      if (lg == 0) st4(scr + 2 * 16 * SW_SOC_TLD + 4 * ln, f32x4{f0, f1, f2, 0.f});   // feat[pair ln][0..2]
+      wave_lds_fence();
+      ta[0] = tr_get(scr, ln, lg);
+      ta[1] = tr_get(scr + 16 * SW_SOC_TLD, ln, lg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x4 ft = ld4(scr + 2 * 16 * SW_SOC_TLD + 4 * (4 * lg + r));
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          w0s[jt][0] = fmaf(ta[jt][r], ft[0], w0s[jt][0]);
+          w0s[jt][1] = fmaf(ta[jt][r], ft[1], w0s[jt][1]);
+          w0s[jt][2] = fmaf(ta[jt][r], ft[2], w0s[jt][2]);
+          b1s[jt] += ta[jt][r];
+        }
+      }
+      wave_lds_fence();
+    }
+    __syncthreads();  // f rows of this scene are visible to the whole workgroup (same CU)
+    // dWh_j = sum_i dsigma_ij f_ij
+    for (int e = threadIdx.x; e < n * 64; e += blockDim.x) {
+      int j = e >> 6, u = e & 63;
+      float acc = 0.f;
+      for (int i = 0; i < n; ++i) acc = fmaf(dsg[i * sa + j], f_rows[(size_t)(p0 + i * n + j) * 64 + u], acc);
+      dwh[j * 68 + u] = acc;
+      dwh_rows[(size_t)(s0 + j) * 64 + u] = acc;
+    }
+    sw_barrier();
+    // dh_j += sum_i a_ij dS_i  +  W^T dWh_j
+    for (int e = threadIdx.x; e < n * 64; e += blockDim.x) {
+      int j = e >> 6, u = e & 63;
+      float acc = 0.f;
+      for (int i = 0; i < n; ++i) acc = fmaf(sig[i * sa + j], dsl[i * 68 + u], acc);
+      const float* wc = att_w + swp::ATT_W + u;
+      for (int k = 0; k < 64; ++k) acc = fmaf(wc[k * 64], dwh[j * 68 + k], acc);
+      dh[(size_t)(s0 + j) * 64 + u] += acc;
+    }
+  }
+  // ---- epilogue: this workgroup's partial = sum of its 4 waves, in a fixed order through LDS ------
+  // finish the lane-partial sums over the 4 lane groups (fixed shuffle tree)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    b3s[t] += __shfl_xor(b3s[t], 16); b3s[t] += __shfl_xor(b3s[t], 32);
+    b2s[t] += __shfl_xor(b2s[t], 16); b2s[t] += __shfl_xor(b2s[t], 32);
+  }
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    b1s[jt] += __shfl_xor(b1s[jt], 16); b1s[jt] += __shfl_xor(b1s[jt], 32);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { w0s[jt][c] += __shfl_xor(w0s[jt][c], 16); w0s[jt][c] += __shfl_xor(w0s[jt][c], 32); }
+  }
+  __syncthreads();
+  float* red = w2s;   // SW_SOC_PART floats (weight images + scratch are dead): [64][65] | [64][33] | [32][4]
+  float* r3 = red, *r2 = red + 64 * 65, *r1 = r2 + 64 * 33;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int mo = 0; mo < 4; ++mo) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nrow = 16 * mo + 4 * lg + r;
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) {
+            float* q = r3 + nrow * 65 + 16 * kt + ln;
+            *q = (w == 0 ? 0.f : *q) + acc3[mo][kt][r];
+          }
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) {
+            float* q = r2 + nrow * 33 + 16 * jt + ln;
+            *q = (w == 0 ? 0.f : *q) + acc2[mo][jt][r];
+          }
+        }
+      }
+      if (lg == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float* q3 = r3 + (16 * t + ln) * 65 + 64;
+          float* q2 = r2 + (16 * t + ln) * 33 + 32;
+          *q3 = (w == 0 ? 0.f : *q3) + b3s[t];
+          *q2 = (w == 0 ? 0.f : *q2) + b2s[t];
+        }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          float* q = r1 + (16 * jt + ln) * 4;
+          q[0] = (w == 0 ? 0.f : q[0]) + w0s[jt][0];
+          q[1] = (w == 0 ? 0.f : q[1]) + w0s[jt][1];
+          q[2] = (w == 0 ? 0.f : q[2]) + w0s[jt][2];
+          q[3] = (w == 0 ? 0.f : q[3]) + b1s[jt];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* o3 = part.p3 + (size_t)blockIdx.x * 64 * 65;
+  float* o2 = part.p2 + (size_t)blockIdx.x * 64 * 33;
+  float* o1 = part.p1 + (size_t)blockIdx.x * 32 * 4;
+  for (int e = threadIdx.x; e < 64 * 65; e += blockDim.x) o3[e] = r3[e];
+  for (int e = threadIdx.x; e < 64 * 33; e += blockDim.x) o2[e] = r2[e];
+  for (int e = threadIdx.x; e < 32 * 4; e += blockDim.x) o1[e] = r1[e];
+}
+
+// ---- variant for SMALL scenes: per-pair rows + deferred GEMM --------------------------------------
+// With a handful of pair tiles per scene (8-agent scenes: one tile per wave) the in-register
+// accumulation above cannot amortise its fixed costs (weight staging, the 4-wave partial reduction, a
+// 25 KB partial per scene); there the backward leaves per-pair rows (f, dz3, h2, dh2 [64], h1, dh1
+// [32], feat [4] = 324 floats per pair) for the grouped weight-gradient GEMM of sw_wgrad.hip instead.
 struct PairRows {
   float *f, *dz3, *h2, *dh2, *h1, *dh1, *feat;
 };
@@ -261,7 +591,7 @@ __host__ __device__ inline PairRows pair_rows(float* base, long long P) {
 }
 #define SW_PAIR_ROW_FLOATS 324
 
-__global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
+__global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_rows_kernel(
     const float* __restrict__ obsv, int To, const float* __restrict__ h, const int* __restrict__ scene_off,
     const long long* __restrict__ pair_off, const float* __restrict__ emb_w, const float* __restrict__ att_w,
     const float* __restrict__ attn, const float* __restrict__ dS, float* __restrict__ dh,
@@ -563,26 +893,52 @@ extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, con
     return SW_EARG;
   if (Amax > SW_AMAX) return SW_ESHAPE;
   if (S == 0 || B == 0) return SW_OK;
+  const int a16 = Amax < 16 ? 16 : ((Amax + 15) & ~15);
+  const int lds = (soc_lds(a16).bwd_total + 64 * SW_SOC_W2LD + 64 * SW_SOC_W1LD + 4 * SW_SOC_SCR) * 4;
+  static_assert(64 * SW_SOC_W2LD + 64 * SW_SOC_W1LD + 4 * SW_SOC_SCR >= SW_SOC_PART, "epilogue staging area");
   static bool attr = false;
   if (!attr) {
-    if (int rc = set_lds((const void*)social_pool_bwd_kernel, soc_lds(SW_AMAX).bwd_total * 4)) return rc;
+    const int lds_max = (soc_lds(SW_AMAX).bwd_total + 64 * SW_SOC_W2LD + 64 * SW_SOC_W1LD + 4 * SW_SOC_SCR) * 4;
+    if (int rc = set_lds((const void*)social_pool_bwd_kernel, lds_max)) return rc;
     attr = true;
   }
-  const int a16 = Amax < 16 ? 16 : ((Amax + 15) & ~15);
-  // pair_ws: [B][64] dWh rows, then the per-pair rows
+  // pair_ws: [B][64] dWh rows, then the pair rows
   float* dwh_rows = pair_ws;
-  PairRows pr = pair_rows(pair_ws + (size_t)B * 64, P);
-  hipLaunchKernelGGL(social_pool_bwd_kernel, dim3(S), dim3(SW_THREADS), soc_lds(a16).bwd_total * 4, (hipStream_t)stream,
-                     obsv, To, h, scene_off, pair_off, emb_w, att_w, attn, dS, dh, dwh_rows, pr, a16);
-  SW_CHECK_LAUNCH("social_pool_bwd_kernel");
+  if (P < (long long)S * SW_SOC_FUSE_MIN_PAIRS) {   // small scenes: per-pair rows + deferred GEMM
+    static bool attr2 = false;
+    if (!attr2) {
+      if (int rc = set_lds((const void*)social_pool_bwd_rows_kernel, soc_lds(SW_AMAX).bwd_total * 4)) return rc;
+      attr2 = true;
+    }
+    PairRows pr = pair_rows(pair_ws + (size_t)B * 64, P);
+    hipLaunchKernelGGL(social_pool_bwd_rows_kernel, dim3(S), dim3(SW_THREADS), soc_lds(a16).bwd_total * 4,
+                       (hipStream_t)stream, obsv, To, h, scene_off, pair_off, emb_w, att_w, attn, dS, dh, dwh_rows, pr, a16);
+    SW_CHECK_LAUNCH("social_pool_bwd_rows_kernel");
+    WgBatch wr;
+    int rc_r = 0;
+    rc_r |= wg_add(wr, dwh_rows, 64, h, 64, B, 64, 64, d_att_w + swp::ATT_W, 64, d_att_w + swp::ATT_B, nullptr, 0);
+    if (P > 0) {
+      rc_r |= wg_add(wr, pr.dz3, 64, pr.h2, 64, (int)P, 64, 64, d_emb_w + swp::EMB_W2, 64, d_emb_w + swp::EMB_B2, nullptr, 0);
+      rc_r |= wg_add(wr, pr.dh2, 64, pr.h1, 32, (int)P, 64, 32, d_emb_w + swp::EMB_W1, 32, d_emb_w + swp::EMB_B1, nullptr, 0);
+      rc_r |= wg_add(wr, pr.dh1, 32, pr.feat, 4, (int)P, 32, 3, d_emb_w + swp::EMB_W0, 3, d_emb_w + swp::EMB_B0, nullptr, 0);
+    }
+    if (rc_r) return SW_ESHAPE;
+    return wg_launch(wr, wgrad_ws, (hipStream_t)stream);
+  }
+  float* f_rows = pair_ws + (size_t)B * 64;
+  const int G = S < 1024 ? S : 1024;   // workgroups: each walks scenes g, g+G, .. and leaves ONE weight-gradient partial
   WgBatch wb;
   int rc_add = 0;
   rc_add |= wg_add(wb, dwh_rows, 64, h, 64, B, 64, 64, d_att_w + swp::ATT_W, 64, d_att_w + swp::ATT_B, nullptr, 0);
-  if (P > 0) {
-    rc_add |= wg_add(wb, pr.dz3, 64, pr.h2, 64, (int)P, 64, 64, d_emb_w + swp::EMB_W2, 64, d_emb_w + swp::EMB_B2, nullptr, 0);
-    rc_add |= wg_add(wb, pr.dh2, 64, pr.h1, 32, (int)P, 64, 32, d_emb_w + swp::EMB_W1, 32, d_emb_w + swp::EMB_B1, nullptr, 0);
-    rc_add |= wg_add(wb, pr.dh1, 32, pr.feat, 4, (int)P, 32, 3, d_emb_w + swp::EMB_W0, 3, d_emb_w + swp::EMB_B0, nullptr, 0);
-  }
+  const int i3 = wb.np, i2 = wb.np + 1, i1 = wb.np + 2;
+  rc_add |= wg_add_pre(wb, 64, 64, d_emb_w + swp::EMB_W2, 64, d_emb_w + swp::EMB_B2, G);
+  rc_add |= wg_add_pre(wb, 64, 32, d_emb_w + swp::EMB_W1, 32, d_emb_w + swp::EMB_B1, G);
+  rc_add |= wg_add_pre(wb, 32, 3, d_emb_w + swp::EMB_W0, 3, d_emb_w + swp::EMB_B0, G);
   if (rc_add) return SW_ESHAPE;
-  return wg_launch(wb, wgrad_ws, (hipStream_t)stream);
+  if (wg_finalize(wb) > SW_WG_WS_FLOATS) return SW_ESHAPE;
+  SocPart part{wgrad_ws + wb.p[i3].ws_off, wgrad_ws + wb.p[i2].ws_off, wgrad_ws + wb.p[i1].ws_off};
+  hipLaunchKernelGGL(social_pool_bwd_kernel, dim3(G), dim3(SW_THREADS), lds, (hipStream_t)stream, obsv, To, h,
+                     scene_off, pair_off, S, emb_w, att_w, attn, dS, dh, dwh_rows, f_rows, part, a16);
+  SW_CHECK_LAUNCH("social_pool_bwd_kernel");
+  return wg_launch_finalized(wb, wgrad_ws, (hipStream_t)stream);
 }

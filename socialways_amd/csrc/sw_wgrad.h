@@ -18,6 +18,7 @@ struct WgProblem {      // one column block (<= 64 act columns, optional trailin
   size_t ws_off;
   int ldd, lda, ldw, R, N, K, ones, accumulate;
   int nbn, nbk, nsplit, job0, out0;
+  int pre;              // > 0: the `pre` slice partials are produced elsewhere (fused kernels); only reduced here
 };
 struct WgBatch {
   WgProblem p[SW_WG_MAXP];
@@ -29,3 +30,7 @@ int wg_add(WgBatch& b, const float* delta, int ldd, const float* act, int lda, i
 double wg_total_work(const WgBatch& b);
 size_t wg_finalize(WgBatch& b);
 int wg_launch(WgBatch& b, float* ws, hipStream_t stream);
+// A problem whose per-slice partials [nslices][N][K+1] (bias in column K) another kernel writes at ws + ws_off
+// (known after wg_finalize); wg_launch_finalized then only reduces it.
+int wg_add_pre(WgBatch& b, int N, int K, float* dW, int ldw, float* db, int nslices);
+int wg_launch_finalized(WgBatch& b, float* ws, hipStream_t stream);

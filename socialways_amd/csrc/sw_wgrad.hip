@@ -189,9 +189,20 @@ int wg_add(WgBatch& b, const float* delta, int ldd, const float* act, int lda, i
     P.R = R; P.N = N; P.K = (c1 - c0) - (has_ones ? 1 : 0); P.ones = has_ones ? 1 : 0;
     P.dW = dW + c0; P.ldw = ldw; P.db = has_ones ? db : nullptr; P.db2 = has_ones ? db2 : nullptr;
     P.accumulate = accumulate;
+    P.pre = 0;
     P.nbn = (N + 15) / 16;
     P.nbk = (c1 - c0 + 15) / 16;
   }
+  return SW_OK;
+}
+
+int wg_add_pre(WgBatch& b, int N, int K, float* dW, int ldw, float* db, int nslices) {
+  if (b.np >= SW_WG_MAXP || N < 1 || K < 1 || !db || nslices < 1) return SW_ESHAPE;
+  WgProblem& P = b.p[b.np++];
+  P.delta = nullptr; P.act = nullptr; P.ldd = P.lda = 0; P.R = 0;
+  P.N = N; P.K = K; P.ones = 1; P.dW = dW; P.ldw = ldw; P.db = db; P.db2 = nullptr; P.accumulate = 0;
+  P.nbn = (N + 15) / 16; P.nbk = (K + 1 + 15) / 16;
+  P.pre = nslices;
   return SW_OK;
 }
 
@@ -210,7 +221,8 @@ static double wg_cost(const WgProblem& P) {
 }
 double wg_total_work(const WgBatch& b) {
   double w = 0;
-  for (int i = 0; i < b.np; ++i) w += wg_cost(b.p[i]);
+  for (int i = 0; i < b.np; ++i)
+    if (!b.p[i].pre) w += wg_cost(b.p[i]);
   return w;
 }
 
@@ -227,14 +239,19 @@ size_t wg_finalize(WgBatch& b) {
   for (int i = 0; i < b.np; ++i) {
     WgProblem& P = b.p[i];
     const int NB = (P.N + 63) / 64;
-    int ns = (int)(target * wg_cost(P) / total / NB + 0.5);   // workgroups (4 row slices each) per output block
-    int cap = (P.R + 127) / 128;  // at least 32 rows per wave
-    if (ns > cap) ns = cap;
-    if (ns > SW_WG_MAXSPLIT) ns = SW_WG_MAXSPLIT;
-    if (ns < 1) ns = 1;
+    int ns;
+    if (P.pre) {
+      ns = P.pre;
+    } else {
+      ns = (int)(target * wg_cost(P) / total / NB + 0.5);   // workgroups (4 row slices each) per output block
+      int cap = (P.R + 127) / 128;  // at least 32 rows per wave
+      if (ns > cap) ns = cap;
+      if (ns > SW_WG_MAXSPLIT) ns = SW_WG_MAXSPLIT;
+      if (ns < 1) ns = 1;
+    }
     P.nsplit = ns;
     P.job0 = job;
-    job += ns * NB;
+    if (!P.pre) job += ns * NB;
     P.out0 = out;
     const int Kc = P.K + P.ones;
     out += P.N * Kc;
@@ -250,9 +267,15 @@ int wg_launch(WgBatch& b, float* ws, hipStream_t stream) {
   if (b.np == 0) return SW_OK;
   size_t need = wg_finalize(b);
   if (need > SW_WG_WS_FLOATS) return SW_ESHAPE;
-  if (b.total_jobs == 0 || b.total_out == 0) return SW_OK;
-  hipLaunchKernelGGL(wgrad_partial_kernel, dim3(b.total_jobs), dim3(SW_THREADS), 0, stream, b, ws);
-  SW_CHECK_LAUNCH("wgrad_partial_kernel");
+  return wg_launch_finalized(b, ws, stream);
+}
+
+int wg_launch_finalized(WgBatch& b, float* ws, hipStream_t stream) {
+  if (b.total_out == 0) return SW_OK;
+  if (b.total_jobs > 0) {
+    hipLaunchKernelGGL(wgrad_partial_kernel, dim3(b.total_jobs), dim3(SW_THREADS), 0, stream, b, ws);
+    SW_CHECK_LAUNCH("wgrad_partial_kernel");
+  }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((b.total_out * 16 + 255) / 256), dim3(256), 0, stream, b, ws);
   SW_CHECK_LAUNCH("wgrad_reduce_kernel");
   return SW_OK;
