@@ -34,12 +34,15 @@ class PackedAdam:
     optimizer state_dict (train.py:659,662 / 631,634): `slices` = [(offset, numel, shape)] in the
     reference's parameter order.  Padding floats have zero gradients and stay zero."""
 
-    CHUNK = 2048   # torch's multi-tensor Adam gives one workgroup per (tensor, 64K chunk): feed it many small views
+    # torch's multi-tensor Adam gives one workgroup per (tensor, 64K chunk): feed it many small views - but at
+    # most MAX_CHUNKS of them, beyond which the update is split into a second kernel launch (~5 us per graph node)
+    MIN_CHUNK, MAX_CHUNKS = 2048, 30
 
     def __init__(self, flat, gflat, slices, lr, betas=(0.9, 0.999), fused=True, capturable=False):
         self.slices = slices
         self.flat = flat
-        n, c = flat.numel(), self.CHUNK
+        n = flat.numel()
+        c = self.CHUNK = max(self.MIN_CHUNK, (-(-n // self.MAX_CHUNKS) + 255) // 256 * 256)
         self.ps = []
         for o in range(0, n, c):
             p = torch.nn.Parameter(flat[o:min(o + c, n)], requires_grad=True)   # shares storage with the packed buffer
