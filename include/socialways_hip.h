@@ -184,12 +184,15 @@ int sw_copy3_f32(float* d0, const float* s0, long long n0, float* d1, const floa
 
 /* ---- input staging of a hipGraph-replayed step, one kernel with fixed arguments.  `slot` = host-pinned
  *      (device-mapped) words the host rewrites before each replay: [0,1] device pointer of obsv (B,To,2),
- *      [2,3] device pointer of pred (B,Tp,2), [4] zeros_val, [5] ones_val, [6,7] reserved, [8..] z (B*32).
+ *      [2,3] device pointer of pred (B,Tp,2), [4] zeros_val, [5] ones_val, [6] / [7] number of D / G Adam
+ *      updates applied so far, [8..] z (B*32).
  *      Writes the static buffers of the graph: tracks, real future as (p,v) rows (train.py:135-137),
- *      label-noise scalars and z. ------------------------------------------------------------------- */
+ *      label-noise scalars, z and (steps_dst != NULL) the 1-based Adam step indices of this step's
+ *      n_d_updates discriminator updates followed by the generator update. -------------------------- */
 #define SW_STAGE_HEADER 8
 int sw_stage_step(const float* slot, int B, int To, int Tp, float* obsv_dst /*[B,To,2]*/, float* pred_dst /*[B,Tp,2]*/,
-                  float* pred4_dst /*[B,Tp,4]*/, float* targets_dst /*[2]*/, float* z_dst /*[B,32]*/, void* stream);
+                  float* pred4_dst /*[B,Tp,4]*/, float* targets_dst /*[2]*/, float* z_dst /*[B,32]*/,
+                  float* steps_dst /*[n_d_updates+1] or NULL*/, int n_d_updates, void* stream);
 
 /* ---- ADE/FDE partial sums of train.py:546-551:
  *      out[3] = { sum_{b,t} err / Tp, sum_b err[:, -1], sum_{b,t} err^2 },  err = |(p_hat - p) / ss|   */

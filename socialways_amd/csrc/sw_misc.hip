@@ -426,20 +426,24 @@ extern "C" int sw_copy3_f32(float* d0, const float* s0, long long n0, float* d1,
 // ---- one-kernel input staging of a hipGraph-replayed training step ---------------------------------
 // `slot` is a host-pinned (device-mapped) buffer the host fills before every replay, 4-byte words:
 //   [0,1] device pointer of obsv (B,To,2)   [2,3] device pointer of pred (B,Tp,2)
-//   [4] zeros_val  [5] ones_val (train.py:471-472)   [6,7] reserved   [8 ..] z (B*32, train.py:473)
+//   [4] zeros_val  [5] ones_val (train.py:471-472)   [6] D updates applied so far  [7] G updates applied so far
+//   [8 ..] z (B*32, train.py:473)
 // The kernel is a node of the captured graph with FIXED arguments; what changes per step travels through
 // the slot.  It copies the tracks into the graph's static buffers, forms the real future as (p, v) rows
 // (get_traj_4d, train.py:135-137) and pulls the scalars + z over PCIe.
 __global__ __launch_bounds__(256) void stage_step_kernel(const float* __restrict__ slot, int B, int To, int Tp,
                                                           float* __restrict__ obsv_dst, float* __restrict__ pred_dst,
                                                           float* __restrict__ pred4_dst, float* __restrict__ targets_dst,
-                                                          float* __restrict__ z_dst) {
+                                                          float* __restrict__ z_dst, float* __restrict__ steps_dst,
+                                                          int n_d_updates) {
   const unsigned long long* ptrs = reinterpret_cast<const unsigned long long*>(slot);
   const float* obsv = reinterpret_cast<const float*>(ptrs[0]);
   const float* pred = reinterpret_cast<const float*>(ptrs[1]);
   const int gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
   for (int i = gid; i < B * SW_Z / 4; i += gsz) st4(z_dst + 4 * (size_t)i, ld4(slot + 8 + 4 * (size_t)i));
   if (gid < 2) targets_dst[gid] = slot[4 + gid];
+  // 1-based Adam step indices of this training step's updates: D update u -> [u], the G update -> [n_d_updates]
+  if (steps_dst && gid <= n_d_updates) steps_dst[gid] = gid < n_d_updates ? slot[6] + 1.0f + (float)gid : slot[7] + 1.0f;
   for (int i = gid; i < B * To; i += gsz)
     *reinterpret_cast<float2*>(obsv_dst + 2 * (size_t)i) = *reinterpret_cast<const float2*>(obsv + 2 * (size_t)i);
   for (int k = gid; k < B * Tp; k += gsz) {
@@ -451,13 +455,16 @@ __global__ __launch_bounds__(256) void stage_step_kernel(const float* __restrict
   }
 }
 extern "C" int sw_stage_step(const float* slot, int B, int To, int Tp, float* obsv_dst, float* pred_dst,
-                             float* pred4_dst, float* targets_dst, float* z_dst, void* stream) {
-  if (!slot || !obsv_dst || !pred_dst || !pred4_dst || !targets_dst || !z_dst || B < 1 || To < 2 || Tp < 1) return SW_EARG;
+                             float* pred4_dst, float* targets_dst, float* z_dst, float* steps_dst, int n_d_updates,
+                             void* stream) {
+  if (!slot || !obsv_dst || !pred_dst || !pred4_dst || !targets_dst || !z_dst || B < 1 || To < 2 || Tp < 1 ||
+      n_d_updates < 0 || n_d_updates > 254)
+    return SW_EARG;
   int n = B * SW_Z / 4;
   int blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(stage_step_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slot, B, To, Tp, obsv_dst,
-                     pred_dst, pred4_dst, targets_dst, z_dst);
+                     pred_dst, pred4_dst, targets_dst, z_dst, steps_dst, n_d_updates);
   SW_CHECK_LAUNCH("stage_step_kernel");
   return SW_OK;
 }

@@ -29,77 +29,80 @@ from .model import Discriminator, Generator, predict_cv
 
 
 class PackedAdam:
-    """torch.optim.Adam over ONE packed parameter buffer - one fused multi-tensor kernel launch per
-    update instead of a 20-tensor list - that still reads and writes the reference's per-parameter
-    optimizer state_dict (train.py:659,662 / 631,634): `slices` = [(offset, numel, shape)] in the
-    reference's parameter order.  Padding floats have zero gradients and stay zero."""
+    """Adam (train.py:379-385: lr, betas (0.9, 0.999), eps 1e-8, no weight decay) over ONE packed parameter
+    buffer, executed by torch's own fused multi-tensor Adam kernel (`torch._fused_adam_`, the op behind
+    `torch.optim.Adam(fused=True)`) on chunk views of the buffer: one kernel launch per update.  The step
+    counter is a device scalar the CALLER may supply (`step(step_tensor)`): a hipGraph-replayed training step
+    gets its counters from the staging kernel instead of spending a graph node per update on incrementing
+    them.  Reads and writes the reference's per-parameter optimizer state_dict (train.py:659,662 / 631,634):
+    `slices` = [(offset, numel, shape)] in the reference's parameter order.  Padding floats have zero
+    gradients and stay zero."""
 
-    # torch's multi-tensor Adam gives one workgroup per (tensor, 64K chunk): feed it many small views - but at
+    # torch's multi-tensor kernel gives one workgroup per (tensor, 64K chunk): feed it many small views - but at
     # most MAX_CHUNKS of them, beyond which the update is split into a second kernel launch (~5 us per graph node)
     MIN_CHUNK, MAX_CHUNKS = 2048, 30
 
-    def __init__(self, flat, gflat, slices, lr, betas=(0.9, 0.999), fused=True, capturable=False):
+    def __init__(self, flat, gflat, slices, lr, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         self.slices = slices
         self.flat = flat
         n = flat.numel()
         c = self.CHUNK = max(self.MIN_CHUNK, (-(-n // self.MAX_CHUNKS) + 255) // 256 * 256)
-        self.ps = []
-        for o in range(0, n, c):
-            p = torch.nn.Parameter(flat[o:min(o + c, n)], requires_grad=True)   # shares storage with the packed buffer
-            p.grad = gflat[o:min(o + c, n)]
-            self.ps.append(p)
-        kw = dict(fused=True, capturable=capturable) if fused else {}
-        self.inner = opt.Adam(self.ps, lr=lr, betas=betas, **kw)
+        self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
+        cut = lambda t: [t[o:min(o + c, n)] for o in range(0, n, c)]
+        self.ps, self.gs, self.ms, self.vs = cut(flat), cut(gflat), cut(self.m), cut(self.v)
+        self.t = 0                                              # updates applied so far
+        self.step_t = torch.zeros((), device=flat.device)       # device copy of `t` for self-counted updates
+        self.group = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False, maximize=False,
+                          foreach=None, capturable=capturable, differentiable=False, fused=True)
 
-    def step(self):
-        self.inner.step()
+    @torch.no_grad()
+    def step(self, step_tensor=None):
+        """One update.  `step_tensor` = device scalar holding the 1-based index of this update (the caller
+        then also advances `self.t`); without it the optimizer counts itself."""
+        if step_tensor is None:
+            self.t += 1
+            self.step_t.fill_(float(self.t))      # eager only: a captured update always gets its index from the caller
+            step_tensor = self.step_t
+        g = self.group
+        torch._fused_adam_(self.ps, self.gs, self.ms, self.vs, [], [step_tensor] * len(self.ps), amsgrad=False,
+                           lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], weight_decay=g["weight_decay"],
+                           eps=g["eps"], maximize=False, grad_scale=None, found_inf=None)
 
     def zero_grad(self, set_to_none=False):
-        for p in self.ps:
-            p.grad.zero_()
+        for t in self.gs:
+            t.zero_()
 
     @property
     def param_groups(self):
-        return self.inner.param_groups
-
-    def _flat_state(self, key):
-        return torch.cat([self.inner.state[p][key].reshape(-1) for p in self.ps])
+        return [self.group]
 
     def state_dict(self):
-        g = {k: v for k, v in self.inner.param_groups[0].items() if k != "params"}
+        g = dict(self.group)
         g["params"] = list(range(len(self.slices)))
         state = {}
-        if self.inner.state.get(self.ps[0]):
-            m, v = self._flat_state("exp_avg"), self._flat_state("exp_avg_sq")
-            step = self.inner.state[self.ps[0]]["step"]
+        if self.t > 0:
             for i, (off, n, shape) in enumerate(self.slices):
-                state[i] = {"step": step.detach().clone(), "exp_avg": m[off:off + n].view(shape).clone(),
-                            "exp_avg_sq": v[off:off + n].view(shape).clone()}
+                state[i] = {"step": torch.tensor(float(self.t)), "exp_avg": self.m[off:off + n].view(shape).clone(),
+                            "exp_avg_sq": self.v[off:off + n].view(shape).clone()}
         return {"state": state, "param_groups": [g]}
 
     def load_state_dict(self, sd):
         grp = sd["param_groups"][0]
-        for k in ("lr", "betas", "eps", "weight_decay", "amsgrad", "maximize"):
+        for k in ("lr", "betas", "eps", "weight_decay"):
             if k in grp:
-                self.inner.param_groups[0][k] = grp[k]
+                self.group[k] = tuple(grp[k]) if k == "betas" else grp[k]
         state = sd.get("state", {})
-        if not state:
-            self.inner.state.clear()
-            return
-        dev = self.flat.device
-        m, v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
-        step = None
+        self.m.zero_()
+        self.v.zero_()
+        self.t = 0
         for i, (off, n, shape) in enumerate(self.slices):
+            if not state:
+                break
             e = state[i] if i in state else state[str(i)]
-            m[off:off + n] = e["exp_avg"].to(dev).reshape(-1)
-            v[off:off + n] = e["exp_avg_sq"].to(dev).reshape(-1)
-            step = e["step"]
-        capt = bool(self.inner.param_groups[0].get("capturable", False))
-        c = self.CHUNK
-        for k, p in enumerate(self.ps):
-            self.inner.state[p] = {"step": torch.as_tensor(float(step), dtype=torch.float32, device=dev if capt else "cpu"),
-                                   "exp_avg": m[k * c:k * c + p.numel()].clone(),
-                                   "exp_avg_sq": v[k * c:k * c + p.numel()].clone()}
+            self.m[off:off + n] = e["exp_avg"].to(self.flat.device).reshape(-1)
+            self.v[off:off + n] = e["exp_avg_sq"].to(self.flat.device).reshape(-1)
+            self.t = int(float(e["step"]))
+        self.step_t.fill_(float(self.t))
 
 
 class SocialWaysTrainer:
@@ -128,15 +131,14 @@ class SocialWaysTrainer:
         self._force_dist = os.environ.get("SW_FORCE_DIST", "") == "1"   # 1-rank group still runs the collectives (tests)
         packed = fused_adam and self.device.type == "cuda"
         if packed:
-            self.predictor_optimizer = PackedAdam(self.G._flat_all, self.G._gflat_all, self.G.packed_slices(), lr_g,
-                                                  capturable=self.use_graph)
+            self.predictor_optimizer = PackedAdam(self.G._flat_all, self.G._gflat_all, self.G.packed_slices(), lr_g)
         else:       # per-parameter torch Adam (CPU tests, literal autograd formulation)
             self.predictor_optimizer = opt.Adam(self.G.predictor_params(), lr=lr_g, betas=(0.9, 0.999))
         self.D = Discriminator(n_next, hidden_size, n_latent_codes, device=self.device)
         if packed:
             self.D_optimizer = PackedAdam(self.D._flat, self.D._gflat,
                                           [(off, k, tuple(p.shape)) for (off, k), p in
-                                           zip(self.D._slices, self.D.parameters())], lr_d, capturable=self.use_graph)
+                                           zip(self.D._slices, self.D.parameters())], lr_d)
         else:
             self.D_optimizer = opt.Adam(self.D.parameters(), lr=lr_d, betas=(0.9, 0.999))
         self.pg = process_group
@@ -207,6 +209,7 @@ class SocialWaysTrainer:
                 n=0, graph=None, flip=0, scenes=scenes, obsv=torch.empty(B, To, 2, device=dev),
                 pred=torch.empty(B, Tp, 2, device=dev), pred4=torch.empty(B, Tp, 4, device=dev),
                 targets=torch.empty(4, device=dev), noise=torch.empty(B, self.noise_len, device=dev),
+                steps=torch.zeros(self.n_unrolling_steps + 2, device=dev),   # Adam step indices of the U+1 D updates, the G update
                 out=torch.zeros(self.n_unrolling_steps + 3, (B + 15) // 16, 3, device=dev),
                 slots=[(torch.zeros(HDR + B * self.noise_len, dtype=torch.float32).pin_memory(), torch.cuda.Event())
                        for _ in range(2)], keep=[None, None])
@@ -222,12 +225,19 @@ class SocialWaysTrainer:
         hn = host.numpy()
         hn[:4].view(np.uint64)[:] = (obsv.data_ptr(), pred.data_ptr())
         hn[4], hn[5] = float(zeros_val), float(ones_val)
+        packed = isinstance(self.D_optimizer, PackedAdam)
+        if packed:            # updates applied so far: the staging kernel turns them into this step's Adam step indices
+            hn[6], hn[7] = float(self.D_optimizer.t), float(self.predictor_optimizer.t)
+            self.D_optimizer.t += self.n_unrolling_steps + 1
+            self.predictor_optimizer.t += 1
         np.copyto(hn[HDR:].reshape(B, self.noise_len), (noise.cpu() if noise.is_cuda else noise).numpy())   # plain memcpy
 
         def stage(kk):
             L.call("sw_stage_step", st["slots"][kk][0].data_ptr(), B, To, Tp, L.ptr(st["obsv"]), L.ptr(st["pred"]),
-                   L.ptr(st["pred4"]), L.ptr(st["targets"]), L.ptr(st["noise"]), L.stream())
-        args = (st["obsv"], st["pred"], st["pred4"], scenes, st["targets"], st["noise"], ss, Bg, st["out"])
+                   L.ptr(st["pred4"]), L.ptr(st["targets"]), L.ptr(st["noise"]), L.ptr(st["steps"]), self.n_unrolling_steps + 1,
+                   L.stream())
+        args = (st["obsv"], st["pred"], st["pred4"], scenes, st["targets"], st["noise"], ss, Bg, st["out"],
+                st["steps"] if packed else None)
         if st["graph"] is not None:
             st["flip"] = k
             for g, buf in st["graph"][k]:
@@ -272,17 +282,18 @@ class SocialWaysTrainer:
         done.record()
         return st["out"]
 
-    def _step_impl(self, obsv, pred, pred4, scenes, targets, noise, ss, Bg, out):
+    def _step_impl(self, obsv, pred, pred4, scenes, targets, noise, ss, Bg, out, steps=None):
         """Eager step: run the segments, all-reducing the packed gradient buffer each one hands back."""
-        for buf in self._step_gen(obsv, pred, pred4, scenes, targets, noise, ss, Bg, out):
+        for buf in self._step_gen(obsv, pred, pred4, scenes, targets, noise, ss, Bg, out, steps):
             self._allreduce(buf)
         return out
 
-    def _step_gen(self, obsv, pred, pred4, scenes, targets, noise, ss, Bg, out, pre=None):
+    def _step_gen(self, obsv, pred, pred4, scenes, targets, noise, ss, Bg, out, steps=None, pre=None):
         """Device-only body of the step (no host syncs, no host-dependent values: capturable) as a
         generator: it yields the packed gradient buffer at each of the 3 points where data-parallel
         ranks must all-reduce before the optimizer step (D, D, G).  `out` (U+3, tiles, 3) receives the
-        per-tile loss / ADE partial sums; `pre` = the input staging of a captured step."""
+        per-tile loss / ADE partial sums; `steps` (U+2 device scalars) = the Adam step indices of this
+        step's updates when the staging kernel provides them; `pre` = the input staging of a captured step."""
         G, D = self.G, self.D
         B, Tp = obsv.shape[0], self.n_next
         dev = self.device
@@ -312,7 +323,7 @@ class SocialWaysTrainer:
             ops.disc_backward_gan(D._flat, dctx, labels, codes, targets, (0, 1), noise, g_label, g_code, d_gflat, (), ws=ws,
                                   loss_part=out[u])
             yield d_gflat
-            self.D_optimizer.step()
+            self.D_optimizer.step() if steps is None else self.D_optimizer.step(steps[u])
             if u == 0 and self.n_unrolling_steps > 0:
                 backup = ws.get("d_backup", D._flat.numel())
                 backup[:D._flat.numel()].copy_(D._flat)
@@ -334,7 +345,7 @@ class SocialWaysTrainer:
         ops.gen_backward(enc._flat, emb._flat, att._flat, dec._flat, gctx, dpred, enc._gflat, emb._gflat, att._gflat,
                          dec._gflat, ws=ws, side=None)   # (side-stream wgrad starves the BPTT chain of CUs: measured slower)
         yield G._gflat_all
-        self.predictor_optimizer.step()
+        self.predictor_optimizer.step() if steps is None else self.predictor_optimizer.step(steps[U + 1])
         self.last_pred_hat = pred_hat
 
     # ------------------------------------------------------------------------------------------
