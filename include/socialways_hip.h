@@ -80,10 +80,18 @@ int sw_enc_lstm_bwd(const float* enc_w, const float* act, const float* c0, const
 
 /* ---- SocialFeatures + EmbedSocialFeatures + AttentionPooling (train.py:153-241), fused,
  *      block-diagonal: only in-scene pairs are formed (identical math) -------- */
+/* Scenes of up to SW_AMAX = 64 agents run one workgroup per scene (scores in LDS).  Larger scenes are
+ * listed by the caller as blocks of 16 query agents, big_blocks = int32 [NB][8] records
+ *   { scene, i0, partial row base of the block, partial row base of its scene, blocks in the scene,
+ *     block index in the scene, 0, 0 }
+ * (partial rows: 128 floats each, sum over big scenes of blocks*agents rows - used by the backward), and
+ * run as row-block kernels with an online softmax; wh_ws [B,64] receives W h + b, ml [B,2] the softmax
+ * statistics (running max, normaliser) the backward needs.  Amax = largest scene NOT in big_blocks.     */
 int sw_social_pool_fwd(const float* obsv /*[B,To,2]*/, int To, const float* h /*[B,64]*/,
-                       const int* scene_off, int S, int B, int Amax /*largest scene, <= 64*/,
+                       const int* scene_off, int S, int B, int Amax /*<= 64*/,
                        const float* emb_w, const float* att_w, float* S_out /*[B,64]*/,
-                       float* attn /*[B,64] softmax weights (row i, column j_local) or NULL*/, void* stream);
+                       float* attn /*[B,64] softmax weights (row i, column j_local) or NULL*/,
+                       const int* big_blocks /*or NULL*/, int NB, float* wh_ws, float* ml /*or NULL*/, void* stream);
 /* dense SocialFeatures (train.py:229-241) for the reference's module-level API on small batches */
 int sw_social_features(const float* x4_last /*[B,4]*/, int B, float* feat /*[B,B,3]*/, void* stream);
 /* EmbedSocialFeatures.forward on R rows of 3 features -> [R,64]; AttentionPooling.forward on a
@@ -99,7 +107,10 @@ int sw_social_pool_bwd(const float* obsv, int To, const float* h, const int* sce
                        const long long* pair_off, int S, int B, int Amax, long long P,
                        const float* emb_w, const float* att_w, const float* attn, const float* dS,
                        float* dh, float* d_emb_w, float* d_att_w, float* pair_ws, float* wgrad_ws,
-                       void* stream);
+                       /* scenes above 64 agents (see sw_social_pool_fwd): the forward's big_blocks, wh_ws, ml, its
+                        * output S_pool, and big_part_ws = 128 floats per partial row (blocks*agents rows per scene) */
+                       const int* big_blocks /*or NULL*/, int NB, const float* wh_ws, const float* ml,
+                       const float* S_pool, float* big_part_ws, void* stream);
 
 /* ---- predict() decode loop (train.py:415-432): DecoderFC + position integration + the
  *      re-fed EncoderLstm step, Tp times, one persistent kernel -------------------------------- */

@@ -29,12 +29,12 @@ PROTOTYPES = {
     "sw_traj_4d": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "sw_enc_lstm_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sw_enc_lstm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "sw_social_pool_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "sw_social_pool_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "sw_social_features": (_i, [_vp, _i, _vp, _vp]),
     "sw_embed_features": (_i, [_vp, _ll, _vp, _vp, _vp]),
     "sw_attention_pool_dense": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "sw_social_pool_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                _vp, _vp, _vp]),
+                                _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "sw_dec_rollout_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
     "sw_dec_rollout_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sw_gen_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),

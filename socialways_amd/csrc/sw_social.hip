@@ -204,7 +204,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_fwd_kernel(
   const float* w0b = smem + Ls.w0b;
   const float* b12 = smem + Ls.b12;
   const int s0 = scene_off[blockIdx.x], n = scene_off[blockIdx.x + 1] - s0;
-  if (n <= 0) return;
+  if (n <= 0 || n > SW_AMAX) return;   // scenes above SW_AMAX agents go through the row-block kernels below
   if (n == 1) {  // train.py:165: single-agent scenes keep S = 0
     if (threadIdx.x < 16) st4(S_out + (size_t)s0 * 64 + 4 * threadIdx.x, f32x4{0.f, 0.f, 0.f, 0.f});
     if (attn && threadIdx.x == 0) attn[(size_t)s0 * SW_AMAX] = 0.f;
@@ -271,6 +271,214 @@ __device__ __forceinline__ f32x4 tr_get(const float* tile, int ln, int lg) { ret
 // fence would also drain the wave's outstanding GLOBAL stores - the f rows - at every transposition.)
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("" ::: "memory"); }
 
+// In-register gradients of the pair MLP (C layout: [out unit 4lg+r][in unit ln] per 16x16 tile) + lane partials
+struct PairGrad {
+  f32x4 acc3[4][4], acc2[4][2];   // fc.4.weight (64x64), fc.2.weight (64x32)
+  float b3s[4], b2s[4], b1s[2];   // bias sums: unit 16t + ln, partial over (lg, r)
+  float w0s[2][3];                // fc.0.weight[unit 16jt + ln][c], partial over (lg, r)
+};
+__device__ __forceinline__ void pair_grad_zero(PairGrad& G) {
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) G.acc3[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    G.acc2[a][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    G.acc2[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    G.b3s[a] = 0.f;
+    G.b2s[a] = 0.f;
+  }
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    G.b1s[jt] = 0.f;
+    G.w0s[jt][0] = G.w0s[jt][1] = G.w0s[jt][2] = 0.f;
+  }
+}
+
+// One 16-pair tile: given the recomputed activations (h1, h2 post-ReLU) and dz3 = d(loss)/d(f_ij) (C layout,
+// exact zeros for invalid pairs), back-propagate through fc.4 / fc.2 and add this tile's contribution to all
+// weight gradients.  w2s / w1s: row-major LDS images of fc.4.weight [64][68] / fc.2.weight [64][36];
+// scr: this wave's transposition scratch.
+__device__ __forceinline__ void pair_tile_bwd(PairGrad& G, float* scr, const float* w2s, const float* w1s,
+                                              const f32x4 h1[2], const f32x4 h2[4], const f32x4 dz3[4], float f0,
+                                              float f1, float f2, int ln, int lg) {
+  // dW3 += dz3 h2^T (k = pairs): both operands through the transposition scratch
+  f32x4 ta[4], tb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) tr_put(scr + t * 16 * SW_SOC_TLD, dz3[t], ln, lg);
+  wave_lds_fence();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) ta[t] = tr_get(scr + t * 16 * SW_SOC_TLD, ln, lg);
+  wave_lds_fence();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) tr_put(scr + t * 16 * SW_SOC_TLD, h2[t], ln, lg);
+  wave_lds_fence();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) tb[t] = tr_get(scr + t * 16 * SW_SOC_TLD, ln, lg);
+  wave_lds_fence();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) G.acc3[mo][kt] = SW_MFMA(ta[mo][r], tb[kt][r], G.acc3[mo][kt]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) G.b3s[t] += (ta[t][0] + ta[t][1]) + (ta[t][2] + ta[t][3]);
+  // dh2 = (W2^T dz3) * relu'(h2): A operand = W2[16mo+4lg+r][16mt+ln] read transposed from the LDS image
+  f32x4 dh2[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) dh2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int mo = 0; mo < 4; ++mo) {
+    float wt[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) wt[r][mt] = w2s[(16 * mo + 4 * lg + r) * SW_SOC_W2LD + 16 * mt + ln];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) dh2[mt] = SW_MFMA(wt[r][mt], dz3[mo][r], dh2[mt]);
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dh2[mt][r] = h2[mt][r] > 0.f ? dh2[mt][r] : 0.f;
+  }
+  // dW2 += dh2 h1^T
+#pragma unroll
+  for (int t = 0; t < 4; ++t) tr_put(scr + t * 16 * SW_SOC_TLD, dh2[t], ln, lg);
+  wave_lds_fence();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) ta[t] = tr_get(scr + t * 16 * SW_SOC_TLD, ln, lg);
+  wave_lds_fence();
+  tr_put(scr, h1[0], ln, lg);
+  tr_put(scr + 16 * SW_SOC_TLD, h1[1], ln, lg);
+  wave_lds_fence();
+  tb[0] = tr_get(scr, ln, lg);
+  tb[1] = tr_get(scr + 16 * SW_SOC_TLD, ln, lg);
+  wave_lds_fence();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      G.acc2[mt][0] = SW_MFMA(ta[mt][r], tb[0][r], G.acc2[mt][0]);
+      G.acc2[mt][1] = SW_MFMA(ta[mt][r], tb[1][r], G.acc2[mt][1]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) G.b2s[t] += (ta[t][0] + ta[t][1]) + (ta[t][2] + ta[t][3]);
+  // dh1 = (W1^T dh2) * relu'(h1)
+  f32x4 dh1[2];
+  dh1[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  dh1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    float wt[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      wt[r][0] = w1s[(16 * mt + 4 * lg + r) * SW_SOC_W1LD + ln];
+      wt[r][1] = w1s[(16 * mt + 4 * lg + r) * SW_SOC_W1LD + 16 + ln];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      dh1[0] = SW_MFMA(wt[r][0], dh2[mt][r], dh1[0]);
+      dh1[1] = SW_MFMA(wt[r][1], dh2[mt][r], dh1[1]);
+    }
+  }
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dh1[jt][r] = h1[jt][r] > 0.f ? dh1[jt][r] : 0.f;
+  }
+  // dW1 += dh1 feat^T, db1 += dh1 (VALU): transposed dh1 against the features of pairs 4lg + r
+  tr_put(scr, dh1[0], ln, lg);
+  tr_put(scr + 16 * SW_SOC_TLD, dh1[1], ln, lg);
+  if (lg == 0) st4(scr + 2 * 16 * SW_SOC_TLD + 4 * ln, f32x4{f0, f1, f2, 0.f});   // feat[pair ln][0..2]
+  wave_lds_fence();
+  ta[0] = tr_get(scr, ln, lg);
+  ta[1] = tr_get(scr + 16 * SW_SOC_TLD, ln, lg);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const f32x4 ft = ld4(scr + 2 * 16 * SW_SOC_TLD + 4 * (4 * lg + r));
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      G.w0s[jt][0] = fmaf(ta[jt][r], ft[0], G.w0s[jt][0]);
+      G.w0s[jt][1] = fmaf(ta[jt][r], ft[1], G.w0s[jt][1]);
+      G.w0s[jt][2] = fmaf(ta[jt][r], ft[2], G.w0s[jt][2]);
+      G.b1s[jt] += ta[jt][r];
+    }
+  }
+  wave_lds_fence();
+}
+
+// Workgroup partial = sum of its 4 waves' PairGrad in a fixed order through LDS (`red`: SW_SOC_PART floats,
+// everything else in LDS is dead), then to the wgrad workspace slices [64][65] | [64][33] | [32][4].
+__device__ __forceinline__ void pair_grad_store(PairGrad& G, float* red, const SocPart& part, int slice, int wave, int ln,
+                                                int lg) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {   // finish the lane-partial sums over the 4 lane groups (fixed shuffle tree)
+    G.b3s[t] += __shfl_xor(G.b3s[t], 16); G.b3s[t] += __shfl_xor(G.b3s[t], 32);
+    G.b2s[t] += __shfl_xor(G.b2s[t], 16); G.b2s[t] += __shfl_xor(G.b2s[t], 32);
+  }
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    G.b1s[jt] += __shfl_xor(G.b1s[jt], 16); G.b1s[jt] += __shfl_xor(G.b1s[jt], 32);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { G.w0s[jt][c] += __shfl_xor(G.w0s[jt][c], 16); G.w0s[jt][c] += __shfl_xor(G.w0s[jt][c], 32); }
+  }
+  __syncthreads();
+  float* r3 = red, *r2 = red + 64 * 65, *r1 = r2 + 64 * 33;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int mo = 0; mo < 4; ++mo) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nrow = 16 * mo + 4 * lg + r;
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) {
+            float* q = r3 + nrow * 65 + 16 * kt + ln;
+            *q = (w == 0 ? 0.f : *q) + G.acc3[mo][kt][r];
+          }
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) {
+            float* q = r2 + nrow * 33 + 16 * jt + ln;
+            *q = (w == 0 ? 0.f : *q) + G.acc2[mo][jt][r];
+          }
+        }
+      }
+      if (lg == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float* q3 = r3 + (16 * t + ln) * 65 + 64;
+          float* q2 = r2 + (16 * t + ln) * 33 + 32;
+          *q3 = (w == 0 ? 0.f : *q3) + G.b3s[t];
+          *q2 = (w == 0 ? 0.f : *q2) + G.b2s[t];
+        }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          float* q = r1 + (16 * jt + ln) * 4;
+          q[0] = (w == 0 ? 0.f : q[0]) + G.w0s[jt][0];
+          q[1] = (w == 0 ? 0.f : q[1]) + G.w0s[jt][1];
+          q[2] = (w == 0 ? 0.f : q[2]) + G.w0s[jt][2];
+          q[3] = (w == 0 ? 0.f : q[3]) + G.b1s[jt];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* o3 = part.p3 + (size_t)slice * 64 * 65;
+  float* o2 = part.p2 + (size_t)slice * 64 * 33;
+  float* o1 = part.p1 + (size_t)slice * 32 * 4;
+  for (int e = threadIdx.x; e < 64 * 65; e += blockDim.x) o3[e] = r3[e];
+  for (int e = threadIdx.x; e < 64 * 33; e += blockDim.x) o2[e] = r2[e];
+  for (int e = threadIdx.x; e < 32 * 4; e += blockDim.x) o1[e] = r1[e];
+}
+
 __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
     const float* __restrict__ obsv, int To, const float* __restrict__ h, const int* __restrict__ scene_off,
     const long long* __restrict__ pair_off, int S, const float* __restrict__ emb_w, const float* __restrict__ att_w,
@@ -302,22 +510,12 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
   }
   PairW W;
   load_pair_w(W, emb_w, ln, lg);
-  // accumulators of this wave (C layout: [out unit 4lg+r][in unit ln] per tile)
-  f32x4 acc3[4][4], acc2[4][2];
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc3[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc2[a][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc2[a][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  float b3s[4] = {0.f, 0.f, 0.f, 0.f}, b2s[4] = {0.f, 0.f, 0.f, 0.f};   // bias sums: unit 16t + ln, partial over (lg, r)
-  float b1s[2] = {0.f, 0.f};
-  float w0s[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};                 // dW1[unit 16jt + ln][c], partial over (lg, r)
+  PairGrad G;
+  pair_grad_zero(G);
 
   for (int sc = blockIdx.x; sc < S; sc += gridDim.x) {
     const int s0 = scene_off[sc], n = scene_off[sc + 1] - s0;
-    if (n <= 0) continue;
+    if (n <= 0 || n > SW_AMAX) continue;
     if (n == 1) {  // S = 0 constant: no gradient anywhere; dWh row is zero
       if (threadIdx.x < 16) st4(dwh_rows + (size_t)s0 * 64 + 4 * threadIdx.x, f32x4{0.f, 0.f, 0.f, 0.f});
       continue;
@@ -374,118 +572,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) dz3[mo][r] = dsv * w[r];
       }
-      // dW3 += dz3 h2^T (k = pairs): both operands through the transposition scratch
-      f32x4 ta[4], tb[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) tr_put(scr + t * 16 * SW_SOC_TLD, dz3[t], ln, lg);
-      wave_lds_fence();
-#pragma unroll
-      for (int t = 0; t < 4; ++t) ta[t] = tr_get(scr + t * 16 * SW_SOC_TLD, ln, lg);
-      wave_lds_fence();
-#pragma unroll
-      for (int t = 0; t < 4; ++t) tr_put(scr + t * 16 * SW_SOC_TLD, h2[t], ln, lg);
-      wave_lds_fence();
-#pragma unroll
-      for (int t = 0; t < 4; ++t) tb[t] = tr_get(scr + t * 16 * SW_SOC_TLD, ln, lg);
-      wave_lds_fence();
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int mo = 0; mo < 4; ++mo) {
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt) acc3[mo][kt] = SW_MFMA(ta[mo][r], tb[kt][r], acc3[mo][kt]);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) b3s[t] += (ta[t][0] + ta[t][1]) + (ta[t][2] + ta[t][3]);
-      // dh2 = (W2^T dz3) * relu'(h2): A operand = W2[16mo+4lg+r][16mt+ln] read transposed from the LDS image
-      f32x4 dh2[4];
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) dh2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int mo = 0; mo < 4; ++mo) {
-        float wt[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) wt[r][mt] = w2s[(16 * mo + 4 * lg + r) * SW_SOC_W2LD + 16 * mt + ln];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) dh2[mt] = SW_MFMA(wt[r][mt], dz3[mo][r], dh2[mt]);
-        }
-      }
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dh2[mt][r] = h2[mt][r] > 0.f ? dh2[mt][r] : 0.f;
-      }
-      // dW2 += dh2 h1^T
-#pragma unroll
-      for (int t = 0; t < 4; ++t) tr_put(scr + t * 16 * SW_SOC_TLD, dh2[t], ln, lg);
-      wave_lds_fence();
-#pragma unroll
-      for (int t = 0; t < 4; ++t) ta[t] = tr_get(scr + t * 16 * SW_SOC_TLD, ln, lg);
-      wave_lds_fence();
-      tr_put(scr, h1[0], ln, lg);
-      tr_put(scr + 16 * SW_SOC_TLD, h1[1], ln, lg);
-      wave_lds_fence();
-      tb[0] = tr_get(scr, ln, lg);
-      tb[1] = tr_get(scr + 16 * SW_SOC_TLD, ln, lg);
-      wave_lds_fence();
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          acc2[mt][0] = SW_MFMA(ta[mt][r], tb[0][r], acc2[mt][0]);
-          acc2[mt][1] = SW_MFMA(ta[mt][r], tb[1][r], acc2[mt][1]);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) b2s[t] += (ta[t][0] + ta[t][1]) + (ta[t][2] + ta[t][3]);
-      // dh1 = (W1^T dh2) * relu'(h1)
-      f32x4 dh1[2];
-      dh1[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dh1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        float wt[4][2];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          wt[r][0] = w1s[(16 * mt + 4 * lg + r) * SW_SOC_W1LD + ln];
-          wt[r][1] = w1s[(16 * mt + 4 * lg + r) * SW_SOC_W1LD + 16 + ln];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          dh1[0] = SW_MFMA(wt[r][0], dh2[mt][r], dh1[0]);
-          dh1[1] = SW_MFMA(wt[r][1], dh2[mt][r], dh1[1]);
-        }
-      }
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dh1[jt][r] = h1[jt][r] > 0.f ? dh1[jt][r] : 0.f;
-      }
-      // dW1 += dh1 feat^T, db1 += dh1 (VALU): transposed dh1 against the features of pairs 4lg + r
-      tr_put(scr, dh1[0], ln, lg);
-      tr_put(scr + 16 * SW_SOC_TLD, dh1[1], ln, lg);
-      if (lg == 0) st4(scr + 2 * 16 * SW_SOC_TLD + 4 * ln, f32x4{f0, f1, f2, 0.f});   // feat[pair ln][0..2]
-      wave_lds_fence();
-      ta[0] = tr_get(scr, ln, lg);
-      ta[1] = tr_get(scr + 16 * SW_SOC_TLD, ln, lg);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const f32x4 ft = ld4(scr + 2 * 16 * SW_SOC_TLD + 4 * (4 * lg + r));
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-          w0s[jt][0] = fmaf(ta[jt][r], ft[0], w0s[jt][0]);
-          w0s[jt][1] = fmaf(ta[jt][r], ft[1], w0s[jt][1]);
-          w0s[jt][2] = fmaf(ta[jt][r], ft[2], w0s[jt][2]);
-          b1s[jt] += ta[jt][r];
-        }
-      }
-      wave_lds_fence();
+      pair_tile_bwd(G, scr, w2s, w1s, h1, h2, dz3, f0, f1, f2, ln, lg);
     }
     __syncthreads();  // f rows of this scene are visible to the whole workgroup (same CU)
     // dWh_j = sum_i dsigma_ij f_ij
@@ -508,66 +595,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
     }
   }
   // ---- epilogue: this workgroup's partial = sum of its 4 waves, in a fixed order through LDS ------
-  // finish the lane-partial sums over the 4 lane groups (fixed shuffle tree)
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    b3s[t] += __shfl_xor(b3s[t], 16); b3s[t] += __shfl_xor(b3s[t], 32);
-    b2s[t] += __shfl_xor(b2s[t], 16); b2s[t] += __shfl_xor(b2s[t], 32);
-  }
-#pragma unroll
-  for (int jt = 0; jt < 2; ++jt) {
-    b1s[jt] += __shfl_xor(b1s[jt], 16); b1s[jt] += __shfl_xor(b1s[jt], 32);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { w0s[jt][c] += __shfl_xor(w0s[jt][c], 16); w0s[jt][c] += __shfl_xor(w0s[jt][c], 32); }
-  }
-  __syncthreads();
-  float* red = w2s;   // SW_SOC_PART floats (weight images + scratch are dead): [64][65] | [64][33] | [32][4]
-  float* r3 = red, *r2 = red + 64 * 65, *r1 = r2 + 64 * 33;
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int mo = 0; mo < 4; ++mo) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int nrow = 16 * mo + 4 * lg + r;
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt) {
-            float* q = r3 + nrow * 65 + 16 * kt + ln;
-            *q = (w == 0 ? 0.f : *q) + acc3[mo][kt][r];
-          }
-#pragma unroll
-          for (int jt = 0; jt < 2; ++jt) {
-            float* q = r2 + nrow * 33 + 16 * jt + ln;
-            *q = (w == 0 ? 0.f : *q) + acc2[mo][jt][r];
-          }
-        }
-      }
-      if (lg == 0) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          float* q3 = r3 + (16 * t + ln) * 65 + 64;
-          float* q2 = r2 + (16 * t + ln) * 33 + 32;
-          *q3 = (w == 0 ? 0.f : *q3) + b3s[t];
-          *q2 = (w == 0 ? 0.f : *q2) + b2s[t];
-        }
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-          float* q = r1 + (16 * jt + ln) * 4;
-          q[0] = (w == 0 ? 0.f : q[0]) + w0s[jt][0];
-          q[1] = (w == 0 ? 0.f : q[1]) + w0s[jt][1];
-          q[2] = (w == 0 ? 0.f : q[2]) + w0s[jt][2];
-          q[3] = (w == 0 ? 0.f : q[3]) + b1s[jt];
-        }
-      }
-    }
-    __syncthreads();
-  }
-  float* o3 = part.p3 + (size_t)blockIdx.x * 64 * 65;
-  float* o2 = part.p2 + (size_t)blockIdx.x * 64 * 33;
-  float* o1 = part.p1 + (size_t)blockIdx.x * 32 * 4;
-  for (int e = threadIdx.x; e < 64 * 65; e += blockDim.x) o3[e] = r3[e];
-  for (int e = threadIdx.x; e < 64 * 33; e += blockDim.x) o2[e] = r2[e];
-  for (int e = threadIdx.x; e < 32 * 4; e += blockDim.x) o1[e] = r1[e];
+  pair_grad_store(G, w2s, part, blockIdx.x, wave, ln, lg);
 }
 
 // ---- variant for SMALL scenes: per-pair rows + deferred GEMM --------------------------------------
@@ -609,7 +637,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_rows_kernel(
   float* dsg = smem + Ls.dsg;
   float* dwh = smem + Ls.dwh;
   const int s0 = scene_off[blockIdx.x], n = scene_off[blockIdx.x + 1] - s0;
-  if (n <= 0) return;
+  if (n <= 0 || n > SW_AMAX) return;
   if (n == 1) {  // S = 0 constant: no gradient anywhere; dWh row is zero
     if (threadIdx.x < 16) st4(dwh_rows + (size_t)s0 * 64 + 4 * threadIdx.x, f32x4{0.f, 0.f, 0.f, 0.f});
     return;
@@ -747,6 +775,292 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_rows_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Scenes with more than SW_AMAX agents: ROW-BLOCK kernels.  The scene no longer fits one workgroup's LDS
+// (scores are n x n), so the work unit is a block of 16 query agents i of one scene: each of the 4 waves
+// owns 4 rows and walks the scene's agents j in tiles of 16 pairs (i fixed, 16 consecutive j) with an
+// ONLINE softmax (running max m, normaliser l, weighted sum of h_j) - no n x n array exists anywhere.
+// W h_j + b is precomputed per agent (social_wh_kernel).  The backward recomputes sigma_ij and uses the saved
+// (m_i, l_i).  Same mathematics as AttentionPooling.forward (train.py:153-175) for any scene size.
+// big_blocks: int32 [NB][8] = { scene, i0, partial row base of this block, partial row base of the scene,
+//             blocks in the scene, block index in the scene, 0, 0 }.
+// ---------------------------------------------------------------------------------------------
+#define SW_BIG_REC 8
+__device__ __forceinline__ f32x4 agent_x4(const float* obsv, int To, int a) {
+  const float* p = obsv + ((size_t)a * To + To - 2) * 2;  // last two observed points -> (p, v)
+  return f32x4{p[2], p[3], p[2] - p[0], p[3] - p[1]};
+}
+
+// Wh = W h + b for the 16 agents of a block (one MFMA tile per wave: units 16w..)
+__global__ __launch_bounds__(SW_THREADS) void social_wh_kernel(const float* __restrict__ h, const int* __restrict__ scene_off,
+                                                               const int* __restrict__ blocks, const float* __restrict__ att_w,
+                                                               float* __restrict__ wh) {
+  const int* rec = blocks + (size_t)blockIdx.x * SW_BIG_REC;
+  const int s0 = scene_off[rec[0]], n = scene_off[rec[0] + 1] - s0, i0 = rec[1];
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  const int a = s0 + min(i0 + ln, n - 1);
+  f32x4 wr[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wr[j] = ld4(att_w + swp::ATT_W + (16 * wave + ln) * 64 + 16 * j + 4 * lg);
+  f32x4 acc = ld4(att_w + swp::ATT_B + 16 * wave + 4 * lg);
+  acc = tile_mm_reg<4>(wr, h + (size_t)a * 64 + 4 * lg, acc);
+  if (i0 + ln < n) st4(wh + (size_t)a * 64 + 16 * wave + 4 * lg, acc);
+}
+
+__global__ __launch_bounds__(SW_THREADS) void social_big_fwd_kernel(
+    const float* __restrict__ obsv, int To, const float* __restrict__ h, const float* __restrict__ wh,
+    const int* __restrict__ scene_off, const int* __restrict__ blocks, const float* __restrict__ emb_w,
+    float* __restrict__ S_out, float* __restrict__ ml) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const SocL Ls = soc_lds(16);
+  const float* w0b = smem + Ls.w0b;
+  const float* b12 = smem + Ls.b12;
+  stage_pair_consts(smem, Ls, emb_w);
+  const int* rec = blocks + (size_t)blockIdx.x * SW_BIG_REC;
+  const int s0 = scene_off[rec[0]], n = scene_off[rec[0] + 1] - s0, i0 = rec[1];
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  PairW W;
+  load_pair_w(W, emb_w, ln, lg);
+  sw_barrier();
+  for (int q = 0; q < 4; ++q) {
+    const int i = i0 + 4 * wave + q;
+    if (i >= n) break;
+    const f32x4 xi = agent_x4(obsv, To, s0 + i);
+    float m = -INFINITY, l = 0.f, acc = 0.f;   // acc: unit `lane` of sum_j e^(sigma_ij - m) h_j
+    for (int j0 = 0; j0 < n; j0 += 16) {
+      const int j = j0 + ln;
+      const bool jv = j < n;
+      const int jc = min(j, n - 1);
+      float f0, f1, f2;
+      pair_feat(xi, agent_x4(obsv, To, s0 + jc), f0, f1, f2);
+      f32x4 h1[2], h2[4], f[4];
+      pair_l1(w0b, lg, f0, f1, f2, h1);
+      pair_l23(W, b12, b12 + 64, lg, h1, h2, f);
+      float part = 0.f;
+#pragma unroll
+      for (int mo = 0; mo < 4; ++mo) {
+        f32x4 w = ld4(wh + (size_t)(s0 + jc) * 64 + 16 * mo + 4 * lg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part = fmaf(f[mo][r], w[r], part);
+      }
+      part += __shfl_xor(part, 16);
+      part += __shfl_xor(part, 32);
+      const float sg = !jv ? -INFINITY : (jc == i ? -1000.0f : part);   // train.py:170
+      float tmax = sg;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o));
+      const float mn = fmaxf(m, tmax);
+      const float keep = expf(m - mn);              // 0 on the first tile (m = -inf)
+      const float pj = jv ? expf(sg - mn) : 0.f;
+      float tsum = pj;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) tsum += __shfl_xor(tsum, o);
+      l = fmaf(l, keep, tsum);
+      acc *= keep;
+      const int jn = min(16, n - j0);
+      for (int jj = 0; jj < jn; ++jj) acc = fmaf(__shfl(pj, jj), h[(size_t)(s0 + j0 + jj) * 64 + lane], acc);
+      m = mn;
+    }
+    S_out[(size_t)(s0 + i) * 64 + lane] = acc / l;
+    if (ml && lane == 0) {
+      ml[(size_t)(s0 + i) * 2] = m;
+      ml[(size_t)(s0 + i) * 2 + 1] = l;
+    }
+  }
+}
+
+// layers 2, 3 with the weights read from the row-major LDS images (the row-block backward has no registers
+// to spare for a register-resident copy next to the gradient accumulators)
+__device__ __forceinline__ void pair_l23_lds(const float* w1s, const float* w2s, const float* b1, const float* b2, int ln,
+                                             int lg, const f32x4 h1[2], f32x4 h2[4], f32x4 f[4]) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    f32x4 acc = ld4(b1 + 16 * mt + 4 * lg);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const f32x4 w = ld4(w1s + (16 * mt + ln) * SW_SOC_W1LD + 16 * j + 4 * lg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = SW_MFMA(w[r], h1[j][r], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h2[mt][r] = fmaxf(acc[r], 0.f);
+  }
+#pragma unroll
+  for (int mo = 0; mo < 4; ++mo) f[mo] = ld4(b2 + 16 * mo + 4 * lg);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f32x4 w[4];
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) w[mo] = ld4(w2s + (16 * mo + ln) * SW_SOC_W2LD + 16 * k + 4 * lg);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int mo = 0; mo < 4; ++mo) f[mo] = SW_MFMA(w[mo][r], h2[k][r], f[mo]);
+    }
+  }
+}
+
+// Backward of one 16-query-agent block of a large scene.  For every j tile (outer loop) the wave visits its
+// <= 4 rows i (inner loop): recompute f_ij and sigma_ij, a_ij = e^(sigma_ij - m_i) / l_i,
+// dsigma_ij = a_ij (<dS_i, h_j> - <dS_i, S_i>), back-propagate the pair MLP and accumulate its weight gradients
+// in registers (pair_tile_bwd).  The two sums over i that belong to agent j,
+//   dWh_j = sum_i dsigma_ij f_ij      and      sum_i a_ij dS_i   (part of dh_j),
+// are lane-local over the wave's rows (pair lane = j), summed over the 4 waves through LDS and left as one
+// partial row (128 floats) per (block, j); social_big_finish_kernel adds the blocks of a scene.
+__global__ __launch_bounds__(SW_THREADS) void social_big_bwd_kernel(
+    const float* __restrict__ obsv, int To, const float* __restrict__ h, const float* __restrict__ wh,
+    const int* __restrict__ scene_off, const int* __restrict__ blocks, const float* __restrict__ emb_w,
+    const float* __restrict__ S_pool, const float* __restrict__ ml, const float* __restrict__ dS,
+    float* __restrict__ part_rows, SocPart part, int slice0) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const SocL Ls = soc_lds(16);
+  const float* w0b = smem + Ls.w0b;
+  const float* b12 = smem + Ls.b12;
+  float* w2s = smem + Ls.fwd_total;                   // fc.4.weight [64][68]
+  float* w1s = w2s + 64 * SW_SOC_W2LD;                // fc.2.weight [64][36]
+  float* scr_all = w1s + 64 * SW_SOC_W1LD;            // [4 waves][4 tiles][16][20]
+  float* jred = scr_all + 4 * SW_SOC_SCR;             // [16 j][128]: dWh | sum a dS of the current j tile
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  float* scr = scr_all + wave * SW_SOC_SCR;
+  stage_pair_consts(smem, Ls, emb_w);
+  for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {
+    int r = i >> 4, q = i & 15;
+    st4(&w2s[r * SW_SOC_W2LD + 4 * q], ld4(emb_w + swp::EMB_W2 + r * 64 + 4 * q));
+    if (q < 8) st4(&w1s[r * SW_SOC_W1LD + 4 * q], ld4(emb_w + swp::EMB_W1 + r * 32 + 4 * q));
+  }
+  const int* rec = blocks + (size_t)blockIdx.x * SW_BIG_REC;
+  const int s0 = scene_off[rec[0]], n = scene_off[rec[0] + 1] - s0, i0 = rec[1], prow0 = rec[2];
+  PairGrad G;
+  pair_grad_zero(G);
+  // the wave's rows: position/velocity, softmax statistics, D_i = <dS_i, S_i>
+  const int nrows = max(0, min(4, n - (i0 + 4 * wave)));
+  f32x4 xi[4];
+  float mi[4], rli[4], Di[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int a = s0 + min(i0 + 4 * wave + q, n - 1);
+    xi[q] = agent_x4(obsv, To, a);
+    mi[q] = ml[(size_t)a * 2];
+    rli[q] = 1.0f / ml[(size_t)a * 2 + 1];
+    float d = dS[(size_t)a * 64 + lane] * S_pool[(size_t)a * 64 + lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    Di[q] = d;
+  }
+  sw_barrier();
+  for (int j0 = 0; j0 < n; j0 += 16) {
+    const int j = j0 + ln;
+    const bool jv = j < n;
+    const int jc = min(j, n - 1);
+    const f32x4 xj = agent_x4(obsv, To, s0 + jc);
+    f32x4 whj[4], hj[4], dwh_acc[4], dhj_acc[4];
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) {
+      whj[mo] = ld4(wh + (size_t)(s0 + jc) * 64 + 16 * mo + 4 * lg);
+      hj[mo] = ld4(h + (size_t)(s0 + jc) * 64 + 16 * mo + 4 * lg);
+      dwh_acc[mo] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dhj_acc[mo] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 1
+    for (int q = 0; q < nrows; ++q) {
+      const int i = i0 + 4 * wave + q;
+      const f32x4 xq = q == 0 ? xi[0] : (q == 1 ? xi[1] : (q == 2 ? xi[2] : xi[3]));
+      const float mq = q == 0 ? mi[0] : (q == 1 ? mi[1] : (q == 2 ? mi[2] : mi[3]));
+      const float rlq = q == 0 ? rli[0] : (q == 1 ? rli[1] : (q == 2 ? rli[2] : rli[3]));
+      const float Dq = q == 0 ? Di[0] : (q == 1 ? Di[1] : (q == 2 ? Di[2] : Di[3]));
+      float f0, f1, f2;
+      pair_feat(xq, xj, f0, f1, f2);
+      f32x4 h1[2], h2[4], f[4];
+      pair_l1(w0b, lg, f0, f1, f2, h1);
+      pair_l23_lds(w1s, w2s, b12, b12 + 64, ln, lg, h1, h2, f);
+      float part_s = 0.f, da = 0.f;
+      f32x4 dsi[4];
+#pragma unroll
+      for (int mo = 0; mo < 4; ++mo) {
+        dsi[mo] = ld4(dS + (size_t)(s0 + i) * 64 + 16 * mo + 4 * lg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          part_s = fmaf(f[mo][r], whj[mo][r], part_s);
+          da = fmaf(dsi[mo][r], hj[mo][r], da);
+        }
+      }
+      part_s += __shfl_xor(part_s, 16);
+      part_s += __shfl_xor(part_s, 32);
+      da += __shfl_xor(da, 16);
+      da += __shfl_xor(da, 32);
+      const float sg = jc == i ? -1000.0f : part_s;                       // train.py:170
+      const float a = jv ? expf(sg - mq) * rlq : 0.f;
+      const float dsv = a * (da - Dq);                                     // softmax backward; 0 for invalid lanes
+      f32x4 dz3[4];
+#pragma unroll
+      for (int mo = 0; mo < 4; ++mo) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dz3[mo][r] = dsv * whj[mo][r];
+          dwh_acc[mo][r] = fmaf(dsv, f[mo][r], dwh_acc[mo][r]);
+          dhj_acc[mo][r] = fmaf(a, dsi[mo][r], dhj_acc[mo][r]);
+        }
+      }
+      pair_tile_bwd(G, scr, w2s, w1s, h1, h2, dz3, f0, f1, f2, ln, lg);
+    }
+    // sum the 4 waves' j-tile partials in a fixed order, then one partial row per agent j of the tile
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int mo = 0; mo < 4; ++mo) {
+          float* a0 = jred + ln * 128 + 16 * mo + 4 * lg;
+          st4(a0, w == 0 ? dwh_acc[mo] : ld4(a0) + dwh_acc[mo]);
+          st4(a0 + 64, w == 0 ? dhj_acc[mo] : ld4(a0 + 64) + dhj_acc[mo]);
+        }
+      }
+      sw_barrier();
+    }
+    const int jn = min(16, n - j0);
+    for (int e = threadIdx.x; e < jn * 32; e += blockDim.x) {
+      const int jr = e >> 5, c4 = e & 31;
+      st4(part_rows + ((size_t)prow0 + j0 + jr) * 128 + 4 * c4, ld4(jred + jr * 128 + 4 * c4));
+    }
+    sw_barrier();
+  }
+  pair_grad_store(G, w2s, part, slice0 + blockIdx.x, wave, ln, lg);
+}
+
+// Per 16 agents j of a large scene: dWh_j = sum over the scene's blocks, dh_j += sum_blocks (sum_i a_ij dS_i) + W^T dWh_j
+__global__ __launch_bounds__(SW_THREADS) void social_big_finish_kernel(const int* __restrict__ scene_off,
+                                                                       const int* __restrict__ blocks,
+                                                                       const float* __restrict__ att_w,
+                                                                       const float* __restrict__ part_rows,
+                                                                       float* __restrict__ dh, float* __restrict__ dwh_rows) {
+  __shared__ float dwh[16][68];
+  const int* rec = blocks + (size_t)blockIdx.x * SW_BIG_REC;
+  const int s0 = scene_off[rec[0]], n = scene_off[rec[0] + 1] - s0, j0 = rec[1], srow0 = rec[3], nblk = rec[4];
+  const int jn = min(16, n - j0);
+  float dhj[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int q = 0, e = threadIdx.x; q < 4; ++q, e += 256) {   // 16 x 64 elements, 4 per thread
+    const int jr = e >> 6, u = e & 63;
+    float sw = 0.f, sh = 0.f;
+    if (jr < jn) {
+      for (int k = 0; k < nblk; ++k) {
+        const float* row = part_rows + ((size_t)srow0 + (size_t)k * n + j0 + jr) * 128;
+        sw += row[u];
+        sh += row[64 + u];
+      }
+      dwh_rows[(size_t)(s0 + j0 + jr) * 64 + u] = sw;
+    }
+    dwh[jr][u] = sw;
+    dhj[q] = sh;
+  }
+  __syncthreads();
+  for (int q = 0, e = threadIdx.x; q < 4; ++q, e += 256) {
+    const int jr = e >> 6, u = e & 63;
+    if (jr >= jn) continue;
+    float acc = dhj[q];
+    const float* wc = att_w + swp::ATT_W + u;
+    for (int k = 0; k < 64; ++k) acc = fmaf(wc[k * 64], dwh[jr][k], acc);
+    dh[(size_t)(s0 + j0 + jr) * 64 + u] += acc;
+  }
+}
+
 // dense SocialFeatures for the module-level API (train.py:229-241): feat[i][j][0..2]
 __global__ void social_features_kernel(const float* __restrict__ x4, int B, float* __restrict__ feat) {
   size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -867,9 +1181,10 @@ extern "C" int sw_social_features(const float* x4_last, int B, float* feat, void
 
 extern "C" int sw_social_pool_fwd(const float* obsv, int To, const float* h, const int* scene_off, int S, int B,
                                   int Amax, const float* emb_w, const float* att_w, float* S_out, float* attn,
-                                  void* stream) {
-  if (!obsv || !h || !scene_off || !emb_w || !att_w || !S_out || S < 0 || B < 0 || To < 2) return SW_EARG;
-  if (Amax > SW_AMAX) return SW_ESHAPE;
+                                  const int* big_blocks, int NB, float* wh_ws, float* ml, void* stream) {
+  if (!obsv || !h || !scene_off || !emb_w || !att_w || !S_out || S < 0 || B < 0 || To < 2 || NB < 0) return SW_EARG;
+  if (NB > 0 && (!big_blocks || !wh_ws)) return SW_EARG;
+  if (Amax > SW_AMAX) return SW_ESHAPE;      // Amax = largest scene handled by the one-workgroup-per-scene kernel
   if (S == 0 || B == 0) return SW_OK;
   static bool attr = false;
   if (!attr) {
@@ -880,6 +1195,14 @@ extern "C" int sw_social_pool_fwd(const float* obsv, int To, const float* h, con
   hipLaunchKernelGGL(social_pool_fwd_kernel, dim3(S), dim3(SW_THREADS), soc_lds(a16).fwd_total * 4, (hipStream_t)stream,
                      obsv, To, h, scene_off, emb_w, att_w, S_out, attn, a16);
   SW_CHECK_LAUNCH("social_pool_fwd_kernel");
+  if (NB > 0) {   // scenes above SW_AMAX agents
+    hipLaunchKernelGGL(social_wh_kernel, dim3(NB), dim3(SW_THREADS), 0, (hipStream_t)stream, h, scene_off, big_blocks, att_w,
+                       wh_ws);
+    SW_CHECK_LAUNCH("social_wh_kernel");
+    hipLaunchKernelGGL(social_big_fwd_kernel, dim3(NB), dim3(SW_THREADS), soc_lds(16).fwd_total * 4, (hipStream_t)stream,
+                       obsv, To, h, wh_ws, scene_off, big_blocks, emb_w, S_out, ml);
+    SW_CHECK_LAUNCH("social_big_fwd_kernel");
+  }
   return SW_OK;
 }
 
@@ -887,32 +1210,37 @@ extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, con
                                   const long long* pair_off, int S, int B, int Amax, long long P,
                                   const float* emb_w, const float* att_w, const float* attn, const float* dS,
                                   float* dh, float* d_emb_w, float* d_att_w, float* pair_ws, float* wgrad_ws,
-                                  void* stream) {
+                                  const int* big_blocks, int NB, const float* wh_ws, const float* ml,
+                                  const float* S_pool, float* big_part_ws, void* stream) {
   if (!obsv || !h || !scene_off || !pair_off || !emb_w || !att_w || !attn || !dS || !dh || !d_emb_w || !d_att_w ||
-      !pair_ws || !wgrad_ws || S < 0 || B < 0 || P < 0 || To < 2)
+      !pair_ws || !wgrad_ws || S < 0 || B < 0 || P < 0 || To < 2 || NB < 0)
     return SW_EARG;
+  if (NB > 0 && (!big_blocks || !wh_ws || !ml || !S_pool || !big_part_ws)) return SW_EARG;
   if (Amax > SW_AMAX) return SW_ESHAPE;
   if (S == 0 || B == 0) return SW_OK;
+  hipStream_t st = (hipStream_t)stream;
   const int a16 = Amax < 16 ? 16 : ((Amax + 15) & ~15);
-  const int lds = (soc_lds(a16).bwd_total + 64 * SW_SOC_W2LD + 64 * SW_SOC_W1LD + 4 * SW_SOC_SCR) * 4;
+  const int extra = 64 * SW_SOC_W2LD + 64 * SW_SOC_W1LD + 4 * SW_SOC_SCR;
+  const int lds = (soc_lds(a16).bwd_total + extra) * 4;
+  const int lds_big = (soc_lds(16).fwd_total + extra + 16 * 128) * 4;
   static_assert(64 * SW_SOC_W2LD + 64 * SW_SOC_W1LD + 4 * SW_SOC_SCR >= SW_SOC_PART, "epilogue staging area");
   static bool attr = false;
   if (!attr) {
-    const int lds_max = (soc_lds(SW_AMAX).bwd_total + 64 * SW_SOC_W2LD + 64 * SW_SOC_W1LD + 4 * SW_SOC_SCR) * 4;
-    if (int rc = set_lds((const void*)social_pool_bwd_kernel, lds_max)) return rc;
+    if (int rc = set_lds((const void*)social_pool_bwd_kernel, (soc_lds(SW_AMAX).bwd_total + extra) * 4)) return rc;
+    if (int rc = set_lds((const void*)social_big_bwd_kernel, lds_big)) return rc;
     attr = true;
   }
   // pair_ws: [B][64] dWh rows, then the pair rows
   float* dwh_rows = pair_ws;
-  if (P < (long long)S * SW_SOC_FUSE_MIN_PAIRS) {   // small scenes: per-pair rows + deferred GEMM
+  if (NB == 0 && P < (long long)S * SW_SOC_FUSE_MIN_PAIRS) {   // small scenes only: per-pair rows + deferred GEMM
     static bool attr2 = false;
     if (!attr2) {
       if (int rc = set_lds((const void*)social_pool_bwd_rows_kernel, soc_lds(SW_AMAX).bwd_total * 4)) return rc;
       attr2 = true;
     }
     PairRows pr = pair_rows(pair_ws + (size_t)B * 64, P);
-    hipLaunchKernelGGL(social_pool_bwd_rows_kernel, dim3(S), dim3(SW_THREADS), soc_lds(a16).bwd_total * 4,
-                       (hipStream_t)stream, obsv, To, h, scene_off, pair_off, emb_w, att_w, attn, dS, dh, dwh_rows, pr, a16);
+    hipLaunchKernelGGL(social_pool_bwd_rows_kernel, dim3(S), dim3(SW_THREADS), soc_lds(a16).bwd_total * 4, st, obsv, To, h,
+                       scene_off, pair_off, emb_w, att_w, attn, dS, dh, dwh_rows, pr, a16);
     SW_CHECK_LAUNCH("social_pool_bwd_rows_kernel");
     WgBatch wr;
     int rc_r = 0;
@@ -923,22 +1251,32 @@ extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, con
       rc_r |= wg_add(wr, pr.dh1, 32, pr.feat, 4, (int)P, 32, 3, d_emb_w + swp::EMB_W0, 3, d_emb_w + swp::EMB_B0, nullptr, 0);
     }
     if (rc_r) return SW_ESHAPE;
-    return wg_launch(wr, wgrad_ws, (hipStream_t)stream);
+    return wg_launch(wr, wgrad_ws, st);
   }
+  // in-register weight gradients: one partial slice per workgroup of the scene kernel (G) and of the row-block
+  // kernel (NB), reduced together
   float* f_rows = pair_ws + (size_t)B * 64;
   const int G = S < 1024 ? S : 1024;   // workgroups: each walks scenes g, g+G, .. and leaves ONE weight-gradient partial
   WgBatch wb;
   int rc_add = 0;
   rc_add |= wg_add(wb, dwh_rows, 64, h, 64, B, 64, 64, d_att_w + swp::ATT_W, 64, d_att_w + swp::ATT_B, nullptr, 0);
   const int i3 = wb.np, i2 = wb.np + 1, i1 = wb.np + 2;
-  rc_add |= wg_add_pre(wb, 64, 64, d_emb_w + swp::EMB_W2, 64, d_emb_w + swp::EMB_B2, G);
-  rc_add |= wg_add_pre(wb, 64, 32, d_emb_w + swp::EMB_W1, 32, d_emb_w + swp::EMB_B1, G);
-  rc_add |= wg_add_pre(wb, 32, 3, d_emb_w + swp::EMB_W0, 3, d_emb_w + swp::EMB_B0, G);
+  rc_add |= wg_add_pre(wb, 64, 64, d_emb_w + swp::EMB_W2, 64, d_emb_w + swp::EMB_B2, G + NB);
+  rc_add |= wg_add_pre(wb, 64, 32, d_emb_w + swp::EMB_W1, 32, d_emb_w + swp::EMB_B1, G + NB);
+  rc_add |= wg_add_pre(wb, 32, 3, d_emb_w + swp::EMB_W0, 3, d_emb_w + swp::EMB_B0, G + NB);
   if (rc_add) return SW_ESHAPE;
   if (wg_finalize(wb) > SW_WG_WS_FLOATS) return SW_ESHAPE;
   SocPart part{wgrad_ws + wb.p[i3].ws_off, wgrad_ws + wb.p[i2].ws_off, wgrad_ws + wb.p[i1].ws_off};
-  hipLaunchKernelGGL(social_pool_bwd_kernel, dim3(G), dim3(SW_THREADS), lds, (hipStream_t)stream, obsv, To, h,
-                     scene_off, pair_off, S, emb_w, att_w, attn, dS, dh, dwh_rows, f_rows, part, a16);
+  if (NB > 0) {   // scenes above SW_AMAX agents: fills dh / dwh_rows of their agents
+    hipLaunchKernelGGL(social_big_bwd_kernel, dim3(NB), dim3(SW_THREADS), lds_big, st, obsv, To, h, wh_ws, scene_off,
+                       big_blocks, emb_w, S_pool, ml, dS, big_part_ws, part, G);
+    SW_CHECK_LAUNCH("social_big_bwd_kernel");
+    hipLaunchKernelGGL(social_big_finish_kernel, dim3(NB), dim3(SW_THREADS), 0, st, scene_off, big_blocks, att_w,
+                       big_part_ws, dh, dwh_rows);
+    SW_CHECK_LAUNCH("social_big_finish_kernel");
+  }
+  hipLaunchKernelGGL(social_pool_bwd_kernel, dim3(G), dim3(SW_THREADS), lds, st, obsv, To, h, scene_off, pair_off, S,
+                     emb_w, att_w, attn, dS, dh, dwh_rows, f_rows, part, a16);
   SW_CHECK_LAUNCH("social_pool_bwd_kernel");
-  return wg_launch_finalized(wb, wgrad_ws, (hipStream_t)stream);
+  return wg_launch_finalized(wb, wgrad_ws, st);
 }

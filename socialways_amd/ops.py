@@ -13,7 +13,8 @@ from . import _lib as L
 
 class SceneIndex:
     """Device-side form of the reference's `sub_batches` ((S,2) [start,end) rows, train.py:446-461):
-    int32 prefix offsets, int64 pair offsets (n^2 per scene with n > 1), the largest scene."""
+    int32 prefix offsets; scenes of up to AMAX agents: int64 pair offsets (n^2 per scene with n > 1) and
+    their largest size; larger scenes: the row-block records of include/socialways_hip.h (`big_blocks`)."""
 
     def __init__(self, sub_batches, B, device):
         sb = np.asarray(sub_batches, dtype=np.int64).reshape(-1, 2)
@@ -26,8 +27,18 @@ class SceneIndex:
             raise ValueError("empty scene in sub_batches")
         self.S = len(sb)
         self.B = int(B)
-        self.amax = int(n.max())
-        pairs = np.where(n > 1, n * n, 0)
+        small = n <= L.AMAX
+        self.amax = int(n[small].max()) if small.any() else 0      # largest one-workgroup scene
+        pairs = np.where((n > 1) & small, n * n, 0)
+        recs, row = [], 0
+        for sc in np.nonzero(~small)[0]:                          # scenes above AMAX agents: blocks of 16 query agents
+            ns = int(n[sc])
+            nblk = (ns + 15) // 16
+            for k in range(nblk):
+                recs.append((sc, 16 * k, row + k * ns, row, nblk, k, 0, 0))
+            row += nblk * ns
+        self.NB, self.big_rows = len(recs), row
+        self.big_blocks = torch.tensor(recs, dtype=torch.int32).reshape(-1, 8).to(device) if recs else None
         poff = np.concatenate([[0], np.cumsum(pairs)]).astype(np.int64)
         self.P = int(poff[-1])
         off = np.concatenate([sb[:, 0], [B]]).astype(np.int32)
@@ -75,7 +86,7 @@ def default_ws(device):
 
 
 class GenCtx:
-    __slots__ = ("obsv", "noise", "scenes", "hT", "cT", "S", "attn", "gsave", "B", "To", "Tp", "use_social")
+    __slots__ = ("obsv", "noise", "scenes", "hT", "cT", "S", "attn", "gsave", "B", "To", "Tp", "use_social", "wh", "ml")
 
 
 def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_social, save, ws=None, tag="g", ade=None):
@@ -102,14 +113,15 @@ def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_soc
     x4s_off = (To + n_next - 1) * B * 384
     L.call("sw_enc_lstm_fwd", L.ptr(obsv), 0, L.ptr(enc_w), None, None, B, To, L.ptr(hT), L.ptr(cT), None,
            L.ptr(gsave), (gsave.data_ptr() + 4 * x4s_off) if save else None, 0, st)
-    attn = None
+    attn = wh = ml = None
     if use_social:
-        if scenes.amax > L.AMAX:
-            raise L.SocialWaysHipError("scene with %d agents > %d supported per scene" % (scenes.amax, L.AMAX))
         S = torch.empty(B, 64, device=dev)
         attn = torch.empty(B, L.AMAX, device=dev) if save else None
+        if scenes.NB:          # scenes above AMAX agents: W h + b per agent and the softmax statistics of every row
+            wh = torch.empty(B, 64, device=dev)
+            ml = torch.empty(B, 2, device=dev) if save else None
         L.call("sw_social_pool_fwd", L.ptr(obsv), To, L.ptr(hT), L.ptr(scenes.scene_off), scenes.S, B, scenes.amax,
-               L.ptr(emb_w), L.ptr(att_w), L.ptr(S), L.ptr(attn), st)
+               L.ptr(emb_w), L.ptr(att_w), L.ptr(S), L.ptr(attn), L.ptr(scenes.big_blocks), scenes.NB, L.ptr(wh), L.ptr(ml), st)
     else:
         S = torch.zeros(B, 64, device=dev)                                   # train.py:413
     L.call("sw_dec_rollout_fwd", L.ptr(obsv), To, L.ptr(noise), L.ptr(S), L.ptr(hT), L.ptr(cT), L.ptr(enc_w),
@@ -120,6 +132,7 @@ def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_soc
     ctx = GenCtx()
     ctx.obsv, ctx.noise, ctx.scenes, ctx.hT, ctx.cT, ctx.S, ctx.attn = obsv, noise, scenes, hT, cT, S, attn
     ctx.gsave, ctx.B, ctx.To, ctx.Tp, ctx.use_social = gsave, B, To, n_next, use_social
+    ctx.wh, ctx.ml = wh, ml
     return pred4, ctx
 
 
@@ -150,12 +163,14 @@ def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d
         side.wait_stream(main)
         with torch.cuda.stream(side):
             wgrad_part(1, ws.get("wgrad.side", L.workspace_floats(L.WS_WGRAD, B, To, Tp)))
-    if ctx.use_social and ctx.scenes.P > 0:
+    if ctx.use_social and (ctx.scenes.P > 0 or ctx.scenes.NB > 0):
         sc = ctx.scenes
         pws = ws.get("pairs", L.workspace_floats(L.WS_PAIRS, B, To, Tp, 1, sc.P))
+        bigp = ws.get("bigpart", sc.big_rows * 128) if sc.NB else None      # scenes above AMAX agents: per-block partial rows
         L.call("sw_social_pool_bwd", L.ptr(ctx.obsv), To, L.ptr(ctx.hT), L.ptr(sc.scene_off), L.ptr(sc.pair_off), sc.S,
                B, sc.amax, sc.P, L.ptr(emb_w), L.ptr(att_w), L.ptr(ctx.attn), L.ptr(dS), L.ptr(dhT), L.ptr(d_emb),
-               L.ptr(d_att), L.ptr(pws), L.ptr(wgrad), L.stream())
+               L.ptr(d_att), L.ptr(pws), L.ptr(wgrad), L.ptr(sc.big_blocks), sc.NB, L.ptr(ctx.wh), L.ptr(ctx.ml),
+               L.ptr(ctx.S), L.ptr(bigp), L.stream())
     else:
         d_emb.zero_()
         d_att.zero_()

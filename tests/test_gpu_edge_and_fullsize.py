@@ -48,15 +48,72 @@ def test_step_matches_oracle_on_odd_shapes(sizes, To, Tp):
             assert bad.float().mean().item() == 0.0, (name, k)
 
 
-def test_scene_larger_than_64_agents_is_refused_loudly():
+@pytest.mark.parametrize("sizes", [[65], [70, 5, 130, 64, 1], [200, 3]])
+def test_scenes_larger_than_64_agents_forward(sizes):
+    """Scenes above 64 agents run the row-block kernels (online softmax over the scene): same rollout as the
+    oracle, mixed freely with small scenes; deterministic."""
     import socialways_amd as sw
-    t = sw.synth_tracks(1, 65)
-    G = sw.Generator(use_social=True, device="cuda:0")
+    t = sw.synth_tracks(len(sizes), sizes, seed=5)
+    tr, orc = pair(12)
+    B = int(np.sum(sizes))
     obsv = torch.from_numpy(t["obsvs"]).cuda()
-    with pytest.raises(sw.SocialWaysHipError):
-        G(obsv, torch.rand(65, 32).cuda(), 12, [[0, 65]])
-    G.use_social = False                      # without the social block any batch size is fine
-    assert G(obsv, torch.rand(65, 32).cuda(), 12, [[0, 65]]).shape == (65, 12, 4)
+    sb = np.asarray(t["batches"])
+    torch.manual_seed(7)
+    z = torch.rand(B, 32)
+    with torch.no_grad():
+        a = tr.G(obsv, z.cuda(), 12, sb)
+        b = tr.G(obsv, z.cuda(), 12, sb)
+        ref = orc.predict(obsv.cpu(), z, 12, sb)
+    assert torch.equal(a, b)
+    assert_close(a.cpu(), ref, 3e-5, 3e-6, "rollout with scenes > 64 agents")
+
+
+@pytest.mark.parametrize("sizes", [[65], [70, 5, 130, 64, 1], [200, 3]])
+def test_scenes_larger_than_64_agents_backward(sizes):
+    """Gradients of every generator parameter through the row-block social kernels (scenes above 64 agents,
+    mixed with small ones) against the oracle's autograd, for a random cotangent on the rollout."""
+    import socialways_amd as sw
+    t = sw.synth_tracks(len(sizes), sizes, seed=6)
+    tr, orc = pair(12)
+    B = int(np.sum(sizes))
+    obsv = torch.from_numpy(t["obsvs"]).cuda()
+    sb = np.asarray(t["batches"])
+    torch.manual_seed(8)
+    z, cot = torch.rand(B, 32), torch.randn(B, 12, 4) * 0.1
+    out = tr.G(obsv, z.cuda(), 12, sb)
+    out.backward(cot.cuda())
+    ref = orc.predict(obsv.cpu(), z, 12, sb)
+    ref.backward(cot)
+    assert_close(out.detach().cpu(), ref.detach(), 3e-5, 3e-6, "rollout")
+    for name in ("attention", "feature_embedder", "encoder", "decoder"):
+        for (k, p), (_, q) in zip(getattr(tr.G, name).named_parameters(), getattr(orc, name).named_parameters()):
+            want = q.grad if q.grad is not None else torch.zeros_like(q)
+            # sums over up to 40 000 pairs in fp32 on both sides: tolerance relative to the tensor's largest entry
+            assert_close(p.grad.cpu(), want, 3e-4, (3e-4 if B > 150 else 3e-5) * max(float(want.abs().max()), 1e-12), "%s.%s" % (name, k))
+
+
+def test_training_step_with_large_scenes_matches_oracle():
+    """One whole GAN step on a packed batch that holds 100- and 70-agent scenes next to small ones."""
+    import socialways_amd as sw
+    sizes = [100, 8, 70, 2, 1]
+    t = sw.synth_tracks(len(sizes) + 2, sizes + [2, 2], 8, 12, seed=12)
+    data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
+    tr, orc = pair(12)
+    B = int(np.sum(sizes))
+    sb = data.the_batches[:len(sizes)]
+    torch.manual_seed(3)
+    noise = torch.rand(B, 32)
+    out = tr.step(data.obsv[:B], data.pred[:B], sb, 0.07, 0.91, noise, data.ss)
+    got = tr.losses_from(out, [B], 12, data.ss)[0]
+    want, ade, fde = orc.train_step(data.obsv[:B].cpu(), data.pred[:B].cpu(), sb, 0.07, 0.91, noise, data.ss)
+    assert_close(got, np.asarray(want), 5e-5, 2e-6, "9 MSE terms")
+    o = out.double().cpu().numpy()
+    assert abs(o[-1, 0] - ade) < 1e-4 * max(1.0, abs(ade)) and abs(o[-1, 1] - fde) < 1e-4 * max(1.0, abs(fde))
+    for name, mod in (("encoder", tr.G.encoder), ("decoder", tr.G.decoder), ("feature_embedder", tr.G.feature_embedder),
+                      ("attention", tr.G.attention), ("D", tr.D)):
+        ref = getattr(orc, name).state_dict()
+        for k, v in mod.state_dict().items():      # after Adam: elementwise agreement bounded by ~lr
+            assert ((v.cpu() - ref[k]).abs() > 2e-3 * 1.01).float().mean().item() == 0.0, (name, k)
 
 
 def test_empty_sub_batches_means_one_scene():
