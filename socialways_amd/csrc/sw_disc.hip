@@ -157,15 +157,18 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
   lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
 
   // ---- LSTM over the observation (4-d state formed on the fly, train.py:130-133) ---------------
+  // the input of step t+1 is fetched while step t computes (its latency would sit in front of every step's MFMAs)
+  auto load_x = [&](int t) {
+    if (x_mode == 1) return obsv[((size_t)b * To + t) * 4 + lg];
+    const float* p = obsv + (size_t)b * To * 2;
+    if (lg < 2) return p[t * 2 + lg];
+    const int tt = t == 0 ? 1 : t;
+    return p[tt * 2 + lg - 2] - p[(tt - 1) * 2 + lg - 2];
+  };
+  float xnext = load_x(0);
   for (int t = 0; t < To; ++t) {
-    float xb;
-    if (x_mode == 1) {
-      xb = obsv[((size_t)b * To + t) * 4 + lg];
-    } else {
-      const float* p = obsv + (size_t)b * To * 2;
-      if (lg < 2) xb = p[t * 2 + lg];
-      else { int tt = t == 0 ? 1 : t; xb = p[tt * 2 + lg - 2] - p[(tt - 1) * 2 + lg - 2]; }
-    }
+    const float xb = xnext;
+    if (t + 1 < To) xnext = load_x(t + 1);
     f32x4 gate[4];
     lstm_cell(W, xb, &hbuf[(t & 1) * 16 * SW_HLD + ln * SW_HLD + 4 * lg], gate, c, h);
     st4(&hbuf[((t + 1) & 1) * 16 * SW_HLD + ln * SW_HLD + u0 + 4 * lg], h);

@@ -38,8 +38,13 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
   sw_barrier();
   lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
 
+  // the input of step t+1 is fetched while step t computes: its L2/HBM latency would otherwise sit in front of
+  // the first MFMA of every step
+  auto load_x = [&](int t) { return x_mode == 0 ? obs_x4(x, b, t, T, lg) : x[((size_t)b * T + t) * 4 + lg]; };
+  float xnext = load_x(0);
   for (int t = 0; t < T; ++t) {
-    float xb = x_mode == 0 ? obs_x4(x, b, t, T, lg) : x[((size_t)b * T + t) * 4 + lg];
+    const float xb = xnext;
+    if (t + 1 < T) xnext = load_x(t + 1);
     f32x4 gate[4];
     lstm_cell(W, xb, &hbuf[t & 1][ln * SW_HLD + 4 * lg], gate, c, h);
     st4(&hbuf[(t + 1) & 1][ln * SW_HLD + u0 + 4 * lg], h);
