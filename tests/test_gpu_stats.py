@@ -60,3 +60,19 @@ def test_statistics_of_written_predictions(tmp_path):
     assert list(s1) == [5] and abs(s1[5] - a1 / len(files)) < 1e-12 and abs(sw_[5] - aw / len(files)) < 1e-6
     st = np.load(tmp_path / "stats20.npz")
     assert st["stats_1nn"].shape == (1,) and abs(st["stats_wst"][0] - sw_[5]) < 1e-12
+
+
+def test_end_to_end_example(tmp_path):
+    """examples/train_toy.py: toy data -> epochs of training -> test() + npz -> checkpoint -> statistics;
+    the losses stay finite, ADE improves over the first epochs and every artefact is written."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_toy", os.path.join(root, "examples", "train_toy.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    tr, s1, emd = mod.main(["--epochs", "6", "--test-every", "3", "--n-samples", "384", "--out", str(tmp_path)])
+    assert sorted(s1) == [3, 6] and all(np.isfinite(list(emd.values()))) and all(0.0 <= v <= 1.0 for v in s1.values())
+    ck = torch.load(tmp_path / "toy.pt", weights_only=False)
+    assert sorted(ck) == sorted(['epoch', 'attentioner_dict', 'feature_embedder_dict', 'encoder_dict', 'decoder_dict',
+                                 'pred_optimizer', 'D_dict', 'D_optimizer'])
+    assert len(os.listdir(tmp_path / "preds" / "6")) > 0 and (tmp_path / "stats20.npz").exists()
