@@ -72,7 +72,6 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
   float* a1buf = smem + FwdLds::a1buf;
   float* a2buf = smem + FwdLds::a2buf;
   float* a3buf = smem + FwdLds::a3buf;
-  float* xbuf = smem + FwdLds::xbuf;
   float* bbuf = smem + FwdLds::bbuf;
   float* szbuf = a1buf;           // prologue alias
   float* wx_lds = a2buf;          // prologue alias (1024)
