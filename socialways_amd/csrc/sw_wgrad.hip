@@ -16,6 +16,7 @@
 #include "../../include/socialways_hip.h"
 #include "sw_common.h"
 #include "sw_wgrad.h"
+#include <stdlib.h>
 
 // One wave = one job: a 64 x 64 output block (4 x 4 MFMA tiles, 16 accumulators) of one column block
 // of one problem over one row slice.  Operands come straight from global memory in MFMA layout
@@ -231,9 +232,11 @@ size_t wg_finalize(WgBatch& b) {
   const double total = wg_total_work(b) + 1.0;
   // workgroups per launch: every wave should carry >= ~16K cycles of work (fixed per-workgroup costs -
   // pipeline fill, LDS reduction, partial store - are ~8 us), at most 1024 (two rounds of residency)
-  double target = total / 16384.0 / 4.0;
+  static const double grain = getenv("SW_WG_GRAIN") ? atof(getenv("SW_WG_GRAIN")) : 8192.0;   // tuning knob (cycles of work per wave)
+  double target = total / grain / 4.0;
   if (target < 64.0) target = 64.0;
-  if (target > 1024.0) target = 1024.0;
+  static const double maxwg = getenv("SW_WG_MAXWG") ? atof(getenv("SW_WG_MAXWG")) : 1024.0;
+  if (target > maxwg) target = maxwg;
   size_t ws = 0;
   int job = 0, out = 0;
   for (int i = 0; i < b.np; ++i) {
