@@ -16,6 +16,9 @@
 #include "../../include/socialways_hip.h"
 #include "sw_common.h"
 #include "sw_wgrad.h"
+#ifndef SW_WG_DEPTH
+#define SW_WG_DEPTH 6
+#endif
 #include <stdlib.h>
 
 // One wave = one job: a 64 x 64 output block (4 x 4 MFMA tiles, 16 accumulators) of one column block
@@ -39,7 +42,7 @@ __device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const fl
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) acc[i][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  constexpr int DEPTH = 6;  // groups in flight
+  constexpr int DEPTH = SW_WG_DEPTH;  // groups in flight
   float a[DEPTH][NI], b[DEPTH][KT];
   auto load = [&](int r0, float* av, float* bv) {
     const int r = r0 + lg;
