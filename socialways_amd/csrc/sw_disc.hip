@@ -109,7 +109,7 @@ __host__ __device__ inline HeadLds head_lds(int Tp, int base) {
 __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
     const float* __restrict__ obsv, int To, int x_mode, const float* __restrict__ pred_a,
     const float* __restrict__ pred_b, int nb, const float* __restrict__ d_w, int B, int Tp, float* __restrict__ label_a, float* __restrict__ label_b,
-    float* __restrict__ code_a, float* __restrict__ code_b, float* __restrict__ dsave, int save_lstm) {
+    float* __restrict__ code_a, float* __restrict__ code_b, float* __restrict__ dsave, int save_lstm, int split) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // LSTM part
   float* hbuf = smem;                        // [2][16][68]
@@ -120,7 +120,13 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
   const DSave ds = dsave_layout(B, To, Tp, nb);
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
   const int u0 = wave * 16;
-  const int a0 = blockIdx.x * SW_TILE;
+  // split: the two branches of a tile run in two workgroups (each repeats the shared observation LSTM - free
+  // while the launch leaves CUs idle - and does ONE head pass); the branch-1 workgroup saves no observation rows
+  const int tiles = (B + SW_TILE - 1) / SW_TILE;
+  const int bsel = split ? (int)(blockIdx.x >= (unsigned)tiles) : -1;
+  const int k_lo = bsel == 1 ? 1 : 0, k_hi = bsel == 0 ? 1 : nb;
+  const bool save_obs = bsel != 1;
+  const int a0 = (blockIdx.x - (bsel == 1 ? tiles : 0)) * SW_TILE;
   const int b = min(a0 + ln, B - 1);
   const bool live = (a0 + ln) < B;
   const int K4 = 4 * Tp;
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
     f32x4 gate[4];
     lstm_cell(W, xb, &hbuf[(t & 1) * 16 * SW_HLD + ln * SW_HLD + 4 * lg], gate, c, h);
     st4(&hbuf[((t + 1) & 1) * 16 * SW_HLD + ln * SW_HLD + u0 + 4 * lg], h);
-    if (dsave && save_lstm && live) {
+    if (dsave && save_lstm && live && save_obs) {
       float* row = dsave + ds.act + ((size_t)t * B + b) * 384 + u0 + 4 * lg;
 #pragma unroll
       for (int g = 0; g < 4; ++g) st4(row + g * 64, gate[g]);
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu(acc[r]);
     st4(smem + L.o1 + ln * LD32 + m0 + 4 * lg, acc);
-    if (dsave && live) st4(dsave + ds.o1 + (size_t)b * 32 + m0 + 4 * lg, acc);
+    if (dsave && live && save_obs) st4(dsave + ds.o1 + (size_t)b * 32 + m0 + 4 * lg, acc);
   }
   sw_barrier();
   // phase B: obsv_code = of1 o1 + b  -> both[:, 0:32]  (waves 0,1)
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
     acc = tile_mm_rt(smem + L.of1 + (m0 + ln) * LD32 + 4 * lg, smem + L.o1 + ln * LD32 + 4 * lg, 2, acc);
     st4(smem + L.both + ln * LD64 + m0 + 4 * lg, acc);
   }
-  for (int k = 0; k < nb; ++k) {
+  for (int k = k_lo; k < k_hi; ++k) {
     const float* pred = k == 0 ? pred_a : pred_b;
     float* label = k == 0 ? label_a : label_b;
     float* code = k == 0 ? code_a : code_b;
@@ -295,6 +301,8 @@ __host__ __device__ inline HeadLdsB head_lds_b(int Tp, int base) {
   return L;
 }
 }  // namespace
+
+#define SW_SPLIT_MAX_WGS 256   // CUs of an MI355X: splitting only pays while the launch leaves some of them idle
 
 // GAN mode of the backward kernel: dlabel_* / dcode_* then carry the forward OUTPUTS (label, code) and
 // the loss gradients are formed in the kernel, so no separate loss kernel sits on the critical path.
@@ -511,9 +519,11 @@ extern "C" int sw_disc_fwd(const float* obsv, int To, int x_mode, const float* c
     if (int rc = set_lds((const void*)disc_fwd_kernel, lds)) return rc;
     attr = lds;
   }
-  hipLaunchKernelGGL(disc_fwd_kernel, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS), lds, (hipStream_t)stream,
+  const int tiles = (B + SW_TILE - 1) / SW_TILE;
+  const int split = (nb == 2 && 2 * tiles <= SW_SPLIT_MAX_WGS) ? 1 : 0;   // idle CUs: one workgroup per (tile, branch)
+  hipLaunchKernelGGL(disc_fwd_kernel, dim3(split ? 2 * tiles : tiles), dim3(SW_THREADS), lds, (hipStream_t)stream,
                      obsv, To, x_mode, pred4[0], nb > 1 ? pred4[1] : nullptr, nb, d_w, B, Tp, label[0],
-                     nb > 1 ? label[1] : nullptr, code[0], nb > 1 ? code[1] : nullptr, dsave, save_lstm);
+                     nb > 1 ? label[1] : nullptr, code[0], nb > 1 ? code[1] : nullptr, dsave, save_lstm, split);
   SW_CHECK_LAUNCH("disc_fwd_kernel");
   return SW_OK;
 }
