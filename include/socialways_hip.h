@@ -103,6 +103,12 @@ int sw_attention_pool_dense(const float* f /*[B,B,64]*/, const float* h /*[B,64]
 /* pair_off = int64[S+1] prefix sums of n_s^2 over scenes with n_s > 1 (single-agent scenes own no
  * pair rows), P = pair_off[S].  dh is accumulated into.  d_emb_w / d_att_w are overwritten.
  * pair_ws holds sw_workspace_floats(SW_WS_PAIRS, ...) floats.                                    */
+/* Host-side handle carrying weight-gradient problems from one call to a later launch (the grouped GEMM launches
+ * are occupancy-bound: one launch per backward pass beats one per module).  Not thread-safe per handle.     */
+typedef struct sw_wgrad_batch sw_wgrad_batch;
+sw_wgrad_batch* sw_wgrad_batch_new(void);
+void sw_wgrad_batch_free(sw_wgrad_batch* h);
+
 int sw_social_pool_bwd(const float* obsv, int To, const float* h, const int* scene_off,
                        const long long* pair_off, int S, int B, int Amax, long long P,
                        const float* emb_w, const float* att_w, const float* attn, const float* dS,
@@ -110,7 +116,10 @@ int sw_social_pool_bwd(const float* obsv, int To, const float* h, const int* sce
                        /* scenes above 64 agents (see sw_social_pool_fwd): the forward's big_blocks, wh_ws, ml, its
                         * output S_pool, and big_part_ws = 128 floats per partial row (blocks*agents rows per scene) */
                        const int* big_blocks /*or NULL*/, int NB, const float* wh_ws, const float* ml,
-                       const float* S_pool, float* big_part_ws, void* stream);
+                       const float* S_pool, float* big_part_ws,
+                       sw_wgrad_batch* defer /*NULL: reduce the weight gradients now; else leave the problems in the
+                                               handle for the next sw_gen_wgrad on the same workspace*/,
+                       void* stream);
 
 /* ---- predict() decode loop (train.py:415-432): DecoderFC + position integration + the
  *      re-fed EncoderLstm step, Tp times, one persistent kernel -------------------------------- */
@@ -133,7 +142,9 @@ int sw_dec_rollout_bwd(const float* dpred4 /*[B,Tp,4]*/, const float* enc_w, con
  * may run on different streams with different `wgrad_ws`; `tmp` (2048 floats) links them.        */
 int sw_gen_wgrad(const float* enc_w, const float* gsave, const float* gdelta, const float* z,
                  const float* S_pool, int B, int To, int Tp, float* d_enc_w, float* d_dec_w, int part,
-                 float* wgrad_ws, float* tmp /*[2048]*/, void* stream);
+                 float* wgrad_ws, float* tmp /*[2048]*/,
+                 sw_wgrad_batch* pending /*or NULL: problems deferred by sw_social_pool_bwd join this launch*/,
+                 void* stream);
 
 /* ---- Discriminator.forward (train.py:294-309) for nb prediction branches sharing one
  *      observation encoding (fake / real of the same batch) ----------------------------------- */

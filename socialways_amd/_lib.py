@@ -34,10 +34,12 @@ PROTOTYPES = {
     "sw_embed_features": (_i, [_vp, _ll, _vp, _vp, _vp]),
     "sw_attention_pool_dense": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "sw_social_pool_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+                                _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sw_dec_rollout_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
     "sw_dec_rollout_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "sw_gen_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "sw_gen_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "sw_wgrad_batch_new": (_vp, []),
+    "sw_wgrad_batch_free": (None, [_vp]),
     "sw_disc_fwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "sw_disc_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sw_disc_bwd_gan": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void enc_compose_bwd_kernel(const float* __res
 // the 256x4 + 256 composed-matrix gradient between them.
 extern "C" int sw_gen_wgrad(const float* enc_w, const float* gsave, const float* gdelta, const float* z,
                             const float* S_pool, int B, int To, int Tp, float* d_enc_w, float* d_dec_w, int part,
-                            float* wgrad_ws, float* tmp, void* stream) {
+                            float* wgrad_ws, float* tmp, sw_wgrad_batch* pending, void* stream) {
   if (!enc_w || !gsave || !gdelta || !z || !S_pool || !d_enc_w || !d_dec_w || !wgrad_ws || !tmp || B < 1 || To < 2 ||
       Tp < 1 || part < 0 || part > 2)
     return SW_EARG;
@@ -147,6 +147,10 @@ extern "C" int sw_gen_wgrad(const float* enc_w, const float* gsave, const float*
   float* dbx = tmp + 1024;
   hipStream_t st = (hipStream_t)stream;
   WgBatch wb;
+  if (pending) {   // problems another module left for this launch (sw_social_pool_bwd with `defer`)
+    wb = *wg_pending(pending);
+    *wg_pending(pending) = WgBatch();
+  }
   int rc_add = 0;
   // EncoderLstm: W_hh against h_{t-1} (rows t >= 1), composed input matrix against x4 (all rows)
   const int t_lo = part == 1 ? To : 0, t_hi = part == 2 ? To : Ta;   // LSTM rows [t_lo, t_hi)

@@ -1211,7 +1211,7 @@ extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, con
                                   const float* emb_w, const float* att_w, const float* attn, const float* dS,
                                   float* dh, float* d_emb_w, float* d_att_w, float* pair_ws, float* wgrad_ws,
                                   const int* big_blocks, int NB, const float* wh_ws, const float* ml,
-                                  const float* S_pool, float* big_part_ws, void* stream) {
+                                  const float* S_pool, float* big_part_ws, sw_wgrad_batch* defer, void* stream) {
   if (!obsv || !h || !scene_off || !pair_off || !emb_w || !att_w || !attn || !dS || !dh || !d_emb_w || !d_att_w ||
       !pair_ws || !wgrad_ws || S < 0 || B < 0 || P < 0 || To < 2 || NB < 0)
     return SW_EARG;
@@ -1242,7 +1242,9 @@ extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, con
     hipLaunchKernelGGL(social_pool_bwd_rows_kernel, dim3(S), dim3(SW_THREADS), soc_lds(a16).bwd_total * 4, st, obsv, To, h,
                        scene_off, pair_off, emb_w, att_w, attn, dS, dh, dwh_rows, pr, a16);
     SW_CHECK_LAUNCH("social_pool_bwd_rows_kernel");
-    WgBatch wr;
+    WgBatch wr_local;
+    WgBatch& wr = defer ? *wg_pending(defer) : wr_local;
+    wr = WgBatch();
     int rc_r = 0;
     rc_r |= wg_add(wr, dwh_rows, 64, h, 64, B, 64, 64, d_att_w + swp::ATT_W, 64, d_att_w + swp::ATT_B, nullptr, 0);
     if (P > 0) {
@@ -1251,13 +1253,16 @@ extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, con
       rc_r |= wg_add(wr, pr.dh1, 32, pr.feat, 4, (int)P, 32, 3, d_emb_w + swp::EMB_W0, 3, d_emb_w + swp::EMB_B0, nullptr, 0);
     }
     if (rc_r) return SW_ESHAPE;
+    if (defer) return SW_OK;   // launched together with the caller's later problems (sw_gen_wgrad)
     return wg_launch(wr, wgrad_ws, st);
   }
   // in-register weight gradients: one partial slice per workgroup of the scene kernel (G) and of the row-block
   // kernel (NB), reduced together
   float* f_rows = pair_ws + (size_t)B * 64;
   const int G = S < 1024 ? S : 1024;   // workgroups: each walks scenes g, g+G, .. and leaves ONE weight-gradient partial
-  WgBatch wb;
+  WgBatch wb_local;
+  WgBatch& wb = defer ? *wg_pending(defer) : wb_local;
+  wb = WgBatch();
   int rc_add = 0;
   rc_add |= wg_add(wb, dwh_rows, 64, h, 64, B, 64, 64, d_att_w + swp::ATT_W, 64, d_att_w + swp::ATT_B, nullptr, 0);
   const int i3 = wb.np, i2 = wb.np + 1, i1 = wb.np + 2;
@@ -1265,7 +1270,6 @@ extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, con
   rc_add |= wg_add_pre(wb, 64, 32, d_emb_w + swp::EMB_W1, 32, d_emb_w + swp::EMB_B1, G + NB);
   rc_add |= wg_add_pre(wb, 32, 3, d_emb_w + swp::EMB_W0, 3, d_emb_w + swp::EMB_B0, G + NB);
   if (rc_add) return SW_ESHAPE;
-  if (wg_finalize(wb) > SW_WG_WS_FLOATS) return SW_ESHAPE;
   SocPart part{wgrad_ws + wb.p[i3].ws_off, wgrad_ws + wb.p[i2].ws_off, wgrad_ws + wb.p[i1].ws_off};
   if (NB > 0) {   // scenes above SW_AMAX agents: fills dh / dwh_rows of their agents
     hipLaunchKernelGGL(social_big_bwd_kernel, dim3(NB), dim3(SW_THREADS), lds_big, st, obsv, To, h, wh_ws, scene_off,
@@ -1278,5 +1282,6 @@ extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, con
   hipLaunchKernelGGL(social_pool_bwd_kernel, dim3(G), dim3(SW_THREADS), lds, st, obsv, To, h, scene_off, pair_off, S,
                      emb_w, att_w, attn, dS, dh, dwh_rows, f_rows, part, a16);
   SW_CHECK_LAUNCH("social_pool_bwd_kernel");
-  return wg_launch_finalized(wb, wgrad_ws, st);
+  if (defer) return SW_OK;
+  return wg_launch(wb, wgrad_ws, st);
 }

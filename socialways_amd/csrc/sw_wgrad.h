@@ -23,6 +23,7 @@ struct WgProblem {      // one column block (<= 64 act columns, optional trailin
 struct WgBatch {
   WgProblem p[SW_WG_MAXP];
   int np = 0, total_jobs = 0, total_out = 0;
+  size_t top_reserved = 0;   // floats handed out from the TOP of the workspace to precomputed-partial problems
 };
 
 int wg_add(WgBatch& b, const float* delta, int ldd, const float* act, int lda, int R, int N, int K, float* dW,
@@ -30,7 +31,9 @@ int wg_add(WgBatch& b, const float* delta, int ldd, const float* act, int lda, i
 double wg_total_work(const WgBatch& b);
 size_t wg_finalize(WgBatch& b);
 int wg_launch(WgBatch& b, float* ws, hipStream_t stream);
-// A problem whose per-slice partials [nslices][N][K+1] (bias in column K) another kernel writes at ws + ws_off
-// (known after wg_finalize); wg_launch_finalized then only reduces it.
+// A problem whose per-slice partials [nslices][N][K+1] (bias in column K) another kernel writes at ws + ws_off;
+// ws_off is fixed here (allocated from the top of the workspace), the launch then only reduces it.
 int wg_add_pre(WgBatch& b, int N, int K, float* dW, int ldw, float* db, int nslices);
 int wg_launch_finalized(WgBatch& b, float* ws, hipStream_t stream);
+struct sw_wgrad_batch;
+WgBatch* wg_pending(sw_wgrad_batch* h);   // the batch inside a handle (null -> null)

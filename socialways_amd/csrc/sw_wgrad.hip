@@ -207,6 +207,9 @@ int wg_add_pre(WgBatch& b, int N, int K, float* dW, int ldw, float* db, int nsli
   P.N = N; P.K = K; P.ones = 1; P.dW = dW; P.ldw = ldw; P.db = db; P.db2 = nullptr; P.accumulate = 0;
   P.nbn = (N + 15) / 16; P.nbk = (K + 1 + 15) / 16;
   P.pre = nslices;
+  b.top_reserved += (size_t)nslices * N * (K + 1);
+  if (b.top_reserved > SW_WG_WS_FLOATS) return SW_ESHAPE;
+  P.ws_off = SW_WG_WS_FLOATS - b.top_reserved;
   return SW_OK;
 }
 
@@ -261,13 +264,24 @@ size_t wg_finalize(WgBatch& b) {
     P.out0 = out;
     const int Kc = P.K + P.ones;
     out += P.N * Kc;
-    P.ws_off = ws;
-    ws += (size_t)ns * P.N * Kc;
+    if (!P.pre) {
+      P.ws_off = ws;
+      ws += (size_t)ns * P.N * Kc;
+    }
   }
   b.total_jobs = job;
   b.total_out = out;
-  return ws;
+  return ws + b.top_reserved;
 }
+
+// Host-side handle that carries the problems of one kernel sequence to a later launch (one wgrad launch per
+// backward pass instead of one per module: the launches are occupancy-bound, not work-bound).
+struct sw_wgrad_batch {
+  WgBatch b;
+};
+extern "C" sw_wgrad_batch* sw_wgrad_batch_new(void) { return new sw_wgrad_batch(); }
+extern "C" void sw_wgrad_batch_free(sw_wgrad_batch* h) { delete h; }
+WgBatch* wg_pending(sw_wgrad_batch* h) { return h ? &h->b : nullptr; }
 
 int wg_launch(WgBatch& b, float* ws, hipStream_t stream) {
   if (b.np == 0) return SW_OK;

@@ -62,11 +62,24 @@ class SceneIndex:
 
 
 class Workspaces:
-    """Grow-only fp32 scratch buffers keyed by name (saves, deltas, split-K partials)."""
+    """Grow-only fp32 scratch buffers keyed by name (saves, deltas, split-K partials) and the host-side handle
+    that lets the weight-gradient problems of one backward pass share a launch."""
 
     def __init__(self, device):
         self.device = device
         self.buf = {}
+        self._wgb = None
+
+    @property
+    def wgrad_batch(self):
+        if self._wgb is None:
+            self._wgb = L.load().sw_wgrad_batch_new()
+        return self._wgb
+
+    def __del__(self):
+        if getattr(self, "_wgb", None):
+            L.load().sw_wgrad_batch_free(self._wgb)
+            self._wgb = None
 
     def get(self, name, nfloats):
         t = self.buf.get(name)
@@ -154,9 +167,12 @@ def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d
     L.call("sw_dec_rollout_bwd", L.ptr(dpred4), L.ptr(enc_w), L.ptr(dec_w), L.ptr(ctx.gsave), B, To, Tp,
            L.ptr(gdelta), L.ptr(dhT), L.ptr(dcT), L.ptr(dS), L.stream())
 
-    def wgrad_part(part, wsbuf):
+    # the social block's weight-gradient problems ride in the generator's (single) launch at the end of the pass
+    defer = ws.wgrad_batch if side is None else None
+
+    def wgrad_part(part, wsbuf, pending=None):
         L.call("sw_gen_wgrad", L.ptr(enc_w), L.ptr(ctx.gsave), L.ptr(gdelta), L.ptr(ctx.noise), L.ptr(ctx.S), B, To, Tp,
-               L.ptr(d_enc), L.ptr(d_dec), part, L.ptr(wsbuf), L.ptr(tmp), L.stream())
+               L.ptr(d_enc), L.ptr(d_dec), part, L.ptr(wsbuf), L.ptr(tmp), pending, L.stream())
 
     if side is not None:
         main = torch.cuda.current_stream()
@@ -170,17 +186,19 @@ def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d
         L.call("sw_social_pool_bwd", L.ptr(ctx.obsv), To, L.ptr(ctx.hT), L.ptr(sc.scene_off), L.ptr(sc.pair_off), sc.S,
                B, sc.amax, sc.P, L.ptr(emb_w), L.ptr(att_w), L.ptr(ctx.attn), L.ptr(dS), L.ptr(dhT), L.ptr(d_emb),
                L.ptr(d_att), L.ptr(pws), L.ptr(wgrad), L.ptr(sc.big_blocks), sc.NB, L.ptr(ctx.wh), L.ptr(ctx.ml),
-               L.ptr(ctx.S), L.ptr(bigp), L.stream())
+               L.ptr(ctx.S), L.ptr(bigp), defer, L.stream())
+        social_deferred = defer is not None
     else:
         d_emb.zero_()
         d_att.zero_()
+        social_deferred = False
     L.call("sw_enc_lstm_bwd", L.ptr(enc_w), L.ptr(ctx.gsave), None, L.ptr(dhT), L.ptr(dcT), None, B, To, 0,
            L.ptr(gdelta), None, None, L.stream())
     if side is not None:
         torch.cuda.current_stream().wait_stream(side)
         wgrad_part(2, wgrad)
     else:
-        wgrad_part(0, wgrad)
+        wgrad_part(0, wgrad, defer if social_deferred else None)
 
 
 class DiscCtx:
