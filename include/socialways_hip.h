@@ -72,6 +72,12 @@ int sw_traj_4d(const float* obsv /*[B,To,2]*/, const float* pred /*[B,Tp,2] or N
 int sw_enc_lstm_fwd(const float* x, int x_mode, const float* enc_w, const float* h0, const float* c0,
                     int B, int T, float* hT, float* cT, float* y /*[B,T,64]*/, float* act,
                     float* x4s, int t0, void* stream);
+/* Same, plus an auxiliary copy aux_src -> aux_dst (aux_n floats, multiple of 4; aux_src may be host-pinned memory)
+ * done by extra workgroups of the same launch: the LSTM kernel is latency-bound and leaves CUs idle, so the
+ * training step fetches z from its pinned slot here instead of in a kernel of its own.                        */
+int sw_enc_lstm_fwd_aux(const float* x, int x_mode, const float* enc_w, const float* h0, const float* c0, int B, int T,
+                        float* hT, float* cT, float* y, float* act, float* x4s, int t0, const float* aux_src,
+                        float* aux_dst, long long aux_n, void* stream);
 /* BPTT over rows t0+T-1 .. t0 of `act`; dhT/dcT = gradient w.r.t. the final state (dcT may be
  * NULL); dy optional [B,T,64].  Writes dgates rows [t][B][256]; dh0/dc0 optional outputs.       */
 int sw_enc_lstm_bwd(const float* enc_w, const float* act, const float* c0, const float* dhT,
@@ -209,7 +215,7 @@ int sw_copy3_f32(float* d0, const float* s0, long long n0, float* d1, const floa
  *      [2,3] device pointer of pred (B,Tp,2), [4] zeros_val, [5] ones_val, [6] / [7] number of D / G Adam
  *      updates applied so far, [8..] z (B*32).
  *      Writes the static buffers of the graph: tracks, real future as (p,v) rows (train.py:135-137),
- *      label-noise scalars, z and (steps_dst != NULL) the 1-based Adam step indices of this step's
+ *      label-noise scalars, z (z_dst may be NULL: fetched elsewhere) and (steps_dst != NULL) the 1-based Adam step indices of this step's
  *      n_d_updates discriminator updates followed by the generator update. -------------------------- */
 #define SW_STAGE_HEADER 8
 int sw_stage_step(const float* slot, int B, int To, int Tp, float* obsv_dst /*[B,To,2]*/, float* pred_dst /*[B,Tp,2]*/,

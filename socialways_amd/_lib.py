@@ -28,6 +28,7 @@ PROTOTYPES = {
     "sw_workspace_floats": (ctypes.c_size_t, [_i, _i, _i, _i, _i, _ll]),
     "sw_traj_4d": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "sw_enc_lstm_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "sw_enc_lstm_fwd_aux": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _ll, _vp]),
     "sw_enc_lstm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "sw_social_pool_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "sw_social_features": (_i, [_vp, _i, _vp, _vp]),

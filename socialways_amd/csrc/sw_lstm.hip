@@ -16,7 +16,17 @@ __device__ __forceinline__ float obs_x4(const float* pos, int b, int t, int T, i
 __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
     const float* __restrict__ x, int x_mode, const float* __restrict__ enc_w, const float* __restrict__ h0,
     const float* __restrict__ c0, int B, int T, float* __restrict__ hT, float* __restrict__ cT,
-    float* __restrict__ y, float* __restrict__ act, float* __restrict__ x4s, int t0) {
+    float* __restrict__ y, float* __restrict__ act, float* __restrict__ x4s, int t0, const float* __restrict__ aux_src,
+    float* __restrict__ aux_dst, long long aux_n) {
+  // Workgroups beyond the agent tiles only copy aux_src -> aux_dst (the training step pulls z out of its pinned
+  // host slot here: 128 tiles leave half of the CUs idle for the whole latency-bound kernel, the PCIe read is free)
+  const int tiles = (B + SW_TILE - 1) / SW_TILE;
+  if ((int)blockIdx.x >= tiles) {
+    const long long n4 = aux_n >> 2, stride = (long long)(gridDim.x - tiles) * SW_THREADS;
+    for (long long i = (long long)(blockIdx.x - tiles) * SW_THREADS + threadIdx.x; i < n4; i += stride)
+      st4(aux_dst + 4 * i, ld4(aux_src + 4 * i));
+    return;
+  }
   __shared__ __attribute__((aligned(16))) float hbuf[2][SW_TILE * SW_HLD];
   __shared__ __attribute__((aligned(16))) float wx_lds[256 * 4];
   __shared__ __attribute__((aligned(16))) float bx_lds[256];
@@ -156,16 +166,26 @@ extern "C" int sw_traj_4d(const float* obsv, const float* pred, int B, int To, i
   return SW_OK;
 }
 
+extern "C" int sw_enc_lstm_fwd_aux(const float* x, int x_mode, const float* enc_w, const float* h0,
+                                   const float* c0, int B, int T, float* hT, float* cT, float* y, float* act,
+                                   float* x4s, int t0, const float* aux_src, float* aux_dst, long long aux_n,
+                                   void* stream) {
+  if (!x || !enc_w || !hT || !cT || B < 0 || T < 1 || t0 < 0 || (x_mode != 0 && x_mode != 1)) return SW_EARG;
+  if (aux_n < 0 || (aux_n & 3) || (aux_n > 0 && (!aux_src || !aux_dst))) return SW_EARG;
+  if (x_mode == 0 && T < 2) return SW_ESHAPE;  // the observation velocity rule needs 2 points
+  if (B == 0) return SW_OK;
+  const int tiles = (B + SW_TILE - 1) / SW_TILE;
+  int extra = aux_n > 0 ? (int)((aux_n / 4 + SW_THREADS - 1) / SW_THREADS) : 0;
+  if (extra > 64) extra = 64;
+  hipLaunchKernelGGL(enc_lstm_fwd_kernel, dim3(tiles + extra), dim3(SW_THREADS), 0, (hipStream_t)stream, x, x_mode, enc_w,
+                     h0, c0, B, T, hT, cT, y, act, x4s, t0, aux_src, aux_dst, aux_n);
+  SW_CHECK_LAUNCH("enc_lstm_fwd_kernel");
+  return SW_OK;
+}
 extern "C" int sw_enc_lstm_fwd(const float* x, int x_mode, const float* enc_w, const float* h0,
                                const float* c0, int B, int T, float* hT, float* cT, float* y, float* act,
                                float* x4s, int t0, void* stream) {
-  if (!x || !enc_w || !hT || !cT || B < 0 || T < 1 || t0 < 0 || (x_mode != 0 && x_mode != 1)) return SW_EARG;
-  if (x_mode == 0 && T < 2) return SW_ESHAPE;  // the observation velocity rule needs 2 points
-  if (B == 0) return SW_OK;
-  hipLaunchKernelGGL(enc_lstm_fwd_kernel, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS), 0,
-                     (hipStream_t)stream, x, x_mode, enc_w, h0, c0, B, T, hT, cT, y, act, x4s, t0);
-  SW_CHECK_LAUNCH("enc_lstm_fwd_kernel");
-  return SW_OK;
+  return sw_enc_lstm_fwd_aux(x, x_mode, enc_w, h0, c0, B, T, hT, cT, y, act, x4s, t0, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int sw_enc_lstm_bwd(const float* enc_w, const float* act, const float* c0, const float* dhT,

@@ -444,7 +444,8 @@ __global__ __launch_bounds__(256) void stage_step_kernel(const float* __restrict
   const float* obsv = reinterpret_cast<const float*>(ptrs[0]);
   const float* pred = reinterpret_cast<const float*>(ptrs[1]);
   const int gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
-  for (int i = gid; i < B * SW_Z / 4; i += gsz) st4(z_dst + 4 * (size_t)i, ld4(slot + 8 + 4 * (size_t)i));
+  if (z_dst)
+    for (int i = gid; i < B * SW_Z / 4; i += gsz) st4(z_dst + 4 * (size_t)i, ld4(slot + 8 + 4 * (size_t)i));
   if (gid < 2) targets_dst[gid] = slot[4 + gid];
   // 1-based Adam step indices of this training step's updates: D update u -> [u], the G update -> [n_d_updates]
   if (steps_dst && gid <= n_d_updates) steps_dst[gid] = gid < n_d_updates ? slot[6] + 1.0f + (float)gid : slot[7] + 1.0f;
@@ -461,10 +462,10 @@ __global__ __launch_bounds__(256) void stage_step_kernel(const float* __restrict
 extern "C" int sw_stage_step(const float* slot, int B, int To, int Tp, float* obsv_dst, float* pred_dst,
                              float* pred4_dst, float* targets_dst, float* z_dst, float* steps_dst, int n_d_updates,
                              void* stream) {
-  if (!slot || !obsv_dst || !pred_dst || !pred4_dst || !targets_dst || !z_dst || B < 1 || To < 2 || Tp < 1 ||
+  if (!slot || !obsv_dst || !pred_dst || !pred4_dst || !targets_dst || B < 1 || To < 2 || Tp < 1 ||
       n_d_updates < 0 || n_d_updates > 254)
     return SW_EARG;
-  int n = B * SW_Z / 4;
+  int n = z_dst ? B * SW_Z / 4 : B * (To > Tp ? To : Tp);
   int blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(stage_step_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slot, B, To, Tp, obsv_dst,

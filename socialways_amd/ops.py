@@ -102,11 +102,13 @@ class GenCtx:
     __slots__ = ("obsv", "noise", "scenes", "hT", "cT", "S", "attn", "gsave", "B", "To", "Tp", "use_social", "wh", "ml")
 
 
-def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_social, save, ws=None, tag="g", ade=None):
+def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_social, save, ws=None, tag="g", ade=None,
+                noise_src=None):
     """predict(): encode obs (train.py:397-404), social pooling (408-413), decode loop (415-432).
     Returns pred_hat_4d (B, n_next, 4) and, if `save`, the context backward needs.
     ade = (gt (B,n_next,2), 1/ss, out (ceil(B/16),3)): the decode kernel also leaves the per-tile ADE/FDE
-    partial sums of train.py:546-551 in `out`."""
+    partial sums of train.py:546-551 in `out`.
+    noise_src: address `noise` is filled from (pinned host memory) by idle workgroups of the encoder launch."""
     L.require_gpu(obsv)
     obsv = obsv.contiguous()
     noise = noise.contiguous()
@@ -124,8 +126,9 @@ def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_soc
         gsave = ws.get(tag + ".gsave", nfl) if ws is not None else torch.empty(nfl, device=dev)
     # act rows live at offset 0 of gsave, x4s right behind (sw_common.h:gsave_layout)
     x4s_off = (To + n_next - 1) * B * 384
-    L.call("sw_enc_lstm_fwd", L.ptr(obsv), 0, L.ptr(enc_w), None, None, B, To, L.ptr(hT), L.ptr(cT), None,
-           L.ptr(gsave), (gsave.data_ptr() + 4 * x4s_off) if save else None, 0, st)
+    L.call("sw_enc_lstm_fwd_aux", L.ptr(obsv), 0, L.ptr(enc_w), None, None, B, To, L.ptr(hT), L.ptr(cT), None,
+           L.ptr(gsave), (gsave.data_ptr() + 4 * x4s_off) if save else None, 0,
+           noise_src, L.ptr(noise) if noise_src else None, noise.numel() if noise_src else 0, st)
     attn = wh = ml = None
     if use_social:
         S = torch.empty(B, 64, device=dev)

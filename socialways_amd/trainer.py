@@ -145,6 +145,7 @@ class SocialWaysTrainer:
         self.rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
         self.ws = ops.Workspaces(self.device)
         self._lin_mask = None
+        self._noise_src = None
         self.epoch = 0
 
     # ------------------------------------------------------------------------------------------
@@ -234,8 +235,9 @@ class SocialWaysTrainer:
 
         def stage(kk):
             L.call("sw_stage_step", st["slots"][kk][0].data_ptr(), B, To, Tp, L.ptr(st["obsv"]), L.ptr(st["pred"]),
-                   L.ptr(st["pred4"]), L.ptr(st["targets"]), L.ptr(st["noise"]), L.ptr(st["steps"]), self.n_unrolling_steps + 1,
+                   L.ptr(st["pred4"]), L.ptr(st["targets"]), None, L.ptr(st["steps"]), self.n_unrolling_steps + 1,
                    L.stream())
+            self._noise_src = st["slots"][kk][0].data_ptr() + 4 * HDR     # z: pulled by idle workgroups of the encoder launch
         args = (st["obsv"], st["pred"], st["pred4"], scenes, st["targets"], st["noise"], ss, Bg, st["out"],
                 st["steps"] if packed else None)
         if st["graph"] is not None:
@@ -305,6 +307,7 @@ class SocialWaysTrainer:
         # this runtime - more than any of the small kernels that could be overlapped (measured).
         if pre is not None:
             pre()
+        noise_src, self._noise_src = self._noise_src, None      # set by the staging of this step (graph / warm-up path)
         if pred4 is None:          # real future as 4-d (train.py:470); the observation stays 2-d: kernels form (p, v) on the fly
             pred4 = torch.empty(B, Tp, 4, device=dev)
             o4_scratch = ws.get("o4", B * obsv.shape[1] * 4)
@@ -313,7 +316,8 @@ class SocialWaysTrainer:
         enc, emb, att, dec = G.encoder, G.feature_embedder, G.attention, G.decoder
         # the decode kernel also leaves the ADE/FDE partial sums of the prediction (train.py:546-551)
         pred_hat, gctx = ops.gen_forward(enc._flat, emb._flat, att._flat, dec._flat, obsv, noise, scenes, Tp,
-                                         G.use_social, save=True, ws=ws, ade=(pred, 1.0 / float(ss), out[U + 2]))
+                                         G.use_social, save=True, ws=ws, ade=(pred, 1.0 / float(ss), out[U + 2]),
+                                         noise_src=noise_src)
         d_gflat = D.grad_views()
         backup = None
         # ---- discriminator updates (train.py:476-499) ------------------------------------------------
