@@ -142,6 +142,11 @@ int sw_dec_rollout_fwd(const float* obsv /*[B,To,2]*/, int To, const float* z /*
 int sw_dec_rollout_bwd(const float* dpred4 /*[B,Tp,4]*/, const float* enc_w, const float* dec_w,
                        const float* gsave, int B, int To, int Tp, float* gdelta,
                        float* dhT, float* dcT, float* dS_pool /*[B,64]*/, void* stream);
+/* Same, plus an auxiliary masked copy aux_dst[i] = aux_mask[i] > 0 ? aux_src[i] : aux_dst[i] (aux_n floats) done by
+ * extra workgroups of the launch (idle CUs): the training step's D.load(backup) (train.py:541-542).          */
+int sw_dec_rollout_bwd_aux(const float* dpred4, const float* enc_w, const float* dec_w, const float* gsave, int B,
+                           int To, int Tp, float* gdelta, float* dhT, float* dcT, float* dS_pool,
+                           const float* aux_src, float* aux_dst, const float* aux_mask, long long aux_n, void* stream);
 /* weight gradients of the whole generator rollout (encoder + decoder) from gsave/gdelta.
  * part 0 = all; 1 = what dec_rollout_bwd produced (decoder layers + LSTM rows t >= To); 2 = LSTM rows
  * t < To (after enc_lstm_bwd) accumulated onto part 1, then the embed / W_ih split.  Parts 1 and 2
@@ -159,6 +164,7 @@ int sw_disc_fwd(const float* obsv, int To, int x_mode, const float* const* pred4
                 int nb, const float* d_w, int B, int Tp, float* const* label /*nb x [B,1]*/,
                 float* const* code /*nb x [B,2]*/, float* dsave /*or NULL*/,
                 int save_lstm /*0: head activations only - enough for a backward that wants d/dpred only*/,
+                float* w_snapshot /*or NULL: receives a copy of d_w (sw_param_count floats) - deepcopy(D), train.py:499*/,
                 void* stream);
 /* dlabel/dcode: nb x gradients of the loss w.r.t. label / code.  d_d_w NULL = skip weight grads
  * (generator phase), dpred4[k] NULL = skip input grad of branch k.                              */

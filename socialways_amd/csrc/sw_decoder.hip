@@ -226,7 +226,19 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
 __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
     const float* __restrict__ dpred4, const float* __restrict__ enc_w, const float* __restrict__ dec_w,
     const float* __restrict__ gsave, int B, int To, int Tp, float* __restrict__ gdelta,
-    float* __restrict__ dhT, float* __restrict__ dcT, float* __restrict__ dS_pool) {
+    float* __restrict__ dhT, float* __restrict__ dcT, float* __restrict__ dS_pool, const float* __restrict__ aux_src,
+    float* __restrict__ aux_dst, const float* __restrict__ aux_mask, long long aux_n) {
+  // Workgroups beyond the agent tiles run an auxiliary masked copy dst[i] = mask[i] > 0 ? src[i] : dst[i]
+  // (the training step's D.load(backup), train.py:541-542, on CUs this latency-bound launch leaves idle)
+  {
+    const int tiles = (B + SW_TILE - 1) / SW_TILE;
+    if ((int)blockIdx.x >= tiles) {
+      const long long stride = (long long)(gridDim.x - tiles) * SW_THREADS;
+      for (long long i = (long long)(blockIdx.x - tiles) * SW_THREADS + threadIdx.x; i < aux_n; i += stride)
+        if (aux_mask[i] > 0.f) aux_dst[i] = aux_src[i];
+      return;
+    }
+  }
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W1hT = smem + BwdLds::W1hT;
   float* W2T = smem + BwdLds::W2T;
@@ -444,20 +456,31 @@ extern "C" int sw_dec_rollout_fwd(const float* obsv, int To, const float* z, con
   return SW_OK;
 }
 
-extern "C" int sw_dec_rollout_bwd(const float* dpred4, const float* enc_w, const float* dec_w,
-                                  const float* gsave, int B, int To, int Tp, float* gdelta, float* dhT,
-                                  float* dcT, float* dS_pool, void* stream) {
+extern "C" int sw_dec_rollout_bwd_aux(const float* dpred4, const float* enc_w, const float* dec_w,
+                                      const float* gsave, int B, int To, int Tp, float* gdelta, float* dhT,
+                                      float* dcT, float* dS_pool, const float* aux_src, float* aux_dst,
+                                      const float* aux_mask, long long aux_n, void* stream) {
   if (!dpred4 || !enc_w || !dec_w || !gsave || !gdelta || !dhT || !dcT || B < 0 || To < 2 || Tp < 1)
     return SW_EARG;
+  if (aux_n < 0 || (aux_n > 0 && (!aux_src || !aux_dst || !aux_mask))) return SW_EARG;
   if (B == 0) return SW_OK;
   static bool attr = false;
   if (!attr) {
     if (int rc = set_lds((const void*)dec_rollout_bwd_kernel, BwdLds::total * 4)) return rc;
     attr = true;
   }
-  hipLaunchKernelGGL(dec_rollout_bwd_kernel, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS),
-                     BwdLds::total * 4, (hipStream_t)stream, dpred4, enc_w, dec_w, gsave, B, To, Tp, gdelta,
-                     dhT, dcT, dS_pool);
+  const int tiles = (B + SW_TILE - 1) / SW_TILE;
+  int extra = aux_n > 0 ? (int)((aux_n + SW_THREADS - 1) / SW_THREADS) : 0;
+  if (extra > 64) extra = 64;
+  hipLaunchKernelGGL(dec_rollout_bwd_kernel, dim3(tiles + extra), dim3(SW_THREADS), BwdLds::total * 4, (hipStream_t)stream,
+                     dpred4, enc_w, dec_w, gsave, B, To, Tp, gdelta, dhT, dcT, dS_pool, aux_src, aux_dst, aux_mask, aux_n);
   SW_CHECK_LAUNCH("dec_rollout_bwd_kernel");
   return SW_OK;
+}
+
+extern "C" int sw_dec_rollout_bwd(const float* dpred4, const float* enc_w, const float* dec_w,
+                                  const float* gsave, int B, int To, int Tp, float* gdelta, float* dhT,
+                                  float* dcT, float* dS_pool, void* stream) {
+  return sw_dec_rollout_bwd_aux(dpred4, enc_w, dec_w, gsave, B, To, Tp, gdelta, dhT, dcT, dS_pool, nullptr, nullptr,
+                                nullptr, 0, stream);
 }

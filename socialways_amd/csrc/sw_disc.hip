@@ -109,7 +109,8 @@ __host__ __device__ inline HeadLds head_lds(int Tp, int base) {
 __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
     const float* __restrict__ obsv, int To, int x_mode, const float* __restrict__ pred_a,
     const float* __restrict__ pred_b, int nb, const float* __restrict__ d_w, int B, int Tp, float* __restrict__ label_a, float* __restrict__ label_b,
-    float* __restrict__ code_a, float* __restrict__ code_b, float* __restrict__ dsave, int save_lstm, int split) {
+    float* __restrict__ code_a, float* __restrict__ code_b, float* __restrict__ dsave, int save_lstm, int split,
+    float* __restrict__ w_snap) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // LSTM part
   float* hbuf = smem;                        // [2][16][68]
@@ -133,6 +134,8 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
 
   LstmW W;
   lstm_load_whh(W, d_w + O.whh, u0, ln, lg);   // global loads in flight during the LDS staging
+  if (w_snap)   // deepcopy(D) of train.py:499: the weights this pass runs with, a few floats per thread
+    for (int i = blockIdx.x * SW_THREADS + threadIdx.x; i < O.n; i += gridDim.x * SW_THREADS) w_snap[i] = d_w[i];
   // ---- stage head weights / biases ------------------------------------------------------------
   stage_w(smem + L.of0, LD64, 32, d_w + O.of0w, 64, 32, 64);
   stage_w(smem + L.of1, LD32, 32, d_w + O.of1w, 32, 32, 32);
@@ -504,7 +507,7 @@ size_t sw_ddelta_floats(int B, int To, int Tp, int nb) { return ddelta_layout(B,
 
 extern "C" int sw_disc_fwd(const float* obsv, int To, int x_mode, const float* const* pred4, int nb,
                            const float* d_w, int B, int Tp, float* const* label, float* const* code, float* dsave,
-                           int save_lstm, void* stream) {
+                           int save_lstm, float* w_snapshot, void* stream) {
   if (!obsv || !pred4 || !d_w || !label || !code || nb < 1 || nb > SW_DISC_MAXB || B < 0 || To < 1 || Tp < 1 ||
       (x_mode != 0 && x_mode != 1) || (x_mode == 0 && To < 2))
     return SW_EARG;
@@ -523,7 +526,7 @@ extern "C" int sw_disc_fwd(const float* obsv, int To, int x_mode, const float* c
   const int split = (nb == 2 && 2 * tiles <= SW_SPLIT_MAX_WGS) ? 1 : 0;   // idle CUs: one workgroup per (tile, branch)
   hipLaunchKernelGGL(disc_fwd_kernel, dim3(split ? 2 * tiles : tiles), dim3(SW_THREADS), lds, (hipStream_t)stream,
                      obsv, To, x_mode, pred4[0], nb > 1 ? pred4[1] : nullptr, nb, d_w, B, Tp, label[0],
-                     nb > 1 ? label[1] : nullptr, code[0], nb > 1 ? code[1] : nullptr, dsave, save_lstm, split);
+                     nb > 1 ? label[1] : nullptr, code[0], nb > 1 ? code[1] : nullptr, dsave, save_lstm, split, w_snapshot);
   SW_CHECK_LAUNCH("disc_fwd_kernel");
   return SW_OK;
 }

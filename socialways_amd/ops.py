@@ -152,7 +152,8 @@ def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_soc
     return pred4, ctx
 
 
-def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d_dec, ws=None, tag="g", side=None):
+def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d_dec, ws=None, tag="g", side=None,
+                 aux=None):
     """Backward of predict(): decode BPTT -> social block -> obs BPTT -> deferred weight GEMMs.
     d_* are the packed gradient buffers (overwritten).  With a `side` stream the weight-gradient GEMMs
     of the decode phase (all-CU, independent of the social / observation BPTT that follows on a
@@ -167,8 +168,10 @@ def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d
     dhT = torch.empty(B, 64, device=dev)
     dcT = torch.empty(B, 64, device=dev)
     dS = torch.empty(B, 64, device=dev)
-    L.call("sw_dec_rollout_bwd", L.ptr(dpred4), L.ptr(enc_w), L.ptr(dec_w), L.ptr(ctx.gsave), B, To, Tp,
-           L.ptr(gdelta), L.ptr(dhT), L.ptr(dcT), L.ptr(dS), L.stream())
+    # aux = (src, dst, mask): masked copy dst = mask > 0 ? src : dst done by idle workgroups of the decode BPTT launch
+    L.call("sw_dec_rollout_bwd_aux", L.ptr(dpred4), L.ptr(enc_w), L.ptr(dec_w), L.ptr(ctx.gsave), B, To, Tp,
+           L.ptr(gdelta), L.ptr(dhT), L.ptr(dcT), L.ptr(dS), L.ptr(aux[0]) if aux else None, L.ptr(aux[1]) if aux else None,
+           L.ptr(aux[2]) if aux else None, aux[1].numel() if aux else 0, L.stream())
 
     # the social block's weight-gradient problems ride in the generator's (single) launch at the end of the pass
     defer = ws.wgrad_batch if side is None else None
@@ -208,7 +211,7 @@ class DiscCtx:
     __slots__ = ("dsave", "B", "To", "Tp", "nb")
 
 
-def disc_forward(d_w, obsv, preds, save, ws=None, tag="d", save_lstm=True):
+def disc_forward(d_w, obsv, preds, save, ws=None, tag="d", save_lstm=True, w_snapshot=None):
     """Discriminator.forward for 1 or 2 future branches sharing the observation encoding.
     Returns ([label_k (B,1)], [code_k (B,2)], ctx)."""
     L.require_gpu(obsv)
@@ -229,7 +232,7 @@ def disc_forward(d_w, obsv, preds, save, ws=None, tag="d", save_lstm=True):
     lp, _k2 = L.ptr_array(labels)
     cp, _k3 = L.ptr_array(codes)
     L.call("sw_disc_fwd", L.ptr(obsv), To, x_mode, pp, nb, L.ptr(d_w), B, Tp, lp, cp, L.ptr(dsave), 1 if save_lstm else 0,
-           L.stream())
+           L.ptr(w_snapshot), L.stream())
     if not save:
         return labels, codes, None
     ctx = DiscCtx()

@@ -145,6 +145,7 @@ class SocialWaysTrainer:
         self.rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
         self.ws = ops.Workspaces(self.device)
         self._lin_mask = None
+        self._lin_maskf = None
         self._noise_src = None
         self.epoch = 0
 
@@ -322,15 +323,15 @@ class SocialWaysTrainer:
         backup = None
         # ---- discriminator updates (train.py:476-499) ------------------------------------------------
         for u in range(self.n_unrolling_steps + 1):
-            labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat, pred4], save=True, ws=ws)
+            if u == 1:     # deepcopy(D) after the first update (train.py:498-499) = the weights of this forward pass
+                backup = ws.get("d_backup", D._flat.numel())
+            labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat, pred4], save=True, ws=ws,
+                                                   w_snapshot=backup if u == 1 else None)
             # the loss gradients AND the reported loss sums (per-tile partials) are formed inside the backward kernel
             ops.disc_backward_gan(D._flat, dctx, labels, codes, targets, (0, 1), noise, g_label, g_code, d_gflat, (), ws=ws,
                                   loss_part=out[u])
             yield d_gflat
             self.D_optimizer.step() if steps is None else self.D_optimizer.step(steps[u])
-            if u == 0 and self.n_unrolling_steps > 0:
-                backup = ws.get("d_backup", D._flat.numel())
-                backup[:D._flat.numel()].copy_(D._flat)
         # ---- generator update (train.py:503-539) ----------------------------------------------------
         labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat], save=True, ws=ws, save_lstm=False)   # only d/dpred is needed
         dpred = ops.disc_backward_gan(D._flat, dctx, labels, codes, targets, (1, 1), noise, g_label, g_code, None, (True,),
@@ -341,13 +342,14 @@ class SocialWaysTrainer:
             r = 19 - self._row0
             if 0 <= r < B:
                 L.call("sw_l2_grad", L.ptr(pred_hat), L.ptr(pred), B, Tp, r, r + 1, self.loss_l2_w / Tp, L.ptr(dpred), L.stream())
-        if self.n_unrolling_steps > 0:                                       # D.load(backup), Linear only: D is not
-            if self._lin_mask is None:                                      # read again in this step -> side stream
-                self._lin_mask = D.linear_mask() > 0
-            torch.where(self._lin_mask, backup[:D._flat.numel()], D._flat, out=D._flat)
+        restore = None
+        if self.n_unrolling_steps > 0:     # D.load(backup) restores the Linear layers only (train.py:311-316, 541-542); D is
+            if self._lin_maskf is None:    # not read again in this step: done by idle workgroups of the decode BPTT launch
+                self._lin_maskf = D.linear_mask().float().contiguous()
+            restore = (backup[:D._flat.numel()], D._flat, self._lin_maskf)
         G.grad_views()
         ops.gen_backward(enc._flat, emb._flat, att._flat, dec._flat, gctx, dpred, enc._gflat, emb._gflat, att._gflat,
-                         dec._gflat, ws=ws, side=None)   # (side-stream wgrad starves the BPTT chain of CUs: measured slower)
+                         dec._gflat, ws=ws, side=None, aux=restore)   # (side-stream wgrad starves the BPTT chain of CUs: measured slower)
         yield G._gflat_all
         self.predictor_optimizer.step() if steps is None else self.predictor_optimizer.step(steps[U + 1])
         self.last_pred_hat = pred_hat
