@@ -137,11 +137,17 @@ __global__ __launch_bounds__(SW_THREADS) void wgrad_partial_kernel(WgBatch batch
   }
 }
 
-// out element e of problem p = sum over slices, 16 lanes per element (slices q = lane&15, +16, ...),
-// combined by a fixed shuffle tree.
+// out element e of problem p = sum over slices.  A wave owns SW_WG_REL consecutive elements (lanes el = lane %
+// REL: one coalesced segment per slice) and splits the slices SW_WG_RSUB ways (sub = lane / REL handles slices
+// q = sub, sub + RSUB, ..), 4 independent loads in flight per lane; the sub-sums meet in a fixed shuffle tree.
+#ifndef SW_WG_RSUB
+#define SW_WG_RSUB 4
+#endif
+#define SW_WG_REL (64 / SW_WG_RSUB)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgBatch batch, const float* __restrict__ ws) {
-  int gid = blockIdx.x * 256 + threadIdx.x;
-  int i = gid >> 4, sub = gid & 15;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int lane = gid & 63, el = lane % SW_WG_REL, sub = lane / SW_WG_REL;
+  const int i = (gid >> 6) * SW_WG_REL + el;
   bool live = i < batch.total_out;
   int ii = live ? i : batch.total_out - 1;
   int p = 0;
@@ -155,18 +161,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgBatch batch, const 
   float s = 0.f;
   float s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int q = sub;
-  for (; q + 48 < P.nsplit; q += 64) {  // 4 independent loads in flight per lane, fixed combination order
+  for (; q + 3 * SW_WG_RSUB < P.nsplit; q += 4 * SW_WG_RSUB) {  // fixed combination order
     s += src[(size_t)q * stride];
-    s1 += src[(size_t)(q + 16) * stride];
-    s2 += src[(size_t)(q + 32) * stride];
-    s3 += src[(size_t)(q + 48) * stride];
+    s1 += src[(size_t)(q + SW_WG_RSUB) * stride];
+    s2 += src[(size_t)(q + 2 * SW_WG_RSUB) * stride];
+    s3 += src[(size_t)(q + 3 * SW_WG_RSUB) * stride];
   }
-  for (; q < P.nsplit; q += 16) s += src[(size_t)q * stride];
+  for (; q < P.nsplit; q += SW_WG_RSUB) s += src[(size_t)q * stride];
   s = (s + s1) + (s2 + s3);
-  s += __shfl_xor(s, 1);
-  s += __shfl_xor(s, 2);
-  s += __shfl_xor(s, 4);
-  s += __shfl_xor(s, 8);
+#pragma unroll
+  for (int o = SW_WG_REL; o < 64; o <<= 1) s += __shfl_xor(s, o);
   if (!live || sub != 0) return;
   int n = e / Kc, k = e - n * Kc;
   if (k < P.K) {
@@ -296,7 +300,7 @@ int wg_launch_finalized(WgBatch& b, float* ws, hipStream_t stream) {
     hipLaunchKernelGGL(wgrad_partial_kernel, dim3(b.total_jobs), dim3(SW_THREADS), 0, stream, b, ws);
     SW_CHECK_LAUNCH("wgrad_partial_kernel");
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((b.total_out * 16 + 255) / 256), dim3(256), 0, stream, b, ws);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((b.total_out * SW_WG_RSUB + 255) / 256), dim3(256), 0, stream, b, ws);
   SW_CHECK_LAUNCH("wgrad_reduce_kernel");
   return SW_OK;
 }
