@@ -210,12 +210,6 @@ int sw_l2_grad(const float* pred4_hat /*[B,Tp,4]*/, const float* gt /*[B,Tp,2]*/
 int sw_traj_dist(const float* a /*[Na,nPed,T,2]*/, const float* b /*[Nb,nPed,T,2]*/, int Na, int Nb, int nPed, int T,
                  int t0, float* D /*[nPed,Na,Nb]*/, void* stream);
 
-/* ---- staging copy by a device kernel: `src` may be host-pinned (device-mapped) memory; used to feed
- *      z / label-noise scalars to hipGraph-replayed steps without a blocking hipMemcpyAsync ---------- */
-int sw_copy_f32(float* dst, const float* src, long long n, void* stream);
-int sw_copy3_f32(float* d0, const float* s0, long long n0, float* d1, const float* s1, long long n1,
-                 float* d2, const float* s2, long long n2, void* stream);
-
 /* ---- input staging of a hipGraph-replayed step, one kernel with fixed arguments.  `slot` = host-pinned
  *      (device-mapped) words the host rewrites before each replay: [0,1] device pointer of obsv (B,To,2),
  *      [2,3] device pointer of pred (B,Tp,2), [4] zeros_val, [5] ones_val, [6] / [7] number of D / G Adam

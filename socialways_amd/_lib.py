@@ -49,8 +49,6 @@ PROTOTYPES = {
     "sw_l2_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "sw_traj_dist": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "sw_stage_step": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
-    "sw_copy_f32": (_i, [_vp, _vp, _ll, _vp]),
-    "sw_copy3_f32": (_i, [_vp, _vp, _ll, _vp, _vp, _ll, _vp, _vp, _ll, _vp]),
     "sw_ade_fde": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
 }
 

@@ -384,49 +384,6 @@ extern "C" int sw_traj_dist(const float* a, const float* b, int Na, int Nb, int 
   return SW_OK;
 }
 
-// ---- staging copy: device kernel that reads a (host-pinned, device-mapped) source -----------------
-// A hipMemcpyAsync host-to-device enqueued behind hipGraph launches blocks the calling host thread
-// until the stream drains on this runtime; a kernel launch never does.  256 KB of z per step over
-// PCIe is ~5 us.
-__global__ void copy_f32_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  long long stride = (long long)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) dst[i] = src[i];
-}
-extern "C" int sw_copy_f32(float* dst, const float* src, long long n, void* stream) {
-  if (!dst || !src || n < 0) return SW_EARG;
-  if (n == 0) return SW_OK;
-  int blocks = (int)((n + 255) / 256);
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(copy_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dst, src, n);
-  SW_CHECK_LAUNCH("copy_f32_kernel");
-  return SW_OK;
-}
-
-// Three staging copies in one launch (tracks of the packed batch + host-pinned z / scalars).
-__global__ void copy3_f32_kernel(float* __restrict__ d0, const float* __restrict__ s0, long long n0,
-                                 float* __restrict__ d1, const float* __restrict__ s1, long long n1,
-                                 float* __restrict__ d2, const float* __restrict__ s2, long long n2) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long k = i; k < n0; k += stride) d0[k] = s0[k];
-  for (long long k = i; k < n1; k += stride) d1[k] = s1[k];
-  for (long long k = i; k < n2; k += stride) d2[k] = s2[k];
-}
-extern "C" int sw_copy3_f32(float* d0, const float* s0, long long n0, float* d1, const float* s1, long long n1,
-                            float* d2, const float* s2, long long n2, void* stream) {
-  if ((n0 > 0 && (!d0 || !s0)) || (n1 > 0 && (!d1 || !s1)) || (n2 > 0 && (!d2 || !s2)) || n0 < 0 || n1 < 0 || n2 < 0)
-    return SW_EARG;
-  long long n = n0 > n1 ? n0 : n1;
-  n = n > n2 ? n : n2;
-  if (n == 0) return SW_OK;
-  int blocks = (int)((n + 255) / 256);
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(copy3_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d0, s0, n0, d1, s1, n1, d2, s2, n2);
-  SW_CHECK_LAUNCH("copy3_f32_kernel");
-  return SW_OK;
-}
-
 // ---- one-kernel input staging of a hipGraph-replayed training step ---------------------------------
 // `slot` is a host-pinned (device-mapped) buffer the host fills before every replay, 4-byte words:
 //   [0,1] device pointer of obsv (B,To,2)   [2,3] device pointer of pred (B,Tp,2)

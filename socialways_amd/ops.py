@@ -152,12 +152,12 @@ def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_soc
     return pred4, ctx
 
 
-def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d_dec, ws=None, tag="g", side=None,
-                 aux=None):
-    """Backward of predict(): decode BPTT -> social block -> obs BPTT -> deferred weight GEMMs.
-    d_* are the packed gradient buffers (overwritten).  With a `side` stream the weight-gradient GEMMs
-    of the decode phase (all-CU, independent of the social / observation BPTT that follows on a
-    128-workgroup critical path) run concurrently with them."""
+def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d_dec, ws=None, tag="g", aux=None):
+    """Backward of predict(): decode BPTT -> social block -> obs BPTT -> ONE grouped weight-gradient GEMM launch
+    (the social block's problems ride in it).  d_* are the packed gradient buffers (overwritten).
+    aux = (src, dst, mask): masked copy dst = mask > 0 ? src : dst done by idle workgroups of the decode BPTT
+    launch.  (Running part of the weight GEMMs on a side stream under the BPTT was measured slower: it takes
+    CUs from the latency-bound chain and every cross-stream edge of a captured graph costs 5-10 us.)"""
     dev = dpred4.device
     ws = ws or default_ws(dev)
     B, To, Tp = ctx.B, ctx.To, ctx.Tp
@@ -168,43 +168,26 @@ def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d
     dhT = torch.empty(B, 64, device=dev)
     dcT = torch.empty(B, 64, device=dev)
     dS = torch.empty(B, 64, device=dev)
-    # aux = (src, dst, mask): masked copy dst = mask > 0 ? src : dst done by idle workgroups of the decode BPTT launch
     L.call("sw_dec_rollout_bwd_aux", L.ptr(dpred4), L.ptr(enc_w), L.ptr(dec_w), L.ptr(ctx.gsave), B, To, Tp,
            L.ptr(gdelta), L.ptr(dhT), L.ptr(dcT), L.ptr(dS), L.ptr(aux[0]) if aux else None, L.ptr(aux[1]) if aux else None,
            L.ptr(aux[2]) if aux else None, aux[1].numel() if aux else 0, L.stream())
-
-    # the social block's weight-gradient problems ride in the generator's (single) launch at the end of the pass
-    defer = ws.wgrad_batch if side is None else None
-
-    def wgrad_part(part, wsbuf, pending=None):
-        L.call("sw_gen_wgrad", L.ptr(enc_w), L.ptr(ctx.gsave), L.ptr(gdelta), L.ptr(ctx.noise), L.ptr(ctx.S), B, To, Tp,
-               L.ptr(d_enc), L.ptr(d_dec), part, L.ptr(wsbuf), L.ptr(tmp), pending, L.stream())
-
-    if side is not None:
-        main = torch.cuda.current_stream()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            wgrad_part(1, ws.get("wgrad.side", L.workspace_floats(L.WS_WGRAD, B, To, Tp)))
+    pending = None
     if ctx.use_social and (ctx.scenes.P > 0 or ctx.scenes.NB > 0):
         sc = ctx.scenes
+        pending = ws.wgrad_batch
         pws = ws.get("pairs", L.workspace_floats(L.WS_PAIRS, B, To, Tp, 1, sc.P))
         bigp = ws.get("bigpart", sc.big_rows * 128) if sc.NB else None      # scenes above AMAX agents: per-block partial rows
         L.call("sw_social_pool_bwd", L.ptr(ctx.obsv), To, L.ptr(ctx.hT), L.ptr(sc.scene_off), L.ptr(sc.pair_off), sc.S,
                B, sc.amax, sc.P, L.ptr(emb_w), L.ptr(att_w), L.ptr(ctx.attn), L.ptr(dS), L.ptr(dhT), L.ptr(d_emb),
                L.ptr(d_att), L.ptr(pws), L.ptr(wgrad), L.ptr(sc.big_blocks), sc.NB, L.ptr(ctx.wh), L.ptr(ctx.ml),
-               L.ptr(ctx.S), L.ptr(bigp), defer, L.stream())
-        social_deferred = defer is not None
+               L.ptr(ctx.S), L.ptr(bigp), pending, L.stream())
     else:
         d_emb.zero_()
         d_att.zero_()
-        social_deferred = False
     L.call("sw_enc_lstm_bwd", L.ptr(enc_w), L.ptr(ctx.gsave), None, L.ptr(dhT), L.ptr(dcT), None, B, To, 0,
            L.ptr(gdelta), None, None, L.stream())
-    if side is not None:
-        torch.cuda.current_stream().wait_stream(side)
-        wgrad_part(2, wgrad)
-    else:
-        wgrad_part(0, wgrad, defer if social_deferred else None)
+    L.call("sw_gen_wgrad", L.ptr(enc_w), L.ptr(ctx.gsave), L.ptr(gdelta), L.ptr(ctx.noise), L.ptr(ctx.S), B, To, Tp,
+           L.ptr(d_enc), L.ptr(d_dec), 0, L.ptr(wgrad), L.ptr(tmp), pending, L.stream())
 
 
 class DiscCtx:

@@ -154,11 +154,6 @@ class SocialWaysTrainer:
     def use_social(self):
         return self.G.use_social
 
-    def _sides(self):
-        if getattr(self, "_side_streams", None) is None:
-            self._side_streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
-        return self._side_streams
-
     def _allreduce(self, flat):
         if self.pg is not None and (self.world > 1 or self._force_dist):
             torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
@@ -349,7 +344,7 @@ class SocialWaysTrainer:
             restore = (backup[:D._flat.numel()], D._flat, self._lin_maskf)
         G.grad_views()
         ops.gen_backward(enc._flat, emb._flat, att._flat, dec._flat, gctx, dpred, enc._gflat, emb._gflat, att._gflat,
-                         dec._gflat, ws=ws, side=None, aux=restore)   # (side-stream wgrad starves the BPTT chain of CUs: measured slower)
+                         dec._gflat, ws=ws, aux=restore)
         yield G._gflat_all
         self.predictor_optimizer.step() if steps is None else self.predictor_optimizer.step(steps[U + 1])
         self.last_pred_hat = pred_hat
