@@ -1,0 +1,90 @@
+"""Host-side logic that needs no GPU: the packed Adam wrapper (torch's fused kernel called directly) against
+torch.optim.Adam incl. the reference's optimizer state_dict format, and the scene index (pair offsets of small
+scenes, row-block records of scenes above 64 agents)."""
+import numpy as np
+import pytest
+import torch
+
+from socialways_amd.ops import SceneIndex
+from socialways_amd.trainer import PackedAdam
+
+SHAPES = [(7, 3), (5,), (64, 32), (1,), (33, 4)]
+
+
+def _packed(shapes):
+    offs, o = [], 0
+    for s in shapes:
+        k = int(np.prod(s))
+        offs.append((o, k, s))
+        o = (o + k + 3) // 4 * 4                       # every tensor on a 16-byte boundary
+    return offs, o
+
+
+def test_packed_adam_equals_torch_adam_and_reference_state_dict():
+    torch.manual_seed(0)
+    offs, n = _packed(SHAPES)
+    flat, gflat = torch.randn(n), torch.zeros(n)
+    for a, k, _ in offs:                               # padding floats are zero and must stay zero
+        nxt = min([b for b, _, _ in offs if b > a] + [n])
+        flat[a + k:nxt] = 0
+    ref = [torch.nn.Parameter(flat[a:a + k].view(s).clone()) for a, k, s in offs]
+    opt = torch.optim.Adam(ref, lr=1e-3, betas=(0.9, 0.999))          # train.py:379-385
+    pa = PackedAdam(flat, gflat, offs, 1e-3)
+    ext = torch.zeros(())
+    for it in range(6):
+        for (a, k, s), p in zip(offs, ref):
+            g = torch.randn(s)
+            p.grad = g.clone()
+            gflat[a:a + k] = g.reshape(-1)
+        opt.step()
+        if it % 2 == 0:
+            pa.step()                                  # self-counted
+        else:                                          # counter supplied by the caller (the staging kernel's job)
+            ext.fill_(float(it + 1))
+            pa.t += 1
+            pa.step(ext)
+    for (a, k, s), p in zip(offs, ref):
+        assert torch.equal(flat[a:a + k].view(s), p.detach())
+    used = torch.zeros(n, dtype=torch.bool)
+    for a, k, _ in offs:
+        used[a:a + k] = True
+    assert float(flat[~used].abs().max()) == 0.0
+    sd, rd = pa.state_dict(), opt.state_dict()
+    assert sd["param_groups"][0]["params"] == rd["param_groups"][0]["params"]
+    for k in ("lr", "betas", "eps", "weight_decay", "amsgrad"):
+        assert sd["param_groups"][0][k] == rd["param_groups"][0][k]
+    for i in range(len(offs)):
+        assert float(sd["state"][i]["step"]) == float(rd["state"][i]["step"]) == 6.0
+        assert torch.equal(sd["state"][i]["exp_avg"], rd["state"][i]["exp_avg"])
+        assert torch.equal(sd["state"][i]["exp_avg_sq"], rd["state"][i]["exp_avg_sq"])
+    # resume: a fresh wrapper loaded from the REFERENCE optimizer's state continues identically
+    flat2, g2 = flat.clone(), torch.zeros(n)
+    pb = PackedAdam(flat2, g2, offs, 1e-3)
+    pb.load_state_dict(rd)
+    for (a, k, s), p in zip(offs, ref):
+        g = torch.randn(s)
+        p.grad = g.clone()
+        g2[a:a + k] = g.reshape(-1)
+    opt.step()
+    pb.step()
+    for (a, k, s), p in zip(offs, ref):
+        assert torch.equal(flat2[a:a + k].view(s), p.detach())
+
+
+def test_scene_index_small_and_large_scenes():
+    sizes = [3, 1, 70, 64, 130]
+    ends = np.cumsum(sizes)
+    sb = np.stack([ends - sizes, ends], axis=1)
+    sc = SceneIndex(sb, int(ends[-1]), "cpu")
+    assert sc.S == 5 and sc.amax == 64 and sc.P == 9 + 64 * 64               # single-agent and >64 scenes own no pair rows
+    assert sc.pair_off.tolist() == [0, 9, 9, 9, 9 + 4096, 9 + 4096]
+    rec = sc.big_blocks.numpy()
+    assert sc.NB == 5 + 9 and rec.shape == (14, 8)
+    assert rec[:5, 0].tolist() == [2] * 5 and rec[:5, 1].tolist() == [0, 16, 32, 48, 64]
+    assert rec[:5, 2].tolist() == [0, 70, 140, 210, 280] and (rec[:5, 3] == 0).all() and (rec[:5, 4] == 5).all()
+    assert rec[5, 0] == 4 and rec[5, 2] == 5 * 70 and rec[5, 3] == 350 and rec[5, 4] == 9
+    assert sc.big_rows == 5 * 70 + 9 * 130
+    with pytest.raises(ValueError):
+        SceneIndex(np.array([[0, 3], [4, 6]]), 6, "cpu")                     # must tile [0, B)
+    one = SceneIndex([], 9, "cpu")                                           # predict() default: one scene
+    assert one.S == 1 and one.amax == 9 and one.NB == 0
