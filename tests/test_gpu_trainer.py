@@ -256,3 +256,33 @@ def test_loss_and_unrolling_switches(name):
     o = out.double().cpu().numpy()
     af = g[name + ".ade_fde"]
     assert abs(o[-1, 0] / data.n_train_samples - af[0]) < 1e-5 and abs(o[-1, 1] / data.n_train_samples - af[1]) < 1e-5
+
+
+def test_biwi_format_crowd_epoch_matches_oracle():
+    """BASELINE config 2 stand-in (no ETH/UCY data exists here): a synthetic BIWI-format recording
+    through the reference-checked window extraction (tests/golden/biwi_synth.npz), then one epoch of train() with
+    --batch-size 32 on ragged scenes of 1..11 pedestrians: per-step MSE terms and epoch ADE/FDE vs the CPU oracle on
+    identical draws."""
+    import socialways_amd as sw
+    import sw_oracle as O
+    g = golden("biwi_synth")
+    data = sw.SceneDataset(g["obsvs"], g["preds"], g["batches"], g["times"], device="cuda:0")
+    odata = O.load_and_normalise(g["obsvs"], g["preds"], g["batches"])
+    assert abs(data.ss - odata["ss"]) < 1e-12 and int(np.diff(g["batches"], axis=1).max()) <= 16
+    torch.manual_seed(1)
+    tr = sw.SocialWaysTrainer(12, use_social=True, device="cuda:0")
+    orc = O.SocialWaysOracle(12, use_social=True)
+    orc.load_state({k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in tr.checkpoint().items() if k.endswith("_dict")})
+    rng = np.random.default_rng(3)
+    draws = []
+
+    def draw(bs):
+        d = (float(rng.uniform(0, 0.1)), float(rng.uniform(0.9, 1.0)), torch.from_numpy(rng.random((bs, 32), dtype=np.float32)))
+        draws.append(d)
+        return d
+    ade, fde, losses, sizes = tr.train_epoch(data, 32, draw=draw)
+    it = iter(draws)
+    oade, ofde, olosses, oshapes = orc.train_epoch(odata, 32, draw=lambda bs: next(it))
+    assert [s[0] for s in sizes] == [s[0] for s in oshapes] and len(sizes) >= 4
+    assert_close(losses, np.asarray(olosses), 3e-4, 3e-6, "MSE terms of the epoch")
+    assert abs(ade - oade) < 1e-4 and abs(fde - ofde) < 1e-4, (ade, oade, fde, ofde)
