@@ -560,10 +560,9 @@ static int disc_bwd_impl(const float* d_w, const float* dsave, const float* cons
   WgBatch wb;
   int rc_add = 0;
   // LSTM: dW_hh over rows t >= 1 against h_{t-1}; dW_ih / biases over all rows against x4
-  rc_add |= wg_add(wb, ddelta + dd.dgates + (size_t)B * 256, 256, dsave + ds.act + 320, 384, (To - 1) * B, 256, 64,
-         d_d_w + O.whh, 64, nullptr, nullptr, 0);
-  rc_add |= wg_add(wb, ddelta + dd.dgates, 256, dsave + ds.x4s, 4, To * B, 256, 4, d_d_w + O.wih, 4, d_d_w + O.bih,
-         d_d_w + O.bhh, 0);
+  rc_add |= wg_add_tail(wb, ddelta + dd.dgates, 256, dsave + ds.act + 320 - (ptrdiff_t)B * 384, 384, To * B, 256, 64,
+                        d_d_w + O.whh, 64, dsave + ds.x4s, 4, 4, d_d_w + O.wih, 4, B /*h_{t-1}: rows t >= 1*/,
+                        d_d_w + O.bih, d_d_w + O.bhh, 0);
   rc_add |= wg_add(wb, ddelta + dd.do1, 32, dsave + ds.act + (size_t)(To - 1) * B * 384 + 320, 384, B, 32, 64, d_d_w + O.of0w,
          64, d_d_w + O.of0b, nullptr, 0);
   rc_add |= wg_add(wb, ddelta + dd.docode, 32, dsave + ds.o1, 32, B, 32, 32, d_d_w + O.of1w, 32, d_d_w + O.of1b, nullptr, 0);

@@ -155,13 +155,13 @@ extern "C" int sw_gen_wgrad(const float* enc_w, const float* gsave, const float*
   // EncoderLstm: W_hh against h_{t-1} (rows t >= 1), composed input matrix against x4 (all rows)
   const int t_lo = part == 1 ? To : 0, t_hi = part == 2 ? To : Ta;   // LSTM rows [t_lo, t_hi)
   const int acc = part == 2 ? 1 : 0;
-  const int h_lo = t_lo < 1 ? 1 : t_lo;
-  if (t_hi > h_lo)
-    rc_add |= wg_add(wb, gdelta + gd.dgates + (size_t)h_lo * B * 256, 256, gsave + gs.act + (size_t)(h_lo - 1) * B * 384 + 320,
-                     384, (t_hi - h_lo) * B, 256, 64, d_enc_w + ENC_WHH, 64, nullptr, nullptr, acc);
+  // W_hh against h_{t-1} (rows t >= 1) and the composed input matrix against x4 (all rows) share the dgates rows:
+  // one problem with a tail segment, dgates fetched once.  Logical row r = (t - t_lo) B + b.
   if (t_hi > t_lo)
-    rc_add |= wg_add(wb, gdelta + gd.dgates + (size_t)t_lo * B * 256, 256, gsave + gs.x4s + (size_t)t_lo * B * 4, 4,
-                     (t_hi - t_lo) * B, 256, 4, dWx, 4, dbx, nullptr, acc);
+    rc_add |= wg_add_tail(wb, gdelta + gd.dgates + (size_t)t_lo * B * 256, 256,
+                          gsave + gs.act + ((ptrdiff_t)t_lo - 1) * B * 384 + 320, 384, (t_hi - t_lo) * B, 256, 64,
+                          d_enc_w + ENC_WHH, 64, gsave + gs.x4s + (size_t)t_lo * B * 4, 4, 4, dWx, 4,
+                          t_lo < 1 ? B : 0 /*t = 0 has no h_{t-1}: zero initial state (train.py:399-400)*/, dbx, nullptr, acc);
   if (part != 2) {
     // DecoderFC: fc1.0 split in its h / S / z column blocks; h of decode step i is LSTM row To-1+i
     rc_add |= wg_add(wb, gdelta + gd.dz1, 160, gsave + gs.act + (size_t)(To - 1) * B * 384 + 320, 384, Tp * B, 160, 64,

@@ -19,6 +19,12 @@ struct WgProblem {      // one column block (<= 64 act columns, optional trailin
   int ldd, lda, ldw, R, N, K, ones, accumulate;
   int nbn, nbk, nsplit, job0, out0;
   int pre;              // > 0: the `pre` slice partials are produced elsewhere (fused kernels); only reduced here
+  // optional TAIL segment: K2 (< 16) more act columns from a second array, placed in the k tile after the K
+  // (multiple of 16) columns of `act`, in front of the ones column - the LSTM's x_t next to h_{t-1}, so that the
+  // dgates rows are fetched once for W_hh, W_ih and the biases.  Rows r < row0 have no `act` operand (t = 0).
+  const float* act2;
+  float* dW2;
+  int lda2, ldw2, K2, row0;
 };
 struct WgBatch {
   WgProblem p[SW_WG_MAXP];
@@ -28,6 +34,10 @@ struct WgBatch {
 
 int wg_add(WgBatch& b, const float* delta, int ldd, const float* act, int lda, int R, int N, int K, float* dW,
            int ldw, float* db, float* db2, int accumulate);
+// same with a tail segment (see WgProblem): K % 16 == 0, K <= 64, K2 + (db ? 1 : 0) <= 16
+int wg_add_tail(WgBatch& b, const float* delta, int ldd, const float* act, int lda, int R, int N, int K, float* dW,
+                int ldw, const float* act2, int lda2, int K2, float* dW2, int ldw2, int row0, float* db, float* db2,
+                int accumulate);
 double wg_total_work(const WgBatch& b);
 size_t wg_finalize(WgBatch& b);
 int wg_launch(WgBatch& b, float* ws, hipStream_t stream);

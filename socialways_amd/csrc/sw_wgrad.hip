@@ -31,29 +31,32 @@
 // this wave's 64x64 block): loads are unconditional from clamped addresses and masked by a 0/1
 // factor, so the hot loop is NI+KT loads, a few multiplies and NI*KT MFMAs - no exec-mask branches,
 // no accumulator shuffling through control flow.
+#define SW_WG_RLD 69   // LDS row stride of a wave's 64 x (<= 69) block: 64 act columns + tail segment + ones
 template <int NI, int KT>
 __device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const float* __restrict__ abase, int ldd, int lda,
                                        int rbeg, int rend, int rmax, const int* acol, const float* amask,
                                        const int* bcol, const float* bmask, const float* bone, int lg, int ln,
-                                       float* __restrict__ mine) {
+                                       float* __restrict__ mine, const float* __restrict__ abase2, int lda2, int row0) {
   f32x4 acc[NI][KT];
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) acc[i][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  constexpr int DEPTH = SW_WG_DEPTH;  // groups in flight
+  constexpr int DEPTH = KT == 5 ? SW_WG_DEPTH - 2 : SW_WG_DEPTH;  // groups in flight (256 registers per lane at 2 waves per SIMD)
   float a[DEPTH][NI], b[DEPTH][KT];
   auto load = [&](int r0, float* av, float* bv) {
     const int r = r0 + lg;
     const float rs = r < rend ? 1.0f : 0.0f;
     const int rc = min(r, rmax);
     const float* dr = dbase + (size_t)rc * ldd;
-    const float* ar = abase + (size_t)rc * lda;
+    const float* ar = abase + (size_t)max(rc, row0) * lda;     // rows below row0 have no `act` operand
+    const float rs0 = r >= row0 ? rs : 0.0f;
 #pragma unroll
     for (int i = 0; i < NI; ++i) av[i] = dr[acol[i]] * (amask[i] * rs);
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) bv[kt] = fmaf(ar[bcol[kt]], bmask[kt], bone[kt]) * rs;
+    for (int kt = 0; kt < (KT < 5 ? KT : 4); ++kt) bv[kt] = fmaf(ar[bcol[kt]], bmask[kt], bone[kt]) * (bone[kt] > 0.f ? rs : rs0);
+    if (KT == 5) bv[4] = fmaf((abase2 + (size_t)rc * lda2)[bcol[4]], bmask[4], bone[4]) * rs;   // tail segment | ones
   };
 #pragma unroll
   for (int q = 0; q < DEPTH - 1; ++q) load(rbeg + 4 * q, a[q], b[q]);
@@ -73,7 +76,8 @@ __device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const fl
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) mine[(i * 16 + 4 * lg + r) * 65 + kt * 16 + ln] = acc[i][kt][r];
+      for (int r = 0; r < 4; ++r)
+        if (kt < 4 || ln < SW_WG_RLD - 64) mine[(i * 16 + 4 * lg + r) * SW_WG_RLD + kt * 16 + ln] = acc[i][kt][r];
     }
   }
 }
@@ -83,8 +87,8 @@ __device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const fl
 // B: act[r0+lg][16kt+ln], 64 B contiguous per 16 lanes), software pipelined 5 four-row groups ahead; no
 // LDS in the loop, no barriers - every wave streams independently, 3 waves per SIMD.  The 4 waves of a
 // workgroup take 4 consecutive row slices of the same block and sum them through LDS at the end.
-__global__ __launch_bounds__(SW_THREADS) void wgrad_partial_kernel(WgBatch batch, float* __restrict__ ws) {
-  __shared__ __attribute__((aligned(16))) float red[4][64 * 65];   // per-wave 64x64 block (+1 pad), summed before the store
+__global__ __launch_bounds__(SW_THREADS, 2) void wgrad_partial_kernel(WgBatch batch, float* __restrict__ ws) {
+  __shared__ __attribute__((aligned(16))) float red[4][64 * SW_WG_RLD];   // per-wave 64 x <=69 block, summed before the store
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
   const int job = blockIdx.x;            // one workgroup = 4 consecutive row slices of one output block
   int p = 0;
@@ -95,15 +99,15 @@ __global__ __launch_bounds__(SW_THREADS) void wgrad_partial_kernel(WgBatch batch
   const int NB = (P.N + 63) >> 6;       // 64-row output blocks
   const int sg = j / NB, nb = j - sg * NB;
   const int s = sg * 4 + wave;          // this wave's row slice (may be empty)
-  const int N = P.N, K = P.K, Kc = P.K + P.ones;
+  const int N = P.N, K = P.K, Kc = P.K + P.K2 + P.ones;
   const int n0 = nb * 64;
   const int NI = min(4, (N - n0 + 15) >> 4), KT = (Kc + 15) >> 4;
   const int nsub = P.nsplit * 4;
   const int rows_per = (((P.R + nsub - 1) / nsub) + 3) & ~3;
   const int rbeg = min(P.R, s * rows_per);
   const int rend = min(P.R, rbeg + rows_per);
-  int acol[4], bcol[4];
-  float amask[4], bmask[4], bone[4];
+  int acol[4], bcol[5];
+  float amask[4], bmask[5], bone[5];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int n = n0 + 16 * i + ln, k = 16 * i + ln;
@@ -111,27 +115,34 @@ __global__ __launch_bounds__(SW_THREADS) void wgrad_partial_kernel(WgBatch batch
     amask[i] = n < N ? 1.0f : 0.0f;
     bcol[i] = min(k, max(K - 1, 0));
     bmask[i] = k < K ? 1.0f : 0.0f;
-    bone[i] = (P.ones && k == K) ? 1.0f : 0.0f;
+    bone[i] = (P.ones && k == K + P.K2) ? 1.0f : 0.0f;
+  }
+  {  // k tile 4 exists only with a tail segment (K == 64): columns of act2, then the ones column
+    const int c = ln;
+    bcol[4] = min(c, max(P.K2 - 1, 0));
+    bmask[4] = c < P.K2 ? 1.0f : 0.0f;
+    bone[4] = (P.ones && c == P.K2) ? 1.0f : 0.0f;
   }
   float* mine = red[wave];
 #define WG_CASE(ni, kt)                                                                                          \
-  case ni * 4 + kt:                                                                                              \
-    wg_run<ni, kt>(P.delta, P.act, P.ldd, P.lda, rbeg, rend, P.R - 1, acol, amask, bcol, bmask, bone, lg, ln, mine); \
+  case ni * 8 + kt:                                                                                              \
+    wg_run<ni, kt>(P.delta, P.act, P.ldd, P.lda, rbeg, rend, P.R - 1, acol, amask, bcol, bmask, bone, lg, ln, mine, \
+                   P.act2 ? P.act2 : P.delta, P.act2 ? P.lda2 : P.ldd, P.row0);                                  \
     break;
-  switch (NI * 4 + KT) {
-    WG_CASE(1, 1) WG_CASE(1, 2) WG_CASE(1, 3) WG_CASE(1, 4)
-    WG_CASE(2, 1) WG_CASE(2, 2) WG_CASE(2, 3) WG_CASE(2, 4)
-    WG_CASE(3, 1) WG_CASE(3, 2) WG_CASE(3, 3) WG_CASE(3, 4)
-    WG_CASE(4, 1) WG_CASE(4, 2) WG_CASE(4, 3) WG_CASE(4, 4)
+  switch (NI * 8 + KT) {
+    WG_CASE(1, 1) WG_CASE(1, 2) WG_CASE(1, 3) WG_CASE(1, 4) WG_CASE(1, 5)
+    WG_CASE(2, 1) WG_CASE(2, 2) WG_CASE(2, 3) WG_CASE(2, 4) WG_CASE(2, 5)
+    WG_CASE(3, 1) WG_CASE(3, 2) WG_CASE(3, 3) WG_CASE(3, 4) WG_CASE(3, 5)
+    WG_CASE(4, 1) WG_CASE(4, 2) WG_CASE(4, 3) WG_CASE(4, 4) WG_CASE(4, 5)
   }
 #undef WG_CASE
   sw_barrier();
   // one partial per workgroup (4 row slices summed): ws[ws_off + (sg*N + n)*Kc + k]
   float* out = ws + P.ws_off + (size_t)sg * N * Kc;
-  const int rows = min(64, N - n0), cols = min(64, Kc);
+  const int rows = min(64, N - n0), cols = min(SW_WG_RLD, Kc);
   for (int e = threadIdx.x; e < rows * cols; e += SW_THREADS) {
     int rr = e / cols, cc = e - rr * cols;
-    int o = rr * 65 + cc;
+    int o = rr * SW_WG_RLD + cc;
     float v = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
     out[(size_t)(n0 + rr) * Kc + cc] = v;
   }
@@ -155,7 +166,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgBatch batch, const 
   while (p + 1 < batch.np && ii >= batch.p[p + 1].out0) ++p;
   const WgProblem& P = batch.p[p];
   const int e = ii - P.out0;
-  const int Kc = P.K + P.ones;
+  const int Kc = P.K + P.K2 + P.ones;
   const size_t stride = (size_t)P.N * Kc;
   const float* src = ws + P.ws_off + e;
   float s = 0.f;
@@ -175,6 +186,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgBatch batch, const 
   int n = e / Kc, k = e - n * Kc;
   if (k < P.K) {
     float* dst = P.dW + (size_t)n * P.ldw + k;
+    *dst = P.accumulate ? *dst + s : s;
+  } else if (k < P.K + P.K2) {
+    float* dst = P.dW2 + (size_t)n * P.ldw2 + (k - P.K);
     *dst = P.accumulate ? *dst + s : s;
   } else {
     P.db[n] = P.accumulate ? P.db[n] + s : s;
@@ -198,9 +212,24 @@ int wg_add(WgBatch& b, const float* delta, int ldd, const float* act, int lda, i
     P.dW = dW + c0; P.ldw = ldw; P.db = has_ones ? db : nullptr; P.db2 = has_ones ? db2 : nullptr;
     P.accumulate = accumulate;
     P.pre = 0;
+    P.act2 = nullptr; P.dW2 = nullptr; P.lda2 = P.ldw2 = P.K2 = P.row0 = 0;
     P.nbn = (N + 15) / 16;
     P.nbk = (c1 - c0 + 15) / 16;
   }
+  return SW_OK;
+}
+
+int wg_add_tail(WgBatch& b, const float* delta, int ldd, const float* act, int lda, int R, int N, int K, float* dW,
+                int ldw, const float* act2, int lda2, int K2, float* dW2, int ldw2, int row0, float* db, float* db2,
+                int accumulate) {
+  if (N > 256 || (ldd & 3) || (lda & 3) || K != 64 || K2 < 1 || K2 + (db ? 1 : 0) > SW_WG_RLD - 64 || b.np >= SW_WG_MAXP)
+    return SW_ESHAPE;
+  WgProblem& P = b.p[b.np++];
+  P.delta = delta; P.ldd = ldd; P.act = act; P.lda = lda; P.R = R; P.N = N; P.K = K; P.ones = db ? 1 : 0;
+  P.dW = dW; P.ldw = ldw; P.db = db; P.db2 = db ? db2 : nullptr; P.accumulate = accumulate; P.pre = 0;
+  P.act2 = act2; P.lda2 = lda2; P.K2 = K2; P.dW2 = dW2; P.ldw2 = ldw2; P.row0 = row0;
+  P.nbn = (N + 15) / 16;
+  P.nbk = 5;
   return SW_OK;
 }
 
@@ -210,6 +239,7 @@ int wg_add_pre(WgBatch& b, int N, int K, float* dW, int ldw, float* db, int nsli
   P.delta = nullptr; P.act = nullptr; P.ldd = P.lda = 0; P.R = 0;
   P.N = N; P.K = K; P.ones = 1; P.dW = dW; P.ldw = ldw; P.db = db; P.db2 = nullptr; P.accumulate = 0;
   P.nbn = (N + 15) / 16; P.nbk = (K + 1 + 15) / 16;
+  P.act2 = nullptr; P.dW2 = nullptr; P.lda2 = P.ldw2 = P.K2 = P.row0 = 0;
   P.pre = nslices;
   b.top_reserved += (size_t)nslices * N * (K + 1);
   if (b.top_reserved > SW_WG_WS_FLOATS) return SW_ESHAPE;
@@ -266,7 +296,7 @@ size_t wg_finalize(WgBatch& b) {
     P.job0 = job;
     if (!P.pre) job += ns * NB;
     P.out0 = out;
-    const int Kc = P.K + P.ones;
+    const int Kc = P.K + P.K2 + P.ones;
     out += P.N * Kc;
     if (!P.pre) {
       P.ws_off = ws;
