@@ -27,6 +27,9 @@ struct WgProblem {      // one column block (<= 64 act columns, optional trailin
   int lda2, ldw2, K2, row0;
 };
 struct WgBatch {
+  // compact search keys first: a workgroup finds its problem by scanning these (kernel-argument memory is
+  // fetched by dependent scalar loads: one or two cache lines here instead of one per problem descriptor)
+  int job0s[SW_WG_MAXP], out0s[SW_WG_MAXP];
   WgProblem p[SW_WG_MAXP];
   int np = 0, total_jobs = 0, total_out = 0;
   size_t top_reserved = 0;   // floats handed out from the TOP of the workspace to precomputed-partial problems

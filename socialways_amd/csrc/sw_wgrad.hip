@@ -93,7 +93,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void wgrad_partial_kernel(WgBatch ba
   const int job = blockIdx.x;            // one workgroup = 4 consecutive row slices of one output block
   int p = 0;
 #pragma unroll 1
-  while (p + 1 < batch.np && job >= batch.p[p + 1].job0) ++p;
+  while (p + 1 < batch.np && job >= batch.job0s[p + 1]) ++p;
   const WgProblem& P = batch.p[p];
   const int j = job - P.job0;
   const int NB = (P.N + 63) >> 6;       // 64-row output blocks
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgBatch batch, const 
   int ii = live ? i : batch.total_out - 1;
   int p = 0;
 #pragma unroll 1
-  while (p + 1 < batch.np && ii >= batch.p[p + 1].out0) ++p;
+  while (p + 1 < batch.np && ii >= batch.out0s[p + 1]) ++p;
   const WgProblem& P = batch.p[p];
   const int e = ii - P.out0;
   const int Kc = P.K + P.K2 + P.ones;
@@ -294,6 +294,8 @@ size_t wg_finalize(WgBatch& b) {
     }
     P.nsplit = ns;
     P.job0 = job;
+    b.job0s[i] = job;
+    b.out0s[i] = out;
     if (!P.pre) job += ns * NB;
     P.out0 = out;
     const int Kc = P.K + P.K2 + P.ones;
