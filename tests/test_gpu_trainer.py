@@ -225,6 +225,46 @@ def test_two_rank_data_parallel_step_equals_reference():
     assert ret[0][2] == ret[1][2] and ret[0][3] == ret[1][3], "replicas diverged"
 
 
+def _rccl_worker(rank, world, port, ret):
+    import os
+    import torch.distributed as dist
+    import socialways_amd as sw
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["SW_FORCE_DIST"] = "1"                     # a 1-rank group still runs the three all-reduces
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    t = sw.synth_tracks(24, 8, seed=9)
+    data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
+    B, sb = data.n_train_samples, data.train_batches
+    res = []
+    for pg in (dist.group.WORLD, None):
+        torch.manual_seed(0)
+        tr = sw.SocialWaysTrainer(12, use_social=True, device="cuda:0", process_group=pg)
+        if pg is None:
+            tr._force_dist = False
+        gen = torch.Generator().manual_seed(5)
+        outs = [tr.step(data.obsv[:B], data.pred[:B], sb, 0.01 * i, 0.9 + 0.01 * i, torch.rand(B, 32, generator=gen), data.ss).cpu()
+                for i in range(6)]                        # eager, eager, capture (segmented), replay x3
+        res.append((torch.stack(outs), tr.D._flat.cpu().clone(), tr.G._flat_all.cpu().clone()))
+    ret[rank] = all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+    dist.destroy_process_group()
+
+
+def test_rccl_path_segmented_graphs_equal_single_process():
+    """backend "nccl" (= RCCL) with a 1-rank group: the step captured as graph SEGMENTS around three eager
+    all-reduces must reproduce the single-graph single-process trajectory bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_rccl_worker, args=(1, port, ret), nprocs=1, join=True)
+    assert ret[0] is True
+
+
 @pytest.mark.parametrize("name", ["l2", "variety", "unroll0", "unroll2", "noinfo"])
 def test_loss_and_unrolling_switches(name):
     """The reference's module-global switches (train.py:61-69): L2 term, variety term as written
