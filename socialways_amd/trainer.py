@@ -129,6 +129,9 @@ class SocialWaysTrainer:
         self.max_graphs = 8
         self._graphs = {}
         self._force_dist = os.environ.get("SW_FORCE_DIST", "") == "1"   # 1-rank group still runs the collectives (tests)
+        # SW_GRAPH_COLLECTIVES=1: capture the RCCL all-reduces inside the step graph (one graph per step instead of
+        # four segments).  Off by default: validated on a 1-rank group only (no multi-GPU box was available).
+        self._graph_collectives = os.environ.get("SW_GRAPH_COLLECTIVES", "") == "1"
         packed = fused_adam and self.device.type == "cuda"
         if packed:
             self.predictor_optimizer = PackedAdam(self.G._flat_all, self.G._gflat_all, self.G.packed_slices(), lr_g)
@@ -267,8 +270,12 @@ class SocialWaysTrainer:
                                 buf = next(gen)
                             except StopIteration:
                                 buf, fin = None, True
-                            if fin or self.world > 1 or self._force_dist:
+                            if fin:
                                 break
+                            if self.world > 1 or self._force_dist:
+                                if not self._graph_collectives:
+                                    break                      # segment boundary: the all-reduce runs eagerly
+                                self._allreduce(buf)           # opt-in: RCCL all-reduce recorded inside the graph
                     graphs.append((g, buf))
                     pool = g.pool()
                 sets.append(graphs)
