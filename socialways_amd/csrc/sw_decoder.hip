@@ -220,6 +220,16 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+#ifdef SW_PHASE_STAMPS
+__device__ long long sw_stamps[8];
+#define SW_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); long long _t = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) sw_stamps[k] += _t - _tprev; _tprev = _t; __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int sw_debug_stamps(long long* out, int reset) {
+  if (reset) { long long z[8] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(sw_stamps), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sw_stamps), 8 * sizeof(long long));
+}
+#else
+#define SW_STAMP(k)
+#endif
 // Backward of the decode loop.  Propagates data gradients only; every weight gradient is a
 // deferred GEMM over the time-major delta / activation rows written here (sw_wgrad.hip).
 // ---------------------------------------------------------------------------------------------
@@ -290,7 +300,11 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
   // per-agent running gradient w.r.t. the position (lanes lg==0 of wave 0)
   float dpx = 0.f, dpy = 0.f;
 
+#ifdef SW_PHASE_STAMPS
+  long long _tprev = clock64();
+#endif
   for (int i = Tp - 1; i >= 0; --i) {
+    SW_STAMP(7);
     // ---- prefetch everything this iteration reads from HBM/L2 (saved activations, upstream grad):
     //      the loads fly under the LSTM-step MFMAs instead of stalling each decoder layer ----------
     f32x4 gate[4], ct, cprev;
@@ -326,6 +340,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
         if (live) st4(dgg + g * 64, dgate[g]);
       }
       sw_barrier();
+    SW_STAMP(0);
       dh = lstm_dh_prev(WT, &dgbuf[ln * SW_GLD + 4 * lg]);
       // dx4 = Wx^T dgates: each wave reduces its own quarter of K, partials through LDS
       {
@@ -334,6 +349,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
         if (lg == 0) st4(&dxpart[(wave * 16 + ln) * 4], acc);
       }
       sw_barrier();
+    SW_STAMP(1);
       dx4 = ld4(&dxpart[ln * 4]) + ld4(&dxpart[(16 + ln) * 4]) + ld4(&dxpart[(32 + ln) * 4]) +
             ld4(&dxpart[(48 + ln) * 4]);
     }
@@ -356,6 +372,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
       if (live && m0 + 4 * lg < 40) st4(gdelta + gd.da3 + ((size_t)i * B + b) * 40 + m0 + 4 * lg, acc);
     }
     sw_barrier();
+    SW_STAMP(2);
     // dz2 = (W3^T da3) * lrelu'(a2)   (80)
 #pragma unroll
     for (int q2 = 0; q2 < 2; ++q2) {
@@ -371,6 +388,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
       if (live) st4(gdelta + gd.dz2 + ((size_t)i * B + b) * 80 + m0 + 4 * lg, acc);
     }
     sw_barrier();
+    SW_STAMP(3);
     // dz1 = (W2^T dz2) * lrelu'(a1)   (160)
     {
 #pragma unroll
@@ -391,6 +409,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
       }
     }
     sw_barrier();
+    SW_STAMP(4);
     // dh_{To+i-1} += W1h^T dz1   (wave w owns units 16w.. : same layout as dh)
     {
       f32x4 acc = (i < Tp - 1) ? dh : f32x4{0.f, 0.f, 0.f, 0.f};
