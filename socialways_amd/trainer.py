@@ -106,6 +106,8 @@ class PackedAdam:
 
 
 class SocialWaysTrainer:
+    STEPS_PER_LAUNCH = 4    # train_epoch: consecutive packed batches of one scene layout per graph launch (step_many)
+
     def __init__(self, n_next, hidden_size=64, lr_g=1e-4, lr_d=1e-3, n_unrolling_steps=1, use_social=True,
                  use_info_loss=True, loss_info_w=0.5, n_latent_codes=2, device="cuda", process_group=None,
                  fused_adam=True, use_graph=None, use_l2_loss=False, use_variety_loss=False, loss_l2_w=0.5):
@@ -184,8 +186,8 @@ class SocialWaysTrainer:
             # one graph set per packed-batch layout; datasets with ragged scenes produce many layouts, so the
             # number of captured layouts is capped and the rest of the steps run eagerly
             scenes = ops.SceneIndex.get(sub_batches, B, dev)
-            if (scenes.key, obsv.shape[1], float(ss), Bg, self._row0) in self._graphs or len(self._graphs) < self.max_graphs:
-                part = self._step_graph(obsv, pred, sub_batches, zeros_val, ones_val, noise, float(ss), Bg)
+            if (scenes.key, obsv.shape[1], float(ss), Bg, self._row0, 1) in self._graphs or len(self._graphs) < self.max_graphs:
+                part = self._step_graph([(obsv, pred, zeros_val, ones_val, noise)], sub_batches, float(ss), Bg)[0]
         if part is None:
             part = torch.zeros(self.n_unrolling_steps + 3, (B + 15) // 16, 3, device=dev)
             scenes = ops.SceneIndex.get(sub_batches, B, dev)
@@ -197,11 +199,29 @@ class SocialWaysTrainer:
             return part
         return part.sum(1, dtype=torch.float64)
 
-    def _step_graph(self, obsv, pred, sub_batches, zeros_val, ones_val, noise, ss, Bg):
-        B, To, Tp = obsv.shape[0], obsv.shape[1], self.n_next
+    def step_many(self, batches, sub_batches, ss=1.0, global_B=None, out=None):
+        """K consecutive training steps on K packed batches of the SAME scene layout in ONE graph launch:
+        `batches` = [(obsv, pred, zeros_val, ones_val, noise), ...].  Exactly the K `step()` calls in order (same
+        kernels, same results); what it saves is the gap between two graph launches (~13 us, the system-scope
+        fence at the end of a hipGraph) on K-1 of the K steps.  Returns the list of the K step results."""
+        if not self.use_graph or len(batches) == 1 or self.use_variety_loss:
+            return [self.step(o, p, sub_batches, zv, ov, nz, ss, global_B, out) for o, p, zv, ov, nz in batches]
+        B = batches[0][0].shape[0]
+        Bg = float(global_B if global_B is not None else B)
+        self._row0 = 0
+        scenes = ops.SceneIndex.get(sub_batches, B, self.device)
+        key = (scenes.key, batches[0][0].shape[1], float(ss), Bg, 0, len(batches))
+        if key not in self._graphs and len(self._graphs) >= self.max_graphs:
+            return [self.step(o, p, sub_batches, zv, ov, nz, ss, global_B, out) for o, p, zv, ov, nz in batches]
+        parts = self._step_graph(batches, sub_batches, float(ss), Bg)
+        return parts if out is False else [q.sum(1, dtype=torch.float64) for q in parts]
+
+    def _step_graph(self, batches, sub_batches, ss, Bg):
+        K = len(batches)
+        B, To, Tp = batches[0][0].shape[0], batches[0][0].shape[1], self.n_next
         dev = self.device
         scenes = ops.SceneIndex.get(sub_batches, B, dev)
-        key = (scenes.key, To, ss, Bg, self._row0)
+        key = (scenes.key, To, ss, Bg, self._row0, K)
         st = self._graphs.get(key)
         HDR = 8                                                   # SW_STAGE_HEADER words in front of z
         if st is None:
@@ -210,35 +230,45 @@ class SocialWaysTrainer:
                 pred=torch.empty(B, Tp, 2, device=dev), pred4=torch.empty(B, Tp, 4, device=dev),
                 targets=torch.empty(4, device=dev), noise=torch.empty(B, self.noise_len, device=dev),
                 steps=torch.zeros(self.n_unrolling_steps + 2, device=dev),   # Adam step indices of the U+1 D updates, the G update
-                out=torch.zeros(self.n_unrolling_steps + 3, (B + 15) // 16, 3, device=dev),
-                slots=[(torch.zeros(HDR + B * self.noise_len, dtype=torch.float32).pin_memory(), torch.cuda.Event())
-                       for _ in range(2)], keep=[None, None])
-        # Inputs of the step travel through a pinned host slot that the graph's first node (sw_stage_step)
-        # reads itself: the device pointers of this batch's track slices, the two label-noise scalars and z.
-        # A hipMemcpyAsync enqueued behind graph launches would block the host until the stream drains; a
-        # kernel reading device-mapped host memory does not.  One slot per graph executable.
+                outs=[torch.zeros(self.n_unrolling_steps + 3, (B + 15) // 16, 3, device=dev) for _ in range(K)],
+                slots=[[torch.zeros(HDR + B * self.noise_len, dtype=torch.float32).pin_memory() for _ in range(K)]
+                       for _ in range(2)],
+                done=[torch.cuda.Event(), torch.cuda.Event()], keep=[None, None])
+        # Inputs of a step travel through a pinned host slot that the step's first graph node (sw_stage_step)
+        # reads itself: the device pointers of this batch's track slices, the two label-noise scalars, the Adam
+        # counters and z.  A hipMemcpyAsync enqueued behind graph launches would block the host until the stream
+        # drains; a kernel reading device-mapped host memory does not.  One slot per (graph executable, sub-step).
         k = (st["flip"] ^ 1) if st["graph"] is not None else 0
-        host, done = st["slots"][k]
-        done.synchronize()                                     # the replay that last read this slot has finished
-        obsv, pred = obsv.contiguous(), pred.contiguous()
-        st["keep"][k] = (obsv, pred)                           # alive until the slot is rewritten
-        hn = host.numpy()
-        hn[:4].view(np.uint64)[:] = (obsv.data_ptr(), pred.data_ptr())
-        hn[4], hn[5] = float(zeros_val), float(ones_val)
+        st["done"][k].synchronize()                            # the replay that last read these slots has finished
         packed = isinstance(self.D_optimizer, PackedAdam)
-        if packed:            # updates applied so far: the staging kernel turns them into this step's Adam step indices
-            hn[6], hn[7] = float(self.D_optimizer.t), float(self.predictor_optimizer.t)
-            self.D_optimizer.t += self.n_unrolling_steps + 1
-            self.predictor_optimizer.t += 1
-        np.copyto(hn[HDR:].reshape(B, self.noise_len), (noise.cpu() if noise.is_cuda else noise).numpy())   # plain memcpy
+        keep = []
+        for j, (obsv, pred, zeros_val, ones_val, noise) in enumerate(batches):
+            obsv, pred = obsv.contiguous(), pred.contiguous()
+            keep.append((obsv, pred))                          # alive until the slot is rewritten
+            hn = st["slots"][k][j].numpy()
+            hn[:4].view(np.uint64)[:] = (obsv.data_ptr(), pred.data_ptr())
+            hn[4], hn[5] = float(zeros_val), float(ones_val)
+            if packed:        # updates applied so far: the staging kernel turns them into this step's Adam step indices
+                hn[6], hn[7] = float(self.D_optimizer.t), float(self.predictor_optimizer.t)
+                self.D_optimizer.t += self.n_unrolling_steps + 1
+                self.predictor_optimizer.t += 1
+            np.copyto(hn[HDR:].reshape(B, self.noise_len), (noise.cpu() if noise.is_cuda else noise).numpy())   # plain memcpy
+        st["keep"][k] = keep
 
-        def stage(kk):
-            L.call("sw_stage_step", st["slots"][kk][0].data_ptr(), B, To, Tp, L.ptr(st["obsv"]), L.ptr(st["pred"]),
+        def stage(kk, j):
+            slot = st["slots"][kk][j]
+            L.call("sw_stage_step", slot.data_ptr(), B, To, Tp, L.ptr(st["obsv"]), L.ptr(st["pred"]),
                    L.ptr(st["pred4"]), L.ptr(st["targets"]), None, L.ptr(st["steps"]), self.n_unrolling_steps + 1,
                    L.stream())
-            self._noise_src = st["slots"][kk][0].data_ptr() + 4 * HDR     # z: pulled by idle workgroups of the encoder launch
-        args = (st["obsv"], st["pred"], st["pred4"], scenes, st["targets"], st["noise"], ss, Bg, st["out"],
-                st["steps"] if packed else None)
+            self._noise_src = slot.data_ptr() + 4 * HDR        # z: pulled by idle workgroups of the encoder launch
+
+        def args(j):
+            return (st["obsv"], st["pred"], st["pred4"], scenes, st["targets"], st["noise"], ss, Bg, st["outs"][j],
+                    st["steps"] if packed else None)
+
+        def body(kk):          # the K steps of one executable, back to back
+            for j in range(K):
+                yield from self._step_gen(*args(j), pre=lambda j=j: stage(kk, j))
         if st["graph"] is not None:
             st["flip"] = k
             for g, buf in st["graph"][k]:
@@ -247,19 +277,20 @@ class SocialWaysTrainer:
                     self._allreduce(buf)
         elif st["n"] < 2:          # first steps of a layout run eagerly (lazy inits, workspace growth)
             st["n"] += 1
-            stage(0)
-            self._step_impl(*args)
+            for j in range(K):
+                stage(0, j)
+                self._step_impl(*args(j))
         else:
-            # Capture.  Single GPU: one graph for the whole step.  Data parallel: one graph per segment
+            # Capture.  Single GPU: one graph for the K steps.  Data parallel: one graph per segment
             # between the all-reduce points (the collectives themselves stay eager: no RCCL-in-graph
             # dependency), all segments sharing one memory pool so intermediates stay alive.
-            # The step is captured TWICE and the two executables alternate: launching an executable
+            # Everything is captured TWICE and the two executables alternate: launching an executable
             # that is still running makes hipGraphLaunch wait for it, which would put the host-side
             # launch cost (~150 us for ~40 nodes) on the critical path of every step.
             torch.cuda.synchronize()
             pool, sets = None, []
             for kk in range(2):
-                gen = self._step_gen(*args, pre=lambda kk=kk: stage(kk))
+                gen = body(kk)
                 graphs, fin = [], False
                 while not fin:
                     g = torch.cuda.CUDAGraph()
@@ -284,8 +315,8 @@ class SocialWaysTrainer:
                 g.replay()
                 if buf is not None:
                     self._allreduce(buf)
-        done.record()
-        return st["out"]
+        st["done"][k].record()
+        return st["outs"]
 
     def _step_impl(self, obsv, pred, pred4, scenes, targets, noise, ss, Bg, out, steps=None):
         """Eager step: run the segments, all-reducing the packed gradient buffer each one hands back."""
@@ -376,6 +407,13 @@ class SocialWaysTrainer:
         """train() (train.py:439-557).  `draw(bs)` -> (zeros_val, ones_val, noise_cpu) overrides the
         RNG draws of train.py:471-473 (tests feed the reference's recorded values)."""
         outs, sizes = [], []
+        pend, pend_key = [], None        # single GPU: consecutive packed batches of one layout share a graph launch
+
+        def flush():
+            nonlocal pend, pend_key
+            if pend:
+                outs.extend(self.step_many([p[0] for p in pend], pend[0][1], data.ss))
+                pend, pend_key = [], None
         for a, b, sb in data.packed_steps(batch_size):
             bs = b - a
             if draw is None:
@@ -384,18 +422,23 @@ class SocialWaysTrainer:
                 noise = torch.rand(bs, self.noise_len)                       # train.py:473 (CPU generator)
             else:
                 zv, ov, noise = draw(bs)
+            sizes.append((bs, len(sb)))
             if self.world > 1:
                 lo, hi = shard_scenes(sb, self.world)[self.rank]
                 if hi > lo:
                     r0, r1 = int(sb[lo, 0]), int(sb[hi - 1, 1])
                     out = self.step(data.obsv[a + r0:a + r1], data.pred[a + r0:a + r1], sb[lo:hi] - r0, zv, ov,
-                                    noise[r0:r1].to(self.device), data.ss, global_B=bs, global_row0=r0)
+                                    noise[r0:r1], data.ss, global_B=bs, global_row0=r0)
                 else:
                     out = self._empty_step()
-            else:
-                out = self.step(data.obsv[a:b], data.pred[a:b], sb, zv, ov, noise.to(self.device), data.ss)
-            outs.append(out)
-            sizes.append((bs, len(sb)))
+                outs.append(out)
+                continue
+            key = (bs, np.asarray(sb).tobytes())
+            if key != pend_key or len(pend) == self.STEPS_PER_LAUNCH:
+                flush()
+                pend_key = key
+            pend.append(((data.obsv[a:b], data.pred[a:b], zv, ov, noise), sb))
+        flush()
         allo = torch.stack(outs)
         self._allreduce(allo)
         o = allo.double().cpu().numpy()

@@ -200,3 +200,28 @@ def test_graph_replay_equals_eager():
             outs.append(tr.step(data.obsv[:B], data.pred[:B], sb, 0.01 * i, 0.9 + 0.01 * i, noise, data.ss).clone())
         res.append((torch.stack(outs).cpu(), tr.D._flat.clone().cpu(), tr.G._flat_all.clone().cpu()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+def test_step_many_equals_consecutive_steps():
+    """K steps in one graph launch (step_many) continue the exact trajectory of K single-step launches."""
+    import socialways_amd as sw
+    t = sw.synth_tracks(24, 8, seed=9)
+    data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
+    B, sb = data.n_train_samples, data.train_batches
+    res = []
+    for many in (True, False):
+        torch.manual_seed(0)
+        tr = sw.SocialWaysTrainer(12, use_social=True, device="cuda:0")
+        gen = torch.Generator().manual_seed(5)
+        outs = []
+        for rep in range(5):       # eager, eager, capture, replay, replay (x3 steps each)
+            batch = [(data.obsv[:B], data.pred[:B], 0.01 * (3 * rep + j), 0.9 + 0.01 * j, torch.rand(B, 32, generator=gen))
+                     for j in range(3)]
+            if many:
+                outs += [o.clone() for o in tr.step_many(batch, sb, data.ss)]
+            else:
+                outs += [tr.step(o, p, sb, zv, ov, nz, data.ss).clone() for o, p, zv, ov, nz in batch]
+        res.append((torch.stack(outs).cpu(), tr.D._flat.clone().cpu(), tr.G._flat_all.clone().cpu(),
+                    tr.D_optimizer.t, tr.predictor_optimizer.t))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert res[0][3] == res[1][3] == 30 and res[0][4] == res[1][4] == 15
