@@ -27,6 +27,9 @@ Cases (all fp32, torch CPU; `threads` recorded in every file)
   test_eval
         test(n_gen_samples=4, write_to_file=...) on 2 held-out scenes: K predictions, the four
         metrics and the prediction-npz arrays (schema of train.py:598-599).
+  toy_multi
+        toy (768,8,3), --batch-size 64, use_social on, FIVE consecutive epochs of train() in one process: per-epoch
+        ADE/FDE and MSE terms plus every RNG draw, to check that parity holds beyond the first epoch.
   syn_variants
         the syn_s16a8_on step again with the reference's loss / unrolling switches flipped (module
         globals of train.py:61-69): use_l2_loss, use_variety_loss (as written in train.py:527-536),
@@ -346,6 +349,41 @@ def test_eval_case():
     return out
 
 
+def multi_epoch_case(dataset, n_epochs=5, batch_size=64, seed=0):
+    """n_epochs of the reference's train() back to back (the module-level epoch loop of train.py:646-650 without
+    the checkpointing), recording every draw so that the runs under test can be fed identically."""
+    m = import_reference(dataset, batch_size, seed, True)
+    out = dict(threads=torch.get_num_threads(), batch_size=batch_size, n_epochs=n_epochs)
+    out.update(flat_state(m, "w0."))
+    rec = Recorder(m)
+    np.random.seed(seed)
+    per = 3 * (m.n_unrolling_steps + 1) + 3
+    calls_per_step = 2 * (m.n_unrolling_steps + 1) + 1
+    preds_per_step = (m.n_unrolling_steps + 1) + 1
+    s_done = 0
+    for ep in range(n_epochs):
+        m.epoch = ep + 1
+        with contextlib.redirect_stdout(io.StringIO()):
+            m.train()
+        n_steps = len(rec.g_grads) - s_done
+        ade = fde = 0.0
+        for s in range(s_done, s_done + n_steps):       # same expressions as train.py:546-557
+            pred_hat = rec.predicts[s * preds_per_step + preds_per_step - 1]
+            pred = rec.d_calls[s * calls_per_step + 1][1][:, :, :2]
+            err = torch.pow((pred_hat[:, :, :2] - pred) / m.ss, 2).sum(dim=2).sqrt()
+            ade += err.sum().item() / m.n_next
+            fde += err[:, -1].sum().item()
+        out["ade.%d" % ep], out["fde.%d" % ep] = ade / m.n_train_samples, fde / m.n_train_samples
+        out["losses.%d" % ep] = np.asarray(rec.mse[s_done * per:(s_done + n_steps) * per], np.float64).reshape(n_steps, per)
+        out["uniform.%d" % ep] = np.asarray(rec.uniform[2 * s_done:2 * (s_done + n_steps)], np.float64).reshape(n_steps, 2)
+        for s in range(n_steps):
+            out["noise.%d.%d" % (ep, s)] = rec.noise[s_done + s].numpy()
+        s_done += n_steps
+    rec.close()
+    m._cleanup()
+    return out
+
+
 VARIANTS = {
     "l2": dict(use_l2_loss=True),
     "variety": dict(use_variety_loss=True),
@@ -461,6 +499,8 @@ def main():
     syn = sw_oracle.synth_dataset(20, 8, seed=1234)                  # 16 train scenes x 8
     if only is None or "syn_variants" in only:
         save("syn_variants", variants_case(syn))
+    if only is None or "toy_multi" in only:
+        save("toy_multi", multi_epoch_case(toy_dataset(768, 8, 3)))
     if only is None or "biwi_synth" in only:
         save("biwi_synth", biwi_case())
     if only is None or "toy_stats" in only:

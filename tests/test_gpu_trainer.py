@@ -326,3 +326,26 @@ def test_biwi_format_crowd_epoch_matches_oracle():
     assert [s[0] for s in sizes] == [s[0] for s in oshapes] and len(sizes) >= 4
     assert_close(losses, np.asarray(olosses), 3e-4, 3e-6, "MSE terms of the epoch")
     assert abs(ade - oade) < 1e-4 and abs(fde - ofde) < 1e-4, (ade, oade, fde, ofde)
+
+
+def test_five_toy_epochs_track_the_reference():
+    """BASELINE config 1 over FIVE epochs (50 GAN steps) on the GPU with the reference's recorded draws: per-epoch
+    ADE/FDE and all 450 MSE terms stay within the north-star 1e-4 in every epoch (observed <= 2.2e-6 after five)."""
+    import socialways_amd as sw
+    g = golden("toy_multi")
+    toy = golden("toy_768_8_3")
+    data = sw.SceneDataset(toy["obsvs"], toy["preds"], toy["batches"], toy["times"], device="cuda:0")
+    tr = make_trainer(g, 2, True)
+    errs = []
+    for ep in range(int(g["n_epochs"])):
+        steps = iter(range(len(g["losses.%d" % ep])))
+
+        def draw(bs, ep=ep, steps=steps):
+            s = next(steps)
+            return float(g["uniform.%d" % ep][s, 0]), float(g["uniform.%d" % ep][s, 1]), torch.from_numpy(g["noise.%d.%d" % (ep, s)])
+        ade, fde, losses, _ = tr.train_epoch(data, int(g["batch_size"]), draw=draw)
+        errs.append((abs(ade - float(g["ade.%d" % ep])), abs(fde - float(g["fde.%d" % ep])),
+                     float(np.abs(losses - g["losses.%d" % ep]).max())))
+    print("per-epoch |dADE|, |dFDE|, max |dMSE|:", errs)
+    assert all(max(e[:2]) < 1e-4 for e in errs), errs          # north-star tolerance, every epoch (observed <= 2.2e-6)
+    assert all(e[2] < 1e-4 for e in errs), errs

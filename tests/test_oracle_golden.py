@@ -191,3 +191,23 @@ def test_toy_statistics_1nn_and_emd():
         assert abs(O.compute_wasserstein(g["real"], g["fake.%d" % i]) - float(g["emd.%d" % i])) < 1e-7
     assert_close(O.compute_1nn(g["g.real"], g["g.fake"], 3), g["g.one_nn"], 0, 1e-12, "1nn generic")
     assert abs(O.compute_wasserstein(g["g.real"], g["g.fake"], 3) - float(g["g.emd"])) < 1e-7
+
+
+def test_five_toy_epochs_track_the_reference():
+    """Five consecutive epochs of train() on the toy set (50 Adam-updated GAN steps): the oracle fed with the
+    reference's recorded draws reproduces its per-epoch ADE/FDE and MSE terms; the tolerance grows with the
+    horizon (chaotic amplification of fp32 summation-order differences), it does not drift."""
+    g = golden("toy_multi")
+    toy = golden("toy_768_8_3")
+    data = O.load_and_normalise(toy["obsvs"], toy["preds"], toy["batches"])
+    o = make_oracle(g, 2, True, "blockdiag")
+    for ep in range(int(g["n_epochs"])):
+        steps = iter(range(len(g["losses.%d" % ep])))
+
+        def draw(bs, ep=ep, steps=steps):
+            s = next(steps)
+            return float(g["uniform.%d" % ep][s, 0]), float(g["uniform.%d" % ep][s, 1]), torch.from_numpy(g["noise.%d.%d" % (ep, s)])
+        ade, fde, losses, _ = o.train_epoch(data, int(g["batch_size"]), draw=draw)
+        tol = 1e-5 * 10 ** ep
+        assert abs(ade - float(g["ade.%d" % ep])) < tol and abs(fde - float(g["fde.%d" % ep])) < tol, (ep, ade, fde)
+        assert_close(np.asarray(losses), g["losses.%d" % ep], 1e-4 * 10 ** ep, 1e-6, "MSE terms of epoch %d" % (ep + 1))
