@@ -27,6 +27,9 @@ Cases (all fp32, torch CPU; `threads` recorded in every file)
   test_eval
         test(n_gen_samples=4, write_to_file=...) on 2 held-out scenes: K predictions, the four
         metrics and the prediction-npz arrays (schema of train.py:598-599).
+  syn_big_on
+        like syn_ragged_on with scenes of 70 and 90 agents (above the 64-agent limit of the one-workgroup-per-scene
+        kernels): one packed train() step of the reference with every intermediate and gradient.
   toy_multi
         toy (768,8,3), --batch-size 64, use_social on, FIVE consecutive epochs of train() in one process: per-epoch
         ADE/FDE and MSE terms plus every RNG draw, to check that parity holds beyond the first epoch.
@@ -499,6 +502,12 @@ def main():
     syn = sw_oracle.synth_dataset(20, 8, seed=1234)                  # 16 train scenes x 8
     if only is None or "syn_variants" in only:
         save("syn_variants", variants_case(syn))
+    if only is None or "syn_big_on" in only:      # scenes above 64 agents (the build's row-block kernels) straight from the reference
+        big = sw_oracle.synth_dataset(5, [70, 3, 90, 8, 2], seed=77)
+        out = run_one_step(big, True)
+        for k in ("obsvs", "preds", "batches"):
+            out["ds." + k] = big[k]
+        save("syn_big_on", out)
     if only is None or "toy_multi" in only:
         save("toy_multi", multi_epoch_case(toy_dataset(768, 8, 3)))
     if only is None or "biwi_synth" in only:

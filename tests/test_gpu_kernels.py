@@ -41,7 +41,7 @@ def cmp_grads(got, g, prefix, rtol, atol_rel):
         assert_close(v.detach().cpu().numpy(), ref, rtol, atol_rel * max(np.abs(ref).max(), 1e-12), prefix + k)
 
 
-@pytest.mark.parametrize("case", ["syn_s16a8_off", "syn_s16a8_on", "syn_ragged_on"])
+@pytest.mark.parametrize("case", ["syn_s16a8_off", "syn_s16a8_on", "syn_ragged_on", "syn_big_on"])
 def test_predict_forward(case):
     g = golden(case)
     G, D, dev = _models(g, 12, bool(g["use_social"]))
@@ -69,7 +69,7 @@ def test_disc_forward(case):
     assert_close(code_f.cpu(), g["d0_fake.code"], RT, AT, "fake code")
 
 
-@pytest.mark.parametrize("case", ["syn_s16a8_off", "syn_s16a8_on", "syn_ragged_on"])
+@pytest.mark.parametrize("case", ["syn_s16a8_off", "syn_s16a8_on", "syn_ragged_on", "syn_big_on"])
 def test_predict_backward(case):
     """dL/dpred_hat of the reference's G phase pushed through the HIP backward: every generator
     gradient must match the reference's autograd."""

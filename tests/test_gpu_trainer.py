@@ -32,7 +32,7 @@ def check_weights(tr, g, rtol, atol, frac_ok=1.0):
                 mod, k, 100 * bad.mean(), np.abs(a - b).max())
 
 
-@pytest.mark.parametrize("case", ["syn_s16a8_off", "syn_s16a8_on", "syn_ragged_on"])
+@pytest.mark.parametrize("case", ["syn_s16a8_off", "syn_s16a8_on", "syn_ragged_on", "syn_big_on"])
 def test_one_step(case):
     import socialways_amd as sw
     g = golden(case)

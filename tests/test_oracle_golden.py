@@ -69,7 +69,7 @@ def test_toy_epoch_own_rng_stream():
     assert abs(ade - float(g["ade"])) < 1e-5
 
 
-@pytest.mark.parametrize("case,social", [("syn_s16a8_off", "blockdiag"), ("syn_s16a8_on", "blockdiag"),
+@pytest.mark.parametrize("case,social", [("syn_s16a8_off", "blockdiag"), ("syn_s16a8_on", "blockdiag"), ("syn_big_on", "blockdiag"),
                                          ("syn_s16a8_on", "faithful"), ("syn_ragged_on", "blockdiag"),
                                          ("syn_ragged_on", "faithful")])
 def test_one_step_all_intermediates(case, social):
