@@ -151,7 +151,7 @@ int sw_dec_rollout_bwd_aux(const float* dpred4, const float* enc_w, const float*
  * part 0 = all; 1 = what dec_rollout_bwd produced (decoder layers + LSTM rows t >= To); 2 = LSTM rows
  * t < To (after enc_lstm_bwd) accumulated onto part 1, then the embed / W_ih split.  Parts 1 and 2
  * may run on different streams with different `wgrad_ws`; `tmp` (2048 floats) links them.        */
-int sw_gen_wgrad(const float* enc_w, const float* gsave, const float* gdelta, const float* z,
+int sw_gen_wgrad(const float* enc_w, const float* dec_w, const float* gsave, const float* gdelta, const float* z,
                  const float* S_pool, int B, int To, int Tp, float* d_enc_w, float* d_dec_w, int part,
                  float* wgrad_ws, float* tmp /*[2048]*/,
                  sw_wgrad_batch* pending /*or NULL: problems deferred by sw_social_pool_bwd join this launch*/,

@@ -25,15 +25,15 @@ constexpr int LD2 = sw_ld(2);      // 20
 struct FwdLds {
   static constexpr int W1h = 0;                        // [160][68]
   static constexpr int W2 = W1h + 160 * LD64;          // [80][164]
-  static constexpr int W3 = W2 + 80 * LD160;           // [48][84]   rows >= 40 zero
-  static constexpr int W4 = W3 + 48 * LD80;            // [16][52]   rows >= 2 zero
-  static constexpr int hbuf = W4 + 16 * LD40;          // [2][16][68]
+  static constexpr int W43 = W2 + 80 * LD160;          // [16][84]   fc4 . fc3 composed (2 x 80), rows >= 2 zero
+  static constexpr int W3tmp = W43 + 16 * LD80;        // [40][84]   fc3 weight, prologue only (operand of the composition)
+  static constexpr int hbuf = W3tmp + 40 * LD80;       // [2][16][68]
   static constexpr int ubuf = hbuf + 2 * 16 * LD64;    // [16][164]
   static constexpr int a1buf = ubuf + 16 * LD160;      // [16][164]  (prologue: [S|z] tile [16][100])
   static constexpr int a2buf = a1buf + 16 * LD160;     // [16][84]   (prologue: wx_lds, bx_lds)
-  static constexpr int a3buf = a2buf + 16 * LD80;      // [16][52]
+  static constexpr int a3buf = a2buf + 16 * LD80;      // [16][52]   (prologue alias only)
   static constexpr int xbuf = a3buf + 16 * LD40;       // [16][4]
-  static constexpr int bbuf = xbuf + 64;               // b2[80] | b3[48] | b4[16]
+  static constexpr int bbuf = xbuf + 64;               // b2[80] | - | b43[16]
   static constexpr int total = bbuf + 144;
 };
 static_assert(16 * LD80 + 16 * LD40 >= 1280, "prologue alias");
@@ -43,9 +43,9 @@ static_assert(FwdLds::total * 4 <= 163840, "LDS budget");
 struct BwdLds {
   static constexpr int W1hT = 0;                       // [64][164]   W1hT[m][k] = W1[k][m], m < 64
   static constexpr int W2T = W1hT + 64 * LD160;        // [160][84]
-  static constexpr int W3T = W2T + 160 * LD80;         // [80][52]
-  static constexpr int W4T = W3T + 80 * LD40;          // [48][20]    rows >= 40 zero, cols >= 2 zero
-  static constexpr int dgbuf = W4T + 48 * LD2;         // [16][260]
+  static constexpr int W43T = W2T + 160 * LD80;        // [80][20]    (fc4 . fc3)^T: W43T[k][c] = W43[c][k], cols >= 2 zero
+  static constexpr int W3tmp = W43T + 80 * LD2;        // [40][84]    fc3 weight, prologue only
+  static constexpr int dgbuf = W3tmp + 40 * LD80;      // [16][260]
   static constexpr int dz1buf = dgbuf + 16 * SW_GLD;   // [16][164]
   static constexpr int dz2buf = dz1buf + 16 * LD160;   // [16][84]
   static constexpr int da3buf = dz2buf + 16 * LD80;    // [16][52]
@@ -65,13 +65,11 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W1h = smem + FwdLds::W1h;
   float* W2 = smem + FwdLds::W2;
-  float* W3 = smem + FwdLds::W3;
-  float* W4 = smem + FwdLds::W4;
+  float* W43 = smem + FwdLds::W43;
   float* hbuf = smem + FwdLds::hbuf;
   float* ubuf = smem + FwdLds::ubuf;
   float* a1buf = smem + FwdLds::a1buf;
   float* a2buf = smem + FwdLds::a2buf;
-  float* a3buf = smem + FwdLds::a3buf;
   float* bbuf = smem + FwdLds::bbuf;
   float* szbuf = a1buf;           // prologue alias
   float* wx_lds = a2buf;          // prologue alias (1024)
@@ -89,13 +87,24 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
   lstm_load_whh(W, enc_w + swp::ENC_WHH, u0, ln, lg);   // global loads in flight during the LDS staging
   stage_w(W1h, LD64, 160, dec_w + swp::DEC_W1, 160, 160, 64);
   stage_w(W2, LD160, 80, dec_w + swp::DEC_W2, 160, 80, 160);
-  stage_w(W3, LD80, 48, dec_w + swp::DEC_W3, 80, 40, 80);
-  stage_w(W4, LD40, 16, dec_w + swp::DEC_W4, 40, 2, 40);
+  // fc3 (80 -> 40) has NO activation in front of fc4 (40 -> 2) (train.py:327-330): the two are ONE 2 x 80 map
+  //   v = W4 (W3 a2 + b3) + b4 = W43 a2 + b43
+  // composed per workgroup after the staging barrier (like W_ih . W_embed of the encoder): one layer less on the
+  // serial chain of every decode step; a3 itself is never needed (its weight gradients are recovered from
+  // dv^T [a2 | 1], sw_misc.hip).
+  stage_w(smem + FwdLds::W3tmp, LD80, 40, dec_w + swp::DEC_W3, 80, 40, 80);
   for (int i = threadIdx.x; i < 144; i += blockDim.x) {
     float v = 0.f;
     if (i < 80) v = dec_w[swp::DEC_B2 + i];
-    else if (i < 120) v = dec_w[swp::DEC_B3 + i - 80];
-    else if (i >= 128 && i < 130) v = dec_w[swp::DEC_B4 + i - 128];
+    else if (i >= 128 && i < 130) {
+      const int c = i - 128;
+      v = dec_w[swp::DEC_B4 + c];
+#pragma unroll
+      for (int m = 0; m < 40; m += 4) {
+        const f32x4 w = ld4(dec_w + swp::DEC_W4 + c * 40 + m), bb = ld4(dec_w + swp::DEC_B3 + m);
+        v = fmaf(w[0], bb[0], fmaf(w[1], bb[1], fmaf(w[2], bb[2], fmaf(w[3], bb[3], v))));
+      }
+    }
     bbuf[i] = v;
   }
   lstm_prep_rows(enc_w + swp::ENC_EMB_W, enc_w + swp::ENC_EMB_B, enc_w + swp::ENC_WIH, enc_w + swp::ENC_BIH,
@@ -111,6 +120,17 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
   st4(&hbuf[ln * LD64 + u0 + 4 * lg], h);
   sw_barrier();
   lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
+  for (int i = threadIdx.x; i < 16 * LD80; i += blockDim.x) {   // W43 = W4 W3 from the staged fc3 image
+    const int c = i / LD80, k = i - c * LD80;
+    float v = 0.f;
+    if (c < 2 && k < 80) {
+      const float* w4 = dec_w + swp::DEC_W4 + c * 40;
+      const float* w3 = smem + FwdLds::W3tmp + k;
+#pragma unroll 8
+      for (int m = 0; m < 40; ++m) v = fmaf(w4[m], w3[m * LD80], v);
+    }
+    W43[i] = v;
+  }
   for (int mt = wave; mt < 10; mt += 4) {
     int m0 = mt * 16;
     f32x4 acc = ld4(dec_w + swp::DEC_B1 + m0 + 4 * lg);
@@ -151,21 +171,12 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
       if (gsave && live) st4(gsave + gs.a2 + ((size_t)i * B + b) * 80 + m0 + 4 * lg, acc);
     }
     sw_barrier();
-    // ---- layer 3: a3 = W3 a2 + b3 (no activation, train.py:327-328) -------------------------
-    if (wave < 3) {
-      int m0 = wave * 16;
-      f32x4 acc = ld4(&bbuf[80 + m0 + 4 * lg]);
-      acc = tile_mm<5>(&W3[(m0 + ln) * LD80 + 4 * lg], &a2buf[ln * LD80 + 4 * lg], acc);
-      st4(&a3buf[ln * LD40 + m0 + 4 * lg], acc);
-      if (gsave && live && m0 + 4 * lg < 40) st4(gsave + gs.a3 + ((size_t)i * B + b) * 40 + m0 + 4 * lg, acc);
-    }
-    sw_barrier();
-    // ---- layer 4 (v = W4 a3 + b4 ; p += v) and the re-fed encoder step (train.py:422-430) --------
-    // Every wave computes the 2-row layer 4 itself (12 MFMAs on otherwise idle SIMDs) and keeps its
-    // own copy of the running position, so the LSTM step needs no barrier / LDS hop for its input.
+    // ---- layers 3+4 composed (v = W43 a2 + b43 ; p += v) and the re-fed encoder step (train.py:422-430) ----
+    // Every wave computes the 2-row map itself (20 MFMAs) and keeps its own copy of the running position, so
+    // the LSTM step needs no barrier / LDS hop for its input.
     {
       f32x4 acc = ld4(&bbuf[128 + 4 * lg]);
-      acc = tile_mm<3>(&W4[ln * LD40 + 4 * lg], &a3buf[ln * LD40 + 4 * lg], acc);
+      acc = tile_mm<5>(&W43[ln * LD80 + 4 * lg], &a2buf[ln * LD80 + 4 * lg], acc);
       // rows 0,1 (= v_x, v_y of agent ln) sit in the lg == 0 lanes; every lane fetches its agent's pair
       float vx = __shfl(acc[0], ln), vy = __shfl(acc[1], ln);
       px += vx;
@@ -252,12 +263,10 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W1hT = smem + BwdLds::W1hT;
   float* W2T = smem + BwdLds::W2T;
-  float* W3T = smem + BwdLds::W3T;
-  float* W4T = smem + BwdLds::W4T;
+  float* W43T = smem + BwdLds::W43T;
   float* dgbuf = smem + BwdLds::dgbuf;
   float* dz1buf = smem + BwdLds::dz1buf;
   float* dz2buf = smem + BwdLds::dz2buf;
-  float* da3buf = smem + BwdLds::da3buf;
   float* dvbuf = smem + BwdLds::dvbuf;
   float* dxpart = smem + BwdLds::dxpart;
   float* wx_lds = dz1buf;          // prologue alias (1024)
@@ -278,13 +287,23 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
   sw_barrier();
   stage_wT(W1hT, LD160, 64, dec_w + swp::DEC_W1, 160, 160, 64);
   stage_wT(W2T, LD80, 160, dec_w + swp::DEC_W2, 160, 80, 160);
-  stage_wT(W3T, LD40, 80, dec_w + swp::DEC_W3, 80, 40, 80);
-  stage_wT(W4T, LD2, 48, dec_w + swp::DEC_W4, 40, 2, 40);
+  stage_w(smem + BwdLds::W3tmp, LD80, 40, dec_w + swp::DEC_W3, 80, 40, 80);   // operand of the fc4 . fc3 composition
   lstm_prep_rows(enc_w + swp::ENC_EMB_W, enc_w + swp::ENC_EMB_B, enc_w + swp::ENC_WIH, enc_w + swp::ENC_BIH,
                  enc_w + swp::ENC_BHH, true, wx_lds, bx_lds);
   for (int i = threadIdx.x; i < 16 * LD2; i += blockDim.x) dvbuf[i] = 0.f;
   sw_barrier();
   // Wx^T slice of this wave's K-quarter as A operands: row c = ln (< 4 live), k = 64*wave + 16j + 4lg + r
+  for (int i = threadIdx.x; i < 80 * LD2; i += blockDim.x) {   // W43^T from the staged fc3 image (see the forward kernel)
+    const int k = i / LD2, c = i - k * LD2;
+    float v = 0.f;
+    if (c < 2) {
+      const float* w4 = dec_w + swp::DEC_W4 + c * 40;
+      const float* w3 = smem + BwdLds::W3tmp + k;
+#pragma unroll 8
+      for (int m = 0; m < 40; ++m) v = fmaf(w4[m], w3[m * LD80], v);
+    }
+    W43T[i] = v;
+  }
   f32x4 wxT[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -362,25 +381,17 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
       f32x4 o = {dvx, dvy, 0.f, 0.f};
       st4(gdelta + gd.dv + ((size_t)i * B + b) * 4, o);
     }
-    if (wave < 3) {  // B operand (k = 4lg + r, only k = 0,1 live) straight from registers
-      int m0 = wave * 16;
-      f32x4 w = ld4(&W4T[(m0 + ln) * LD2 + 4 * lg]);
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      acc = SW_MFMA(w[0], lg == 0 ? dvx : 0.f, acc);
-      acc = SW_MFMA(w[1], lg == 0 ? dvy : 0.f, acc);
-      st4(&da3buf[ln * LD40 + m0 + 4 * lg], acc);
-      if (live && m0 + 4 * lg < 40) st4(gdelta + gd.da3 + ((size_t)i * B + b) * 40 + m0 + 4 * lg, acc);
-    }
-    sw_barrier();
-    SW_STAMP(2);
-    // dz2 = (W3^T da3) * lrelu'(a2)   (80)
+    // dz2 = (W43^T dv) * lrelu'(a2)   (80): fc3 and fc4 are one linear map, so d(a2) comes straight from dv
+    // (2 MFMAs per tile, B operand k = 4lg + r with only k = 0,1 live, straight from registers)
 #pragma unroll
     for (int q2 = 0; q2 < 2; ++q2) {
       int mt = wave + 4 * q2;
       if (mt >= 5) break;
       int m0 = mt * 16;
+      f32x4 w = ld4(&W43T[(m0 + ln) * LD2 + 4 * lg]);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      acc = tile_mm<3>(&W3T[(m0 + ln) * LD40 + 4 * lg], &da3buf[ln * LD40 + 4 * lg], acc);
+      acc = SW_MFMA(w[0], lg == 0 ? dvx : 0.f, acc);
+      acc = SW_MFMA(w[1], lg == 0 ? dvy : 0.f, acc);
       f32x4 a2 = a2pre[q2];
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(a2[r], acc[r]);

@@ -87,11 +87,40 @@ extern "C" size_t sw_workspace_floats(int ws_id, int B, int To, int Tp, int nb, 
 
 // ---- encoder: gradients of the composed input matrix back to embed / W_ih --------------------
 //   Wx = Wih We, bx = Wih be + bih + bhh   (sw_lstm_dev.h)
+// Blocks >= 128 (when dec_w != null): the decoder's fc3 / fc4 run as ONE composed 2 x 80 map in the kernels
+// (v = W43 a2 + b43, sw_decoder.hip); their four gradients follow from M = dv^T a2 (2 x 80) and s = sum dv (2):
+//   dW3 = W4^T M,  db3 = W4^T s,  dW4 = M W3^T + s b3^T,  db4 = s        (exactly autograd's values, reassociated)
+#define SW_DEC_COMPOSE_BLOCKS 13   // 3322 outputs
 __global__ __launch_bounds__(256) void enc_compose_bwd_kernel(const float* __restrict__ enc_w,
                                                               const float* __restrict__ dWx,
                                                               const float* __restrict__ dbx,
-                                                              float* __restrict__ d_enc_w) {
+                                                              float* __restrict__ d_enc_w,
+                                                              const float* __restrict__ dec_w,
+                                                              const float* __restrict__ Ms,
+                                                              float* __restrict__ d_dec_w) {
   using namespace swp;
+  if (blockIdx.x >= 128) {
+    const int o = (blockIdx.x - 128) * 256 + threadIdx.x;
+    const float* M = Ms;            // [2][80]
+    const float* sv = Ms + 160;     // [2]
+    const float* W3 = dec_w + DEC_W3;
+    const float* W4 = dec_w + DEC_W4;
+    if (o < 3200) {                 // dW3[m][k]
+      const int m = o / 80, k = o - m * 80;
+      d_dec_w[DEC_W3 + o] = fmaf(W4[m], M[k], W4[40 + m] * M[80 + k]);
+    } else if (o < 3240) {          // db3[m]
+      const int m = o - 3200;
+      d_dec_w[DEC_B3 + m] = fmaf(W4[m], sv[0], W4[40 + m] * sv[1]);
+    } else if (o < 3320) {          // dW4[c][m]
+      const int c = (o - 3240) / 40, m = (o - 3240) - c * 40;
+      float v = sv[c] * dec_w[DEC_B3 + m];
+      for (int k = 0; k < 80; ++k) v = fmaf(M[c * 80 + k], W3[m * 80 + k], v);
+      d_dec_w[DEC_W4 + c * 40 + m] = v;
+    } else if (o < 3322) {          // db4[c]
+      d_dec_w[DEC_B4 + (o - 3320)] = sv[o - 3320];
+    }
+    return;
+  }
   const float* We = enc_w + ENC_EMB_W;
   const float* be = enc_w + ENC_EMB_B;
   const float* Wih = enc_w + ENC_WIH;
@@ -133,10 +162,10 @@ __global__ __launch_bounds__(256) void enc_compose_bwd_kernel(const float* __res
 // (after enc_lstm_bwd), accumulated on top of part 1, then the composed-input-matrix back-propagation.
 // Parts 1 and 2 may run on different streams (different partial workspaces `wgrad_ws`); `tmp` holds
 // the 256x4 + 256 composed-matrix gradient between them.
-extern "C" int sw_gen_wgrad(const float* enc_w, const float* gsave, const float* gdelta, const float* z,
+extern "C" int sw_gen_wgrad(const float* enc_w, const float* dec_w, const float* gsave, const float* gdelta, const float* z,
                             const float* S_pool, int B, int To, int Tp, float* d_enc_w, float* d_dec_w, int part,
                             float* wgrad_ws, float* tmp, sw_wgrad_batch* pending, void* stream) {
-  if (!enc_w || !gsave || !gdelta || !z || !S_pool || !d_enc_w || !d_dec_w || !wgrad_ws || !tmp || B < 1 || To < 2 ||
+  if (!enc_w || !dec_w || !gsave || !gdelta || !z || !S_pool || !d_enc_w || !d_dec_w || !wgrad_ws || !tmp || B < 1 || To < 2 ||
       Tp < 1 || part < 0 || part > 2)
     return SW_EARG;
   using namespace swp;
@@ -145,6 +174,7 @@ extern "C" int sw_gen_wgrad(const float* enc_w, const float* gsave, const float*
   const int Ta = To + Tp - 1;
   float* dWx = tmp;
   float* dbx = tmp + 1024;
+  float* dM = tmp + 1280;   // [2][80] dv^T a2, then [2] sum dv
   hipStream_t st = (hipStream_t)stream;
   WgBatch wb;
   if (pending) {   // problems another module left for this launch (sw_social_pool_bwd with `defer`)
@@ -170,15 +200,15 @@ extern "C" int sw_gen_wgrad(const float* enc_w, const float* gsave, const float*
     rc_add |= wg_add(wb, gdelta + gd.du, 160, z, 32, B, 160, 32, d_dec_w + DEC_W1 + 128, 160, d_dec_w + DEC_B1, nullptr, 0);
     rc_add |= wg_add(wb, gdelta + gd.dz2, 80, gsave + gs.a1, 160, Tp * B, 80, 160, d_dec_w + DEC_W2, 160, d_dec_w + DEC_B2,
                      nullptr, 0);
-    rc_add |= wg_add(wb, gdelta + gd.da3, 40, gsave + gs.a2, 80, Tp * B, 40, 80, d_dec_w + DEC_W3, 80, d_dec_w + DEC_B3,
-                     nullptr, 0);
-    rc_add |= wg_add(wb, gdelta + gd.dv, 4, gsave + gs.a3, 40, Tp * B, 2, 40, d_dec_w + DEC_W4, 40, d_dec_w + DEC_B4,
-                     nullptr, 0);
+    // fc3 / fc4 (one composed map in the kernels): M = dv^T a2 and s = sum dv; enc_compose_bwd_kernel derives
+    // dW3, db3, dW4, db4 from them
+    rc_add |= wg_add(wb, gdelta + gd.dv, 4, gsave + gs.a2, 80, Tp * B, 2, 80, dM, 80, dM + 160, nullptr, 0);
   }
   if (rc_add) return SW_ESHAPE;
   if (int rc = wg_launch(wb, wgrad_ws, st)) return rc;
   if (part != 1) {
-    hipLaunchKernelGGL(enc_compose_bwd_kernel, dim3(128), dim3(256), 0, st, enc_w, dWx, dbx, d_enc_w);
+    hipLaunchKernelGGL(enc_compose_bwd_kernel, dim3(128 + SW_DEC_COMPOSE_BLOCKS), dim3(256), 0, st, enc_w, dWx, dbx, d_enc_w,
+                       dec_w, dM, d_dec_w);
     SW_CHECK_LAUNCH("enc_compose_bwd_kernel");
   }
   return SW_OK;

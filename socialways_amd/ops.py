@@ -186,7 +186,7 @@ def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d
         d_att.zero_()
     L.call("sw_enc_lstm_bwd", L.ptr(enc_w), L.ptr(ctx.gsave), None, L.ptr(dhT), L.ptr(dcT), None, B, To, 0,
            L.ptr(gdelta), None, None, L.stream())
-    L.call("sw_gen_wgrad", L.ptr(enc_w), L.ptr(ctx.gsave), L.ptr(gdelta), L.ptr(ctx.noise), L.ptr(ctx.S), B, To, Tp,
+    L.call("sw_gen_wgrad", L.ptr(enc_w), L.ptr(dec_w), L.ptr(ctx.gsave), L.ptr(gdelta), L.ptr(ctx.noise), L.ptr(ctx.S), B, To, Tp,
            L.ptr(d_enc), L.ptr(d_dec), 0, L.ptr(wgrad), L.ptr(tmp), pending, L.stream())
 
 
