@@ -150,6 +150,52 @@ __device__ __forceinline__ void stage_wT(float* dst, int ld, int Kp, const float
   }
 }
 
+// Split forms of stage_w / stage_wT: a prologue issues the loads of ALL its matrices first (NV float4 registers
+// per matrix and thread, NV = ceil(#float4 / 256)) and stores them afterwards - one L2 round trip for the whole
+// prologue instead of one per matrix (each staging call used to wait for its own loads before its LDS stores).
+template <int NV>
+__device__ __forceinline__ void stage_w_load(f32x4 (&v)[NV], int ld, int Mp, const float* src, int src_ld, int M, int K) {
+  const int ldq = ld >> 2, n4 = Mp * ldq;
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    int f = threadIdx.x + SW_THREADS * u;
+    int r = f / ldq, c = (f - r * ldq) * 4;
+    v[u] = (f < n4 && r < M && c < K) ? ld4(src + (size_t)r * src_ld + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+template <int NV>
+__device__ __forceinline__ void stage_w_store(const f32x4 (&v)[NV], float* dst, int ld, int Mp) {
+  const int n4 = Mp * (ld >> 2);
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    int f = threadIdx.x + SW_THREADS * u;
+    if (f < n4) st4(dst + (size_t)f * 4, v[u]);
+  }
+}
+template <int NV>
+__device__ __forceinline__ void stage_wT_load(f32x4 (&v)[NV], const float* src, int src_ld, int M, int K) {
+  const int k4 = K >> 2, n4 = M * k4;
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    int f = threadIdx.x + SW_THREADS * u;
+    int r = f / k4, c = (f - r * k4) * 4;
+    v[u] = f < n4 ? ld4(src + (size_t)r * src_ld + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+template <int NV>
+__device__ __forceinline__ void stage_wT_store(const f32x4 (&v)[NV], float* dst, int ld, int M, int K) {
+  const int k4 = K >> 2, n4 = M * k4;
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    int f = threadIdx.x + SW_THREADS * u;
+    int r = f / k4, c = (f - r * k4) * 4;
+    if (f < n4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[(size_t)(c + e) * ld + r] = v[u][e];
+    }
+  }
+}
+
 // LDS leading dimension for a K-wide operand.
 __host__ __device__ constexpr int sw_ld(int K) { return ((K + 15) / 16) * 16 + 4; }
 

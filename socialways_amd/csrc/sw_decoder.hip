@@ -120,16 +120,24 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
   st4(&hbuf[ln * LD64 + u0 + 4 * lg], h);
   sw_barrier();
   lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
-  for (int i = threadIdx.x; i < 16 * LD80; i += blockDim.x) {   // W43 = W4 W3 from the staged fc3 image
-    const int c = i / LD80, k = i - c * LD80;
-    float v = 0.f;
-    if (c < 2 && k < 80) {
-      const float* w4 = dec_w + swp::DEC_W4 + c * 40;
-      const float* w3 = smem + FwdLds::W3tmp + k;
-#pragma unroll 8
-      for (int m = 0; m < 40; ++m) v = fmaf(w4[m], w3[m * LD80], v);
+  for (int i = threadIdx.x; i < 16 * LD80; i += blockDim.x)        // zero padding around the two live rows
+    if (i >= 2 * LD80 || i % LD80 >= 80) W43[i] = 0.f;
+  if (threadIdx.x < 160) {   // W43 = W4 W3 from the staged fc3 image: one output per thread, 4 independent partial sums
+    const int c = threadIdx.x / 80, k = threadIdx.x - c * 80;
+    const float* w4 = dec_w + swp::DEC_W4 + c * 40;
+    const float* w3 = smem + FwdLds::W3tmp + k;
+    f32x4 wv[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) wv[q] = ld4(w4 + 4 * q);
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+      v0 = fmaf(wv[q][0], w3[(4 * q) * LD80], v0);
+      v1 = fmaf(wv[q][1], w3[(4 * q + 1) * LD80], v1);
+      v2 = fmaf(wv[q][2], w3[(4 * q + 2) * LD80], v2);
+      v3 = fmaf(wv[q][3], w3[(4 * q + 3) * LD80], v3);
     }
-    W43[i] = v;
+    W43[c * LD80 + k] = (v0 + v1) + (v2 + v3);
   }
   for (int mt = wave; mt < 10; mt += 4) {
     int m0 = mt * 16;
@@ -281,28 +289,38 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
   const GDelta gd = gdelta_layout(B, To, Tp);
 
   // ---- prologue: transposed decoder weights into LDS, composed Wx^T, W_hh^T into registers ---
+  // All global loads of the prologue are issued before anything waits on them (one L2 round trip, not one per matrix)
   LstmWT WT;
-  lstm_load_wT(WT, enc_w + swp::ENC_WHH, u0, ln, lg);   // global loads in flight during the LDS staging
+  lstm_load_wT(WT, enc_w + swp::ENC_WHH, u0, ln, lg);
+  f32x4 r1[10], r2[13], r3[4];
+  stage_wT_load<10>(r1, dec_w + swp::DEC_W1, 160, 160, 64);
+  stage_wT_load<13>(r2, dec_w + swp::DEC_W2, 160, 80, 160);
+  stage_w_load<4>(r3, LD80, 40, dec_w + swp::DEC_W3, 80, 40, 80);   // operand of the fc4 . fc3 composition
+  const f32x4 w4v = threadIdx.x < 20 ? ld4(dec_w + swp::DEC_W4 + 4 * threadIdx.x) : f32x4{0.f, 0.f, 0.f, 0.f};
   stage_zero(smem, BwdLds::dgbuf);  // transposed images are zero padded
   sw_barrier();
-  stage_wT(W1hT, LD160, 64, dec_w + swp::DEC_W1, 160, 160, 64);
-  stage_wT(W2T, LD80, 160, dec_w + swp::DEC_W2, 160, 80, 160);
-  stage_w(smem + BwdLds::W3tmp, LD80, 40, dec_w + swp::DEC_W3, 80, 40, 80);   // operand of the fc4 . fc3 composition
+  stage_wT_store<10>(r1, W1hT, LD160, 160, 64);
+  stage_wT_store<13>(r2, W2T, LD80, 80, 160);
+  stage_w_store<4>(r3, smem + BwdLds::W3tmp, LD80, 40);
+  if (threadIdx.x < 20) st4(dxpart + 4 * threadIdx.x, w4v);        // fc4 weight (2 x 40), prologue use of dxpart
   lstm_prep_rows(enc_w + swp::ENC_EMB_W, enc_w + swp::ENC_EMB_B, enc_w + swp::ENC_WIH, enc_w + swp::ENC_BIH,
                  enc_w + swp::ENC_BHH, true, wx_lds, bx_lds);
   for (int i = threadIdx.x; i < 16 * LD2; i += blockDim.x) dvbuf[i] = 0.f;
   sw_barrier();
   // Wx^T slice of this wave's K-quarter as A operands: row c = ln (< 4 live), k = 64*wave + 16j + 4lg + r
-  for (int i = threadIdx.x; i < 80 * LD2; i += blockDim.x) {   // W43^T from the staged fc3 image (see the forward kernel)
-    const int k = i / LD2, c = i - k * LD2;
-    float v = 0.f;
-    if (c < 2) {
-      const float* w4 = dec_w + swp::DEC_W4 + c * 40;
-      const float* w3 = smem + BwdLds::W3tmp + k;
-#pragma unroll 8
-      for (int m = 0; m < 40; ++m) v = fmaf(w4[m], w3[m * LD80], v);
+  if (threadIdx.x < 160) {   // W43^T from the staged fc3 image (see the forward kernel): one output per thread,
+    const int c = threadIdx.x / 80, k = threadIdx.x - c * 80;   // 4 independent partial sums (the zero padding is already there)
+    const float* w4 = dxpart + c * 40;
+    const float* w3 = smem + BwdLds::W3tmp + k;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+#pragma unroll
+    for (int m = 0; m < 40; m += 4) {
+      v0 = fmaf(w4[m], w3[m * LD80], v0);
+      v1 = fmaf(w4[m + 1], w3[(m + 1) * LD80], v1);
+      v2 = fmaf(w4[m + 2], w3[(m + 2) * LD80], v2);
+      v3 = fmaf(w4[m + 3], w3[(m + 3) * LD80], v3);
     }
-    W43T[i] = v;
+    W43T[k * LD2 + c] = (v0 + v1) + (v2 + v3);
   }
   f32x4 wxT[4];
 #pragma unroll

@@ -39,10 +39,14 @@ e1.record()
 torch.cuda.synchronize()
 out = (ctypes.c_longlong * 8)()
 lib.sw_debug_stamps(out, 0)
+pro = {5: "prologue: W_hh^T loads issued, LDS zeroed, barrier", 6: "prologue: weight staging + input-matrix rows, barrier",
+       2: "prologue: W43^T / Wx^T composition, barrier"}
 names = {7: "P6 dh += W1h^T dz1 (+ loop top, loads issue)", 0: "P1 cell_bwd, dgates -> LDS/HBM, barrier", 1: "P2 dh_prev + dx4 partial, barrier",
-         2: "P3 dx4 sum, dv, da3, barrier", 3: "P4 dz2, barrier", 4: "P5 dz1, barrier"}
+          3: "P3+P4 dx4 sum, dv, dz2 (composed fc4.fc3), barrier", 4: "P5 dz1, barrier"}
+for k in (5, 6, 2):
+    print("%-60s %7.0f cycles per launch (%.2f us)" % (pro[k], out[k] / N, out[k] / N / 2350.0))
 tot = 0
-for k in (0, 1, 2, 3, 4, 7):
+for k in (0, 1, 3, 4, 7):
     c = out[k] / (N * Tp)
     tot += c
     print("%-52s %7.0f cycles/step" % (names[k], c))
