@@ -183,6 +183,15 @@ int sw_disc_bwd_gan(const float* d_w, const float* dsave, const float* const* la
                                        (label_1-t1)^2}, the reported MSE terms; column 2 untouched if nb == 1*/,
                     void* stream);
 
+/* ---- generator phase in one launch (train.py:510-523, 538): D forward on (obsv, pred_hat) fused with the backward of
+ *      its prediction heads: dpred4 = d(g_loss)/d(pred_hat) with g_loss = mse(label, targets[t_idx]) +
+ *      w mse(code, z[:, :2]) expressed through g_label = 1/B_global, g_code = w/(2 B_global).  No saves; label / code /
+ *      loss_part ([ceil(B/16)][3]: columns 0, 1 = per-tile sums of the squared errors) are optional outputs.   */
+int sw_disc_dpred(const float* obsv, int To, int x_mode, const float* pred4 /*[B,Tp,4]*/, const float* d_w, int B, int Tp,
+                  const float* targets, int t_idx, const float* z /*[B,32]*/, float g_label, float g_code,
+                  float* dpred4 /*[B,Tp,4]*/, float* label /*[B,1] or NULL*/, float* code /*[B,2] or NULL*/,
+                  float* loss_part /*or NULL*/, void* stream);
+
 /* ---- LSGAN + InfoGAN losses of train.py:484-494 / 512-523 and their gradients -------------- */
 /* t_a = targets[ia], t_b = targets[ib] (read on the device, so a captured hipGraph sees new values).
  * out_sums[3] = { sum (label_a - t_a)^2, sum (code_a - z[:, :2])^2, sum (label_b - t_b)^2 } over the

@@ -106,11 +106,51 @@ __host__ __device__ inline HeadLds head_lds(int Tp, int base) {
 }
 }  // namespace
 
+namespace {
+struct HeadLdsB {
+  int of0T, of1T, pe0T, pe1T, cl0T, la0T, cl1T, la1T, dlab, dcod, dc1, dl1, dboth, docode, dq1, do1, total, kp;
+};
+__host__ __device__ inline HeadLdsB head_lds_b(int Tp, int base) {
+  HeadLdsB L;
+  L.kp = ((4 * Tp + 15) / 16) * 16;
+  int o = base;
+  L.of0T = o; o += 64 * LD32;       // [64][36]   of0T[m][k] = of0[k][m]
+  L.of1T = o; o += 32 * LD32;
+  L.pe0T = o; o += L.kp * LD32;     // [kp][36]
+  L.pe1T = o; o += 32 * LD32;
+  L.cl0T = o; o += 64 * LD32;
+  L.la0T = o; o += 64 * LD32;
+  L.cl1T = o; o += 32 * LD16;       // [32][20]  (K = 1)
+  L.la1T = o; o += 32 * LD16;       // [32][20]  (K = 2)
+  L.dlab = o; o += 16 * LD16;
+  L.dcod = o; o += 16 * LD16;
+  L.dc1 = o; o += 16 * LD32;
+  L.dl1 = o; o += 16 * LD32;
+  L.dboth = o; o += 16 * LD64;
+  L.docode = o; o += 16 * LD32;
+  L.dq1 = o; o += 16 * LD32;
+  L.do1 = o; o += 16 * LD32;
+  L.total = o;
+  return L;
+}
+}  // namespace
+
+// GAN mode of the backward kernel: dlabel_* / dcode_* then carry the forward OUTPUTS (label, code) and
+// the loss gradients are formed in the kernel, so no separate loss kernel sits on the critical path.
+struct DiscLoss {
+  const float* targets;  // device: label-noise scalars
+  const float* z;        // [B][32] latent
+  int t0, t1;            // target index of branch 0 / 1
+  float g_label, g_code;
+  int on;
+  float* loss_part;      // [tiles][3] per-tile sums of the squared errors (reporting), or null
+};
+
 __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
     const float* __restrict__ obsv, int To, int x_mode, const float* __restrict__ pred_a,
     const float* __restrict__ pred_b, int nb, const float* __restrict__ d_w, int B, int Tp, float* __restrict__ label_a, float* __restrict__ label_b,
     float* __restrict__ code_a, float* __restrict__ code_b, float* __restrict__ dsave, int save_lstm, int split,
-    float* __restrict__ w_snap) {
+    float* __restrict__ w_snap, int fuse, DiscLoss gl, float* __restrict__ dpred_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // LSTM part
   float* hbuf = smem;                        // [2][16][68]
@@ -132,6 +172,10 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
   const bool live = (a0 + ln) < B;
   const int K4 = 4 * Tp;
 
+  // fuse (generator phase, one branch): the backward of the heads down to d(loss)/d(pred) runs in this kernel too -
+  // its transposed weight images and delta buffers follow the forward carve in LDS, the activations never leave LDS
+  const HeadLdsB LB = head_lds_b(Tp, L.total);
+  if (fuse) stage_zero(smem + LB.of0T, LB.dc1 - LB.of0T);   // transposed images (zero padded) + dlab, dcod
   LstmW W;
   lstm_load_whh(W, d_w + O.whh, u0, ln, lg);   // global loads in flight during the LDS staging
   if (w_snap)   // deepcopy(D) of train.py:499: the weights this pass runs with, a few floats per thread
@@ -164,6 +208,14 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
   st4(&hbuf[ln * SW_HLD + u0 + 4 * lg], h);
   sw_barrier();
   lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
+  if (fuse) {
+    stage_wT(smem + LB.pe0T, LD32, LB.kp, d_w + O.pe0w, K4, 32, K4);
+    stage_wT(smem + LB.pe1T, LD32, 32, d_w + O.pe1w, 32, 32, 32);
+    stage_wT(smem + LB.cl0T, LD32, 64, d_w + O.cl0w, 64, 32, 64);
+    stage_wT(smem + LB.la0T, LD32, 64, d_w + O.la0w, 64, 32, 64);
+    stage_wT(smem + LB.cl1T, LD16, 32, d_w + O.cl1w, 32, 1, 32);
+    stage_wT(smem + LB.la1T, LD16, 32, d_w + O.la1w, 32, 2, 32);
+  }
 
   // ---- LSTM over the observation (4-d state formed on the fly, train.py:130-133) ---------------
   // the input of step t+1 is fetched while step t computes (its latency would sit in front of every step's MFMAs)
@@ -266,57 +318,73 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
       f32x4 acc = ld4(smem + L.bias + (cls ? 6 : 7) * 32 + 4 * lg);
       acc = tile_mm_rt(smem + (cls ? L.cl1 : L.la1) + ln * LD32 + 4 * lg, smem + (cls ? L.c1 : L.l1) + ln * LD32 + 4 * lg, 2, acc);
       if (lg == 0 && live) {
-        if (cls) label[b] = acc[0];
-        else { code[(size_t)b * 2] = acc[0]; code[(size_t)b * 2 + 1] = acc[1]; }
+        if (cls) { if (label) label[b] = acc[0]; }
+        else if (code) { code[(size_t)b * 2] = acc[0]; code[(size_t)b * 2 + 1] = acc[1]; }
+      }
+      if (fuse) {   // LSGAN / InfoGAN loss gradients (train.py:512-523) and this tile's reported sums, lanes lg == 0
+        float sl = 0.f;
+        if (lg == 0) {
+          if (cls) {
+            const float e = acc[0] - gl.targets[gl.t0];
+            smem[LB.dlab + ln * LD16] = 2.0f * e * gl.g_label;
+            sl = live ? e * e : 0.f;
+          } else {
+            const float c0 = acc[0] - gl.z[(size_t)b * SW_Z], c1 = acc[1] - gl.z[(size_t)b * SW_Z + 1];
+            smem[LB.dcod + ln * LD16] = 2.0f * c0 * gl.g_code;
+            smem[LB.dcod + ln * LD16 + 1] = 2.0f * c1 * gl.g_code;
+            sl = live ? c0 * c0 + c1 * c1 : 0.f;
+          }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sl += __shfl_xor(sl, o);
+        if (gl.loss_part && lane == 0) gl.loss_part[(size_t)blockIdx.x * 3 + (cls ? 0 : 1)] = sl;
       }
     }
+  }
+  if (!fuse) return;
+  // ---- fused backward of the heads of branch 0: d(loss)/d(pred) only (generator phase) -----------------------
+  sw_barrier();
+  {  // dc1 = (cl1^T dlabel) * lrelu'(c1)  (waves 0,1) ; dl1 = (la1^T dcode) * lrelu'(l1)  (waves 2,3)
+    int m0 = 16 * (wave & 1);
+    bool cls = wave < 2;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = tile_mm_rt(smem + (cls ? LB.cl1T : LB.la1T) + (m0 + ln) * LD16 + 4 * lg,
+                     smem + (cls ? LB.dlab : LB.dcod) + ln * LD16 + 4 * lg, 1, acc);
+    f32x4 a = ld4(smem + (cls ? L.c1 : L.l1) + ln * LD32 + m0 + 4 * lg);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(a[r], acc[r]);
+    st4(smem + (cls ? LB.dc1 : LB.dl1) + ln * LD32 + m0 + 4 * lg, acc);
+  }
+  sw_barrier();
+  if (wave >= 2) {  // d(pred_code) = rows 32..63 of cl0^T dc1 + la0^T dl1
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = tile_mm_rt(smem + LB.cl0T + (u0 + ln) * LD32 + 4 * lg, smem + LB.dc1 + ln * LD32 + 4 * lg, 2, acc);
+    acc = tile_mm_rt(smem + LB.la0T + (u0 + ln) * LD32 + 4 * lg, smem + LB.dl1 + ln * LD32 + 4 * lg, 2, acc);
+    st4(smem + LB.dboth + ln * LD64 + u0 + 4 * lg, acc);
+  }
+  sw_barrier();
+  if (wave < 2) {  // dq1 = (pe1^T dpcode) * lrelu'(q1)
+    int m0 = 16 * wave;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = tile_mm_rt(smem + LB.pe1T + (m0 + ln) * LD32 + 4 * lg, smem + LB.dboth + ln * LD64 + 32 + 4 * lg, 2, acc);
+    f32x4 a = ld4(smem + L.q1 + ln * LD32 + m0 + 4 * lg);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(a[r], acc[r]);
+    st4(smem + LB.dq1 + ln * LD32 + m0 + 4 * lg, acc);
+  }
+  sw_barrier();
+  for (int mt = wave; mt * 16 < K4; mt += 4) {  // dpred = pe0^T dq1   (4Tp rows)
+    int m0 = 16 * mt;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = tile_mm_rt(smem + LB.pe0T + (m0 + ln) * LD32 + 4 * lg, smem + LB.dq1 + ln * LD32 + 4 * lg, 2, acc);
+    if (live && m0 + 4 * lg < K4) st4(dpred_out + (size_t)b * K4 + m0 + 4 * lg, acc);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
-namespace {
-struct HeadLdsB {
-  int of0T, of1T, pe0T, pe1T, cl0T, la0T, cl1T, la1T, dlab, dcod, dc1, dl1, dboth, docode, dq1, do1, total, kp;
-};
-__host__ __device__ inline HeadLdsB head_lds_b(int Tp, int base) {
-  HeadLdsB L;
-  L.kp = ((4 * Tp + 15) / 16) * 16;
-  int o = base;
-  L.of0T = o; o += 64 * LD32;       // [64][36]   of0T[m][k] = of0[k][m]
-  L.of1T = o; o += 32 * LD32;
-  L.pe0T = o; o += L.kp * LD32;     // [kp][36]
-  L.pe1T = o; o += 32 * LD32;
-  L.cl0T = o; o += 64 * LD32;
-  L.la0T = o; o += 64 * LD32;
-  L.cl1T = o; o += 32 * LD16;       // [32][20]  (K = 1)
-  L.la1T = o; o += 32 * LD16;       // [32][20]  (K = 2)
-  L.dlab = o; o += 16 * LD16;
-  L.dcod = o; o += 16 * LD16;
-  L.dc1 = o; o += 16 * LD32;
-  L.dl1 = o; o += 16 * LD32;
-  L.dboth = o; o += 16 * LD64;
-  L.docode = o; o += 16 * LD32;
-  L.dq1 = o; o += 16 * LD32;
-  L.do1 = o; o += 16 * LD32;
-  L.total = o;
-  return L;
-}
-}  // namespace
-
 #define SW_SPLIT_MAX_WGS 256   // CUs of an MI355X: splitting only pays while the launch leaves some of them idle
-
-// GAN mode of the backward kernel: dlabel_* / dcode_* then carry the forward OUTPUTS (label, code) and
-// the loss gradients are formed in the kernel, so no separate loss kernel sits on the critical path.
-struct DiscLoss {
-  const float* targets;  // device: label-noise scalars
-  const float* z;        // [B][32] latent
-  int t0, t1;            // target index of branch 0 / 1
-  float g_label, g_code;
-  int on;
-  float* loss_part;      // [tiles][3] per-tile sums of the squared errors (reporting), or null
-};
 
 __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
     const float* __restrict__ d_w, const float* __restrict__ dsave, const float* __restrict__ dlabel_a,
@@ -502,6 +570,15 @@ static int set_lds(const void* fn, int bytes) {
   return SW_OK;
 }
 
+static int g_disc_fwd_lds = 0;   // largest dynamic-LDS size disc_fwd_kernel has been enabled for (plain + fused launches)
+static int disc_fwd_lds(int bytes) {
+  if (g_disc_fwd_lds < bytes) {
+    if (int rc = set_lds((const void*)disc_fwd_kernel, bytes)) return rc;
+    g_disc_fwd_lds = bytes;
+  }
+  return SW_OK;
+}
+
 size_t sw_dsave_floats(int B, int To, int Tp, int nb) { return dsave_layout(B, To, Tp, nb).total; }
 size_t sw_ddelta_floats(int B, int To, int Tp, int nb) { return ddelta_layout(B, To, Tp, nb).total; }
 
@@ -517,16 +594,34 @@ extern "C" int sw_disc_fwd(const float* obsv, int To, int x_mode, const float* c
   if (B == 0) return SW_OK;
   int lds = head_lds(Tp, 2 * 16 * SW_HLD + 1280).total * 4;
   if (lds > 163840) return SW_ESHAPE;
-  static int attr = 0;
-  if (attr < lds) {
-    if (int rc = set_lds((const void*)disc_fwd_kernel, lds)) return rc;
-    attr = lds;
-  }
+  if (int rc = disc_fwd_lds(lds)) return rc;
   const int tiles = (B + SW_TILE - 1) / SW_TILE;
   const int split = (nb == 2 && 2 * tiles <= SW_SPLIT_MAX_WGS) ? 1 : 0;   // idle CUs: one workgroup per (tile, branch)
   hipLaunchKernelGGL(disc_fwd_kernel, dim3(split ? 2 * tiles : tiles), dim3(SW_THREADS), lds, (hipStream_t)stream,
                      obsv, To, x_mode, pred4[0], nb > 1 ? pred4[1] : nullptr, nb, d_w, B, Tp, label[0],
-                     nb > 1 ? label[1] : nullptr, code[0], nb > 1 ? code[1] : nullptr, dsave, save_lstm, split, w_snapshot);
+                     nb > 1 ? label[1] : nullptr, code[0], nb > 1 ? code[1] : nullptr, dsave, save_lstm, split, w_snapshot, 0, DiscLoss{}, nullptr);
+  SW_CHECK_LAUNCH("disc_fwd_kernel");
+  return SW_OK;
+}
+
+// Generator phase in ONE launch: forward of D on (obsv, pred_hat) and the backward of its prediction heads down to
+// d(g_loss)/d(pred_hat) (train.py:510-523, 538): no saves, no second prologue, activations stay in LDS.
+extern "C" int sw_disc_dpred(const float* obsv, int To, int x_mode, const float* pred4, const float* d_w, int B, int Tp,
+                             const float* targets, int t_idx, const float* z, float g_label, float g_code,
+                             float* dpred4, float* label, float* code, float* loss_part, void* stream) {
+  if (!obsv || !pred4 || !d_w || !targets || !z || !dpred4 || B < 0 || To < 1 || Tp < 1 || t_idx < 0 ||
+      (x_mode != 0 && x_mode != 1) || (x_mode == 0 && To < 2))
+    return SW_EARG;
+  if (Tp > 64) return SW_ESHAPE;
+  if (B == 0) return SW_OK;
+  const int lds = head_lds_b(Tp, head_lds(Tp, 2 * 16 * SW_HLD + 1280).total).total * 4;
+  if (lds > 163840) return SW_ESHAPE;
+  if (int rc = disc_fwd_lds(lds)) return rc;
+  DiscLoss gl{targets, z, t_idx, t_idx, g_label, g_code, 1, loss_part};
+  const int tiles = (B + SW_TILE - 1) / SW_TILE;
+  hipLaunchKernelGGL(disc_fwd_kernel, dim3(tiles), dim3(SW_THREADS), lds, (hipStream_t)stream, obsv, To, x_mode, pred4,
+                     (const float*)nullptr, 1, d_w, B, Tp, label, (float*)nullptr, code, (float*)nullptr, (float*)nullptr, 0, 0,
+                     (float*)nullptr, 1, gl, dpred4);
   SW_CHECK_LAUNCH("disc_fwd_kernel");
   return SW_OK;
 }

@@ -245,6 +245,19 @@ def disc_backward(d_w, ctx, dlabels, dcodes, d_d_w=None, want_dpred=(), ws=None,
     return dpreds
 
 
+def disc_dpred(d_w, obsv, pred_hat, targets, t_idx, z, g_label, g_code, loss_part=None):
+    """Generator phase: D(obsv, pred_hat) forward + the backward of its prediction heads in one launch;
+    returns d(g_loss)/d(pred_hat) (B,Tp,4)."""
+    L.require_gpu(obsv)
+    obsv, pred_hat = obsv.contiguous(), pred_hat.contiguous()
+    B, To, Tp = obsv.shape[0], obsv.shape[1], pred_hat.shape[1]
+    x_mode = {2: 0, 4: 1}[obsv.shape[2]]
+    dpred = torch.empty(B, Tp, 4, device=obsv.device)
+    L.call("sw_disc_dpred", L.ptr(obsv), To, x_mode, L.ptr(pred_hat), L.ptr(d_w), B, Tp, L.ptr(targets), int(t_idx), L.ptr(z),
+           g_label, g_code, L.ptr(dpred), None, None, L.ptr(loss_part), L.stream())
+    return dpred
+
+
 def disc_backward_gan(d_w, ctx, labels, codes, targets, t_idx, z, g_label, g_code, d_d_w=None, want_dpred=(), ws=None,
                       tag="d", loss_part=None):
     """disc_backward with the LSGAN / InfoGAN loss gradients formed inside the kernel from the forward

@@ -366,9 +366,8 @@ class SocialWaysTrainer:
             yield d_gflat
             self.D_optimizer.step() if steps is None else self.D_optimizer.step(steps[u])
         # ---- generator update (train.py:503-539) ----------------------------------------------------
-        labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat], save=True, ws=ws, save_lstm=False)   # only d/dpred is needed
-        dpred = ops.disc_backward_gan(D._flat, dctx, labels, codes, targets, (1, 1), noise, g_label, g_code, None, (True,),
-                                      ws=ws, loss_part=out[U + 1])[0]
+        # D forward on the prediction + backward of its heads down to d(g_loss)/d(pred_hat), one launch, nothing saved
+        dpred = ops.disc_dpred(D._flat, obsv, pred_hat, targets, 1, noise, g_label, g_code, loss_part=out[U + 1])
         if self.use_l2_loss:                                                 # train.py:525-526
             L.call("sw_l2_grad", L.ptr(pred_hat), L.ptr(pred), B, Tp, 0, B, self.loss_l2_w / (Bg * Tp), L.ptr(dpred), L.stream())
         if self.use_variety_loss:                                            # train.py:527-536 as written
