@@ -121,7 +121,7 @@ def main():
     Bg = B * world
     last = [None]
 
-    KG = int(os.environ.get("SW_BENCH_STEPS_PER_LAUNCH", "4")) if world == 1 else 1   # steps per graph launch (step_many)
+    KG = int(os.environ.get("SW_BENCH_STEPS_PER_LAUNCH", "4"))   # steps per graph launch (step_many)
 
     def draw(i):
         a = (i % N_BATCHES) * B
@@ -198,6 +198,7 @@ def main():
                                    "--batch-size %d; use_social=True, n_unrolling_steps=1, info loss on"
                                    % (args.workload, S, A, To, Tp, B),
                        "global_batch_scenes": S * world, "parallelism": "dp%d" % world, "steps_per_graph_launch": KG,
+                       "collectives": (None if pg is None else "in-graph" if tr._graph_collectives else "between graph segments"),
                        "step_alg_gflop": fl["step"] / 1e9,
                        "step_frac_of_fp32_peak": fl["step"] / (dt / args.steps) / (PEAK_FP32_TFLOPS * 1e12)},
             "roofline": {"bound": "mfma", "kernel": args.dominant.replace("sw_", "") + "_kernel", "achieved": achieved,
@@ -213,6 +214,7 @@ def main():
         ctypes.CDLL(None).fflush(None)          # RCCL's version banner sits in the C stdio buffer: keep the JSON line last
         print(json.dumps(res), flush=True)
     if pg is not None:
+        tr.release_graphs()                     # recorded collectives go before their communicator
         torch.distributed.destroy_process_group()
 
 

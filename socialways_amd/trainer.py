@@ -17,6 +17,7 @@ are all-reduced (sum) before each optimizer step - 3 RCCL all-reduces per traini
 """
 import copy
 import os
+import sys
 
 import numpy as np
 import torch
@@ -131,9 +132,12 @@ class SocialWaysTrainer:
         self.max_graphs = 8
         self._graphs = {}
         self._force_dist = os.environ.get("SW_FORCE_DIST", "") == "1"   # 1-rank group still runs the collectives (tests)
-        # SW_GRAPH_COLLECTIVES=1: capture the RCCL all-reduces inside the step graph (one graph per step instead of
-        # four segments).  Off by default: validated on a 1-rank group only (no multi-GPU box was available).
-        self._graph_collectives = os.environ.get("SW_GRAPH_COLLECTIVES", "") == "1"
+        # Data parallel: are the RCCL all-reduces recorded INSIDE the step graph (one launch for K steps) or run
+        # eagerly between graph segments (3 segment boundaries per step)?  SW_GRAPH_COLLECTIVES=1 / 0 decides;
+        # unset = probe once (a small captured all-reduce replayed twice and checked on every rank) and use the
+        # in-graph form only if the whole group agrees that it works.
+        gc_env = os.environ.get("SW_GRAPH_COLLECTIVES", "")
+        self._graph_collectives = True if gc_env == "1" else False if gc_env == "0" else None
         packed = fused_adam and self.device.type == "cuda"
         if packed:
             self.predictor_optimizer = PackedAdam(self.G._flat_all, self.G._gflat_all, self.G.packed_slices(), lr_g)
@@ -163,6 +167,70 @@ class SocialWaysTrainer:
         if self.pg is not None and (self.world > 1 or self._force_dist):
             torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
+    def _probe_graph_collectives(self):
+        """Can this process group's all-reduce be recorded in a hipGraph and replayed?  Only RCCL ("nccl") is
+        tried: a 4 KB SUM all-reduce is captured, replayed twice and compared with the known answer; every rank
+        reports and the group takes the minimum, so all ranks choose the same step structure."""
+        import ctypes
+        import threading
+        dev, W = self.device, self.world
+        if torch.distributed.get_backend(self.pg) != "nccl":      # gloo & co. synchronise the stream: not capturable
+            return False
+        ok = 0.0
+        # a collective that never completes would otherwise block forever in synchronize()
+        guard = threading.Timer(180.0, lambda: (sys.stderr.write("socialways_amd: captured all-reduce probe hung; "
+                                                                 "set SW_GRAPH_COLLECTIVES=0\n"), os._exit(3)))
+        guard.daemon = True
+        guard.start()
+        x = torch.full((1024,), float(self.rank + 1), device=dev)
+        y = torch.zeros_like(x)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=dev)
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                g.capture_begin(capture_error_mode="thread_local")
+                try:
+                    y.copy_(x)
+                    self._allreduce(y)
+                except Exception:
+                    try:
+                        g.capture_end()
+                    except Exception:      # noqa: BLE001 - the capture is already invalid; make sure the stream left it
+                        pass
+                    hip, junk = ctypes.CDLL("libamdhip64.so"), ctypes.c_void_p()
+                    hip.hipStreamEndCapture(ctypes.c_void_p(side.cuda_stream), ctypes.byref(junk))
+                    hip.hipGetLastError()
+                    raise
+                g.capture_end()
+                for _ in range(2):
+                    g.replay()
+            torch.cuda.synchronize()
+            ok = float(bool((y == W * (W + 1) / 2.0).all()))
+            del g
+        except Exception as e:      # noqa: BLE001 - any failure means "do not record collectives"
+            sys.stderr.write("socialways_amd: all-reduce not capturable here (%s: %s); using graph segments\n"
+                             % (type(e).__name__, str(e).splitlines()[0] if str(e) else ""))
+        finally:
+            guard.cancel()
+        torch.cuda.synchronize()
+        flag = torch.tensor([ok], device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=self.pg)
+        return bool(flag.item() > 0.5)
+
+    def _resolve_collectives(self):
+        """Every rank passes here at the start of every packed batch (step / step_many / _empty_step), so the
+        probe's own collectives line up across the group even when some ranks have no scenes in a batch."""
+        if self._graph_collectives is None and self.pg is not None and (self.world > 1 or self._force_dist):
+            self._graph_collectives = bool(self.use_graph) and self._probe_graph_collectives()
+
+    def release_graphs(self):
+        """Drop every captured step graph (they hold the communicator's recorded collectives: release them before
+        the process group is destroyed)."""
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+        self._graphs.clear()
+
     def step(self, obsv, pred, sub_batches, zeros_val, ones_val, noise, ss=1.0, global_B=None, out=None, global_row0=0):
         """One packed batch (train.py:458-554) on this rank's rows.  obsv (B,To,2), pred (B,Tp,2) and
         noise (B,32) are tensors (noise normally lives on the host, like train.py:473); `global_B` = agents
@@ -175,6 +243,7 @@ class SocialWaysTrainer:
         With `use_graph` the whole step - ~35 kernels incl. the input staging and the Adam updates - is
         captured once per batch layout into a hipGraph and replayed: per step the host only fills a pinned
         slot (pointers of the track slices, z, the two label-noise scalars) and launches the graph."""
+        self._resolve_collectives()
         B = obsv.shape[0]
         Bg = float(global_B if global_B is not None else B)
         dev = self.device
@@ -204,6 +273,7 @@ class SocialWaysTrainer:
         `batches` = [(obsv, pred, zeros_val, ones_val, noise), ...].  Exactly the K `step()` calls in order (same
         kernels, same results); what it saves is the gap between two graph launches (~13 us, the system-scope
         fence at the end of a hipGraph) on K-1 of the K steps.  Returns the list of the K step results."""
+        self._resolve_collectives()
         if not self.use_graph or len(batches) == 1 or self.use_variety_loss:
             return [self.step(o, p, sub_batches, zv, ov, nz, ss, global_B, out) for o, p, zv, ov, nz in batches]
         B = batches[0][0].shape[0]
@@ -281,9 +351,10 @@ class SocialWaysTrainer:
                 stage(0, j)
                 self._step_impl(*args(j))
         else:
-            # Capture.  Single GPU: one graph for the K steps.  Data parallel: one graph per segment
-            # between the all-reduce points (the collectives themselves stay eager: no RCCL-in-graph
-            # dependency), all segments sharing one memory pool so intermediates stay alive.
+            # Capture.  Single GPU: one graph for the K steps.  Data parallel: the same with the RCCL
+            # all-reduces recorded in it when the group can do that (see __init__), else one graph per
+            # segment between the all-reduce points with the collectives run eagerly in between, all
+            # segments sharing one memory pool so intermediates stay alive.
             # Everything is captured TWICE and the two executables alternate: launching an executable
             # that is still running makes hipGraphLaunch wait for it, which would put the host-side
             # launch cost (~150 us for ~40 nodes) on the critical path of every step.
@@ -449,6 +520,7 @@ class SocialWaysTrainer:
 
     def _empty_step(self):
         """A rank without scenes in this packed batch still takes part in the 3 all-reduces."""
+        self._resolve_collectives()
         d_g = self.D.grad_views()
         self.G.grad_views()
         for u in range(self.n_unrolling_steps + 1):

@@ -203,7 +203,12 @@ def _dp_worker(rank, world, port, ret):
     B = int(g["step_agents"][0])
     ade, fde, losses, sizes = tr.train_epoch(data, B, draw=lambda bs: (float(g["uniform"][0, 0]), float(g["uniform"][0, 1]),
                                                                          torch.from_numpy(g["noise.0"])))
-    ret[rank] = (losses[0].tolist(), ade, tr.D._flat.double().sum().item(), tr.G._flat_all.double().sum().item())
+    first = (losses[0].tolist(), ade)
+    for e in range(4):         # steps 3.. of a layout are captured: gloo cannot be recorded -> the probe picks segments
+        ade, fde, losses, sizes = tr.train_epoch(data, B, draw=lambda bs: (0.02 * e, 0.95, torch.from_numpy(g["noise.0"])))
+    ret[rank] = first + (tr.D._flat.double().sum().item(), tr.G._flat_all.double().sum().item(), losses[0].tolist(),
+                         tr._graph_collectives)
+    tr.release_graphs()
     dist.destroy_process_group()
 
 
@@ -223,37 +228,70 @@ def test_two_rank_data_parallel_step_equals_reference():
         assert_close(np.asarray(ret[r][0]), g["losses"][0], 5e-5, 1e-6, "rank %d losses" % r)
         assert abs(ret[r][1] - float(g["ade"])) < 1e-5
     assert ret[0][2] == ret[1][2] and ret[0][3] == ret[1][3], "replicas diverged"
+    assert ret[0][5] is False and ret[1][5] is False, "gloo all-reduces cannot be recorded in a graph"
+    # the captured (segmented) steps against a single process doing the same five epochs
+    import socialways_amd as sw
+    ds = dataset_from(g)
+    data = sw.SceneDataset(ds["obsvs"], ds["preds"], ds["batches"], device="cuda:0")
+    tr = sw.SocialWaysTrainer(12, use_social=True, device="cuda:0")
+    tr.load_checkpoint(as_checkpoint(state_from(g, "w0.")))
+    B = int(g["step_agents"][0])
+    draws = [(float(g["uniform"][0, 0]), float(g["uniform"][0, 1]))] + [(0.02 * e, 0.95) for e in range(4)]
+    for zv, ov in draws:
+        ade, fde, losses, sizes = tr.train_epoch(data, B, draw=lambda bs: (zv, ov, torch.from_numpy(g["noise.0"])))
+    assert_close(np.asarray(ret[0][4]), losses[0], 2e-4, 1e-6, "fifth step, 2 ranks vs 1")
 
 
-def _rccl_worker(rank, world, port, ret):
+def _rccl_worker(rank, world, port, ret, mode):
     import os
     import torch.distributed as dist
     import socialways_amd as sw
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["SW_FORCE_DIST"] = "1"                     # a 1-rank group still runs the three all-reduces
+    os.environ.pop("SW_GRAPH_COLLECTIVES", None)
+    if mode in ("segments", "in_graph"):
+        os.environ["SW_GRAPH_COLLECTIVES"] = {"segments": "0", "in_graph": "1"}[mode]
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     t = sw.synth_tracks(24, 8, seed=9)
     data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
     B, sb = data.n_train_samples, data.train_batches
-    res = []
+    res, chosen = [], None
     for pg in (dist.group.WORLD, None):
         torch.manual_seed(0)
         tr = sw.SocialWaysTrainer(12, use_social=True, device="cuda:0", process_group=pg)
         if pg is None:
             tr._force_dist = False
+        elif mode == "probe_fails":       # an all-reduce that cannot be recorded: the probe must clean up and fall back
+            real = tr._allreduce
+
+            def fussy(flat):
+                if torch.cuda.is_current_stream_capturing():
+                    flat.sum().item()     # a host sync: illegal during capture
+                real(flat)
+            tr._allreduce = fussy
         gen = torch.Generator().manual_seed(5)
-        outs = [tr.step(data.obsv[:B], data.pred[:B], sb, 0.01 * i, 0.9 + 0.01 * i, torch.rand(B, 32, generator=gen), data.ss).cpu()
-                for i in range(6)]                        # eager, eager, capture (segmented), replay x3
+        draw = lambda i: (data.obsv[:B], data.pred[:B], 0.01 * i, 0.9 + 0.01 * i, torch.rand(B, 32, generator=gen))
+        outs = []
+        for i in range(6):                                # eager x2, capture, replay x3
+            o, p, zv, ov, nz = draw(i)
+            outs.append(tr.step(o, p, sb, zv, ov, nz, data.ss).cpu())
+        for rep in range(4):                              # the same with three steps per launch
+            outs += [o.cpu() for o in tr.step_many([draw(10 + 3 * rep + j) for j in range(3)], sb, data.ss)]
         res.append((torch.stack(outs), tr.D._flat.cpu().clone(), tr.G._flat_all.cpu().clone()))
-    ret[rank] = all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+        if pg is not None:
+            chosen = tr._graph_collectives
+            tr.release_graphs()
+    ret[rank] = (all(torch.equal(a, b) for a, b in zip(res[0], res[1])), chosen)
     dist.destroy_process_group()
 
 
-def test_rccl_path_segmented_graphs_equal_single_process():
+@pytest.mark.parametrize("mode", ["segments", "in_graph", "probe", "probe_fails"])
+def test_rccl_path_graphs_equal_single_process(mode):
     """backend "nccl" (= RCCL) with a 1-rank group: the step captured as graph SEGMENTS around three eager
-    all-reduces must reproduce the single-graph single-process trajectory bit for bit."""
+    all-reduces, or as ONE graph with the all-reduces recorded in it (forced, and chosen by the start-up probe; a probe that fails falls back to segments),
+    must reproduce the single-graph single-process trajectory bit for bit - single steps and step_many."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -261,8 +299,10 @@ def test_rccl_path_segmented_graphs_equal_single_process():
     port = s.getsockname()[1]
     s.close()
     ret = mp.Manager().dict()
-    mp.spawn(_rccl_worker, args=(1, port, ret), nprocs=1, join=True)
-    assert ret[0] is True
+    mp.spawn(_rccl_worker, args=(1, port, ret, mode), nprocs=1, join=True)
+    same, chosen = ret[0]
+    assert same is True
+    assert chosen is (mode in ("in_graph", "probe")), "collectives mode: %r" % (chosen,)
 
 
 @pytest.mark.parametrize("name", ["l2", "variety", "unroll0", "unroll2", "noinfo"])
