@@ -481,9 +481,8 @@ __device__ __forceinline__ void pair_grad_store(PairGrad& G, float* red, const S
 
 __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
     const float* __restrict__ obsv, int To, const float* __restrict__ h, const int* __restrict__ scene_off,
-    const long long* __restrict__ pair_off, int S, const float* __restrict__ emb_w, const float* __restrict__ att_w,
-    const float* __restrict__ attn, const float* __restrict__ dS, float* __restrict__ dh,
-    float* __restrict__ dwh_rows, float* __restrict__ f_rows, SocPart part, int a16) {
+    int S, const float* __restrict__ emb_w, const float* __restrict__ att_w, const float* __restrict__ attn,
+    const float* __restrict__ dS, float* __restrict__ dh, float* __restrict__ dwh_rows, SocPart part, int a16) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SocL Ls = soc_lds(a16);
   const int sa = Ls.sa;
@@ -520,8 +519,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
       if (threadIdx.x < 16) st4(dwh_rows + (size_t)s0 * 64 + 4 * threadIdx.x, f32x4{0.f, 0.f, 0.f, 0.f});
       continue;
     }
-    const long long p0 = pair_off[sc];
-    __syncthreads();   // previous scene's LDS (and its global f rows) are done with
+    __syncthreads();   // previous scene's LDS is done with
     scene_prologue(smem, Ls, obsv, To, h, emb_w, att_w, s0, n);
     for (int i = threadIdx.x; i < n * 16; i += blockDim.x) {
       int a = i >> 4, q = i & 15;
@@ -549,39 +547,53 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
     }
     sw_barrier();
     // ---- pair tiles: recompute the MLP, back-propagate, accumulate the weight gradients ----------
-    const int P = n * n;
-    for (int pt = wave; pt * 16 < P; pt += 4) {
-      const bool valid = pt * 16 + ln < P;
-      int p = min(pt * 16 + ln, P - 1);
-      int i = p / n, j = p - i * n;
-      float f0, f1, f2;
-      pair_feat(ld4(&x4[i * 4]), ld4(&x4[j * 4]), f0, f1, f2);
-      f32x4 h1[2], h2[4], f[4];
-      pair_l1(w0b, lg, f0, f1, f2, h1);
-      pair_l23(W, b12, b12 + 64, lg, h1, h2, f);
-      const float dsv = valid ? dsg[i * sa + j] : 0.f;   // invalid lanes contribute exact zeros everywhere below
-      if (valid) {
-        const size_t row = (size_t)(p0 + p);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) st4(f_rows + row * 64 + 16 * mt + 4 * lg, f[mt]);
-      }
-      f32x4 dz3[4];
+    // A tile = 16 pairs (i, j = 16 jb + ln) of ONE i: lane column ln is agent j of the block in every tile, so
+    //   dWh_j = sum_i dsigma_ij f_ij   accumulates in registers in the layout the MLP leaves f in (no pair
+    // rows in HBM, no second pass), and x_j / Wh_j are loop invariants.  Per block: 4 wave partials (i = wave,
+    // wave + 4, ..) summed in a fixed order through the waves' scratch tiles.
+    const int nJB = (n + 15) >> 4;
+    for (int jb = 0; jb < nJB; ++jb) {
+      const int j = 16 * jb + ln;
+      const bool valid = j < n;
+      const int jc = min(j, n - 1);
+      const f32x4 xj = ld4(&x4[jc * 4]);
+      f32x4 whj[4], accw[4];
 #pragma unroll
       for (int mo = 0; mo < 4; ++mo) {
-        f32x4 w = ld4(&wh[j * 68 + 16 * mo + 4 * lg]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dz3[mo][r] = dsv * w[r];
+        whj[mo] = ld4(&wh[jc * 68 + 16 * mo + 4 * lg]);
+        accw[mo] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      pair_tile_bwd(G, scr, w2s, w1s, h1, h2, dz3, f0, f1, f2, ln, lg);
-    }
-    __syncthreads();  // f rows of this scene are visible to the whole workgroup (same CU)
-    // dWh_j = sum_i dsigma_ij f_ij
-    for (int e = threadIdx.x; e < n * 64; e += blockDim.x) {
-      int j = e >> 6, u = e & 63;
-      float acc = 0.f;
-      for (int i = 0; i < n; ++i) acc = fmaf(dsg[i * sa + j], f_rows[(size_t)(p0 + i * n + j) * 64 + u], acc);
-      dwh[j * 68 + u] = acc;
-      dwh_rows[(size_t)(s0 + j) * 64 + u] = acc;
+      for (int i = wave; i < n; i += 4) {
+        float f0, f1, f2;
+        pair_feat(ld4(&x4[i * 4]), xj, f0, f1, f2);
+        f32x4 h1[2], h2[4], f[4];
+        pair_l1(w0b, lg, f0, f1, f2, h1);
+        pair_l23(W, b12, b12 + 64, lg, h1, h2, f);
+        const float dsv = valid ? dsg[i * sa + jc] : 0.f;   // invalid lanes contribute exact zeros everywhere below
+        f32x4 dz3[4];
+#pragma unroll
+        for (int mo = 0; mo < 4; ++mo) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            accw[mo][r] = fmaf(dsv, f[mo][r], accw[mo][r]);
+            dz3[mo][r] = dsv * whj[mo][r];
+          }
+        }
+        pair_tile_bwd(G, scr, w2s, w1s, h1, h2, dz3, f0, f1, f2, ln, lg);
+      }
+#pragma unroll
+      for (int mo = 0; mo < 4; ++mo) st4(scr + ln * 68 + 16 * mo + 4 * lg, accw[mo]);
+      __syncthreads();
+      for (int e = threadIdx.x; e < 16 * 64; e += blockDim.x) {
+        const int jj = e >> 6, u = e & 63, j2 = 16 * jb + jj;
+        if (j2 < n) {
+          const float* q = scr_all + jj * 68 + u;
+          const float acc = (q[0] + q[SW_SOC_SCR]) + (q[2 * SW_SOC_SCR] + q[3 * SW_SOC_SCR]);
+          dwh[j2 * 68 + u] = acc;
+          dwh_rows[(size_t)(s0 + j2) * 64 + u] = acc;
+        }
+      }
+      __syncthreads();   // the scratch tiles go back to the transpositions of the next block
     }
     sw_barrier();
     // dh_j += sum_i a_ij dS_i  +  W^T dWh_j
@@ -1258,7 +1270,6 @@ extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, con
   }
   // in-register weight gradients: one partial slice per workgroup of the scene kernel (G) and of the row-block
   // kernel (NB), reduced together
-  float* f_rows = pair_ws + (size_t)B * 64;
   const int G = S < 1024 ? S : 1024;   // workgroups: each walks scenes g, g+G, .. and leaves ONE weight-gradient partial
   WgBatch wb_local;
   WgBatch& wb = defer ? *wg_pending(defer) : wb_local;
@@ -1279,8 +1290,8 @@ extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, con
                        big_part_ws, dh, dwh_rows);
     SW_CHECK_LAUNCH("social_big_finish_kernel");
   }
-  hipLaunchKernelGGL(social_pool_bwd_kernel, dim3(G), dim3(SW_THREADS), lds, st, obsv, To, h, scene_off, pair_off, S,
-                     emb_w, att_w, attn, dS, dh, dwh_rows, f_rows, part, a16);
+  hipLaunchKernelGGL(social_pool_bwd_kernel, dim3(G), dim3(SW_THREADS), lds, st, obsv, To, h, scene_off, S, emb_w,
+                     att_w, attn, dS, dh, dwh_rows, part, a16);
   SW_CHECK_LAUNCH("social_pool_bwd_kernel");
   if (defer) return SW_OK;
   return wg_launch(wb, wgrad_ws, st);
