@@ -249,8 +249,10 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_fwd_kernel(
 // workspace and is reduced in fixed order by wgrad_reduce_kernel.  Only f_ij (64 floats per pair) is
 // still written: dWh_j = sum_i dsigma_ij f_ij needs it after all pairs of the scene are done.
 // ---------------------------------------------------------------------------------------------
-#define SW_SOC_W2LD 68   // LDS row strides of the row-major fc.4 / fc.2 weight images (conflict-free
-#define SW_SOC_W1LD 36   //   transposed reads, see below)
+#define SW_SOC_W2LD 68   // LDS row strides of the row-major fc.4 / fc.2 weight images (forward of the row-block kernel)
+#define SW_SOC_W1LD 36
+#define SW_SOC_WTLD 68   // row stride of the transposed images fc.4.weight^T [64][68], fc.2.weight^T [32][68] (backward)
+#define SW_SOC_WT (96 * SW_SOC_WTLD)
 #define SW_SOC_TLD 20    // row stride of a 16x16 transposition tile
 #define SW_SOC_SCR (4 * 16 * SW_SOC_TLD)   // per-wave scratch: 4 tiles
 #define SW_SOC_FUSE_MIN_PAIRS 256   // mean pairs per scene from which the in-register weight gradients pay (>= 4 tiles per wave)
@@ -294,11 +296,26 @@ __device__ __forceinline__ void pair_grad_zero(PairGrad& G) {
   }
 }
 
+// fc.4.weight^T | fc.2.weight^T into LDS (once per workgroup)
+__device__ __forceinline__ void stage_pair_wt(float* w2t, float* w1t, const float* emb_w) {
+  for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {
+    const int r = i >> 4, q = i & 15;
+    const f32x4 v = ld4(emb_w + swp::EMB_W2 + r * 64 + 4 * q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w2t[(4 * q + e) * SW_SOC_WTLD + r] = v[e];
+    if (q < 8) {
+      const f32x4 u = ld4(emb_w + swp::EMB_W1 + r * 32 + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w1t[(4 * q + e) * SW_SOC_WTLD + r] = u[e];
+    }
+  }
+}
+
 // One 16-pair tile: given the recomputed activations (h1, h2 post-ReLU) and dz3 = d(loss)/d(f_ij) (C layout,
 // exact zeros for invalid pairs), back-propagate through fc.4 / fc.2 and add this tile's contribution to all
-// weight gradients.  w2s / w1s: row-major LDS images of fc.4.weight [64][68] / fc.2.weight [64][36];
-// scr: this wave's transposition scratch.
-__device__ __forceinline__ void pair_tile_bwd(PairGrad& G, float* scr, const float* w2s, const float* w1s,
+// weight gradients.  w2t / w1t: TRANSPOSED LDS images fc.4.weight^T [64 in][68] / fc.2.weight^T [32 in][68] (the
+// A operands of the two data-gradient products as float4s); scr: this wave's transposition scratch.
+__device__ __forceinline__ void pair_tile_bwd(PairGrad& G, float* scr, const float* w2t, const float* w1t,
                                               const f32x4 h1[2], const f32x4 h2[4], const f32x4 dz3[4], float f0,
                                               float f1, float f2, int ln, int lg) {
   // dW3 += dz3 h2^T (k = pairs): both operands through the transposition scratch
@@ -325,22 +342,19 @@ __device__ __forceinline__ void pair_tile_bwd(PairGrad& G, float* scr, const flo
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t) G.b3s[t] += (ta[t][0] + ta[t][1]) + (ta[t][2] + ta[t][3]);
-  // dh2 = (W2^T dz3) * relu'(h2): A operand = W2[16mo+4lg+r][16mt+ln] read transposed from the LDS image
+  // dh2 = (W2^T dz3) * relu'(h2): A operand = W2[16mo+4lg+r][16mt+ln], one float4 per (mt, mo) from the transposed image
   f32x4 dh2[4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) dh2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int mo = 0; mo < 4; ++mo) {
-    float wt[4][4];
+    f32x4 wt[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) wt[mt] = ld4(w2t + (16 * mt + ln) * SW_SOC_WTLD + 16 * mo + 4 * lg);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) wt[r][mt] = w2s[(16 * mo + 4 * lg + r) * SW_SOC_W2LD + 16 * mt + ln];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) dh2[mt] = SW_MFMA(wt[r][mt], dz3[mo][r], dh2[mt]);
+      for (int mt = 0; mt < 4; ++mt) dh2[mt] = SW_MFMA(wt[mt][r], dz3[mo][r], dh2[mt]);
     }
   }
 #pragma unroll
@@ -377,16 +391,12 @@ __device__ __forceinline__ void pair_tile_bwd(PairGrad& G, float* scr, const flo
   dh1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
-    float wt[4][2];
+    const f32x4 wa = ld4(w1t + ln * SW_SOC_WTLD + 16 * mt + 4 * lg);
+    const f32x4 wb = ld4(w1t + (16 + ln) * SW_SOC_WTLD + 16 * mt + 4 * lg);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      wt[r][0] = w1s[(16 * mt + 4 * lg + r) * SW_SOC_W1LD + ln];
-      wt[r][1] = w1s[(16 * mt + 4 * lg + r) * SW_SOC_W1LD + 16 + ln];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      dh1[0] = SW_MFMA(wt[r][0], dh2[mt][r], dh1[0]);
-      dh1[1] = SW_MFMA(wt[r][1], dh2[mt][r], dh1[1]);
+      dh1[0] = SW_MFMA(wa[r], dh2[mt][r], dh1[0]);
+      dh1[1] = SW_MFMA(wb[r], dh2[mt][r], dh1[1]);
     }
   }
 #pragma unroll
@@ -495,18 +505,14 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
   float* dsl = smem + Ls.ds;
   float* dsg = smem + Ls.dsg;
   float* dwh = smem + Ls.dwh;
-  float* w2s = smem + Ls.bwd_total;                   // fc.4.weight [64][68]
-  float* w1s = w2s + 64 * SW_SOC_W2LD;                // fc.2.weight [64][36]
-  float* scr_all = w1s + 64 * SW_SOC_W1LD;            // [4 waves][4 tiles][16][20]
+  float* w2t = smem + Ls.bwd_total;                   // fc.4.weight^T [64][68]
+  float* w1t = w2t + 64 * SW_SOC_WTLD;                // fc.2.weight^T [32][68]
+  float* scr_all = w2t + SW_SOC_WT;                   // [4 waves][4 tiles][16][20]
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
   float* scr = scr_all + wave * SW_SOC_SCR;
 
   // ---- once per workgroup: weights ------------------------------------------------------------
-  for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {
-    int r = i >> 4, q = i & 15;
-    st4(&w2s[r * SW_SOC_W2LD + 4 * q], ld4(emb_w + swp::EMB_W2 + r * 64 + 4 * q));
-    if (q < 8) st4(&w1s[r * SW_SOC_W1LD + 4 * q], ld4(emb_w + swp::EMB_W1 + r * 32 + 4 * q));
-  }
+  stage_pair_wt(w2t, w1t, emb_w);
   PairW W;
   load_pair_w(W, emb_w, ln, lg);
   PairGrad G;
@@ -579,7 +585,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
             dz3[mo][r] = dsv * whj[mo][r];
           }
         }
-        pair_tile_bwd(G, scr, w2s, w1s, h1, h2, dz3, f0, f1, f2, ln, lg);
+        pair_tile_bwd(G, scr, w2t, w1t, h1, h2, dz3, f0, f1, f2, ln, lg);
       }
 #pragma unroll
       for (int mo = 0; mo < 4; ++mo) st4(scr + ln * 68 + 16 * mo + 4 * lg, accw[mo]);
@@ -607,7 +613,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
     }
   }
   // ---- epilogue: this workgroup's partial = sum of its 4 waves, in a fixed order through LDS ------
-  pair_grad_store(G, w2s, part, blockIdx.x, wave, ln, lg);
+  pair_grad_store(G, w2t, part, blockIdx.x, wave, ln, lg);
 }
 
 // ---- variant for SMALL scenes: per-pair rows + deferred GEMM --------------------------------------
@@ -932,6 +938,8 @@ __global__ __launch_bounds__(SW_THREADS) void social_big_bwd_kernel(
   float* w1s = w2s + 64 * SW_SOC_W2LD;                // fc.2.weight [64][36]
   float* scr_all = w1s + 64 * SW_SOC_W1LD;            // [4 waves][4 tiles][16][20]
   float* jred = scr_all + 4 * SW_SOC_SCR;             // [16 j][128]: dWh | sum a dS of the current j tile
+  float* w2t = jred + 16 * 128;                       // fc.4.weight^T [64][68] | fc.2.weight^T [32][68]
+  float* w1t = w2t + 64 * SW_SOC_WTLD;
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
   float* scr = scr_all + wave * SW_SOC_SCR;
   stage_pair_consts(smem, Ls, emb_w);
@@ -940,6 +948,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_big_bwd_kernel(
     st4(&w2s[r * SW_SOC_W2LD + 4 * q], ld4(emb_w + swp::EMB_W2 + r * 64 + 4 * q));
     if (q < 8) st4(&w1s[r * SW_SOC_W1LD + 4 * q], ld4(emb_w + swp::EMB_W1 + r * 32 + 4 * q));
   }
+  stage_pair_wt(w2t, w1t, emb_w);
   const int* rec = blocks + (size_t)blockIdx.x * SW_BIG_REC;
   const int s0 = scene_off[rec[0]], n = scene_off[rec[0] + 1] - s0, i0 = rec[1], prow0 = rec[2];
   PairGrad G;
@@ -1013,7 +1022,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_big_bwd_kernel(
           dhj_acc[mo][r] = fmaf(a, dsi[mo][r], dhj_acc[mo][r]);
         }
       }
-      pair_tile_bwd(G, scr, w2s, w1s, h1, h2, dz3, f0, f1, f2, ln, lg);
+      pair_tile_bwd(G, scr, w2t, w1t, h1, h2, dz3, f0, f1, f2, ln, lg);
     }
     // sum the 4 waves' j-tile partials in a fixed order, then one partial row per agent j of the tile
     for (int w = 0; w < 4; ++w) {
@@ -1232,10 +1241,11 @@ extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, con
   if (S == 0 || B == 0) return SW_OK;
   hipStream_t st = (hipStream_t)stream;
   const int a16 = Amax < 16 ? 16 : ((Amax + 15) & ~15);
-  const int extra = 64 * SW_SOC_W2LD + 64 * SW_SOC_W1LD + 4 * SW_SOC_SCR;
+  const int extra = SW_SOC_WT + 4 * SW_SOC_SCR;       // scene kernel: transposed weight images + scratch
   const int lds = (soc_lds(a16).bwd_total + extra) * 4;
-  const int lds_big = (soc_lds(16).fwd_total + extra + 16 * 128) * 4;
-  static_assert(64 * SW_SOC_W2LD + 64 * SW_SOC_W1LD + 4 * SW_SOC_SCR >= SW_SOC_PART, "epilogue staging area");
+  const int lds_big = (soc_lds(16).fwd_total + 64 * SW_SOC_W2LD + 64 * SW_SOC_W1LD + 4 * SW_SOC_SCR + 16 * 128 + SW_SOC_WT) * 4;
+  static_assert(SW_SOC_WT + 4 * SW_SOC_SCR >= SW_SOC_PART, "epilogue staging area");
+  static_assert(64 * SW_SOC_W2LD + 64 * SW_SOC_W1LD + 4 * SW_SOC_SCR >= SW_SOC_PART, "epilogue staging area (row-block kernel)");
   static bool attr = false;
   if (!attr) {
     if (int rc = set_lds((const void*)social_pool_bwd_kernel, (soc_lds(SW_AMAX).bwd_total + extra) * 4)) return rc;
