@@ -16,6 +16,20 @@
 
 #define SW_AMAX 64  // max agents per scene handled by one workgroup (attn row stride)
 
+#ifdef SW_PHASE_STAMPS
+__device__ long long sw_soc_stamps[8];
+#define SW_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); long long _t = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) sw_soc_stamps[k] += _t - _tprev; _tprev = _t; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SW_STAMP_PARAM , long long& _tprev
+#define SW_STAMP_ARG , _tprev
+extern "C" int sw_debug_soc_stamps(long long* out, int reset) {
+  if (reset) { long long z[8] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(sw_soc_stamps), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sw_soc_stamps), 8 * sizeof(long long));
+}
+#else
+#define SW_STAMP(k)
+#define SW_STAMP_PARAM
+#define SW_STAMP_ARG
+#endif
 namespace {
 struct PairW {            // per-lane register-resident pair-MLP weights
   f32x4 w1[4][2];         // fc.2.weight[16mt + ln][16j + 4lg ..]   (64 x 32)
@@ -317,7 +331,7 @@ __device__ __forceinline__ void stage_pair_wt(float* w2t, float* w1t, const floa
 // A operands of the two data-gradient products as float4s); scr: this wave's transposition scratch.
 __device__ __forceinline__ void pair_tile_bwd(PairGrad& G, float* scr, const float* w2t, const float* w1t,
                                               const f32x4 h1[2], const f32x4 h2[4], const f32x4 dz3[4], float f0,
-                                              float f1, float f2, int ln, int lg) {
+                                              float f1, float f2, int ln, int lg SW_STAMP_PARAM) {
   // dW3 += dz3 h2^T (k = pairs): both operands through the transposition scratch
   f32x4 ta[4], tb[4];
 #pragma unroll
@@ -362,6 +376,7 @@ __device__ __forceinline__ void pair_tile_bwd(PairGrad& G, float* scr, const flo
 #pragma unroll
     for (int r = 0; r < 4; ++r) dh2[mt][r] = h2[mt][r] > 0.f ? dh2[mt][r] : 0.f;
   }
+  SW_STAMP(3);
   // dW2 += dh2 h1^T
 #pragma unroll
   for (int t = 0; t < 4; ++t) tr_put(scr + t * 16 * SW_SOC_TLD, dh2[t], ln, lg);
@@ -404,6 +419,7 @@ __device__ __forceinline__ void pair_tile_bwd(PairGrad& G, float* scr, const flo
 #pragma unroll
     for (int r = 0; r < 4; ++r) dh1[jt][r] = h1[jt][r] > 0.f ? dh1[jt][r] : 0.f;
   }
+  SW_STAMP(4);
   // dW1 += dh1 feat^T, db1 += dh1 (VALU): transposed dh1 against the features of pairs 4lg + r
   tr_put(scr, dh1[0], ln, lg);
   tr_put(scr + 16 * SW_SOC_TLD, dh1[1], ln, lg);
@@ -517,6 +533,9 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
   load_pair_w(W, emb_w, ln, lg);
   PairGrad G;
   pair_grad_zero(G);
+#ifdef SW_PHASE_STAMPS
+  long long _tprev = clock64();
+#endif
 
   for (int sc = blockIdx.x; sc < S; sc += gridDim.x) {
     const int s0 = scene_off[sc], n = scene_off[sc + 1] - s0;
@@ -536,6 +555,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
       sig[i * sa + j] = attn[(size_t)(s0 + i) * SW_AMAX + j];
     }
     sw_barrier();
+    SW_STAMP(0);
     // da_ij = <dS_i, h_j>;  dsigma_ij = a_ij (da_ij - sum_j' a_ij' da_ij')   (softmax backward)
     for (int i = wave; i < n; i += 4) {
       float da = 0.f, a = 0.f;
@@ -552,6 +572,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
       if (lane < n) dsg[i * sa + lane] = a * (da - t);
     }
     sw_barrier();
+    SW_STAMP(1);
     // ---- pair tiles: recompute the MLP, back-propagate, accumulate the weight gradients ----------
     // A tile = 16 pairs (i, j = 16 jb + ln) of ONE i: lane column ln is agent j of the block in every tile, so
     //   dWh_j = sum_i dsigma_ij f_ij   accumulates in registers in the layout the MLP leaves f in (no pair
@@ -585,7 +606,9 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
             dz3[mo][r] = dsv * whj[mo][r];
           }
         }
-        pair_tile_bwd(G, scr, w2t, w1t, h1, h2, dz3, f0, f1, f2, ln, lg);
+        SW_STAMP(2);
+        pair_tile_bwd(G, scr, w2t, w1t, h1, h2, dz3, f0, f1, f2, ln, lg SW_STAMP_ARG);
+        SW_STAMP(5);
       }
 #pragma unroll
       for (int mo = 0; mo < 4; ++mo) st4(scr + ln * 68 + 16 * mo + 4 * lg, accw[mo]);
@@ -600,17 +623,39 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
         }
       }
       __syncthreads();   // the scratch tiles go back to the transpositions of the next block
+      SW_STAMP(6);
     }
     sw_barrier();
-    // dh_j += sum_i a_ij dS_i  +  W^T dWh_j
-    for (int e = threadIdx.x; e < n * 64; e += blockDim.x) {
-      int j = e >> 6, u = e & 63;
-      float acc = 0.f;
-      for (int i = 0; i < n; ++i) acc = fmaf(sig[i * sa + j], dsl[i * 68 + u], acc);
-      const float* wc = att_w + swp::ATT_W + u;
-      for (int k = 0; k < 64; ++k) acc = fmaf(wc[k * 64], dwh[j * 68 + k], acc);
-      dh[(size_t)(s0 + j) * 64 + u] += acc;
+    // dh_j += sum_i a_ij dS_i  +  W^T dWh_j  on the matrix cores: D[unit u][agent j], wave w owns units 16w .. 16w+15;
+    // first product over k = i (rows beyond n masked to exact zeros), second over k = the 64 units of dWh
+    {
+      const int npad = (n + 15) & ~15;
+      f32x4 wT[4];   // A operand of the second product: W[k = 16kt + 4lg + r][u = 16 wave + ln]
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wT[kt][r] = att_w[swp::ATT_W + (16 * kt + 4 * lg + r) * 64 + 16 * wave + ln];
+      }
+      for (int at = 0; at < npad / 16; ++at) {
+        f32x4 acc = tile_mm_reg<4>(wT, &dwh[(16 * at + ln) * 68 + 4 * lg], f32x4{0.f, 0.f, 0.f, 0.f});
+        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < npad / 16; ++kt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * kt + 4 * lg + r;
+            const float av = i < n ? dsl[i * 68 + 16 * wave + ln] : 0.f;
+            const float bv = i < n ? sig[i * sa + 16 * at + ln] : 0.f;
+            acc2 = SW_MFMA(av, bv, acc2);
+          }
+        }
+        const int j = 16 * at + ln;
+        if (j < n) {
+          float* q = dh + (size_t)(s0 + j) * 64 + 16 * wave + 4 * lg;
+          st4(q, ld4(q) + (acc + acc2));
+        }
+      }
     }
+    SW_STAMP(7);
   }
   // ---- epilogue: this workgroup's partial = sum of its 4 waves, in a fixed order through LDS ------
   pair_grad_store(G, w2t, part, blockIdx.x, wave, ln, lg);
@@ -949,6 +994,9 @@ __global__ __launch_bounds__(SW_THREADS) void social_big_bwd_kernel(
     if (q < 8) st4(&w1s[r * SW_SOC_W1LD + 4 * q], ld4(emb_w + swp::EMB_W1 + r * 32 + 4 * q));
   }
   stage_pair_wt(w2t, w1t, emb_w);
+#ifdef SW_PHASE_STAMPS
+  long long _tprev = clock64();
+#endif
   const int* rec = blocks + (size_t)blockIdx.x * SW_BIG_REC;
   const int s0 = scene_off[rec[0]], n = scene_off[rec[0] + 1] - s0, i0 = rec[1], prow0 = rec[2];
   PairGrad G;
@@ -1022,7 +1070,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_big_bwd_kernel(
           dhj_acc[mo][r] = fmaf(a, dsi[mo][r], dhj_acc[mo][r]);
         }
       }
-      pair_tile_bwd(G, scr, w2t, w1t, h1, h2, dz3, f0, f1, f2, ln, lg);
+      pair_tile_bwd(G, scr, w2t, w1t, h1, h2, dz3, f0, f1, f2, ln, lg SW_STAMP_ARG);
     }
     // sum the 4 waves' j-tile partials in a fixed order, then one partial row per agent j of the tile
     for (int w = 0; w < 4; ++w) {

@@ -73,12 +73,13 @@ class Workspaces:
     @property
     def wgrad_batch(self):
         if self._wgb is None:
-            self._wgb = L.load().sw_wgrad_batch_new()
+            lib = L.load()
+            self._wgb, self._free = lib.sw_wgrad_batch_new(), lib.sw_wgrad_batch_free
         return self._wgb
 
-    def __del__(self):
+    def __del__(self):      # may run at interpreter shutdown, when module globals are already gone
         if getattr(self, "_wgb", None):
-            L.load().sw_wgrad_batch_free(self._wgb)
+            self._free(self._wgb)
             self._wgb = None
 
     def get(self, name, nfloats):
