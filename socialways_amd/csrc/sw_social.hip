@@ -707,33 +707,10 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_rows_kernel(
   }
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
   const long long p0 = pair_off[blockIdx.x];
-  scene_prologue(smem, Ls, obsv, To, h, emb_w, att_w, s0, n);
-  for (int i = threadIdx.x; i < n * 16; i += blockDim.x) {
-    int a = i >> 4, q = i & 15;
-    st4(&dsl[a * 68 + 4 * q], ld4(dS + (size_t)(s0 + a) * 64 + 4 * q));
-  }
-  for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
-    int i = e / n, j = e - i * n;
-    sig[i * sa + j] = attn[(size_t)(s0 + i) * SW_AMAX + j];
-  }
-  sw_barrier();
-  // da_ij = <dS_i, h_j>;  dsigma_ij = a_ij (da_ij - sum_j' a_ij' da_ij')   (softmax backward)
-  for (int i = wave; i < n; i += 4) {
-    float da = 0.f, a = 0.f;
-    if (lane < n) {
-      a = sig[i * sa + lane];
-      for (int u = 0; u < 64; u += 4) {
-        f32x4 x = ld4(&dsl[i * 68 + u]), y = ld4(&hs[lane * 68 + u]);
-        da = fmaf(x[0], y[0], da); da = fmaf(x[1], y[1], da); da = fmaf(x[2], y[2], da); da = fmaf(x[3], y[3], da);
-      }
-    }
-    float t = a * da;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-    if (lane < n) dsg[i * sa + lane] = a * (da - t);
-  }
-  sw_barrier();
-  // ---- pair tiles: recompute the MLP, back-propagate, leave rows for the deferred GEMMs --------
+#ifdef SW_PHASE_STAMPS
+  long long _tprev = clock64();
+#endif
+  // the pair-MLP weights (registers, L2 latency) are requested first: they arrive under the scene prologue
   PairW W;
   load_pair_w(W, emb_w, ln, lg);
   f32x4 w2T[4][4];  // fc.4.weight^T: [mt][mo][r] = W2[16mo + 4lg + r][16mt + ln]
@@ -750,6 +727,41 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_rows_kernel(
       w1T[1][mo][r] = row1[16];
     }
   }
+  f32x4 wT[4];   // attention W^T for the dh rows: W[k = 16kt + 4lg + r][u = 16 wave + ln]
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wT[kt][r] = att_w[swp::ATT_W + (16 * kt + 4 * lg + r) * 64 + 16 * wave + ln];
+  }
+  scene_prologue(smem, Ls, obsv, To, h, emb_w, att_w, s0, n);
+  for (int i = threadIdx.x; i < n * 16; i += blockDim.x) {
+    int a = i >> 4, q = i & 15;
+    st4(&dsl[a * 68 + 4 * q], ld4(dS + (size_t)(s0 + a) * 64 + 4 * q));
+  }
+  for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+    int i = e / n, j = e - i * n;
+    sig[i * sa + j] = attn[(size_t)(s0 + i) * SW_AMAX + j];
+  }
+  sw_barrier();
+  SW_STAMP(0);
+  // da_ij = <dS_i, h_j>;  dsigma_ij = a_ij (da_ij - sum_j' a_ij' da_ij')   (softmax backward)
+  for (int i = wave; i < n; i += 4) {
+    float da = 0.f, a = 0.f;
+    if (lane < n) {
+      a = sig[i * sa + lane];
+      for (int u = 0; u < 64; u += 4) {
+        f32x4 x = ld4(&dsl[i * 68 + u]), y = ld4(&hs[lane * 68 + u]);
+        da = fmaf(x[0], y[0], da); da = fmaf(x[1], y[1], da); da = fmaf(x[2], y[2], da); da = fmaf(x[3], y[3], da);
+      }
+    }
+    float t = a * da;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (lane < n) dsg[i * sa + lane] = a * (da - t);
+  }
+  sw_barrier();
+  SW_STAMP(1);
+  // ---- pair tiles: recompute the MLP, back-propagate, leave rows for the deferred GEMMs --------
   const int P = n * n;
   for (int pt = wave; pt * 16 < P; pt += 4) {
     const bool valid = pt * 16 + ln < P;
@@ -817,7 +829,9 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_rows_kernel(
       if (lg == 0) st4(pr.feat + row * 4, f32x4{f0, f1, f2, 0.f});
     }
   }
+  SW_STAMP(2);
   __syncthreads();  // pair rows of this scene are visible to the whole workgroup (same CU)
+  SW_STAMP(3);
   // dWh_j = sum_i dsigma_ij f_ij
   for (int e = threadIdx.x; e < n * 64; e += blockDim.x) {
     int j = e >> 6, u = e & 63;
@@ -827,15 +841,30 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_rows_kernel(
     dwh_rows[(size_t)(s0 + j) * 64 + u] = acc;
   }
   sw_barrier();
-  // dh_j += sum_i a_ij dS_i  +  W^T dWh_j
-  for (int e = threadIdx.x; e < n * 64; e += blockDim.x) {
-    int j = e >> 6, u = e & 63;
-    float acc = 0.f;
-    for (int i = 0; i < n; ++i) acc = fmaf(sig[i * sa + j], dsl[i * 68 + u], acc);
-    const float* wc = att_w + swp::ATT_W + u;
-    for (int k = 0; k < 64; ++k) acc = fmaf(wc[k * 64], dwh[j * 68 + k], acc);
-    dh[(size_t)(s0 + j) * 64 + u] += acc;
+  SW_STAMP(6);
+  // dh_j += sum_i a_ij dS_i  +  W^T dWh_j  on the matrix cores (see social_pool_bwd_kernel)
+  {
+    const int npad = (n + 15) & ~15;
+    for (int at = 0; at < npad / 16; ++at) {
+      f32x4 acc = tile_mm_reg<4>(wT, &dwh[(16 * at + ln) * 68 + 4 * lg], f32x4{0.f, 0.f, 0.f, 0.f});
+      f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+      for (int kt = 0; kt < npad / 16; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * kt + 4 * lg + r;
+          const float av = i < n ? dsl[i * 68 + 16 * wave + ln] : 0.f;
+          const float bv = i < n ? sig[i * sa + 16 * at + ln] : 0.f;
+          acc2 = SW_MFMA(av, bv, acc2);
+        }
+      }
+      const int j = 16 * at + ln;
+      if (j < n) {
+        float* q = dh + (size_t)(s0 + j) * 64 + 16 * wave + 4 * lg;
+        st4(q, ld4(q) + (acc + acc2));
+      }
+    }
   }
+  SW_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------------
