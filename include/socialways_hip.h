@@ -139,6 +139,16 @@ int sw_dec_rollout_fwd(const float* obsv /*[B,To,2]*/, int To, const float* z /*
                         * err = |(p_hat - gt) * inv_ss|; NULL to skip */
                        const float* gt /*[B,Tp,2]*/, float inv_ss, float* ade_part /*[ceil(B/16)][3]*/,
                        void* stream);
+/* Same, plus (d_w, dsave non-NULL) the observation LSTM of Discriminator.forward (train.py:296-299) on the same
+ * positions `obsv` with the packed D weights d_w, run by ceil(B/16) extra workgroups of the launch: the first D
+ * pass of a training step (train.py:476-482) does not depend on the generator, and the rollout leaves CUs idle
+ * for batches below ~2000 agents.  The LSTM rows land in `dsave` where sw_disc_fwd(save_lstm = 1) would put
+ * them; the following sw_disc_fwd(obsv, x_mode = 0, same B / To / d_w, save_lstm = 2) reads them instead of
+ * recomputing.                                                                                             */
+int sw_dec_rollout_fwd_aux(const float* obsv, int To, const float* z, const float* S_pool, const float* hT,
+                           const float* cT, const float* enc_w, const float* dec_w, int B, int Tp, float* pred4,
+                           float* h_end, float* c_end, float* gsave, const float* gt, float inv_ss, float* ade_part,
+                           const float* d_w /*or NULL*/, float* dsave /*or NULL*/, void* stream);
 int sw_dec_rollout_bwd(const float* dpred4 /*[B,Tp,4]*/, const float* enc_w, const float* dec_w,
                        const float* gsave, int B, int To, int Tp, float* gdelta,
                        float* dhT, float* dcT, float* dS_pool /*[B,64]*/, void* stream);
@@ -163,7 +173,9 @@ int sw_gen_wgrad(const float* enc_w, const float* dec_w, const float* gsave, con
 int sw_disc_fwd(const float* obsv, int To, int x_mode, const float* const* pred4 /*nb x [B,Tp,4]*/,
                 int nb, const float* d_w, int B, int Tp, float* const* label /*nb x [B,1]*/,
                 float* const* code /*nb x [B,2]*/, float* dsave /*or NULL*/,
-                int save_lstm /*0: head activations only - enough for a backward that wants d/dpred only*/,
+                int save_lstm /*0: head activations only - enough for a backward that wants d/dpred only; 1: + the
+                                LSTM rows; 2: the LSTM rows are ALREADY in dsave (sw_dec_rollout_fwd_aux): the
+                                observation LSTM is not run again, h_T is read from them*/,
                 float* w_snapshot /*or NULL: receives a copy of d_w (sw_param_count floats) - deepcopy(D), train.py:499*/,
                 void* stream);
 /* dlabel/dcode: nb x gradients of the loss w.r.t. label / code.  d_d_w NULL = skip weight grads

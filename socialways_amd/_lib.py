@@ -37,6 +37,7 @@ PROTOTYPES = {
     "sw_social_pool_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sw_dec_rollout_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
+    "sw_dec_rollout_fwd_aux": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "sw_dec_rollout_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sw_dec_rollout_bwd_aux": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
     "sw_gen_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),

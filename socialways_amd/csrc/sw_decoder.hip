@@ -61,8 +61,17 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
     const float* __restrict__ hT, const float* __restrict__ cT, const float* __restrict__ enc_w,
     const float* __restrict__ dec_w, int B, int Tp, float* __restrict__ pred4, float* __restrict__ h_end,
     float* __restrict__ c_end, float* __restrict__ gsave, const float* __restrict__ gt, float inv_ss,
-    float* __restrict__ ade_part) {
+    float* __restrict__ ade_part, const float* __restrict__ dobs_w, float* __restrict__ dobs_act,
+    float* __restrict__ dobs_x4s) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // Workgroups beyond the agent tiles (only launched while the rollout leaves CUs idle): the observation LSTM of
+  // the discriminator's first pass of this step - it does not depend on the generator - with the rows disc_bwd needs
+  if (blockIdx.x * SW_TILE >= (unsigned)B) {
+    const swp::Disc O = swp::disc(Tp);
+    disc_obs_lstm_tile(smem, obsv, To, 0, dobs_w + O.wih, dobs_w + O.whh, dobs_w + O.bih, dobs_w + O.bhh, B,
+                       (int)(blockIdx.x * SW_TILE) - ((B + SW_TILE - 1) / SW_TILE) * SW_TILE, dobs_act, dobs_x4s);
+    return;
+  }
   float* W1h = smem + FwdLds::W1h;
   float* W2 = smem + FwdLds::W2;
   float* W43 = smem + FwdLds::W43;
@@ -485,23 +494,38 @@ static int set_lds(const void* fn, int bytes) {
   return SW_OK;
 }
 
-extern "C" int sw_dec_rollout_fwd(const float* obsv, int To, const float* z, const float* S_pool,
-                                  const float* hT, const float* cT, const float* enc_w, const float* dec_w,
-                                  int B, int Tp, float* pred4, float* h_end, float* c_end, float* gsave,
-                                  const float* gt, float inv_ss, float* ade_part, void* stream) {
+extern "C" int sw_dec_rollout_fwd_aux(const float* obsv, int To, const float* z, const float* S_pool,
+                                      const float* hT, const float* cT, const float* enc_w, const float* dec_w,
+                                      int B, int Tp, float* pred4, float* h_end, float* c_end, float* gsave,
+                                      const float* gt, float inv_ss, float* ade_part, const float* d_w, float* dsave,
+                                      void* stream) {
   if (!obsv || !z || !hT || !cT || !enc_w || !dec_w || !pred4 || B < 0 || To < 2 || Tp < 1) return SW_EARG;
   if (ade_part && !gt) return SW_EARG;
+  if ((d_w != nullptr) != (dsave != nullptr)) return SW_EARG;
   if (B == 0) return SW_OK;
   static bool attr = false;
   if (!attr) {
     if (int rc = set_lds((const void*)dec_rollout_fwd_kernel, FwdLds::total * 4)) return rc;
     attr = true;
   }
-  hipLaunchKernelGGL(dec_rollout_fwd_kernel, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS),
-                     FwdLds::total * 4, (hipStream_t)stream, obsv, To, z, S_pool, hT, cT, enc_w, dec_w, B, Tp,
-                     pred4, h_end, c_end, gsave, gt, inv_ss, ade_part);
+  static_assert(FwdLds::total >= 2 * 16 * SW_HLD + 1280, "LDS of the observation-LSTM workgroups");
+  const int tiles = (B + SW_TILE - 1) / SW_TILE;
+  // rows of the D observation LSTM inside the save buffer of sw_disc_fwd (independent of its branch count)
+  float* act = dsave;
+  float* x4s = dsave ? dsave + (size_t)To * B * 384 : nullptr;
+  hipLaunchKernelGGL(dec_rollout_fwd_kernel, dim3(d_w ? 2 * tiles : tiles), dim3(SW_THREADS), FwdLds::total * 4,
+                     (hipStream_t)stream, obsv, To, z, S_pool, hT, cT, enc_w, dec_w, B, Tp, pred4, h_end, c_end, gsave, gt,
+                     inv_ss, ade_part, d_w, act, x4s);
   SW_CHECK_LAUNCH("dec_rollout_fwd_kernel");
   return SW_OK;
+}
+
+extern "C" int sw_dec_rollout_fwd(const float* obsv, int To, const float* z, const float* S_pool,
+                                  const float* hT, const float* cT, const float* enc_w, const float* dec_w,
+                                  int B, int Tp, float* pred4, float* h_end, float* c_end, float* gsave,
+                                  const float* gt, float inv_ss, float* ade_part, void* stream) {
+  return sw_dec_rollout_fwd_aux(obsv, To, z, S_pool, hT, cT, enc_w, dec_w, B, Tp, pred4, h_end, c_end, gsave, gt, inv_ss,
+                                ade_part, nullptr, nullptr, stream);
 }
 
 extern "C" int sw_dec_rollout_bwd_aux(const float* dpred4, const float* enc_w, const float* dec_w,

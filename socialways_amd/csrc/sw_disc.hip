@@ -22,7 +22,7 @@ struct DSave {
 __host__ __device__ inline DSave dsave_layout(int B, int To, int Tp, int nb) {
   DSave d;
   size_t b = (size_t)B;
-  d.act = 0;
+  d.act = 0;                                // act / x4s do not depend on nb: sw_dec_rollout_fwd_aux writes them too
   d.x4s = d.act + (size_t)To * b * 384;
   d.o1 = d.x4s + (size_t)To * b * 4;
   d.both = d.o1 + b * 32;
@@ -176,8 +176,9 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
   // its transposed weight images and delta buffers follow the forward carve in LDS, the activations never leave LDS
   const HeadLdsB LB = head_lds_b(Tp, L.total);
   if (fuse) stage_zero(smem + LB.of0T, LB.dc1 - LB.of0T);   // transposed images (zero padded) + dlab, dcod
+  const bool obs_pre = save_lstm == 2;   // LSTM rows already in dsave (sw_dec_rollout_fwd_aux ran the observation LSTM)
   LstmW W;
-  lstm_load_whh(W, d_w + O.whh, u0, ln, lg);   // global loads in flight during the LDS staging
+  if (!obs_pre) lstm_load_whh(W, d_w + O.whh, u0, ln, lg);   // global loads in flight during the LDS staging
   if (w_snap)   // deepcopy(D) of train.py:499: the weights this pass runs with, a few floats per thread
     for (int i = blockIdx.x * SW_THREADS + threadIdx.x; i < O.n; i += gridDim.x * SW_THREADS) w_snap[i] = d_w[i];
   // ---- stage head weights / biases ------------------------------------------------------------
@@ -203,11 +204,16 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
     else v = k < 2 ? d_w[O.la1b + k] : 0.f;
     smem[L.bias + i] = v;
   }
-  lstm_prep_rows(nullptr, nullptr, d_w + O.wih, d_w + O.bih, d_w + O.bhh, false, wx_lds, bx_lds);
   f32x4 c = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};  // h0 = c0 = 0 (train.py:296-297)
-  st4(&hbuf[ln * SW_HLD + u0 + 4 * lg], h);
+  if (!obs_pre) {
+    lstm_prep_rows(nullptr, nullptr, d_w + O.wih, d_w + O.bih, d_w + O.bhh, false, wx_lds, bx_lds);
+    st4(&hbuf[ln * SW_HLD + u0 + 4 * lg], h);
+  } else {   // h_T of the tile from the saved rows
+    st4(&hbuf[(To & 1) * 16 * SW_HLD + ln * SW_HLD + u0 + 4 * lg],
+        ld4(dsave + ds.act + ((size_t)(To - 1) * B + b) * 384 + 320 + u0 + 4 * lg));
+  }
   sw_barrier();
-  lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
+  if (!obs_pre) lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
   if (fuse) {
     stage_wT(smem + LB.pe0T, LD32, LB.kp, d_w + O.pe0w, K4, 32, K4);
     stage_wT(smem + LB.pe1T, LD32, 32, d_w + O.pe1w, 32, 32, 32);
@@ -226,8 +232,8 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
     const int tt = t == 0 ? 1 : t;
     return p[tt * 2 + lg - 2] - p[(tt - 1) * 2 + lg - 2];
   };
-  float xnext = load_x(0);
-  for (int t = 0; t < To; ++t) {
+  float xnext = obs_pre ? 0.f : load_x(0);
+  for (int t = 0; t < (obs_pre ? 0 : To); ++t) {
     const float xb = xnext;
     if (t + 1 < To) xnext = load_x(t + 1);
     f32x4 gate[4];
@@ -586,7 +592,7 @@ extern "C" int sw_disc_fwd(const float* obsv, int To, int x_mode, const float* c
                            const float* d_w, int B, int Tp, float* const* label, float* const* code, float* dsave,
                            int save_lstm, float* w_snapshot, void* stream) {
   if (!obsv || !pred4 || !d_w || !label || !code || nb < 1 || nb > SW_DISC_MAXB || B < 0 || To < 1 || Tp < 1 ||
-      (x_mode != 0 && x_mode != 1) || (x_mode == 0 && To < 2))
+      (x_mode != 0 && x_mode != 1) || (x_mode == 0 && To < 2) || save_lstm < 0 || save_lstm > 2 || (save_lstm == 2 && !dsave))
     return SW_EARG;
   for (int k = 0; k < nb; ++k)
     if (!pred4[k] || !label[k] || !code[k]) return SW_EARG;

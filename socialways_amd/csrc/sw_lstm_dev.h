@@ -160,3 +160,51 @@ __device__ __forceinline__ f32x4 lstm_dh_prev(const LstmWT& W, const float* dgro
   }
   return a0 + a1;
 }
+
+// Observation LSTM of the discriminator (train.py:296-299) for the 16-agent tile at a0, leaving the rows its
+// backward needs: per step t and agent b, act + (t B + b) 384 = gates i|f|g|o [256], c [64], h [64] and the step's
+// 4-d input at x4s + (t B + b) 4.  Exactly the arithmetic of disc_fwd_kernel's own loop; it exists as a function so
+// that idle workgroups of ANOTHER launch can run it (the first D pass of a step does not depend on the generator:
+// sw_dec_rollout_fwd_aux).  smem: [2][16][SW_HLD] h tiles | [256][4] Wx | [256] bx  (2 * 16 * SW_HLD + 1280 floats).
+__device__ __forceinline__ void disc_obs_lstm_tile(float* smem, const float* __restrict__ obsv, int To, int x_mode,
+                                                   const float* wih, const float* whh, const float* bih, const float* bhh,
+                                                   int B, int a0, float* __restrict__ act, float* __restrict__ x4s) {
+  float* hbuf = smem;
+  float* wx_lds = smem + 2 * 16 * SW_HLD;
+  float* bx_lds = wx_lds + 1024;
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  const int u0 = wave * 16;
+  const int b = min(a0 + ln, B - 1);
+  const bool live = (a0 + ln) < B;
+  LstmW W;
+  lstm_load_whh(W, whh, u0, ln, lg);
+  lstm_prep_rows(nullptr, nullptr, wih, bih, bhh, false, wx_lds, bx_lds);
+  f32x4 c = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};
+  st4(&hbuf[ln * SW_HLD + u0 + 4 * lg], h);
+  sw_barrier();
+  lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
+  auto load_x = [&](int t) {
+    if (x_mode == 1) return obsv[((size_t)b * To + t) * 4 + lg];
+    const float* p = obsv + (size_t)b * To * 2;
+    if (lg < 2) return p[t * 2 + lg];
+    const int tt = t == 0 ? 1 : t;
+    return p[tt * 2 + lg - 2] - p[(tt - 1) * 2 + lg - 2];
+  };
+  float xnext = load_x(0);
+  for (int t = 0; t < To; ++t) {
+    const float xb = xnext;
+    if (t + 1 < To) xnext = load_x(t + 1);
+    f32x4 gate[4];
+    lstm_cell(W, xb, &hbuf[(t & 1) * 16 * SW_HLD + ln * SW_HLD + 4 * lg], gate, c, h);
+    st4(&hbuf[((t + 1) & 1) * 16 * SW_HLD + ln * SW_HLD + u0 + 4 * lg], h);
+    if (live) {
+      float* row = act + ((size_t)t * B + b) * 384 + u0 + 4 * lg;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) st4(row + g * 64, gate[g]);
+      st4(row + 256, c);
+      st4(row + 320, h);
+      if (wave == 0) x4s[((size_t)t * B + b) * 4 + lg] = xb;
+    }
+    sw_barrier();
+  }
+}

@@ -104,12 +104,14 @@ class GenCtx:
 
 
 def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_social, save, ws=None, tag="g", ade=None,
-                noise_src=None):
+                noise_src=None, d_obs=None):
     """predict(): encode obs (train.py:397-404), social pooling (408-413), decode loop (415-432).
     Returns pred_hat_4d (B, n_next, 4) and, if `save`, the context backward needs.
     ade = (gt (B,n_next,2), 1/ss, out (ceil(B/16),3)): the decode kernel also leaves the per-tile ADE/FDE
     partial sums of train.py:546-551 in `out`.
-    noise_src: address `noise` is filled from (pinned host memory) by idle workgroups of the encoder launch."""
+    noise_src: address `noise` is filled from (pinned host memory) by idle workgroups of the encoder launch.
+    d_obs = (packed D weights, dsave buffer): idle workgroups of the decode launch run the discriminator's
+    observation LSTM for the next disc_forward(..., save_lstm=2) on the same obsv (see d_obs_buffer)."""
     L.require_gpu(obsv)
     obsv = obsv.contiguous()
     noise = noise.contiguous()
@@ -141,9 +143,10 @@ def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_soc
                L.ptr(emb_w), L.ptr(att_w), L.ptr(S), L.ptr(attn), L.ptr(scenes.big_blocks), scenes.NB, L.ptr(wh), L.ptr(ml), st)
     else:
         S = torch.zeros(B, 64, device=dev)                                   # train.py:413
-    L.call("sw_dec_rollout_fwd", L.ptr(obsv), To, L.ptr(noise), L.ptr(S), L.ptr(hT), L.ptr(cT), L.ptr(enc_w),
+    L.call("sw_dec_rollout_fwd_aux", L.ptr(obsv), To, L.ptr(noise), L.ptr(S), L.ptr(hT), L.ptr(cT), L.ptr(enc_w),
            L.ptr(dec_w), B, n_next, L.ptr(pred4), None, None, L.ptr(gsave),
-           L.ptr(ade[0]) if ade else None, float(ade[1]) if ade else 0.0, L.ptr(ade[2]) if ade else None, st)
+           L.ptr(ade[0]) if ade else None, float(ade[1]) if ade else 0.0, L.ptr(ade[2]) if ade else None,
+           L.ptr(d_obs[0]) if d_obs else None, L.ptr(d_obs[1]) if d_obs else None, st)
     if not save:
         return pred4, None
     ctx = GenCtx()
@@ -195,9 +198,21 @@ class DiscCtx:
     __slots__ = ("dsave", "B", "To", "Tp", "nb")
 
 
+D_OBS_MAX_TILES = 128      # the decode launch has idle CUs for the D observation LSTM up to this many 16-agent tiles
+
+
+def d_obs_buffer(ws, B, To, Tp, nb=2, tag="d"):
+    """The save buffer disc_forward(tag, nb branches) will use, or None when the decode launch has no idle CUs to
+    precompute the observation LSTM in (gen_forward(d_obs=...) / disc_forward(save_lstm=2))."""
+    if (B + 15) // 16 > D_OBS_MAX_TILES:
+        return None
+    return ws.get(tag + ".dsave", L.workspace_floats(L.WS_DSAVE, B, To, Tp, nb))
+
+
 def disc_forward(d_w, obsv, preds, save, ws=None, tag="d", save_lstm=True, w_snapshot=None):
     """Discriminator.forward for 1 or 2 future branches sharing the observation encoding.
-    Returns ([label_k (B,1)], [code_k (B,2)], ctx)."""
+    Returns ([label_k (B,1)], [code_k (B,2)], ctx).  save_lstm=2: the LSTM rows are already in the save buffer
+    (gen_forward(d_obs=...))."""
     L.require_gpu(obsv)
     obsv = obsv.contiguous()
     preds = [p.contiguous() for p in preds]
@@ -215,7 +230,7 @@ def disc_forward(d_w, obsv, preds, save, ws=None, tag="d", save_lstm=True, w_sna
     pp, _k1 = L.ptr_array(preds)
     lp, _k2 = L.ptr_array(labels)
     cp, _k3 = L.ptr_array(codes)
-    L.call("sw_disc_fwd", L.ptr(obsv), To, x_mode, pp, nb, L.ptr(d_w), B, Tp, lp, cp, L.ptr(dsave), 1 if save_lstm else 0,
+    L.call("sw_disc_fwd", L.ptr(obsv), To, x_mode, pp, nb, L.ptr(d_w), B, Tp, lp, cp, L.ptr(dsave), int(save_lstm),
            L.ptr(w_snapshot), L.stream())
     if not save:
         return labels, codes, None

@@ -420,9 +420,11 @@ class SocialWaysTrainer:
         # ---- generator rollout, once (train.py:480/507 are identical) ---------------
         enc, emb, att, dec = G.encoder, G.feature_embedder, G.attention, G.decoder
         # the decode kernel also leaves the ADE/FDE partial sums of the prediction (train.py:546-551)
+        # ... and, while it leaves CUs idle, the observation LSTM of the first D pass (independent of the generator)
+        d_pre = ops.d_obs_buffer(ws, B, obsv.shape[1], Tp) if obsv.shape[2] == 2 else None
         pred_hat, gctx = ops.gen_forward(enc._flat, emb._flat, att._flat, dec._flat, obsv, noise, scenes, Tp,
                                          G.use_social, save=True, ws=ws, ade=(pred, 1.0 / float(ss), out[U + 2]),
-                                         noise_src=noise_src)
+                                         noise_src=noise_src, d_obs=(D._flat, d_pre) if d_pre is not None else None)
         d_gflat = D.grad_views()
         backup = None
         # ---- discriminator updates (train.py:476-499) ------------------------------------------------
@@ -430,6 +432,7 @@ class SocialWaysTrainer:
             if u == 1:     # deepcopy(D) after the first update (train.py:498-499) = the weights of this forward pass
                 backup = ws.get("d_backup", D._flat.numel())
             labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat, pred4], save=True, ws=ws,
+                                                   save_lstm=2 if (u == 0 and d_pre is not None) else 1,
                                                    w_snapshot=backup if u == 1 else None)
             # the loss gradients AND the reported loss sums (per-tile partials) are formed inside the backward kernel
             ops.disc_backward_gan(D._flat, dctx, labels, codes, targets, (0, 1), noise, g_label, g_code, d_gflat, (), ws=ws,

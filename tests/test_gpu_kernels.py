@@ -183,3 +183,37 @@ def test_loss_and_ade_reductions_any_batch_size(B):
         assert_close(dlb, (lb.cpu() - 0.93), 1e-6, 1e-7, "dlabel_b")
         assert float(dcb.abs().max()) == 0.0
     assert torch.equal(res[1][0], res[2][0])
+
+
+@pytest.mark.parametrize("B", [40, 2048])
+def test_disc_observation_lstm_precomputed_by_the_decode_launch(B):
+    """sw_dec_rollout_fwd_aux runs the discriminator's observation LSTM in idle workgroups of the decode launch;
+    sw_disc_fwd(save_lstm=2) then reads the rows: labels, codes and the whole save buffer must equal the plain
+    sw_disc_fwd(save_lstm=1) bit for bit, and the rollout itself is unchanged."""
+    import socialways_amd as sw
+    from socialways_amd import ops, _lib as L
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B)
+    G = sw.Generator(use_social=True, device=dev)
+    G.unify()
+    D = sw.Discriminator(12, 64, 2, device=dev)
+    A = 8
+    sb = np.stack([np.arange(B // A) * A, (np.arange(B // A) + 1) * A], axis=1).astype(np.int64)
+    scenes = ops.SceneIndex.get(sb, B, dev)
+    obsv = torch.randn(B, 8, 2, device=dev).cumsum(1) * 0.1
+    noise = torch.rand(B, 32, device=dev)
+    real = torch.randn(B, 12, 4, device=dev) * 0.1
+    enc, emb, att, dec = G.encoder, G.feature_embedder, G.attention, G.decoder
+    ws_a, ws_b = ops.Workspaces(dev), ops.Workspaces(dev)
+    pre = ops.d_obs_buffer(ws_a, B, 8, 12)
+    assert pre is not None
+    ph_a, _ = ops.gen_forward(enc._flat, emb._flat, att._flat, dec._flat, obsv, noise, scenes, 12, True, save=True, ws=ws_a,
+                              d_obs=(D._flat, pre))
+    ph_b, _ = ops.gen_forward(enc._flat, emb._flat, att._flat, dec._flat, obsv, noise, scenes, 12, True, save=True, ws=ws_b)
+    assert torch.equal(ph_a, ph_b)
+    la, ca, ctx_a = ops.disc_forward(D._flat, obsv, [ph_a, real], save=True, ws=ws_a, save_lstm=2)
+    lb, cb, ctx_b = ops.disc_forward(D._flat, obsv, [ph_b, real], save=True, ws=ws_b, save_lstm=1)
+    for x, y in zip(la + ca, lb + cb):
+        assert torch.equal(x, y)
+    n = L.workspace_floats(L.WS_DSAVE, B, 8, 12, 2)
+    assert torch.equal(ctx_a.dsave[:n], ctx_b.dsave[:n])
