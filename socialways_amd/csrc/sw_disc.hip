@@ -8,6 +8,19 @@
 #include "../../include/socialways_hip.h"
 #include "sw_lstm_dev.h"
 #include "sw_wgrad.h"
+#include <type_traits>
+#ifdef SW_PHASE_STAMPS
+__device__ long long sw_disc_stamps[16];
+#define SW_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); long long _t = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) sw_disc_stamps[k] += _t - _tprev; _tprev = _t; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SW_STAMP_INIT long long _tprev = clock64()
+extern "C" int sw_debug_disc_stamps(long long* out, int reset) {
+  if (reset) { long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(sw_disc_stamps), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sw_disc_stamps), 16 * sizeof(long long));
+}
+#else
+#define SW_STAMP(k)
+#define SW_STAMP_INIT
+#endif
 
 namespace {
 constexpr int LD64 = sw_ld(64);  // 68
@@ -34,7 +47,7 @@ __host__ __device__ inline DSave dsave_layout(int B, int To, int Tp, int nb) {
   return d;
 }
 struct DDelta {
-  size_t dgates, do1, docode, dpcode, dq1, dc1, dl1, dlab, dcod, total;
+  size_t dgates, do1, docode, dpcode, dq1, dc1, dl1, dlab, dcod, trash, total;
 };
 __host__ __device__ inline DDelta ddelta_layout(int B, int To, int Tp, int nb) {
   DDelta d;
@@ -48,7 +61,8 @@ __host__ __device__ inline DDelta ddelta_layout(int B, int To, int Tp, int nb) {
   d.dl1 = d.dc1 + nb * b * 32;
   d.dlab = d.dl1 + nb * b * 32;
   d.dcod = d.dlab + nb * b * 4;
-  d.total = d.dcod + nb * b * 4;
+  d.trash = d.dcod + nb * b * 4;   // 16 x 256 floats nobody reads: where the padding lanes of the last tile store
+  d.total = d.trash + 16 * 256;    //   (unconditional stores keep the s_waitcnt vmcnt bookkeeping of the loops exact)
   return d;
 }
 
@@ -175,6 +189,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
   // fuse (generator phase, one branch): the backward of the heads down to d(loss)/d(pred) runs in this kernel too -
   // its transposed weight images and delta buffers follow the forward carve in LDS, the activations never leave LDS
   const HeadLdsB LB = head_lds_b(Tp, L.total);
+  SW_STAMP_INIT;
   if (fuse) stage_zero(smem + LB.of0T, LB.dc1 - LB.of0T);   // transposed images (zero padded) + dlab, dcod
   const bool obs_pre = save_lstm == 2;   // LSTM rows already in dsave (sw_dec_rollout_fwd_aux ran the observation LSTM)
   LstmW W;
@@ -232,6 +247,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
     const int tt = t == 0 ? 1 : t;
     return p[tt * 2 + lg - 2] - p[(tt - 1) * 2 + lg - 2];
   };
+  SW_STAMP(0);
   float xnext = obs_pre ? 0.f : load_x(0);
   for (int t = 0; t < (obs_pre ? 0 : To); ++t) {
     const float xb = xnext;
@@ -250,6 +266,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
     sw_barrier();
   }
   const float* hlast = &hbuf[(To & 1) * 16 * SW_HLD];
+  SW_STAMP(1);
 
   // ---- heads ------------------------------------------------------------------------------------
   // pred branches into LDS rows [16][ldp] (zero padded), saved flat for the pe0 weight gradient
@@ -271,6 +288,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
     acc = tile_mm_rt(smem + L.of1 + (m0 + ln) * LD32 + 4 * lg, smem + L.o1 + ln * LD32 + 4 * lg, 2, acc);
     st4(smem + L.both + ln * LD64 + m0 + 4 * lg, acc);
   }
+  SW_STAMP(2);
   for (int k = k_lo; k < k_hi; ++k) {
     const float* pred = k == 0 ? pred_a : pred_b;
     float* label = k == 0 ? label_a : label_b;
@@ -347,6 +365,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
       }
     }
   }
+  SW_STAMP(3);
   if (!fuse) return;
   // ---- fused backward of the heads of branch 0: d(loss)/d(pred) only (generator phase) -----------------------
   sw_barrier();
@@ -385,6 +404,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
     acc = tile_mm_rt(smem + LB.pe0T + (m0 + ln) * LD32 + 4 * lg, smem + LB.dq1 + ln * LD32 + 4 * lg, 2, acc);
     if (live && m0 + 4 * lg < K4) st4(dpred_out + (size_t)b * K4 + m0 + 4 * lg, acc);
   }
+  SW_STAMP(4);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -410,6 +430,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
   const bool live = (a0 + ln) < B;
   const int K4 = 4 * Tp;
 
+  SW_STAMP_INIT;
   stage_zero(smem + L.of0T, L.dlab - L.of0T);  // transposed images are zero padded
   sw_barrier();
   stage_wT(smem + L.of0T, LD32, 64, d_w + O.of0w, 64, 32, 64);
@@ -427,6 +448,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
     const float* dcode = k == 0 ? dcode_a : dcode_b;
     float* dpred = k == 0 ? dpred_a : dpred_b;
     sw_barrier();
+    if (k == 0) SW_STAMP(8);
     for (int i = threadIdx.x; i < 16 * LD16; i += blockDim.x) {
       int a = i / LD16, cc = i - a * LD16;
       int bb = min(a0 + a, B - 1);
@@ -518,6 +540,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
   }
   if (!want_w) return;
   sw_barrier();
+  SW_STAMP(9);
   // ---- observation path: of1, of0, LSTM BPTT -------------------------------------------------
   if (live && wave < 2) st4(ddelta + dd.docode + (size_t)b * 32 + u0 + 4 * lg, ld4(smem + L.docode + ln * LD32 + u0 + 4 * lg));
   if (wave < 2) {
@@ -535,36 +558,57 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
   dh = tile_mm_rt(smem + L.of0T + (u0 + ln) * LD32 + 4 * lg, smem + L.do1 + ln * LD32 + 4 * lg, 2, dh);
   LstmWT WT;
   lstm_load_wT(WT, d_w + O.whh, u0, ln, lg);
-  auto load_row = [&](int t, f32x4 g[4], f32x4& ct_, f32x4& cp_) {
-    const float* row = dsave + ds.act + ((size_t)t * B + b) * 384 + u0 + 4 * lg;
+  // Saved rows are fetched one step ahead.  Every memory operation of the loop body is UNCONDITIONAL (the two
+  // boundary steps are peeled; padding lanes of the last tile store to a trash row): with conditional loads or
+  // stores the compiler cannot count what is in flight and waits for everything (s_waitcnt vmcnt(0)) right after
+  // issuing the prefetch - that exposed one HBM round trip in every BPTT step.
+  const float* act_b = dsave + ds.act + (size_t)b * 384 + u0 + 4 * lg;
+  const size_t tstep = (size_t)B * 384;
+  auto load_row = [&](int t, f32x4 g[4], f32x4& ct_, f32x4& cp_, auto has_prev) {
+    const float* row = act_b + (size_t)t * tstep;
 #pragma unroll
     for (int q = 0; q < 4; ++q) g[q] = ld4(row + q * 64);
     ct_ = ld4(row + 256);
-    cp_ = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (t > 0) cp_ = ld4(row - (size_t)B * 384 + 256);
+    if constexpr (decltype(has_prev)::value) cp_ = ld4(row - tstep + 256);
+    else cp_ = f32x4{0.f, 0.f, 0.f, 0.f};   // c_{-1} = 0
   };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
   f32x4 gate[4], ct, cprev;
-  load_row(To - 1, gate, ct, cprev);
-  for (int t = To - 1; t >= 0; --t) {  // saved rows loaded one step ahead (latency under the MFMAs)
+  if (To > 1) load_row(To - 1, gate, ct, cprev, T_{});
+  else load_row(0, gate, ct, cprev, F_{});
+  float* dgg = live ? ddelta + dd.dgates + ((size_t)(To - 1) * B + b) * 256 + u0 + 4 * lg
+                    : ddelta + dd.trash + ln * 256 + u0 + 4 * lg;
+  const ptrdiff_t dgg_step = live ? (ptrdiff_t)B * 256 : 0;
+  SW_STAMP(10);
+  // one BPTT step; pf: rows of step t-1 are prefetched (pp: they have a predecessor row), nx: dh_{t-1} is needed
+  auto step = [&](int t, auto pf, auto pp, auto nx) {
     f32x4 ngate[4], nct, ncp, dgate[4];
-    if (t > 0) load_row(t - 1, ngate, nct, ncp);
+    if constexpr (decltype(pf)::value) load_row(t - 1, ngate, nct, ncp, pp);
     lstm_cell_bwd(gate, ct, cprev, dh, dc, dgate);
     float* dgl = &dgbuf[(t & 1) * 16 * SW_GLD + ln * SW_GLD + u0 + 4 * lg];
-    float* dgg = ddelta + dd.dgates + ((size_t)t * B + b) * 256 + u0 + 4 * lg;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       st4(dgl + g * 64, dgate[g]);
-      if (live) st4(dgg + g * 64, dgate[g]);
+      st4(dgg + g * 64, dgate[g]);
     }
+    dgg -= dgg_step;
+    SW_STAMP(12);
     sw_barrier();
-    if (t > 0) {
-      dh = lstm_dh_prev(WT, &dgbuf[(t & 1) * 16 * SW_GLD + ln * SW_GLD + 4 * lg]);
+    SW_STAMP(13);
+    if constexpr (decltype(nx)::value) dh = lstm_dh_prev(WT, &dgbuf[(t & 1) * 16 * SW_GLD + ln * SW_GLD + 4 * lg]);
+    if constexpr (decltype(pf)::value) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) gate[g] = ngate[g];
       ct = nct;
       cprev = ncp;
     }
-  }
+    SW_STAMP(14);
+  };
+  for (int t = To - 1; t >= 2; --t) step(t, T_{}, T_{}, T_{});
+  if (To > 1) step(1, T_{}, F_{}, T_{});
+  step(0, F_{}, F_{}, F_{});
+  SW_STAMP(11);
 }
 
 static int set_lds(const void* fn, int bytes) {
