@@ -4,17 +4,32 @@
 #include "../../include/socialways_hip.h"
 #include "sw_lstm_dev.h"
 
-// x4[agent][t][comp] for the observation rule of get_traj_4d (train.py:131-133): v_0 := v_1.
-__device__ __forceinline__ float obs_x4(const float* pos, int b, int t, int T, int comp) {
+// x4[agent][t][comp] for the observation rule of get_traj_4d (train.py:131-133): v_0 := v_1, as two raw loads
+// (a, q) with x = a - (comp >= 2 ? q : 0).  Branch-free and split from the arithmetic on purpose: memory operations
+// under lane-dependent branches make the compiler lose count of what is in flight (it then waits for everything,
+// s_waitcnt vmcnt(0)), and arithmetic on a prefetched value gets scheduled right behind its load.
+__device__ __forceinline__ void obs_x4_load(const float* pos, int b, int t, int T, int comp, float& a, float& q) {
   const float* p = pos + (size_t)b * T * 2;
-  if (comp < 2) return p[t * 2 + comp];
-  int c = comp - 2;
-  int tt = t == 0 ? 1 : t;
-  return p[tt * 2 + c] - p[(tt - 1) * 2 + c];
+  const int c = comp & 1, tt = t == 0 ? 1 : t;
+  const bool vel = comp >= 2;
+  a = p[(vel ? tt : t) * 2 + c];
+  q = p[(vel ? tt - 1 : t) * 2 + c];
+}
+__device__ __forceinline__ float obs_x4(const float* pos, int b, int t, int T, int comp) {
+  float a, q;
+  obs_x4_load(pos, b, t, T, comp, a, q);
+  return a - (comp >= 2 ? q : 0.f);
 }
 
+// XMODE 0: x = positions [B][T][2] (4-d state formed on the fly); 1: x = [B][T][4].  ACT / Y / X4S: which per-step
+// rows are stored.  All of them are template parameters so that the step loop has NO conditional memory operation:
+// the compiler then knows how many loads / stores are in flight and never waits for the stores of a step (with
+// run-time conditions it put s_waitcnt vmcnt(0) in front of every step's barrier: one store round trip per step).
+// Padding lanes of the last tile are exact replicas of agent B-1 (every load is clamped to it) and store the same
+// values to the same rows.
+template <int XMODE, bool ACT, bool Y, bool X4S>
 __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
-    const float* __restrict__ x, int x_mode, const float* __restrict__ enc_w, const float* __restrict__ h0,
+    const float* __restrict__ x, const float* __restrict__ enc_w, const float* __restrict__ h0,
     const float* __restrict__ c0, int B, int T, float* __restrict__ hT, float* __restrict__ cT,
     float* __restrict__ y, float* __restrict__ act, float* __restrict__ x4s, int t0, const float* __restrict__ aux_src,
     float* __restrict__ aux_dst, long long aux_n) {
@@ -34,7 +49,6 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
   const int u0 = wave * 16;
   const int a0 = blockIdx.x * SW_TILE;
   const int b = min(a0 + ln, B - 1);
-  const bool live = (a0 + ln) < B;
   LstmW W;
   lstm_load_whh(W, enc_w + swp::ENC_WHH, u0, ln, lg);
 
@@ -49,32 +63,43 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
   lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
 
   // the input of step t+1 is fetched while step t computes: its L2/HBM latency would otherwise sit in front of
-  // the first MFMA of every step
-  auto load_x = [&](int t) { return x_mode == 0 ? obs_x4(x, b, t, T, lg) : x[((size_t)b * T + t) * 4 + lg]; };
-  float xnext = load_x(0);
+  // the first MFMA of every step (the last step re-fetches its own input: no conditional load)
+  float xa, xq = 0.f;
+  auto load_x = [&](int t) {
+    if constexpr (XMODE == 0) obs_x4_load(x, b, t, T, lg, xa, xq);
+    else xa = x[((size_t)b * T + t) * 4 + lg];
+  };
+  load_x(0);
+  asm volatile("" : "+v"(xa), "+v"(xq));   // waited for HERE: the loop header must see no pending load on any path in
+  float* arow = ACT ? act + ((size_t)t0 * B + b) * 384 + u0 + 4 * lg : nullptr;
+  float* yrow = Y ? y + (size_t)b * T * 64 + u0 + 4 * lg : nullptr;
+  float* xrow = X4S ? x4s + ((size_t)t0 * B + b) * 4 + lg : nullptr;
   for (int t = 0; t < T; ++t) {
-    const float xb = xnext;
-    if (t + 1 < T) xnext = load_x(t + 1);
+    const float xb = XMODE == 0 ? xa - (lg >= 2 ? xq : 0.f) : xa;
+    load_x(min(t + 1, T - 1));
     f32x4 gate[4];
     lstm_cell(W, xb, &hbuf[t & 1][ln * SW_HLD + 4 * lg], gate, c, h);
     st4(&hbuf[(t + 1) & 1][ln * SW_HLD + u0 + 4 * lg], h);
-    if (live) {
-      if (act) {
-        float* row = act + ((size_t)(t0 + t) * B + b) * 384 + u0 + 4 * lg;
+    if constexpr (ACT) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) st4(row + g * 64, gate[g]);
-        st4(row + 256, c);
-        st4(row + 320, h);
-      }
-      if (y) st4(y + ((size_t)b * T + t) * 64 + u0 + 4 * lg, h);
-      if (x4s && wave == 0) x4s[((size_t)(t0 + t) * B + b) * 4 + lg] = xb;
+      for (int g = 0; g < 4; ++g) st4(arow + g * 64, gate[g]);
+      st4(arow + 256, c);
+      st4(arow + 320, h);
+      arow += (size_t)B * 384;
+    }
+    if constexpr (Y) {
+      st4(yrow, h);
+      yrow += 64;
+    }
+    if constexpr (X4S) {   // all four waves hold the same x_t: they all store it (no per-wave branch)
+      *xrow = xb;
+      xrow += (size_t)B * 4;
     }
     sw_barrier();
+    asm volatile("" : "+v"(xa), "+v"(xq));   // the prefetched input is not touched before this point
   }
-  if (live) {
-    st4(hT + (size_t)b * 64 + u0 + 4 * lg, h);
-    st4(cT + (size_t)b * 64 + u0 + 4 * lg, c);
-  }
+  st4(hT + (size_t)b * 64 + u0 + 4 * lg, h);
+  st4(cT + (size_t)b * 64 + u0 + 4 * lg, c);
 }
 
 // BPTT.  Per step: elementwise gate gradients (lane-local) -> dgates row to HBM (for the
@@ -177,8 +202,28 @@ extern "C" int sw_enc_lstm_fwd_aux(const float* x, int x_mode, const float* enc_
   const int tiles = (B + SW_TILE - 1) / SW_TILE;
   int extra = aux_n > 0 ? (int)((aux_n / 4 + SW_THREADS - 1) / SW_THREADS) : 0;
   if (extra > 64) extra = 64;
-  hipLaunchKernelGGL(enc_lstm_fwd_kernel, dim3(tiles + extra), dim3(SW_THREADS), 0, (hipStream_t)stream, x, x_mode, enc_w,
-                     h0, c0, B, T, hT, cT, y, act, x4s, t0, aux_src, aux_dst, aux_n);
+#define SW_ENC_FWD(XM, A, Y_, X4)                                                                                   \
+  hipLaunchKernelGGL((enc_lstm_fwd_kernel<XM, A, Y_, X4>), dim3(tiles + extra), dim3(SW_THREADS), 0, (hipStream_t)stream, \
+                     x, enc_w, h0, c0, B, T, hT, cT, y, act, x4s, t0, aux_src, aux_dst, aux_n)
+  switch ((x_mode ? 8 : 0) | (act ? 4 : 0) | (y ? 2 : 0) | (x4s ? 1 : 0)) {
+    case 0: SW_ENC_FWD(0, false, false, false); break;
+    case 1: SW_ENC_FWD(0, false, false, true); break;
+    case 2: SW_ENC_FWD(0, false, true, false); break;
+    case 3: SW_ENC_FWD(0, false, true, true); break;
+    case 4: SW_ENC_FWD(0, true, false, false); break;
+    case 5: SW_ENC_FWD(0, true, false, true); break;
+    case 6: SW_ENC_FWD(0, true, true, false); break;
+    case 7: SW_ENC_FWD(0, true, true, true); break;
+    case 8: SW_ENC_FWD(1, false, false, false); break;
+    case 9: SW_ENC_FWD(1, false, false, true); break;
+    case 10: SW_ENC_FWD(1, false, true, false); break;
+    case 11: SW_ENC_FWD(1, false, true, true); break;
+    case 12: SW_ENC_FWD(1, true, false, false); break;
+    case 13: SW_ENC_FWD(1, true, false, true); break;
+    case 14: SW_ENC_FWD(1, true, true, false); break;
+    default: SW_ENC_FWD(1, true, true, true); break;
+  }
+#undef SW_ENC_FWD
   SW_CHECK_LAUNCH("enc_lstm_fwd_kernel");
   return SW_OK;
 }
