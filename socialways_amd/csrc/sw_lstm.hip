@@ -3,6 +3,7 @@
 // registers, h exchanged through a double-buffered 4 KB LDS tile: one barrier per time step.
 #include "../../include/socialways_hip.h"
 #include "sw_lstm_dev.h"
+#include <type_traits>
 
 // x4[agent][t][comp] for the observation rule of get_traj_4d (train.py:131-133): v_0 := v_1, as two raw loads
 // (a, q) with x = a - (comp >= 2 ? q : 0).  Branch-free and split from the arithmetic on purpose: memory operations
@@ -104,6 +105,11 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
 
 // BPTT.  Per step: elementwise gate gradients (lane-local) -> dgates row to HBM (for the
 // deferred weight-gradient GEMM) and to LDS -> dh_{t-1} = W_hh^T dgates on the matrix cores.
+// The saved rows of step t-1 are fetched while step t computes.  As in enc_lstm_fwd the loop body has NO conditional
+// memory operation (DY is a template parameter, the two boundary steps are peeled, padding lanes of the last tile are
+// replicas of agent B-1 and store the same values): with conditional loads / stores the compiler waited for
+// everything in flight (s_waitcnt vmcnt(0)) behind every step's barrier - the dgates rows just stored included.
+template <bool DY>
 __global__ __launch_bounds__(SW_THREADS) void enc_lstm_bwd_kernel(
     const float* __restrict__ whh, const float* __restrict__ act, const float* __restrict__ c0,
     const float* __restrict__ dhT, const float* __restrict__ dcT, const float* __restrict__ dy, int B, int T,
@@ -113,49 +119,65 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_bwd_kernel(
   const int u0 = wave * 16;
   const int a0 = blockIdx.x * SW_TILE;
   const int b = min(a0 + ln, B - 1);
-  const bool live = (a0 + ln) < B;
   LstmWT W;
   lstm_load_wT(W, whh, u0, ln, lg);
   f32x4 dh = {0.f, 0.f, 0.f, 0.f}, dc = {0.f, 0.f, 0.f, 0.f};
   if (dhT) dh = ld4(dhT + (size_t)b * 64 + u0 + 4 * lg);
   if (dcT) dc = ld4(dcT + (size_t)b * 64 + u0 + 4 * lg);
-  // saved rows of step t are loaded one iteration ahead: their L2/HBM latency hides under the MFMAs
-  auto load_row = [&](int t, f32x4 g[4], f32x4& ct_, f32x4& cp_) {
-    const float* row = act + ((size_t)(t0 + t) * B + b) * 384 + u0 + 4 * lg;
+  const float* act_b = act + ((size_t)t0 * B + b) * 384 + u0 + 4 * lg;
+  const size_t tstep = (size_t)B * 384;
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  // rows of local step t; has_prev: row t-1 exists in `act` (always for t >= 1; for t = 0 only if t0 > 0)
+  auto load_row = [&](int t, f32x4 g[4], f32x4& ct_, f32x4& cp_, auto has_prev) {
+    const float* row = act_b + (size_t)t * tstep;
 #pragma unroll
     for (int q = 0; q < 4; ++q) g[q] = ld4(row + q * 64);
     ct_ = ld4(row + 256);
-    cp_ = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (t0 + t > 0) cp_ = ld4(row - (size_t)B * 384 + 256);
-    else if (c0) cp_ = ld4(c0 + (size_t)b * 64 + u0 + 4 * lg);
+    if constexpr (decltype(has_prev)::value) {
+      cp_ = ld4(row - tstep + 256);
+    } else {   // the sequence start: c_{-1} = c0 or zero (or the row in front of t0)
+      cp_ = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t0 > 0) cp_ = ld4(row - tstep + 256);
+      else if (c0) cp_ = ld4(c0 + (size_t)b * 64 + u0 + 4 * lg);
+    }
   };
   f32x4 gate[4], ct, cprev;
-  load_row(T - 1, gate, ct, cprev);
-  for (int t = T - 1; t >= 0; --t) {
+  if (T > 1) load_row(T - 1, gate, ct, cprev, T_{});
+  else load_row(0, gate, ct, cprev, F_{});
+  float* dgg = dgates + ((size_t)(t0 + T - 1) * B + b) * 256 + u0 + 4 * lg;
+  const float* dyp = DY ? dy + ((size_t)b * T + T - 1) * 64 + u0 + 4 * lg : nullptr;
+  auto step = [&](int t, auto pf, auto pp) {   // pf: prefetch the rows of step t-1 (pp: which have a predecessor row)
     f32x4 ngate[4], nct, ncp, dgate[4];
-    if (t > 0) load_row(t - 1, ngate, nct, ncp);
-    if (dy) dh += ld4(dy + ((size_t)b * T + t) * 64 + u0 + 4 * lg);
+    if constexpr (decltype(pf)::value) load_row(t - 1, ngate, nct, ncp, pp);
+    if constexpr (DY) {
+      dh += ld4(dyp);
+      dyp -= 64;
+    }
     lstm_cell_bwd(gate, ct, cprev, dh, dc, dgate);
     float* dgl = &dgbuf[t & 1][ln * SW_GLD + u0 + 4 * lg];
-    float* dgg = dgates + ((size_t)(t0 + t) * B + b) * 256 + u0 + 4 * lg;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       st4(dgl + g * 64, dgate[g]);
-      if (live) st4(dgg + g * 64, dgate[g]);
+      st4(dgg + g * 64, dgate[g]);
     }
+    dgg -= (size_t)B * 256;
     sw_barrier();
     dh = lstm_dh_prev(W, &dgbuf[t & 1][ln * SW_GLD + 4 * lg]);
-    if (t > 0) {
+    if constexpr (decltype(pf)::value) {
+      // the prefetched rows are not touched before the matrix products above have been issued
+      asm volatile("" : "+v"(ngate[0]), "+v"(ngate[1]), "+v"(ngate[2]), "+v"(ngate[3]), "+v"(nct), "+v"(ncp));
 #pragma unroll
       for (int g = 0; g < 4; ++g) gate[g] = ngate[g];
       ct = nct;
       cprev = ncp;
     }
-  }
-  if (live) {
-    if (dh0) st4(dh0 + (size_t)b * 64 + u0 + 4 * lg, dh);
-    if (dc0) st4(dc0 + (size_t)b * 64 + u0 + 4 * lg, dc);
-  }
+  };
+  for (int t = T - 1; t >= 2; --t) step(t, T_{}, T_{});
+  if (T > 1) step(1, T_{}, F_{});
+  step(0, F_{}, F_{});
+  if (dh0) st4(dh0 + (size_t)b * 64 + u0 + 4 * lg, dh);
+  if (dc0) st4(dc0 + (size_t)b * 64 + u0 + 4 * lg, dc);
 }
 
 // get_traj_4d (train.py:130-138) as a standalone op for the module-level API.
@@ -238,9 +260,12 @@ extern "C" int sw_enc_lstm_bwd(const float* enc_w, const float* act, const float
                                float* dh0, float* dc0, void* stream) {
   if (!enc_w || !act || !dgates || B < 0 || T < 1 || t0 < 0) return SW_EARG;
   if (B == 0) return SW_OK;
-  hipLaunchKernelGGL(enc_lstm_bwd_kernel, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS), 0,
-                     (hipStream_t)stream, enc_w + swp::ENC_WHH, act, c0, dhT, dcT, dy, B, T, t0, dgates, dh0,
-                     dc0);
+  if (dy)
+    hipLaunchKernelGGL(enc_lstm_bwd_kernel<true>, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS), 0,
+                       (hipStream_t)stream, enc_w + swp::ENC_WHH, act, c0, dhT, dcT, dy, B, T, t0, dgates, dh0, dc0);
+  else
+    hipLaunchKernelGGL(enc_lstm_bwd_kernel<false>, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS), 0,
+                       (hipStream_t)stream, enc_w + swp::ENC_WHH, act, c0, dhT, dcT, dy, B, T, t0, dgates, dh0, dc0);
   SW_CHECK_LAUNCH("enc_lstm_bwd_kernel");
   return SW_OK;
 }
