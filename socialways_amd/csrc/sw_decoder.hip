@@ -12,6 +12,7 @@
 //     between layers through small LDS tiles (one barrier per layer).
 #include "../../include/socialways_hip.h"
 #include "sw_lstm_dev.h"
+#include <type_traits>
 
 namespace {
 constexpr int LD64 = sw_ld(64);    // 68
@@ -349,44 +350,56 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
 #ifdef SW_PHASE_STAMPS
   long long _tprev = clock64();
 #endif
-  for (int i = Tp - 1; i >= 0; --i) {
+  // Everything an iteration reads from HBM/L2 (saved LSTM rows, saved a1 / a2 tiles, the upstream gradient) is
+  // fetched ONE ITERATION AHEAD, and the loop body has no conditional memory operation: clamped tile indices
+  // instead of `mt < n ? load : 0`, the first / last iteration peeled instead of `if (i < Tp - 1)`, stores of the
+  // padding lanes of the last tile kept (exact replicas of agent B-1: every load is clamped to it).  With
+  // conditional loads or stores the compiler cannot count what is in flight and waits for EVERYTHING
+  // (s_waitcnt vmcnt(0)) where a loaded value is first used - here that was the top of every step.
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  struct Rows {
+    f32x4 gate[4], ct, cprev;   // LSTM step To + i (consumed x4_i)
+    f32x4 a2[2], a1[3], g4;     // decoder step i
+  };
+  const float* act_b = gsave + gs.act + ((size_t)To * B + b) * 384 + u0 + 4 * lg;
+  const float* a2_b = gsave + gs.a2 + (size_t)b * 80 + 4 * lg;
+  const float* a1_b = gsave + gs.a1 + (size_t)b * 160 + 4 * lg;
+  auto load_rows = [&](int i, Rows& R, auto lstm) {
+    if constexpr (decltype(lstm)::value) {
+      const float* row = act_b + (size_t)i * B * 384;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) R.gate[g] = ld4(row + g * 64);
+      R.ct = ld4(row + 256);
+      R.cprev = ld4(row - (size_t)B * 384 + 256);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) R.a2[q] = ld4(a2_b + (size_t)i * B * 80 + min(wave + 4 * q, 4) * 16);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) R.a1[q] = ld4(a1_b + (size_t)i * B * 160 + min(wave + 4 * q, 9) * 16);
+    R.g4 = ld4(dpred4 + ((size_t)b * Tp + i) * 4);  // every wave keeps its own copy of the p/v gradient state
+  };
+  Rows R;
+  load_rows(Tp - 1, R, F_{});
+  // one decode step backwards; lstm: the step has an LSTM step behind it (all but i = Tp-1); pf: prefetch i-1
+  auto step = [&](int i, auto lstm, auto pf) {
     SW_STAMP(7);
-    // ---- prefetch everything this iteration reads from HBM/L2 (saved activations, upstream grad):
-    //      the loads fly under the LSTM-step MFMAs instead of stalling each decoder layer ----------
-    f32x4 gate[4], ct, cprev;
-    if (i < Tp - 1) {
-      const float* row = gsave + gs.act + ((size_t)(To + i) * B + b) * 384 + u0 + 4 * lg;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) gate[g] = ld4(row + g * 64);
-      ct = ld4(row + 256);
-      cprev = ld4(row - (size_t)B * 384 + 256);
-    }
-    f32x4 a2pre[2], a1pre[3];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      int mt = wave + 4 * q;
-      a2pre[q] = mt < 5 ? ld4(gsave + gs.a2 + ((size_t)i * B + b) * 80 + mt * 16 + 4 * lg) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      int mt = wave + 4 * q;
-      a1pre[q] = mt < 10 ? ld4(gsave + gs.a1 + ((size_t)i * B + b) * 160 + mt * 16 + 4 * lg) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const f32x4 g4 = ld4(dpred4 + ((size_t)b * Tp + i) * 4);  // every wave keeps its own copy of the p/v gradient state
+    Rows N;
+    if constexpr (decltype(pf)::value) load_rows(i - 1, N, T_{});
     f32x4 dx4 = {0.f, 0.f, 0.f, 0.f};  // gradient through the LSTM input (p_i, v_i)
-    if (i < Tp - 1) {
+    if constexpr (decltype(lstm)::value) {
       // ---- LSTM step t = To+i (consumed x4_i, produced h_t) --------------------------------
       const int t = To + i;
       f32x4 dgate[4];
-      lstm_cell_bwd(gate, ct, cprev, dh, dc, dgate);
+      lstm_cell_bwd(R.gate, R.ct, R.cprev, dh, dc, dgate);
       float* dgg = gdelta + gd.dgates + ((size_t)t * B + b) * 256 + u0 + 4 * lg;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         st4(&dgbuf[ln * SW_GLD + g * 64 + u0 + 4 * lg], dgate[g]);
-        if (live) st4(dgg + g * 64, dgate[g]);
+        st4(dgg + g * 64, dgate[g]);
       }
       sw_barrier();
-    SW_STAMP(0);
+      SW_STAMP(0);
       dh = lstm_dh_prev(WT, &dgbuf[ln * SW_GLD + 4 * lg]);
       // dx4 = Wx^T dgates: each wave reduces its own quarter of K, partials through LDS
       {
@@ -395,66 +408,76 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
         if (lg == 0) st4(&dxpart[(wave * 16 + ln) * 4], acc);
       }
       sw_barrier();
-    SW_STAMP(1);
+      SW_STAMP(1);
       dx4 = ld4(&dxpart[ln * 4]) + ld4(&dxpart[(16 + ln) * 4]) + ld4(&dxpart[(32 + ln) * 4]) +
             ld4(&dxpart[(48 + ln) * 4]);
     }
     // ---- decoder step i: dv (registers, every wave) -> da3 = W4^T dv ---------------------------
+    const f32x4 g4 = R.g4;
     dpx += g4[0] + dx4[0];  // dL/dp_i  (p_i also feeds p_{i+1}: carried in dpx)
     dpy += g4[1] + dx4[1];
     const float dvx = g4[2] + dx4[2] + dpx;  // p_i = p_{i-1} + v_i
     const float dvy = g4[3] + dx4[3] + dpy;
-    if (wave == 0 && lg == 0 && live) {
+    {   // every lane of agent ln holds the same pair: all of them store it (no lane-dependent store)
       f32x4 o = {dvx, dvy, 0.f, 0.f};
       st4(gdelta + gd.dv + ((size_t)i * B + b) * 4, o);
     }
     // dz2 = (W43^T dv) * lrelu'(a2)   (80): fc3 and fc4 are one linear map, so d(a2) comes straight from dv
-    // (2 MFMAs per tile, B operand k = 4lg + r with only k = 0,1 live, straight from registers)
+    // (2 MFMAs per tile, B operand k = 4lg + r with only k = 0,1 live, straight from registers).  Waves without a
+    // second tile repeat tile 4 (same values to the same places): no wave-dependent trip count around the stores
 #pragma unroll
     for (int q2 = 0; q2 < 2; ++q2) {
-      int mt = wave + 4 * q2;
-      if (mt >= 5) break;
-      int m0 = mt * 16;
+      const int m0 = min(wave + 4 * q2, 4) * 16;
       f32x4 w = ld4(&W43T[(m0 + ln) * LD2 + 4 * lg]);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       acc = SW_MFMA(w[0], lg == 0 ? dvx : 0.f, acc);
       acc = SW_MFMA(w[1], lg == 0 ? dvy : 0.f, acc);
-      f32x4 a2 = a2pre[q2];
+      f32x4 a2 = R.a2[q2];
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(a2[r], acc[r]);
       st4(&dz2buf[ln * LD80 + m0 + 4 * lg], acc);
-      if (live) st4(gdelta + gd.dz2 + ((size_t)i * B + b) * 80 + m0 + 4 * lg, acc);
+      st4(gdelta + gd.dz2 + ((size_t)i * B + b) * 80 + m0 + 4 * lg, acc);
     }
     sw_barrier();
     SW_STAMP(3);
-    // dz1 = (W2^T dz2) * lrelu'(a1)   (160)
+    // dz1 = (W2^T dz2) * lrelu'(a1)   (160); waves 2, 3 repeat tile 9 as their third (they would idle at the barrier)
     {
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        int mt = wave + 4 * q;
-        if (mt >= 10) break;
-        int m0 = mt * 16;
+        const int mt = wave + 4 * q;
+        const int m0 = min(mt, 9) * 16;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         acc = tile_mm<5>(&W2T[(m0 + ln) * LD80 + 4 * lg], &dz2buf[ln * LD80 + 4 * lg], acc);
-        f32x4 a1 = a1pre[q];
+        f32x4 a1 = R.a1[q];
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(a1[r], acc[r]);
         st4(&dz1buf[ln * LD160 + m0 + 4 * lg], acc);
-        if (live) st4(gdelta + gd.dz1 + ((size_t)i * B + b) * 160 + m0 + 4 * lg, acc);
-        if (q == 0) du[0] += acc;
-        else if (q == 1) du[1] += acc;
-        else du[2] += acc;
+        st4(gdelta + gd.dz1 + ((size_t)i * B + b) * 160 + m0 + 4 * lg, acc);
+        if (mt < 10) du[q] += acc;
       }
     }
     sw_barrier();
     SW_STAMP(4);
     // dh_{To+i-1} += W1h^T dz1   (wave w owns units 16w.. : same layout as dh)
     {
-      f32x4 acc = (i < Tp - 1) ? dh : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 acc = decltype(lstm)::value ? dh : f32x4{0.f, 0.f, 0.f, 0.f};
       acc = tile_mm<10>(&W1hT[(u0 + ln) * LD160 + 4 * lg], &dz1buf[ln * LD160 + 4 * lg], acc);
       dh = acc;
     }
     // (next iteration's first LDS writes are to dgbuf/dvbuf, whose readers are behind barriers)
+    if constexpr (decltype(pf)::value) {
+      // the prefetched rows are not touched before the products above have been issued
+      asm volatile("" : "+v"(N.gate[0]), "+v"(N.gate[1]), "+v"(N.gate[2]), "+v"(N.gate[3]), "+v"(N.ct), "+v"(N.cprev));
+      asm volatile("" : "+v"(N.a2[0]), "+v"(N.a2[1]), "+v"(N.a1[0]), "+v"(N.a1[1]), "+v"(N.a1[2]), "+v"(N.g4));
+      R = N;
+    }
+  };
+  if (Tp > 1) {
+    step(Tp - 1, F_{}, T_{});
+    for (int i = Tp - 2; i >= 1; --i) step(i, T_{}, T_{});
+    step(0, T_{}, F_{});
+  } else {
+    step(0, F_{}, F_{});
   }
   // ---- epilogue: state gradients, du and dS = W1[:,64:128]^T du ---------------------------------
   if (live) {
