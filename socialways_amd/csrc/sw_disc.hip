@@ -238,32 +238,19 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
     stage_wT(smem + LB.la1T, LD16, 32, d_w + O.la1w, 32, 2, 32);
   }
 
-  // ---- LSTM over the observation (4-d state formed on the fly, train.py:130-133) ---------------
-  // the input of step t+1 is fetched while step t computes (its latency would sit in front of every step's MFMAs)
-  auto load_x = [&](int t) {
-    if (x_mode == 1) return obsv[((size_t)b * To + t) * 4 + lg];
-    const float* p = obsv + (size_t)b * To * 2;
-    if (lg < 2) return p[t * 2 + lg];
-    const int tt = t == 0 ? 1 : t;
-    return p[tt * 2 + lg - 2] - p[(tt - 1) * 2 + lg - 2];
-  };
+  // ---- LSTM over the observation (4-d state formed on the fly, train.py:130-133): lstm_obs_loop, chosen once ----
   SW_STAMP(0);
-  float xnext = obs_pre ? 0.f : load_x(0);
-  for (int t = 0; t < (obs_pre ? 0 : To); ++t) {
-    const float xb = xnext;
-    if (t + 1 < To) xnext = load_x(t + 1);
-    f32x4 gate[4];
-    lstm_cell(W, xb, &hbuf[(t & 1) * 16 * SW_HLD + ln * SW_HLD + 4 * lg], gate, c, h);
-    st4(&hbuf[((t + 1) & 1) * 16 * SW_HLD + ln * SW_HLD + u0 + 4 * lg], h);
-    if (dsave && save_lstm && live && save_obs) {
-      float* row = dsave + ds.act + ((size_t)t * B + b) * 384 + u0 + 4 * lg;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) st4(row + g * 64, gate[g]);
-      st4(row + 256, c);
-      st4(row + 320, h);
-      if (wave == 0) dsave[ds.x4s + ((size_t)t * B + b) * 4 + lg] = xb;
+  if (!obs_pre) {
+    const bool sv = dsave && save_lstm && save_obs;
+    float* act = sv ? dsave + ds.act : nullptr;
+    float* x4s = sv ? dsave + ds.x4s : nullptr;
+    if (x_mode == 0) {
+      if (sv) lstm_obs_loop<0, true>(W, hbuf, obsv, To, B, b, c, h, act, x4s);
+      else lstm_obs_loop<0, false>(W, hbuf, obsv, To, B, b, c, h, act, x4s);
+    } else {
+      if (sv) lstm_obs_loop<1, true>(W, hbuf, obsv, To, B, b, c, h, act, x4s);
+      else lstm_obs_loop<1, false>(W, hbuf, obsv, To, B, b, c, h, act, x4s);
     }
-    sw_barrier();
   }
   const float* hlast = &hbuf[(To & 1) * 16 * SW_HLD];
   SW_STAMP(1);

@@ -5,23 +5,6 @@
 #include "sw_lstm_dev.h"
 #include <type_traits>
 
-// x4[agent][t][comp] for the observation rule of get_traj_4d (train.py:131-133): v_0 := v_1, as two raw loads
-// (a, q) with x = a - (comp >= 2 ? q : 0).  Branch-free and split from the arithmetic on purpose: memory operations
-// under lane-dependent branches make the compiler lose count of what is in flight (it then waits for everything,
-// s_waitcnt vmcnt(0)), and arithmetic on a prefetched value gets scheduled right behind its load.
-__device__ __forceinline__ void obs_x4_load(const float* pos, int b, int t, int T, int comp, float& a, float& q) {
-  const float* p = pos + (size_t)b * T * 2;
-  const int c = comp & 1, tt = t == 0 ? 1 : t;
-  const bool vel = comp >= 2;
-  a = p[(vel ? tt : t) * 2 + c];
-  q = p[(vel ? tt - 1 : t) * 2 + c];
-}
-__device__ __forceinline__ float obs_x4(const float* pos, int b, int t, int T, int comp) {
-  float a, q;
-  obs_x4_load(pos, b, t, T, comp, a, q);
-  return a - (comp >= 2 ? q : 0.f);
-}
-
 // XMODE 0: x = positions [B][T][2] (4-d state formed on the fly); 1: x = [B][T][4].  ACT / Y / X4S: which per-step
 // rows are stored.  All of them are template parameters so that the step loop has NO conditional memory operation:
 // the compiler then knows how many loads / stores are in flight and never waits for the stores of a step (with

@@ -161,11 +161,66 @@ __device__ __forceinline__ f32x4 lstm_dh_prev(const LstmWT& W, const float* dgro
   return a0 + a1;
 }
 
+// x4[agent][t][comp] for the observation rule of get_traj_4d (train.py:131-133): v_0 := v_1, as two raw loads
+// (a, q) with x = a - (comp >= 2 ? q : 0).  Branch-free and split from the arithmetic on purpose: memory operations
+// under lane-dependent branches make the compiler lose count of what is in flight (it then waits for everything,
+// s_waitcnt vmcnt(0)), and arithmetic on a prefetched value gets scheduled right behind its load.
+__device__ __forceinline__ void obs_x4_load(const float* pos, int b, int t, int T, int comp, float& a, float& q) {
+  const float* p = pos + (size_t)b * T * 2;
+  const int c = comp & 1, tt = t == 0 ? 1 : t;
+  const bool vel = comp >= 2;
+  a = p[(vel ? tt : t) * 2 + c];
+  q = p[(vel ? tt - 1 : t) * 2 + c];
+}
+__device__ __forceinline__ float obs_x4(const float* pos, int b, int t, int T, int comp) {
+  float a, q;
+  obs_x4_load(pos, b, t, T, comp, a, q);
+  return a - (comp >= 2 ? q : 0.f);
+}
+
+// The time loop of an LSTM over a 4-d input sequence (h0 = c0 given in hbuf[0] / c) for the 16-agent tile of agent
+// row b (clamped), W loaded.  XMODE 0: x = positions [B][T][2]; 1: x = [B][T][4].  SAVE: per step t and agent b,
+// act + (t B + b) 384 = gates i|f|g|o [256], c [64], h [64] and the step's input at x4s + (t B + b) 4.  No
+// conditional memory operation inside (see enc_lstm_fwd_kernel); padding lanes of the last tile are replicas of
+// agent B-1.  On return h_T sits in hbuf[T & 1].
+template <int XMODE, bool SAVE>
+__device__ __forceinline__ void lstm_obs_loop(const LstmW& W, float* hbuf, const float* __restrict__ x, int T, int B, int b,
+                                              f32x4& c, f32x4& h, float* __restrict__ act, float* __restrict__ x4s) {
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  const int u0 = wave * 16;
+  float xa, xq = 0.f;
+  auto load_x = [&](int t) {
+    if constexpr (XMODE == 0) obs_x4_load(x, b, t, T, lg, xa, xq);
+    else xa = x[((size_t)b * T + t) * 4 + lg];
+  };
+  load_x(0);
+  asm volatile("" : "+v"(xa), "+v"(xq));   // waited for HERE: the loop header must see no pending load on any path in
+  float* arow = SAVE ? act + (size_t)b * 384 + u0 + 4 * lg : nullptr;
+  float* xrow = SAVE ? x4s + (size_t)b * 4 + lg : nullptr;
+  for (int t = 0; t < T; ++t) {
+    const float xb = XMODE == 0 ? xa - (lg >= 2 ? xq : 0.f) : xa;
+    load_x(min(t + 1, T - 1));   // the input of step t+1 is fetched while step t computes
+    f32x4 gate[4];
+    lstm_cell(W, xb, &hbuf[(t & 1) * 16 * SW_HLD + ln * SW_HLD + 4 * lg], gate, c, h);
+    st4(&hbuf[((t + 1) & 1) * 16 * SW_HLD + ln * SW_HLD + u0 + 4 * lg], h);
+    if constexpr (SAVE) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) st4(arow + g * 64, gate[g]);
+      st4(arow + 256, c);
+      st4(arow + 320, h);
+      *xrow = xb;   // all four waves hold the same x_t and all store it
+      arow += (size_t)B * 384;
+      xrow += (size_t)B * 4;
+    }
+    sw_barrier();
+    asm volatile("" : "+v"(xa), "+v"(xq));   // the prefetched input is not touched before this point
+  }
+}
+
 // Observation LSTM of the discriminator (train.py:296-299) for the 16-agent tile at a0, leaving the rows its
-// backward needs: per step t and agent b, act + (t B + b) 384 = gates i|f|g|o [256], c [64], h [64] and the step's
-// 4-d input at x4s + (t B + b) 4.  Exactly the arithmetic of disc_fwd_kernel's own loop; it exists as a function so
-// that idle workgroups of ANOTHER launch can run it (the first D pass of a step does not depend on the generator:
-// sw_dec_rollout_fwd_aux).  smem: [2][16][SW_HLD] h tiles | [256][4] Wx | [256] bx  (2 * 16 * SW_HLD + 1280 floats).
+// backward needs (see lstm_obs_loop).  It exists as a function so that idle workgroups of ANOTHER launch can run it
+// (the first D pass of a step does not depend on the generator: sw_dec_rollout_fwd_aux).
+// smem: [2][16][SW_HLD] h tiles | [256][4] Wx | [256] bx  (2 * 16 * SW_HLD + 1280 floats).
 __device__ __forceinline__ void disc_obs_lstm_tile(float* smem, const float* __restrict__ obsv, int To, int x_mode,
                                                    const float* wih, const float* whh, const float* bih, const float* bhh,
                                                    int B, int a0, float* __restrict__ act, float* __restrict__ x4s) {
@@ -175,7 +230,6 @@ __device__ __forceinline__ void disc_obs_lstm_tile(float* smem, const float* __r
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
   const int u0 = wave * 16;
   const int b = min(a0 + ln, B - 1);
-  const bool live = (a0 + ln) < B;
   LstmW W;
   lstm_load_whh(W, whh, u0, ln, lg);
   lstm_prep_rows(nullptr, nullptr, wih, bih, bhh, false, wx_lds, bx_lds);
@@ -183,28 +237,6 @@ __device__ __forceinline__ void disc_obs_lstm_tile(float* smem, const float* __r
   st4(&hbuf[ln * SW_HLD + u0 + 4 * lg], h);
   sw_barrier();
   lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
-  auto load_x = [&](int t) {
-    if (x_mode == 1) return obsv[((size_t)b * To + t) * 4 + lg];
-    const float* p = obsv + (size_t)b * To * 2;
-    if (lg < 2) return p[t * 2 + lg];
-    const int tt = t == 0 ? 1 : t;
-    return p[tt * 2 + lg - 2] - p[(tt - 1) * 2 + lg - 2];
-  };
-  float xnext = load_x(0);
-  for (int t = 0; t < To; ++t) {
-    const float xb = xnext;
-    if (t + 1 < To) xnext = load_x(t + 1);
-    f32x4 gate[4];
-    lstm_cell(W, xb, &hbuf[(t & 1) * 16 * SW_HLD + ln * SW_HLD + 4 * lg], gate, c, h);
-    st4(&hbuf[((t + 1) & 1) * 16 * SW_HLD + ln * SW_HLD + u0 + 4 * lg], h);
-    if (live) {
-      float* row = act + ((size_t)t * B + b) * 384 + u0 + 4 * lg;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) st4(row + g * 64, gate[g]);
-      st4(row + 256, c);
-      st4(row + 320, h);
-      if (wave == 0) x4s[((size_t)t * B + b) * 4 + lg] = xb;
-    }
-    sw_barrier();
-  }
+  if (x_mode == 0) lstm_obs_loop<0, true>(W, hbuf, obsv, To, B, b, c, h, act, x4s);
+  else lstm_obs_loop<1, true>(W, hbuf, obsv, To, B, b, c, h, act, x4s);
 }
