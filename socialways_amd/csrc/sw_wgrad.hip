@@ -44,19 +44,20 @@ __device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const fl
     for (int kt = 0; kt < KT; ++kt) acc[i][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   constexpr int DEPTH = KT == 5 ? SW_WG_DEPTH - 2 : SW_WG_DEPTH;  // groups in flight (256 registers per lane at 2 waves per SIMD)
+  // The pipeline registers hold the RAW loaded values; row masks / the ones column are applied when a group is
+  // consumed.  (Arithmetic attached to the load sits in front of the loop's back edge, so every load of a body
+  // iteration had to complete inside it: the compiler drained the pipeline - s_waitcnt vmcnt(0) - once per DEPTH
+  // groups.)
   float a[DEPTH][NI], b[DEPTH][KT];
   auto load = [&](int r0, float* av, float* bv) {
-    const int r = r0 + lg;
-    const float rs = r < rend ? 1.0f : 0.0f;
-    const int rc = min(r, rmax);
+    const int rc = min(r0 + lg, rmax);
     const float* dr = dbase + (size_t)rc * ldd;
     const float* ar = abase + (size_t)max(rc, row0) * lda;     // rows below row0 have no `act` operand
-    const float rs0 = r >= row0 ? rs : 0.0f;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) av[i] = dr[acol[i]] * (amask[i] * rs);
+    for (int i = 0; i < NI; ++i) av[i] = dr[acol[i]];
 #pragma unroll
-    for (int kt = 0; kt < (KT < 5 ? KT : 4); ++kt) bv[kt] = fmaf(ar[bcol[kt]], bmask[kt], bone[kt]) * (bone[kt] > 0.f ? rs : rs0);
-    if (KT == 5) bv[4] = fmaf((abase2 + (size_t)rc * lda2)[bcol[4]], bmask[4], bone[4]) * rs;   // tail segment | ones
+    for (int kt = 0; kt < (KT < 5 ? KT : 4); ++kt) bv[kt] = ar[bcol[kt]];
+    if (KT == 5) bv[4] = (abase2 + (size_t)rc * lda2)[bcol[4]];   // tail segment | ones
   };
 #pragma unroll
   for (int q = 0; q < DEPTH - 1; ++q) load(rbeg + 4 * q, a[q], b[q]);
@@ -64,10 +65,24 @@ __device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const fl
 #pragma unroll
     for (int q = 0; q < DEPTH; ++q) {
       load(r + 4 * (q + DEPTH - 1), a[(q + DEPTH - 1) % DEPTH], b[(q + DEPTH - 1) % DEPTH]);
+      asm volatile("" ::: "memory");   // the loads are issued HERE (DEPTH - 1 groups ahead), not sunk to their uses
+#pragma unroll
+      for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(a[q][i]));   // ... and group q is first touched here
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) asm volatile("" : "+v"(b[q][kt]));
+      const int rr = r + 4 * q + lg;
+      const float rs = rr < rend ? 1.0f : 0.0f;
+      const float rs0 = rr >= row0 ? rs : 0.0f;
+      float av[NI], bv[KT];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) av[i] = a[q][i] * (amask[i] * rs);
+#pragma unroll
+      for (int kt = 0; kt < (KT < 5 ? KT : 4); ++kt) bv[kt] = fmaf(b[q][kt], bmask[kt], bone[kt]) * (bone[kt] > 0.f ? rs : rs0);
+      if (KT == 5) bv[4] = fmaf(b[q][4], bmask[4], bone[4]) * rs;
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) acc[i][kt] = SW_MFMA(a[q][i], b[q][kt], acc[i][kt]);
+        for (int kt = 0; kt < KT; ++kt) acc[i][kt] = SW_MFMA(av[i], bv[kt], acc[i][kt]);
       }
     }
   }
