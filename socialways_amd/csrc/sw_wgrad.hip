@@ -17,7 +17,10 @@
 #include "sw_common.h"
 #include "sw_wgrad.h"
 #ifndef SW_WG_DEPTH
-#define SW_WG_DEPTH 6
+#define SW_WG_DEPTH 4
+#endif
+#ifndef SW_WG_DEPTH5
+#define SW_WG_DEPTH5 2
 #endif
 #include <stdlib.h>
 
@@ -43,7 +46,7 @@ __device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const fl
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) acc[i][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  constexpr int DEPTH = KT == 5 ? SW_WG_DEPTH - 2 : SW_WG_DEPTH;  // groups in flight (256 registers per lane at 2 waves per SIMD)
+  constexpr int DEPTH = KT == 5 ? SW_WG_DEPTH5 : SW_WG_DEPTH;  // 4-row groups in flight (swept on the GPU: 4 / 2)
   // The pipeline registers hold the RAW loaded values; row masks / the ones column are applied when a group is
   // consumed.  (Arithmetic attached to the load sits in front of the loop's back edge, so every load of a body
   // iteration had to complete inside it: the compiler drained the pipeline - s_waitcnt vmcnt(0) - once per DEPTH
