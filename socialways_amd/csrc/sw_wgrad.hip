@@ -293,7 +293,11 @@ size_t wg_finalize(WgBatch& b) {
   static const double grain = getenv("SW_WG_GRAIN") ? atof(getenv("SW_WG_GRAIN")) : 8192.0;   // tuning knob (cycles of work per wave)
   double target = total / grain / 4.0;
   if (target < 64.0) target = 64.0;
-  static const double maxwg = getenv("SW_WG_MAXWG") ? atof(getenv("SW_WG_MAXWG")) : 1024.0;
+  // ... at most ONE round of residency (2 workgroups x 256 CUs) - a sharp optimum once every workgroup streams with a
+  // full pipeline (swept: 512 -> 63 us, 448 -> 72, 576 -> 78, 1024 -> 69 for the generator pass at m1) - unless the
+  // batch is so large that a second round still leaves each wave several grains of work (dense crowds: better balance)
+  static const double maxwg_env = getenv("SW_WG_MAXWG") ? atof(getenv("SW_WG_MAXWG")) : 0.0;
+  const double maxwg = maxwg_env > 0.0 ? maxwg_env : (target >= 4096.0 ? 1024.0 : 512.0);
   if (target > maxwg) target = maxwg;
   size_t ws = 0;
   int job = 0, out = 0;
