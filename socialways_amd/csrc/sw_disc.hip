@@ -418,6 +418,18 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
   const int K4 = 4 * Tp;
 
   SW_STAMP_INIT;
+  // saved activations the head backward needs (post-lrelu c1 | l1, q1 per branch, o1): requested now, they arrive
+  // under the weight staging instead of one L2 round trip in front of every head layer.  Unconditional loads (every
+  // wave fetches a valid row, waves 2, 3 do not use q1 / o1): see the BPTT loop below.
+  const int m0h = 16 * (wave & 1);
+  f32x4 pc1[2], pq1[2], po1;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const size_t kb = (size_t)min(k, nb - 1) * B + b;
+    pc1[k] = ld4(dsave + (wave < 2 ? ds.c1 : ds.l1) + kb * 32 + m0h + 4 * lg);
+    pq1[k] = ld4(dsave + ds.q1 + kb * 32 + m0h + 4 * lg);
+  }
+  po1 = ld4(dsave + ds.o1 + (size_t)b * 32 + m0h + 4 * lg);
   stage_zero(smem + L.of0T, L.dlab - L.of0T);  // transposed images are zero padded
   sw_barrier();
   stage_wT(smem + L.of0T, LD32, 64, d_w + O.of0w, 64, 32, 64);
@@ -482,7 +494,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       acc = tile_mm_rt(smem + (cls ? L.cl1T : L.la1T) + (m0 + ln) * LD16 + 4 * lg,
                        smem + (cls ? L.dlab : L.dcod) + ln * LD16 + 4 * lg, 1, acc);
-      f32x4 a = ld4(dsave + (cls ? ds.c1 : ds.l1) + ((size_t)k * B + b) * 32 + m0 + 4 * lg);
+      const f32x4 a = k == 0 ? pc1[0] : pc1[1];
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(a[r], acc[r]);
       st4(smem + (cls ? L.dc1 : L.dl1) + ln * LD32 + m0 + 4 * lg, acc);
@@ -508,7 +520,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
       int m0 = 16 * wave;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       acc = tile_mm_rt(smem + L.pe1T + (m0 + ln) * LD32 + 4 * lg, smem + L.dboth + ln * LD64 + 32 + 4 * lg, 2, acc);
-      f32x4 a = ld4(dsave + ds.q1 + ((size_t)k * B + b) * 32 + m0 + 4 * lg);
+      const f32x4 a = k == 0 ? pq1[0] : pq1[1];
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(a[r], acc[r]);
       st4(smem + L.dq1 + ln * LD32 + m0 + 4 * lg, acc);
@@ -534,7 +546,7 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
     int m0 = 16 * wave;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     acc = tile_mm_rt(smem + L.of1T + (m0 + ln) * LD32 + 4 * lg, smem + L.docode + ln * LD32 + 4 * lg, 2, acc);
-    f32x4 a = ld4(dsave + ds.o1 + (size_t)b * 32 + m0 + 4 * lg);
+    const f32x4 a = po1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(a[r], acc[r]);
     st4(smem + L.do1 + ln * LD32 + m0 + 4 * lg, acc);
