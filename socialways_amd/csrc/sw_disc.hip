@@ -196,15 +196,29 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
   if (!obs_pre) lstm_load_whh(W, d_w + O.whh, u0, ln, lg);   // global loads in flight during the LDS staging
   if (w_snap)   // deepcopy(D) of train.py:499: the weights this pass runs with, a few floats per thread
     for (int i = blockIdx.x * SW_THREADS + threadIdx.x; i < O.n; i += gridDim.x * SW_THREADS) w_snap[i] = d_w[i];
-  // ---- stage head weights / biases ------------------------------------------------------------
-  stage_w(smem + L.of0, LD64, 32, d_w + O.of0w, 64, 32, 64);
-  stage_w(smem + L.of1, LD32, 32, d_w + O.of1w, 32, 32, 32);
-  stage_w(smem + L.pe0, L.ldp, 32, d_w + O.pe0w, K4, 32, K4);
-  stage_w(smem + L.pe1, LD32, 32, d_w + O.pe1w, 32, 32, 32);
-  stage_w(smem + L.cl0, LD64, 32, d_w + O.cl0w, 64, 32, 64);
-  stage_w(smem + L.la0, LD64, 32, d_w + O.la0w, 64, 32, 64);
-  stage_w(smem + L.cl1, LD32, 16, d_w + O.cl1w, 32, 1, 32);
-  stage_w(smem + L.la1, LD32, 16, d_w + O.la1w, 32, 2, 32);
+  // ---- stage head weights / biases: ALL global loads first, then the LDS stores (one L2 round trip for the eight
+  //      matrices instead of one each) --------------------------------------------------------------------------
+  {
+    f32x4 s_of0[3], s_of1[2], s_pe0[2], s_pe1[2], s_cl0[3], s_la0[3], s_cl1[1], s_la1[1];
+    const bool pe0_small = 32 * (L.ldp >> 2) <= 2 * SW_THREADS;   // 4 Tp <= 48: the usual horizons
+    stage_w_load<3>(s_of0, LD64, 32, d_w + O.of0w, 64, 32, 64);
+    stage_w_load<2>(s_of1, LD32, 32, d_w + O.of1w, 32, 32, 32);
+    if (pe0_small) stage_w_load<2>(s_pe0, L.ldp, 32, d_w + O.pe0w, K4, 32, K4);
+    stage_w_load<2>(s_pe1, LD32, 32, d_w + O.pe1w, 32, 32, 32);
+    stage_w_load<3>(s_cl0, LD64, 32, d_w + O.cl0w, 64, 32, 64);
+    stage_w_load<3>(s_la0, LD64, 32, d_w + O.la0w, 64, 32, 64);
+    stage_w_load<1>(s_cl1, LD32, 16, d_w + O.cl1w, 32, 1, 32);
+    stage_w_load<1>(s_la1, LD32, 16, d_w + O.la1w, 32, 2, 32);
+    stage_w_store<3>(s_of0, smem + L.of0, LD64, 32);
+    stage_w_store<2>(s_of1, smem + L.of1, LD32, 32);
+    if (pe0_small) stage_w_store<2>(s_pe0, smem + L.pe0, L.ldp, 32);
+    else stage_w(smem + L.pe0, L.ldp, 32, d_w + O.pe0w, K4, 32, K4);
+    stage_w_store<2>(s_pe1, smem + L.pe1, LD32, 32);
+    stage_w_store<3>(s_cl0, smem + L.cl0, LD64, 32);
+    stage_w_store<3>(s_la0, smem + L.la0, LD64, 32);
+    stage_w_store<1>(s_cl1, smem + L.cl1, LD32, 16);
+    stage_w_store<1>(s_la1, smem + L.la1, LD32, 16);
+  }
   {
     int i = threadIdx.x;  // 256 = 8 x 32
     int q = i >> 5, k = i & 31;
@@ -230,12 +244,21 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
   sw_barrier();
   if (!obs_pre) lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
   if (fuse) {
-    stage_wT(smem + LB.pe0T, LD32, LB.kp, d_w + O.pe0w, K4, 32, K4);
-    stage_wT(smem + LB.pe1T, LD32, 32, d_w + O.pe1w, 32, 32, 32);
-    stage_wT(smem + LB.cl0T, LD32, 64, d_w + O.cl0w, 64, 32, 64);
-    stage_wT(smem + LB.la0T, LD32, 64, d_w + O.la0w, 64, 32, 64);
-    stage_wT(smem + LB.cl1T, LD16, 32, d_w + O.cl1w, 32, 1, 32);
-    stage_wT(smem + LB.la1T, LD16, 32, d_w + O.la1w, 32, 2, 32);
+    f32x4 t_pe0[2], t_pe1[1], t_cl0[2], t_la0[2], t_cl1[1], t_la1[1];
+    const bool pe0_small = 8 * K4 <= 2 * SW_THREADS;
+    if (pe0_small) stage_wT_load<2>(t_pe0, d_w + O.pe0w, K4, 32, K4);
+    stage_wT_load<1>(t_pe1, d_w + O.pe1w, 32, 32, 32);
+    stage_wT_load<2>(t_cl0, d_w + O.cl0w, 64, 32, 64);
+    stage_wT_load<2>(t_la0, d_w + O.la0w, 64, 32, 64);
+    stage_wT_load<1>(t_cl1, d_w + O.cl1w, 32, 1, 32);
+    stage_wT_load<1>(t_la1, d_w + O.la1w, 32, 2, 32);
+    if (pe0_small) stage_wT_store<2>(t_pe0, smem + LB.pe0T, LD32, 32, K4);
+    else stage_wT(smem + LB.pe0T, LD32, LB.kp, d_w + O.pe0w, K4, 32, K4);
+    stage_wT_store<1>(t_pe1, smem + LB.pe1T, LD32, 32, 32);
+    stage_wT_store<2>(t_cl0, smem + LB.cl0T, LD32, 32, 64);
+    stage_wT_store<2>(t_la0, smem + LB.la0T, LD32, 32, 64);
+    stage_wT_store<1>(t_cl1, smem + LB.cl1T, LD16, 1, 32);
+    stage_wT_store<1>(t_la1, smem + LB.la1T, LD16, 2, 32);
   }
 
   // ---- LSTM over the observation (4-d state formed on the fly, train.py:130-133): lstm_obs_loop, chosen once ----
@@ -430,16 +453,28 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
     pq1[k] = ld4(dsave + ds.q1 + kb * 32 + m0h + 4 * lg);
   }
   po1 = ld4(dsave + ds.o1 + (size_t)b * 32 + m0h + 4 * lg);
+  // transposed weight images: all global loads are issued before the zero fill and its barrier
+  f32x4 t_of0[2], t_of1[1], t_pe0[2], t_pe1[1], t_cl0[2], t_la0[2], t_cl1[1], t_la1[1];
+  const bool pe0_small = 8 * K4 <= 2 * SW_THREADS;
+  stage_wT_load<2>(t_of0, d_w + O.of0w, 64, 32, 64);
+  stage_wT_load<1>(t_of1, d_w + O.of1w, 32, 32, 32);
+  if (pe0_small) stage_wT_load<2>(t_pe0, d_w + O.pe0w, K4, 32, K4);
+  stage_wT_load<1>(t_pe1, d_w + O.pe1w, 32, 32, 32);
+  stage_wT_load<2>(t_cl0, d_w + O.cl0w, 64, 32, 64);
+  stage_wT_load<2>(t_la0, d_w + O.la0w, 64, 32, 64);
+  stage_wT_load<1>(t_cl1, d_w + O.cl1w, 32, 1, 32);
+  stage_wT_load<1>(t_la1, d_w + O.la1w, 32, 2, 32);
   stage_zero(smem + L.of0T, L.dlab - L.of0T);  // transposed images are zero padded
   sw_barrier();
-  stage_wT(smem + L.of0T, LD32, 64, d_w + O.of0w, 64, 32, 64);
-  stage_wT(smem + L.of1T, LD32, 32, d_w + O.of1w, 32, 32, 32);
-  stage_wT(smem + L.pe0T, LD32, L.kp, d_w + O.pe0w, K4, 32, K4);
-  stage_wT(smem + L.pe1T, LD32, 32, d_w + O.pe1w, 32, 32, 32);
-  stage_wT(smem + L.cl0T, LD32, 64, d_w + O.cl0w, 64, 32, 64);
-  stage_wT(smem + L.la0T, LD32, 64, d_w + O.la0w, 64, 32, 64);
-  stage_wT(smem + L.cl1T, LD16, 32, d_w + O.cl1w, 32, 1, 32);
-  stage_wT(smem + L.la1T, LD16, 32, d_w + O.la1w, 32, 2, 32);
+  stage_wT_store<2>(t_of0, smem + L.of0T, LD32, 32, 64);
+  stage_wT_store<1>(t_of1, smem + L.of1T, LD32, 32, 32);
+  if (pe0_small) stage_wT_store<2>(t_pe0, smem + L.pe0T, LD32, 32, K4);
+  else stage_wT(smem + L.pe0T, LD32, L.kp, d_w + O.pe0w, K4, 32, K4);
+  stage_wT_store<1>(t_pe1, smem + L.pe1T, LD32, 32, 32);
+  stage_wT_store<2>(t_cl0, smem + L.cl0T, LD32, 32, 64);
+  stage_wT_store<2>(t_la0, smem + L.la0T, LD32, 32, 64);
+  stage_wT_store<1>(t_cl1, smem + L.cl1T, LD16, 1, 32);
+  stage_wT_store<1>(t_la1, smem + L.la1T, LD16, 2, 32);
   for (int i = threadIdx.x; i < 16 * LD32; i += blockDim.x) smem[L.docode + i] = 0.f;
 
   for (int k = 0; k < nb; ++k) {
