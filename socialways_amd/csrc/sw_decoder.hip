@@ -95,14 +95,33 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
   // ---- prologue: stage decoder weights, compose the LSTM input matrix, build u ----------------
   LstmW W;
   lstm_load_whh(W, enc_w + swp::ENC_WHH, u0, ln, lg);   // global loads in flight during the LDS staging
-  stage_w(W1h, LD64, 160, dec_w + swp::DEC_W1, 160, 160, 64);
-  stage_w(W2, LD160, 80, dec_w + swp::DEC_W2, 160, 80, 160);
+  // all global loads of the prologue are issued before anything waits on them (one L2 round trip, not one per matrix)
+  f32x4 r1[11], r2[13], r3[4];
+  stage_w_load<11>(r1, LD64, 160, dec_w + swp::DEC_W1, 160, 160, 64);
+  stage_w_load<13>(r2, LD160, 80, dec_w + swp::DEC_W2, 160, 80, 160);
+  stage_w_load<4>(r3, LD80, 40, dec_w + swp::DEC_W3, 80, 40, 80);
+  f32x4 c = ld4(cT + (size_t)b * 64 + u0 + 4 * lg);
+  f32x4 h = ld4(hT + (size_t)b * 64 + u0 + 4 * lg);
+  float szv[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const int i = threadIdx.x + q * SW_THREADS, a = i / 96, cc = i - a * 96;
+    const int bb = min(a0 + a, B - 1);
+    szv[q] = cc < 64 ? (S_pool ? S_pool[(size_t)bb * 64 + cc] : 0.f) : z[(size_t)bb * 32 + cc - 64];
+  }
+  stage_w_store<11>(r1, W1h, LD64, 160);
+  stage_w_store<13>(r2, W2, LD160, 80);
   // fc3 (80 -> 40) has NO activation in front of fc4 (40 -> 2) (train.py:327-330): the two are ONE 2 x 80 map
   //   v = W4 (W3 a2 + b3) + b4 = W43 a2 + b43
   // composed per workgroup after the staging barrier (like W_ih . W_embed of the encoder): one layer less on the
   // serial chain of every decode step; a3 itself is never needed (its weight gradients are recovered from
   // dv^T [a2 | 1], sw_misc.hip).
-  stage_w(smem + FwdLds::W3tmp, LD80, 40, dec_w + swp::DEC_W3, 80, 40, 80);
+  stage_w_store<4>(r3, smem + FwdLds::W3tmp, LD80, 40);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const int i = threadIdx.x + q * SW_THREADS, a = i / 96, cc = i - a * 96;
+    szbuf[a * LD96 + cc] = szv[q];
+  }
   for (int i = threadIdx.x; i < 144; i += blockDim.x) {
     float v = 0.f;
     if (i < 80) v = dec_w[swp::DEC_B2 + i];
@@ -119,14 +138,6 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
   }
   lstm_prep_rows(enc_w + swp::ENC_EMB_W, enc_w + swp::ENC_EMB_B, enc_w + swp::ENC_WIH, enc_w + swp::ENC_BIH,
                  enc_w + swp::ENC_BHH, true, wx_lds, bx_lds);
-  for (int i = threadIdx.x; i < 16 * 96; i += blockDim.x) {
-    int a = i / 96, c = i - a * 96;
-    int bb = min(a0 + a, B - 1);
-    float v = c < 64 ? (S_pool ? S_pool[(size_t)bb * 64 + c] : 0.f) : z[(size_t)bb * 32 + c - 64];
-    szbuf[a * LD96 + c] = v;
-  }
-  f32x4 c = ld4(cT + (size_t)b * 64 + u0 + 4 * lg);
-  f32x4 h = ld4(hT + (size_t)b * 64 + u0 + 4 * lg);
   st4(&hbuf[ln * LD64 + u0 + 4 * lg], h);
   sw_barrier();
   lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
