@@ -184,6 +184,7 @@ class SocialWaysTrainer:
         guard.start()
         x = torch.full((1024,), float(self.rank + 1), device=dev)
         y = torch.zeros_like(x)
+        self._allreduce(y)          # eager first: connections / buffers of the communicator are set up outside capture
         torch.cuda.synchronize()
         side = torch.cuda.Stream(device=dev)
         try:
