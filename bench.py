@@ -179,6 +179,13 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(last[0]).all(), "non-finite losses"
+    replicas_identical = None
+    if world > 1:      # data-parallel replicas must hold bit-identical weights after the same all-reduced updates
+        chk = torch.stack([tr.G._flat_all.double().sum(), tr.D._flat.double().sum()])
+        hi, lo = chk.clone(), chk.clone()
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        replicas_identical = bool(torch.equal(hi, lo))
 
     if rank == 0:
         fl = alg_flops(B, P, To, Tp)
@@ -199,6 +206,7 @@ def main():
                                    % (args.workload, S, A, To, Tp, B),
                        "global_batch_scenes": S * world, "parallelism": "dp%d" % world, "steps_per_graph_launch": KG,
                        "collectives": (None if pg is None else "in-graph" if tr._graph_collectives else "between graph segments"),
+                       "replicas_identical": replicas_identical,
                        "step_alg_gflop": fl["step"] / 1e9,
                        "step_frac_of_fp32_peak": fl["step"] / (dt / args.steps) / (PEAK_FP32_TFLOPS * 1e12)},
             "roofline": {"bound": "mfma", "kernel": args.dominant.replace("sw_", "") + "_kernel", "achieved": achieved,
