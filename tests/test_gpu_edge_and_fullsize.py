@@ -23,10 +23,10 @@ def pair(n_next, use_social=True, seed=0, **kw):
 
 
 @pytest.mark.parametrize("sizes,To,Tp", [([1, 5, 16, 2, 13], 3, 5), ([7], 2, 1), ([1, 1, 1], 8, 12), ([64, 3], 8, 12),
-                                         ([2] * 9 + [3], 5, 7)])
+                                         ([2] * 9 + [3], 5, 7), ([4, 6, 9], 4, 20)])
 def test_step_matches_oracle_on_odd_shapes(sizes, To, Tp):
     """B not a multiple of the 16-agent tile, single-agent scenes only, a 64-agent scene, To/Tp that are
-    not multiples of anything, Tp = 1: losses, rollout and ADE/FDE sums of one full step vs the oracle."""
+    not multiples of anything, Tp = 1, a long horizon (Tp = 20: the wide pred_encoder staging path): losses, rollout and ADE/FDE sums of one full step vs the oracle."""
     import socialways_amd as sw
     t = sw.synth_tracks(len(sizes) + 2, sizes + [2, 2], To, Tp, seed=11)
     data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
