@@ -158,11 +158,19 @@ __global__ __launch_bounds__(SW_THREADS, 2) void wgrad_partial_kernel(WgBatch ba
   // one partial per workgroup (4 row slices summed): ws[ws_off + (sg*N + n)*Kc + k]
   float* out = ws + P.ws_off + (size_t)sg * N * Kc;
   const int rows = min(64, N - n0), cols = min(SW_WG_RLD, Kc);
+  // element e = rr * cols + cc walks the block row-major; (rr, cc) advance incrementally (one division per thread)
+  const int dq = SW_THREADS / cols, dr = SW_THREADS - dq * cols;
+  int rr = threadIdx.x / cols, cc = threadIdx.x - rr * cols;
   for (int e = threadIdx.x; e < rows * cols; e += SW_THREADS) {
-    int rr = e / cols, cc = e - rr * cols;
-    int o = rr * SW_WG_RLD + cc;
-    float v = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+    const int o = rr * SW_WG_RLD + cc;
+    const float v = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
     out[(size_t)(n0 + rr) * Kc + cc] = v;
+    cc += dr;
+    rr += dq;
+    if (cc >= cols) {
+      cc -= cols;
+      ++rr;
+    }
   }
 }
 
