@@ -226,6 +226,14 @@ int sw_gan_loss(const float* label_a, const float* targets /*device [>=2]: label
 int sw_l2_grad(const float* pred4_hat /*[B,Tp,4]*/, const float* gt /*[B,Tp,2]*/, int B, int Tp, int row0, int row1,
                float scale, float* dpred4 /*[B,Tp,4]*/, void* stream);
 
+/* ---- variety loss with its INTENDED semantics (train.py:527-536 is buggy as written - see SURVEY 0.x / DESIGN):
+ *      K rollouts with independent z folded into one batch (copy k = rows [k*B,(k+1)*B)); per agent the copy with
+ *      the smallest mean squared error receives dpred4[k*B+b][t][0:2] += scale * (p_hat - p), scale =
+ *      loss_l2_w / (B_global * Tp).  kmin [B] (int32) / l2min [B] (the per-agent minimum, for the reported loss)
+ *      may be NULL.  K <= 64 (SW_ESHAPE above).                                                              */
+int sw_variety_grad(const float* pred4_hat_K /*[K*B,Tp,4]*/, const float* gt /*[B,Tp,2]*/, int K, int B, int Tp,
+                    float scale, float* dpred4_K /*[K*B,Tp,4]*/, int* kmin, float* l2min, void* stream);
+
 /* ---- toy statistics (calc_statistics.py:7-66): the O(K^2) distance loops of compute_1nn /
  *      compute_wasserstein.  D[k][i][j] = mean over t in [t0,T) of ||a[i][k][t] - b[j][k][t]||.        */
 int sw_traj_dist(const float* a /*[Na,nPed,T,2]*/, const float* b /*[Nb,nPed,T,2]*/, int Na, int Nb, int nPed, int T,

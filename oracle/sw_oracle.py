@@ -5,7 +5,7 @@ This file is a plain PyTorch-CPU fp32 *restatement* of the algorithm of the refe
 checker the HIP path is compared against; it is never the product:
 
   * only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it;
-  * nothing under `socialways_amd/` imports it (tests/test_no_oracle_in_product.py enforces that).
+  * nothing under `socialways_amd/` imports it (tests/test_abi.py::test_product_never_imports_the_oracle enforces that).
 
 Parity status: PINNED.  The reference holds no tests or golden vectors of its own,
 so the pin is the reference itself: `oracle/make_golden.py` imports the unmodified
@@ -308,7 +308,7 @@ class SocialWaysOracle:
 
     def __init__(self, n_next, hidden_size=64, lr_g=1e-4, lr_d=1e-3, n_unrolling_steps=1,
                  use_social=True, social="blockdiag", use_info_loss=True, loss_info_w=0.5,
-                 n_latent_codes=2, use_l2_loss=False, use_variety_loss=False, loss_l2_w=0.5):
+                 n_latent_codes=2, use_l2_loss=False, use_variety_loss=False, loss_l2_w=0.5, variety_k=20):
         self.n_next = n_next
         self.hidden_size = hidden_size
         self.noise_len = hidden_size // 2                                    # train.py:81
@@ -320,7 +320,8 @@ class SocialWaysOracle:
         self.loss_info_w = loss_info_w
         self.n_latent_codes = n_latent_codes
         self.use_l2_loss = use_l2_loss                                       # train.py:67-69
-        self.use_variety_loss = use_variety_loss
+        self.use_variety_loss = use_variety_loss     # False | True = train.py:527-536 as written | "fixed" = best-of-K
+        self.variety_k = variety_k
         self.loss_l2_w = loss_l2_w
         # construction order fixes the RNG -> init mapping (train.py:370-385)
         self.encoder = EncoderLstm(hidden_size, self.n_lstm_layers)
@@ -368,7 +369,7 @@ class SocialWaysOracle:
         return torch.stack(pred_4ds, 1)
 
     # -- train.py:458-554: one packed batch
-    def train_step(self, obsv, pred, sub_batches, zeros_val, ones_val, noise, ss=1.0, record=None):
+    def train_step(self, obsv, pred, sub_batches, zeros_val, ones_val, noise, ss=1.0, record=None, variety_noise=None):
         """Step body.  `zeros_val`/`ones_val` are the two label-noise scalars (train.py:471-472),
         `noise` the (B,noise_len) latent (train.py:473); the caller draws them so RNG streams can be
         shared with the implementation under test.  Returns the 9 MSE values in reference order
@@ -419,7 +420,25 @@ class SocialWaysOracle:
         if self.use_l2_loss:                                                 # train.py:525-526
             g_loss = g_loss + self.loss_l2_w * g_loss_l2
         variety = None
-        if self.use_variety_loss:
+        if self.use_variety_loss == "fixed":
+            # What train.py:527-536 evidently means (NOT reference behaviour - the reference's loop is
+            # buggy, see the branch below): KV rollouts with independent noise (sample 0 = this step's own noise),
+            # per agent the smallest mean squared error over the samples, averaged over the batch.  torch.min
+            # routes the gradient to the arg-min sample only.
+            KV = self.variety_k
+            vn = variety_noise.view(KV - 1, bs, noise.shape[1])
+            l2_k = [((pred_hat_4d[:, :, :2] - pred) ** 2).mean(dim=(1, 2))]
+            for k in range(1, KV):
+                ph_k = self.predict(obsv, vn[k - 1], n_next, sub_batches)
+                l2_k.append(((ph_k[:, :, :2] - pred) ** 2).mean(dim=(1, 2)))
+            l2_k = torch.stack(l2_k)                                         # (KV, bs)
+            l2_min, k_min = torch.min(l2_k, dim=0)
+            variety = l2_min.mean()
+            g_loss = g_loss + self.loss_l2_w * variety
+            if record is not None:
+                record["variety_kmin"] = k_min.clone()
+                record["variety_l2"] = l2_k.detach().clone()
+        elif self.use_variety_loss:
             # train.py:527-536 AS WRITTEN: KV=20 predict() calls with the SAME noise (identical values,
             # SURVEY §0.11), loss k compares AGENT k (not sample k) with its ground truth, and only the
             # last one (k = 19) is appended -> the "variety" term is the L2 of agent 19 alone.

@@ -49,6 +49,7 @@ PROTOTYPES = {
     "sw_disc_dpred": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "sw_gan_loss": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sw_l2_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
+    "sw_variety_grad": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "sw_traj_dist": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "sw_stage_step": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sw_ade_fde": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),

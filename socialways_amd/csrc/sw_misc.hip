@@ -385,6 +385,62 @@ extern "C" int sw_l2_grad(const float* pred4, const float* gt, int B, int Tp, in
   return SW_OK;
 }
 
+// ---- variety loss with its intended semantics (train.py:527-536 fixed; Social-GAN's best-of-K L2) ----
+//   K rollouts of the same batch with independent z are folded into one batch of K*B rows (copy k = rows
+//   [k*B, (k+1)*B)).  Per agent b: l2_k = mean_{t,c} (p_hat_k[b][t][c] - p[b][t][c])^2, k* = argmin_k l2_k (ties: the
+//   smallest k), variety = mean_b l2_{k*}; the gradient reaches copy k* only:
+//       dpred4[k* B + b][t][0:2] += scale * (p_hat - p),   scale = loss_l2_w / (B_global * Tp).
+//   One wave per agent, lane = sample k (K <= 64), lexicographic (l2, k) minimum through a shuffle tree.
+__global__ __launch_bounds__(256) void variety_grad_kernel(const float* __restrict__ predK, const float* __restrict__ gt,
+                                                            int K, int B, int Tp, float scale, float* __restrict__ dpredK,
+                                                            int* __restrict__ kmin_out, float* __restrict__ l2min_out) {
+  const int lane = sw_lane(), b = blockIdx.x * 4 + sw_wave();
+  if (b >= B) return;
+  float l2 = 3.0e38f;
+  if (lane < K) {
+    float s = 0.f;
+    const float* ph = predK + ((size_t)lane * B + b) * Tp * 4;
+    for (int t = 0; t < Tp; ++t) {
+      const f32x4 p = ld4(ph + t * 4);
+      const float2 g = *reinterpret_cast<const float2*>(gt + ((size_t)b * Tp + t) * 2);
+      const float dx = p[0] - g.x, dy = p[1] - g.y;
+      s = fmaf(dx, dx, fmaf(dy, dy, s));
+    }
+    l2 = s / (float)(2 * Tp);
+  }
+  int km = lane;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ol = __shfl_xor(l2, o);
+    const int ok = __shfl_xor(km, o);
+    if (ol < l2 || (ol == l2 && ok < km)) {
+      l2 = ol;
+      km = ok;
+    }
+  }
+  if (lane == 0) {
+    if (kmin_out) kmin_out[b] = km;
+    if (l2min_out) l2min_out[b] = l2;
+  }
+  for (int t = lane; t < Tp; t += 64) {
+    const size_t e = ((size_t)km * B + b) * Tp + t;
+    f32x4 p = ld4(predK + e * 4), d = ld4(dpredK + e * 4);
+    const float2 g = *reinterpret_cast<const float2*>(gt + ((size_t)b * Tp + t) * 2);
+    d[0] = fmaf(scale, p[0] - g.x, d[0]);
+    d[1] = fmaf(scale, p[1] - g.y, d[1]);
+    st4(dpredK + e * 4, d);
+  }
+}
+extern "C" int sw_variety_grad(const float* predK, const float* gt, int K, int B, int Tp, float scale, float* dpredK,
+                               int* kmin, float* l2min, void* stream) {
+  if (!predK || !gt || !dpredK || B < 1 || Tp < 1 || K < 1) return SW_EARG;
+  if (K > 64) return SW_ESHAPE;
+  hipLaunchKernelGGL(variety_grad_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, predK, gt, K, B, Tp, scale,
+                     dpredK, kmin, l2min);
+  SW_CHECK_LAUNCH("variety_grad_kernel");
+  return SW_OK;
+}
+
 // ---- toy statistics: pairwise mean displacement between sample sets (calc_statistics.py:28-32, 56-60) ----
 //   D[k][i][j] = mean_{t >= t0} || a[i][k][t] - b[j][k][t] ||
 __global__ __launch_bounds__(256) void traj_dist_kernel(const float* __restrict__ a, const float* __restrict__ b, int Na,

@@ -45,6 +45,10 @@ class SceneDataset:
         self.the_batches = np.asarray(batches).astype(np.int64)
         self.times = None if times is None else np.asarray(times)
         self.train_size = max(1, (len(self.the_batches) * 4) // 5)
+        # train.py:95-98: both splits are taken BEFORE the single-scene substitution below, which only feeds the
+        # look-ahead `the_batches[ii + 1]` of the packing loop (a one-scene dataset has NO test scene: test() = zeros)
+        self.train_batches = self.the_batches[:self.train_size]
+        self.test_batches = self.the_batches[self.train_size:]
         self.n_past, self.n_next = obsvs.shape[1], preds.shape[1]
         self.n_train_samples = int(self.the_batches[self.train_size - 1][1])
         self.n_test_samples = obsvs.shape[0] - self.n_train_samples
@@ -65,14 +69,6 @@ class SceneDataset:
     def from_npz(cls, path, device="cuda"):
         d = np.load(path)
         return cls(d["obsvs"], d["preds"], d["batches"], d["times"] if "times" in d.files else None, device)
-
-    @property
-    def train_batches(self):
-        return self.the_batches[:self.train_size]
-
-    @property
-    def test_batches(self):
-        return self.the_batches[self.train_size:]
 
     def packed_steps(self, batch_size):
         """Greedy scene packing of train() (train.py:446-456): scenes are appended until the next one

@@ -143,6 +143,10 @@ class AttentionPooling(_Packed):
         L.require_gpu(h)
         B = h.shape[0]
         sc = _scene_index(sub_batches, B, h.device)
+        if sc.NB > 0:      # the dense stand-alone kernel stages one scene in LDS; predict() / the training step route
+            raise L.SocialWaysHipError(       # larger scenes through the row-block kernels and have no such limit
+                "AttentionPooling.forward (dense f) handles scenes of up to %d agents; got a scene of %d - use "
+                "predict() / Generator.forward, which has no scene-size limit" % (L.AMAX, int(sc.sizes.max())))
         S = torch.empty(B, 64, device=h.device)
         L.call("sw_attention_pool_dense", L.ptr(f.contiguous()), L.ptr(h.contiguous()), L.ptr(sc.scene_off), sc.S, B,
                L.ptr(self.packed()), L.ptr(S), L.stream())

@@ -69,6 +69,12 @@ class Workspaces:
         self.device = device
         self.buf = {}
         self._wgb = None
+        # Growth protocol: a captured step graph has the ADDRESSES of these buffers baked in.  When a larger batch
+        # layout needs more space the old tensor is not released - it moves to `retired`, so graphs captured for
+        # smaller layouts keep replaying on live memory - and `version` is bumped; the owner of the graphs
+        # (SocialWaysTrainer) drops its graphs and then calls `release_retired()` at its next safe point.
+        self.retired = []
+        self.version = 0
 
     @property
     def wgrad_batch(self):
@@ -85,8 +91,15 @@ class Workspaces:
     def get(self, name, nfloats):
         t = self.buf.get(name)
         if t is None or t.numel() < nfloats:
+            if t is not None:
+                self.retired.append(t)
+                self.version += 1
             t = self.buf[name] = torch.empty(max(int(nfloats), 1), dtype=torch.float32, device=self.device)
         return t
+
+    def release_retired(self):
+        """Only when nothing captured can still reference the outgrown buffers."""
+        self.retired.clear()
 
 
 _default_ws = {}

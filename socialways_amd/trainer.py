@@ -97,12 +97,15 @@ class PackedAdam:
         self.v.zero_()
         self.t = 0
         for i, (off, n, shape) in enumerate(self.slices):
-            if not state:
-                break
-            e = state[i] if i in state else state[str(i)]
+            # torch Adam keeps state only for parameters that ever received a gradient: the unmodified reference
+            # runs with use_social=False (train.py:83), so its checkpoints hold no entries for the attention /
+            # feature-embedder parameters (optimizer indices 0..7).  Their moments stay zero here.
+            e = state.get(i, state.get(str(i)))
+            if e is None:
+                continue
             self.m[off:off + n] = e["exp_avg"].to(self.flat.device).reshape(-1)
             self.v[off:off + n] = e["exp_avg_sq"].to(self.flat.device).reshape(-1)
-            self.t = int(float(e["step"]))
+            self.t = max(self.t, int(float(e["step"])))       # one shared counter: every present entry was stepped together
         self.step_t.fill_(float(self.t))
 
 
@@ -111,7 +114,7 @@ class SocialWaysTrainer:
 
     def __init__(self, n_next, hidden_size=64, lr_g=1e-4, lr_d=1e-3, n_unrolling_steps=1, use_social=True,
                  use_info_loss=True, loss_info_w=0.5, n_latent_codes=2, device="cuda", process_group=None,
-                 fused_adam=True, use_graph=None, use_l2_loss=False, use_variety_loss=False, loss_l2_w=0.5):
+                 fused_adam=True, use_graph=None, use_l2_loss=False, use_variety_loss=False, loss_l2_w=0.5, variety_k=20):
         self.device = torch.device(device)
         self.n_next = n_next
         self.noise_len = hidden_size // 2
@@ -121,7 +124,15 @@ class SocialWaysTrainer:
         # train.py:67-69.  `use_variety_loss` reproduces train.py:527-536 AS WRITTEN: its 20 predict()
         # calls reuse the same noise (identical values) and only the k = 19 term - the L2 of AGENT 19 of
         # the packed batch - enters the loss; the 20 redundant rollouts are not executed.
+        # `use_variety_loss="fixed"` is the term the reference evidently MEANT (Social-GAN's best-of-K L2):
+        # `variety_k` rollouts with independent z (the step's own z is sample 0), per agent the minimum over the samples
+        # of the mean squared error, averaged over the batch; the gradient reaches the arg-min sample only.  The K
+        # rollouts run as ONE folded batch of K*B agents (like test()), so the generator's work grows K-fold.
+        if use_variety_loss not in (False, True, "fixed"):
+            raise ValueError("use_variety_loss: False, True (train.py:527-536 as written) or 'fixed'")
         self.use_l2_loss, self.use_variety_loss, self.loss_l2_w = use_l2_loss, use_variety_loss, loss_l2_w
+        self.variety_k = int(variety_k)
+        self.last_variety = None             # fixed mode: (per-agent minimum (B,), arg-min sample (B,) int32) of the last step
         # construction order = train.py:370-385 (RNG -> init mapping, optimizer parameter order)
         self.G = Generator(hidden_size, 1, use_social=use_social, device=self.device)
         self.G.unify()
@@ -152,16 +163,56 @@ class SocialWaysTrainer:
             self.D_optimizer = opt.Adam(self.D.parameters(), lr=lr_d, betas=(0.9, 0.999))
         self.pg = process_group
         self.rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
+        self.epoch = 0
+        if self.pg is not None and self.world > 1:
+            self.sync_replicas()
         self.ws = ops.Workspaces(self.device)
+        self._ws_version = 0
         self._lin_mask = None
         self._lin_maskf = None
         self._noise_src = None
-        self.epoch = 0
 
     # ------------------------------------------------------------------------------------------
     @property
     def use_social(self):
         return self.G.use_social
+
+    def sync_replicas(self):
+        """Data-parallel replicas must start from identical weights and optimizer state: rank 0's are broadcast (at
+        construction and after load_checkpoint).  The reference has one process; here a user who does not seed every
+        rank identically would otherwise train diverging replicas on all-reduced gradients."""
+        dist = torch.distributed
+        src = dist.get_global_rank(self.pg, 0)
+        bufs = [self.G._flat_all, self.D._flat]
+        for o in (self.predictor_optimizer, self.D_optimizer):
+            if isinstance(o, PackedAdam):
+                bufs += [o.m, o.v]
+            else:
+                for st in o.state.values():
+                    bufs += [st["exp_avg"], st["exp_avg_sq"]]
+        for b in bufs:
+            dist.broadcast(b, src, group=self.pg)
+        ts = torch.tensor([float(getattr(o, "t", 0)) for o in (self.predictor_optimizer, self.D_optimizer)] + [float(self.epoch)],
+                          device=self.device if dist.get_backend(self.pg) == "nccl" else "cpu")
+        dist.broadcast(ts, src, group=self.pg)
+        for o, t in zip((self.predictor_optimizer, self.D_optimizer), ts.tolist()):
+            if isinstance(o, PackedAdam):
+                o.t = int(t)
+                o.step_t.fill_(float(o.t))
+        self.epoch = int(ts[2].item())
+
+    def sync_rng(self):
+        """train.py:471-473 draws the label-noise scalars and z from the process-global numpy / torch generators.
+        Every rank must draw the SAME values for a packed batch (z is sliced per shard): rank 0's generator states
+        are broadcast once per epoch, so the job as a whole follows rank 0's stream - the stream a single process
+        seeded like rank 0 would follow."""
+        dist = torch.distributed
+        obj = [(np.random.get_state(), torch.get_rng_state())] if self.rank == 0 else [None]
+        dist.broadcast_object_list(obj, src=dist.get_global_rank(self.pg, 0), group=self.pg,
+                                   device=self.device if dist.get_backend(self.pg) == "nccl" else None)
+        if self.rank != 0:
+            np.random.set_state(obj[0][0])
+            torch.set_rng_state(obj[0][1])
 
     def _allreduce(self, flat):
         if self.pg is not None and (self.world > 1 or self._force_dist):
@@ -231,8 +282,25 @@ class SocialWaysTrainer:
         if self.device.type == "cuda":
             torch.cuda.synchronize()
         self._graphs.clear()
+        self.ws.release_retired()
+        self._ws_version = self.ws.version
 
-    def step(self, obsv, pred, sub_batches, zeros_val, ones_val, noise, ss=1.0, global_B=None, out=None, global_row0=0):
+    def _graph_key(self, scenes, To, ss, Bg, K):
+        """Everything a captured step bakes in besides the buffer addresses: the scene layout, the loss switches and
+        weights, the unrolling depth and the optimizer hyper-parameters (host-side scalars of the recorded launches)."""
+        og, od = self.predictor_optimizer.param_groups[0], self.D_optimizer.param_groups[0]
+        return (scenes.key, To, float(ss), float(Bg), self._row0, K, self.n_unrolling_steps, self.use_info_loss,
+                self.loss_info_w, self.use_l2_loss, self.use_variety_loss, self.loss_l2_w, self.variety_k,
+                og["lr"], tuple(og["betas"]), og["eps"], od["lr"], tuple(od["betas"]), od["eps"])
+
+    def _graphs_current(self):
+        """A workspace outgrown since the last capture means captured graphs hold retired addresses: they stay valid
+        (the retired tensors are alive) but pin memory, so all graphs are dropped and re-captured on the new buffers."""
+        if self._ws_version != self.ws.version:
+            self.release_graphs()
+
+    def step(self, obsv, pred, sub_batches, zeros_val, ones_val, noise, ss=1.0, global_B=None, out=None, global_row0=0,
+             variety_noise=None):
         """One packed batch (train.py:458-554) on this rank's rows.  obsv (B,To,2), pred (B,Tp,2) and
         noise (B,32) are tensors (noise normally lives on the host, like train.py:473); `global_B` = agents
         of the whole packed batch over all ranks.
@@ -249,14 +317,21 @@ class SocialWaysTrainer:
         Bg = float(global_B if global_B is not None else B)
         dev = self.device
         self._row0 = int(global_row0)       # first row of this rank's shard in the packed batch (variety term only)
-        if self.use_variety_loss and Bg < 20:
+        if self.use_variety_loss is True and Bg < 20:
             raise ValueError("use_variety_loss indexes agent 19 of the packed batch (train.py:531): batch of %d" % Bg)
+        self._vnoise = None
+        if self.use_variety_loss == "fixed":          # z of the samples 1..K-1: ((K-1)*B, 32), drawn like train.py:473 if not given
+            vn = variety_noise if variety_noise is not None else torch.rand((self.variety_k - 1) * B, self.noise_len)
+            if vn.shape != ((self.variety_k - 1) * B, self.noise_len):
+                raise ValueError("variety_noise must be ((variety_k - 1) * B, %d)" % self.noise_len)
+            self._vnoise = vn.to(dev, non_blocking=True).contiguous()
         part = None
-        if self.use_graph:
+        if self.use_graph and self.use_variety_loss != "fixed":    # the folded K-sample step runs eagerly
             # one graph set per packed-batch layout; datasets with ragged scenes produce many layouts, so the
             # number of captured layouts is capped and the rest of the steps run eagerly
             scenes = ops.SceneIndex.get(sub_batches, B, dev)
-            if (scenes.key, obsv.shape[1], float(ss), Bg, self._row0, 1) in self._graphs or len(self._graphs) < self.max_graphs:
+            self._graphs_current()
+            if self._graph_key(scenes, obsv.shape[1], ss, Bg, 1) in self._graphs or len(self._graphs) < self.max_graphs:
                 part = self._step_graph([(obsv, pred, zeros_val, ones_val, noise)], sub_batches, float(ss), Bg)[0]
         if part is None:
             part = torch.zeros(self.n_unrolling_steps + 3, (B + 15) // 16, 3, device=dev)
@@ -281,7 +356,8 @@ class SocialWaysTrainer:
         Bg = float(global_B if global_B is not None else B)
         self._row0 = 0
         scenes = ops.SceneIndex.get(sub_batches, B, self.device)
-        key = (scenes.key, batches[0][0].shape[1], float(ss), Bg, 0, len(batches))
+        self._graphs_current()
+        key = self._graph_key(scenes, batches[0][0].shape[1], ss, Bg, len(batches))
         if key not in self._graphs and len(self._graphs) >= self.max_graphs:
             return [self.step(o, p, sub_batches, zv, ov, nz, ss, global_B, out) for o, p, zv, ov, nz in batches]
         parts = self._step_graph(batches, sub_batches, float(ss), Bg)
@@ -292,7 +368,7 @@ class SocialWaysTrainer:
         B, To, Tp = batches[0][0].shape[0], batches[0][0].shape[1], self.n_next
         dev = self.device
         scenes = ops.SceneIndex.get(sub_batches, B, dev)
-        key = (scenes.key, To, ss, Bg, self._row0, K)
+        key = self._graph_key(scenes, To, ss, Bg, K)
         st = self._graphs.get(key)
         HDR = 8                                                   # SW_STAGE_HEADER words in front of z
         if st is None:
@@ -420,12 +496,27 @@ class SocialWaysTrainer:
             L.call("sw_traj_4d", L.ptr(obsv), L.ptr(pred), B, obsv.shape[1], Tp, L.ptr(o4_scratch), L.ptr(pred4), L.stream())
         # ---- generator rollout, once (train.py:480/507 are identical) ---------------
         enc, emb, att, dec = G.encoder, G.feature_embedder, G.attention, G.decoder
-        # the decode kernel also leaves the ADE/FDE partial sums of the prediction (train.py:546-551)
-        # ... and, while it leaves CUs idle, the observation LSTM of the first D pass (independent of the generator)
-        d_pre = ops.d_obs_buffer(ws, B, obsv.shape[1], Tp) if obsv.shape[2] == 2 else None
-        pred_hat, gctx = ops.gen_forward(enc._flat, emb._flat, att._flat, dec._flat, obsv, noise, scenes, Tp,
-                                         G.use_social, save=True, ws=ws, ade=(pred, 1.0 / float(ss), out[U + 2]),
-                                         noise_src=noise_src, d_obs=(D._flat, d_pre) if d_pre is not None else None)
+        KV = self.variety_k if self.use_variety_loss == "fixed" else 1
+        if KV > 1:
+            # best-of-K variety term: the K rollouts are K copies of the scenes in one batch; copy 0 (the step's own z)
+            # is the prediction every other loss term and the ADE/FDE sums see
+            sb1 = np.stack([np.cumsum(scenes.sizes) - scenes.sizes, np.cumsum(scenes.sizes)], axis=1)
+            scenes_k = ops.SceneIndex.get(np.concatenate([sb1 + k * B for k in range(KV)]), KV * B, dev)
+            pred_hat_k, gctx = ops.gen_forward(enc._flat, emb._flat, att._flat, dec._flat, obsv.repeat(KV, 1, 1),
+                                               torch.cat([noise, self._vnoise]), scenes_k, Tp, G.use_social, save=True,
+                                               ws=ws, tag="gv")
+            pred_hat = pred_hat_k[:B]
+            out[U + 2].zero_()
+            L.call("sw_ade_fde", L.ptr(pred_hat), L.ptr(pred), B, Tp, 1.0 / float(ss), L.ptr(out[U + 2]),
+                   L.ptr(ws.get("ade_scratch", 3 * L.RED_BLOCKS)), L.stream())
+            d_pre = None
+        else:
+            # the decode kernel also leaves the ADE/FDE partial sums of the prediction (train.py:546-551)
+            # ... and, while it leaves CUs idle, the observation LSTM of the first D pass (independent of the generator)
+            d_pre = ops.d_obs_buffer(ws, B, obsv.shape[1], Tp) if obsv.shape[2] == 2 else None
+            pred_hat, gctx = ops.gen_forward(enc._flat, emb._flat, att._flat, dec._flat, obsv, noise, scenes, Tp,
+                                             G.use_social, save=True, ws=ws, ade=(pred, 1.0 / float(ss), out[U + 2]),
+                                             noise_src=noise_src, d_obs=(D._flat, d_pre) if d_pre is not None else None)
         d_gflat = D.grad_views()
         backup = None
         # ---- discriminator updates (train.py:476-499) ------------------------------------------------
@@ -445,10 +536,18 @@ class SocialWaysTrainer:
         dpred = ops.disc_dpred(D._flat, obsv, pred_hat, targets, 1, noise, g_label, g_code, loss_part=out[U + 1])
         if self.use_l2_loss:                                                 # train.py:525-526
             L.call("sw_l2_grad", L.ptr(pred_hat), L.ptr(pred), B, Tp, 0, B, self.loss_l2_w / (Bg * Tp), L.ptr(dpred), L.stream())
-        if self.use_variety_loss:                                            # train.py:527-536 as written
+        if self.use_variety_loss is True:                                    # train.py:527-536 as written
             r = 19 - self._row0
             if 0 <= r < B:
                 L.call("sw_l2_grad", L.ptr(pred_hat), L.ptr(pred), B, Tp, r, r + 1, self.loss_l2_w / Tp, L.ptr(dpred), L.stream())
+        if KV > 1:                                                           # ... and with its intended semantics
+            dk = torch.zeros(KV * B, Tp, 4, device=dev)
+            dk[:B].copy_(dpred)
+            l2min, kmin = torch.empty(B, device=dev), torch.empty(B, dtype=torch.int32, device=dev)
+            L.call("sw_variety_grad", L.ptr(pred_hat_k), L.ptr(pred), KV, B, Tp, self.loss_l2_w / (Bg * Tp), L.ptr(dk),
+                   L.ptr(kmin), L.ptr(l2min), L.stream())
+            self.last_variety = (l2min, kmin)
+            dpred = dk
         restore = None
         if self.n_unrolling_steps > 0:     # D.load(backup) restores the Linear layers only (train.py:311-316, 541-542); D is
             if self._lin_maskf is None:    # not read again in this step: done by idle workgroups of the decode BPTT launch
@@ -456,10 +555,11 @@ class SocialWaysTrainer:
             restore = (backup[:D._flat.numel()], D._flat, self._lin_maskf)
         G.grad_views()
         ops.gen_backward(enc._flat, emb._flat, att._flat, dec._flat, gctx, dpred, enc._gflat, emb._gflat, att._gflat,
-                         dec._gflat, ws=ws, aux=restore)
+                         dec._gflat, ws=ws, aux=restore, tag="gv" if KV > 1 else "g")
         yield G._gflat_all
         self.predictor_optimizer.step() if steps is None else self.predictor_optimizer.step(steps[U + 1])
         self.last_pred_hat = pred_hat
+        self.last_pred_hat_k = pred_hat_k if KV > 1 else None
 
     # ------------------------------------------------------------------------------------------
     def losses_from(self, out, B_global, Tp=None, ss=1.0):
@@ -481,7 +581,9 @@ class SocialWaysTrainer:
         """train() (train.py:439-557).  `draw(bs)` -> (zeros_val, ones_val, noise_cpu) overrides the
         RNG draws of train.py:471-473 (tests feed the reference's recorded values)."""
         outs, sizes = [], []
-        pend, pend_key = [], None        # single GPU: consecutive packed batches of one layout share a graph launch
+        pend, pend_key = [], None        # consecutive packed batches of one layout share a graph launch
+        if self.world > 1 and draw is None:
+            self.sync_rng()
 
         def flush():
             nonlocal pend, pend_key
@@ -496,16 +598,25 @@ class SocialWaysTrainer:
                 noise = torch.rand(bs, self.noise_len)                       # train.py:473 (CPU generator)
             else:
                 zv, ov, noise = draw(bs)
+            vn = None
+            if self.use_variety_loss == "fixed":      # z of the extra samples, drawn for the whole packed batch
+                vn = torch.rand(self.variety_k - 1, bs, self.noise_len)
             sizes.append((bs, len(sb)))
             if self.world > 1:
                 lo, hi = shard_scenes(sb, self.world)[self.rank]
                 if hi > lo:
                     r0, r1 = int(sb[lo, 0]), int(sb[hi - 1, 1])
                     out = self.step(data.obsv[a + r0:a + r1], data.pred[a + r0:a + r1], sb[lo:hi] - r0, zv, ov,
-                                    noise[r0:r1], data.ss, global_B=bs, global_row0=r0)
+                                    noise[r0:r1], data.ss, global_B=bs, global_row0=r0,
+                                    variety_noise=None if vn is None else vn[:, r0:r1].reshape(-1, self.noise_len))
                 else:
                     out = self._empty_step()
                 outs.append(out)
+                continue
+            if vn is not None:        # the folded K-sample step is not graph-captured: one step() per packed batch
+                flush()
+                outs.append(self.step(data.obsv[a:b], data.pred[a:b], sb, zv, ov, noise, data.ss,
+                                      variety_noise=vn.reshape(-1, self.noise_len)))
                 continue
             key = (bs, np.asarray(sb).tobytes())
             if key != pend_key or len(pend) == self.STEPS_PER_LAUNCH:
@@ -624,4 +735,6 @@ class SocialWaysTrainer:
                 for k, v in keep.items():
                     optim.param_groups[0][k] = v
         self.epoch = int(ck.get('epoch', 0))
+        if self.pg is not None and self.world > 1:
+            self.sync_replicas()
         return self.epoch + 1

@@ -76,6 +76,18 @@ def _worker(rank, world, port, ret):
     w_before = t.D._flat.clone()
     out = t._empty_step()
     ok = ok and torch.equal(t.D._flat, w_before) and float(out.abs().sum()) == 0.0 and t.world == world
+    # replicas seeded DIFFERENTLY are made identical at construction (rank 0's weights / optimizer state are broadcast)
+    # and follow rank 0's RNG stream after sync_rng() (label-noise scalars and z of train.py:471-473)
+    torch.manual_seed(100 + rank)
+    np.random.seed(100 + rank)
+    t2 = sw.SocialWaysTrainer(12, use_social=True, device="cpu", process_group=dist.group.WORLD, fused_adam=False)
+    t2.sync_rng()
+    sig = torch.cat([t2.G._flat_all.double().sum().view(1), t2.D._flat.double().sum().view(1),
+                     torch.rand(3).double(), torch.tensor([np.random.uniform(0, 0.1)], dtype=torch.float64)])
+    hi_, lo_ = sig.clone(), sig.clone()
+    dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+    ok = ok and torch.equal(hi_, lo_)
     ret[rank] = bool(ok), float((dgrad - dref).abs().max()), float((ggrad - gref).abs().max()), (lo, hi)
     dist.destroy_process_group()
 

@@ -225,3 +225,151 @@ def test_step_many_equals_consecutive_steps():
                     tr.D_optimizer.t, tr.predictor_optimizer.t))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
     assert res[0][3] == res[1][3] == 30 and res[0][4] == res[1][4] == 15
+
+
+# ---- BASELINE configs 2 and 4 at full size --------------------------------------------------------------------------
+def _step_vs_oracle(S, A, seed, grads_rtol):
+    """One whole GAN step (2 D updates + 1 G update) of the HIP path vs the block-diagonal oracle on the same weights,
+    noise and label scalars: the 9 MSE terms, the ADE/FDE sums, the gradients the last D update and the G update saw
+    (relative to each tensor's largest entry: fp32 sums over up to 2.1 M pairs on both sides) and the weights after
+    Adam (elementwise within ~lr, see tests/test_gpu_trainer.py::check_weights)."""
+    import socialways_amd as sw
+    t = sw.synth_tracks(S + 2, A, 8, 12, seed=seed)
+    data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
+    tr, orc = pair(12)
+    B, sb = S * A, data.the_batches[:S]
+    torch.manual_seed(4)
+    noise = torch.rand(B, 32)
+    rec = {}
+    out = tr.step(data.obsv[:B], data.pred[:B], sb, 0.02, 0.96, noise, data.ss)
+    got = tr.losses_from(out, [B], 12, data.ss)[0]
+    want, ade, fde = orc.train_step(data.obsv[:B].cpu(), data.pred[:B].cpu(), sb, 0.02, 0.96, noise, data.ss, record=rec)
+    assert_close(got, np.asarray(want), 5e-5, 2e-6, "9 MSE terms")
+    o = out.double().cpu().numpy()
+    assert abs(o[-1, 0] - ade) / ade < 1e-5 and abs(o[-1, 1] - fde) / fde < 1e-5
+    assert_close(tr.last_pred_hat.cpu(), rec["pred_hat_4d"], 3e-5, 3e-6, "rollout")
+    for name in ("attention", "feature_embedder", "encoder", "decoder"):
+        for k, p in getattr(tr.G, name).named_parameters():
+            w = rec["g_grads"][name + "." + k]
+            assert_close(p.grad.cpu(), w, grads_rtol, grads_rtol * max(float(w.abs().max()), 1e-12), "dG %s.%s" % (name, k))
+    # the LAST D update's gradients are taken at weights that already went through one Adam step, whose first update
+    # moves every weight by ~lr * sign(g): where a noise-level gradient has the other sign the two sides' weights differ
+    # by 2e-3, so these gradients agree less tightly than same-weight gradients do (those: the c4 forward/backward test
+    # below and tests/test_gpu_kernels.py)
+    for k, p in tr.D.named_parameters():
+        w = rec["d_grads"][-1][k]
+        assert_close(p.grad.cpu(), w, 4 * grads_rtol, 4 * grads_rtol * max(float(w.abs().max()), 1e-12), "dD %s" % k)
+    for name, mod in (("encoder", tr.G.encoder), ("decoder", tr.G.decoder), ("feature_embedder", tr.G.feature_embedder),
+                      ("attention", tr.G.attention), ("D", tr.D)):
+        ref = getattr(orc, name).state_dict()
+        for k, v in mod.state_dict().items():
+            assert ((v.cpu() - ref[k]).abs() > 2e-3 * 1.01).float().mean().item() == 0.0, (name, k)
+    return tr, data, sb, B
+
+
+def test_c2_training_step_matches_oracle():
+    """BASELINE config 2 (`--batch-size 256`: 32 scenes x 8 agents): 16 agent tiles on 256 CUs."""
+    _step_vs_oracle(32, 8, 21, 2e-4)
+
+
+def test_c4_full_size_training_step_matches_oracle():
+    """BASELINE config 4 at FULL size - 512 scenes x 64 agents = 32 768 agents, 2.1 M pairs in one packed batch
+    (the reference itself cannot run it; the block-diagonal oracle does, ~10 s of host time).  This is
+    the path of 2 048 agent tiles, 1 024-workgroup weight-gradient rounds, in-register pair-MLP gradients and the
+    multi-block second-stage reductions."""
+    tr, data, sb, B = _step_vs_oracle(512, 64, 31, 2e-3)      # gradient tolerance: see the kink note in the next test
+    # the same step again from the same state is bitwise reproducible (fixed-order reductions everywhere)
+    st = {k: (v if not isinstance(v, dict) else {a: (b.clone() if torch.is_tensor(b) else b) for a, b in v.items()})
+          for k, v in tr.checkpoint().items()}
+    torch.manual_seed(9)
+    noise = torch.rand(B, 32)
+    outs = []
+    for rep in range(2):
+        tr.load_checkpoint(st)
+        outs.append((tr.step(data.obsv[:B], data.pred[:B], sb, 0.03, 0.95, noise, data.ss, out=False).clone(),
+                     tr.G._flat_all.clone(), tr.D._flat.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+
+
+def test_c4_full_size_forward_locality_and_sub_batch_equivalence():
+    """Dense crowd at full size: rollout vs the oracle, scene locality (perturbing scene 0 changes nothing else) and
+    sub-batch equivalence (scenes 100..131 alone reproduce their rows of the 512-scene batch) - bit for bit."""
+    import socialways_amd as sw
+    S, A = 512, 64
+    t = sw.synth_tracks(S, A, 8, 12, seed=32)
+    tr, orc = pair(12)
+    B = S * A
+    obsv = torch.from_numpy(t["obsvs"]).cuda()
+    sb = np.asarray(t["batches"])
+    torch.manual_seed(2)
+    z = torch.rand(B, 32)
+    with torch.no_grad():
+        full = tr.G(obsv, z.cuda(), 12, sb)
+        ref = orc.predict(obsv.cpu(), z, 12, sb)
+        assert_close(full.cpu(), ref, 3e-5, 3e-6, "c4 rollout vs oracle")
+        obsv2 = obsv.clone()
+        obsv2[:A] += 0.05
+        pert = tr.G(obsv2, z.cuda(), 12, sb)
+        assert not torch.equal(full[:A], pert[:A]) and torch.equal(full[A:], pert[A:])
+        lo, hi = int(sb[100, 0]), int(sb[131, 1])
+        part = tr.G(obsv[lo:hi], z[lo:hi].cuda(), 12, sb[100:132] - lo)
+        assert torch.equal(part, full[lo:hi])
+    # same-weight gradients at full size: generator (random cotangent on the rollout) and discriminator (random
+    # cotangents on label / code).  A gradient entry here is a sum over up to 2.1 M pair rows of terms of both signs, so
+    # the reference value is the oracle evaluated in FLOAT64.  Tolerance 2e-3 of each tensor's largest entry: a batch
+    # of this size evaluates ~1e8 LeakyReLU / ReLU units, and a handful of their pre-activations land within fp32
+    # rounding of the kink (measured on this very input: agent 410 has a decoder pre-activation of 7e-9), where any
+    # two fp32 evaluation orders disagree on the sign - the slope through that unit then differs by a factor 5 for
+    # one agent-step, ~1 % of that agent's gradient and a few 1e-4 of the batch gradient.  Away from such inputs
+    # the HIP gradients are within 1e-6 of the float64 oracle (tools/dbg/grad_err.py prints both).
+    cot = torch.randn(B, 12, 4) * 0.1
+    out = tr.G(obsv, z.cuda(), 12, sb)
+    out.backward(cot.cuda())
+    torch.set_default_dtype(torch.float64)
+    try:
+        for m in (orc.attention, orc.feature_embedder, orc.encoder, orc.decoder):
+            m.double()
+        ref = orc.predict(obsv.cpu().double(), z.double(), 12, sb)
+        ref.backward(cot.double())
+    finally:
+        torch.set_default_dtype(torch.float32)
+    for name in ("attention", "feature_embedder", "encoder", "decoder"):
+        for (k, p), (_, q) in zip(getattr(tr.G, name).named_parameters(), getattr(orc, name).named_parameters()):
+            want = q.grad if q.grad is not None else torch.zeros_like(q)
+            assert_close(p.grad.cpu(), want, 2e-3, 2e-3 * max(float(want.abs().max()), 1e-12), "dG %s.%s" % (name, k))
+    o4, p4 = sw.get_traj_4d(obsv, torch.from_numpy(t["preds"]).cuda())
+    cl, cc = torch.randn(B, 1), torch.randn(B, 2)
+    lab, code = tr.D(o4, p4)
+    (lab * cl.cuda()).sum().add((code * cc.cuda()).sum()).backward()
+    lab_r, code_r = orc.D(o4.cpu(), p4.cpu())
+    (lab_r * cl).sum().add((code_r * cc).sum()).backward()
+    assert_close(lab.detach().cpu(), lab_r.detach(), 3e-5, 3e-6, "D label")
+    for (k, p), (_, q) in zip(tr.D.named_parameters(), orc.D.named_parameters()):
+        assert_close(p.grad.cpu(), q.grad, 2e-3, 2e-3 * max(float(q.grad.abs().max()), 1e-12), "dD %s" % k)
+
+
+# ---- workspace growth under captured graphs (ADVICE r1) -------------------------------------------------------------
+def test_graphs_survive_workspace_growth():
+    """Layout A is captured, a LARGER layout B then outgrows the shared workspaces, A is replayed again: the
+    trajectory must equal a purely eager trainer's (the outgrown buffers are retired, not freed, and the graphs are
+    re-captured on the new ones)."""
+    import socialways_amd as sw
+    ta, tb = sw.synth_tracks(12, 8, seed=9), sw.synth_tracks(40, 8, seed=10)
+    da = sw.SceneDataset(ta["obsvs"], ta["preds"], ta["batches"], device="cuda:0")
+    db = sw.SceneDataset(tb["obsvs"], tb["preds"], tb["batches"], device="cuda:0")
+    res = []
+    for use_graph in (True, False):
+        torch.manual_seed(0)
+        tr = sw.SocialWaysTrainer(12, use_social=True, device="cuda:0", use_graph=use_graph)
+        gen = torch.Generator().manual_seed(5)
+        outs = []
+        for d, n in ((da, 4), (db, 4), (da, 3), (db, 2)):
+            B, sbx = d.n_train_samples, d.train_batches
+            for i in range(n):
+                noise = torch.rand(B, 32, generator=gen)
+                outs.append(tr.step(d.obsv[:B], d.pred[:B], sbx, 0.01 * i, 0.9 + 0.01 * i, noise, d.ss).clone().cpu())
+        res.append((outs, tr.D._flat.clone().cpu(), tr.G._flat_all.clone().cpu()))
+        if use_graph:
+            assert tr._graphs and not tr.ws.retired
+    assert all(torch.equal(a, b) for a, b in zip(res[0][0], res[1][0]))
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])

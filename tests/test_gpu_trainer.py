@@ -338,6 +338,49 @@ def test_loss_and_unrolling_switches(name):
     assert abs(o[-1, 0] / data.n_train_samples - af[0]) < 1e-5 and abs(o[-1, 1] / data.n_train_samples - af[1]) < 1e-5
 
 
+@pytest.mark.parametrize("K", [20, 3])
+def test_variety_loss_with_intended_semantics_matches_oracle(K):
+    """use_variety_loss="fixed": K rollouts with independent z folded into one batch, per-agent minimum over the K
+    mean squared errors, gradient through the arg-min sample only (what train.py:527-536 evidently means; the branch
+    as written is covered by test_loss_and_unrolling_switches[variety]).  Reference semantics are defined by the
+    oracle here (`use_variety_loss="fixed"`); the oracle's as-written branch stays pinned to the reference golden
+    (tests/test_oracle_golden.py)."""
+    import socialways_amd as sw
+    import sw_oracle as O
+    sizes = [8] * 6 + [3, 1, 5]
+    t = sw.synth_tracks(len(sizes) + 2, sizes + [2, 2], 8, 12, seed=17)
+    data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
+    torch.manual_seed(0)
+    tr = sw.SocialWaysTrainer(12, use_social=True, device="cuda:0", use_variety_loss="fixed", variety_k=K, use_l2_loss=True)
+    orc = O.SocialWaysOracle(12, use_social=True, use_variety_loss="fixed", variety_k=K, use_l2_loss=True)
+    orc.load_state({k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in tr.checkpoint().items() if k.endswith("_dict")})
+    B, sb = int(np.sum(sizes)), data.the_batches[:len(sizes)]
+    torch.manual_seed(3)
+    noise, vn = torch.rand(B, 32), torch.rand((K - 1) * B, 32)
+    rec = {}
+    out = tr.step(data.obsv[:B], data.pred[:B], sb, 0.04, 0.93, noise, data.ss, variety_noise=vn)
+    want, ade, fde = orc.train_step(data.obsv[:B].cpu(), data.pred[:B].cpu(), sb, 0.04, 0.93, noise, data.ss, record=rec,
+                                    variety_noise=vn)
+    assert_close(tr.losses_from(out, [B], 12, data.ss)[0], np.asarray(want), 5e-5, 2e-6, "9 MSE terms")
+    o = out.double().cpu().numpy()
+    assert abs(o[-1, 0] - ade) < 1e-4 * max(1.0, abs(ade)) and abs(o[-1, 1] - fde) < 1e-4 * max(1.0, abs(fde))
+    l2min, kmin = tr.last_variety
+    l2 = rec["variety_l2"].numpy()                            # (K, B)
+    # an arg-min may legitimately differ where two samples tie within fp32 noise: compare through the oracle's values
+    km = kmin.cpu().numpy().astype(np.int64)
+    assert (l2[km, np.arange(B)] <= l2.min(0) * (1 + 1e-4) + 1e-9).all()
+    assert (km == rec["variety_kmin"].numpy()).mean() > 0.97
+    assert_close(l2min.cpu(), l2.min(0), 1e-4, 1e-8, "per-agent best-of-K error")
+    assert abs(float(l2min.sum()) / B - rec["variety"]) < 1e-5 * max(1.0, rec["variety"])
+    for mname, mod in (("attention", tr.G.attention), ("feature_embedder", tr.G.feature_embedder),
+                       ("encoder", tr.G.encoder), ("decoder", tr.G.decoder)):
+        for k, p in mod.named_parameters():
+            ref = rec["g_grads"][mname + "." + k].numpy()
+            assert_close(p.grad.cpu(), ref, 3e-4, 3e-5 * max(np.abs(ref).max(), 1e-12), "ggrad.%s.%s" % (mname, k))
+    # a training epoch runs with it (own RNG stream), graphs of the other modes are untouched
+    tr.train_epoch(data, 64)
+
+
 def test_biwi_format_crowd_epoch_matches_oracle():
     """BASELINE config 2 stand-in (no ETH/UCY data exists here): a synthetic BIWI-format recording
     through the reference-checked window extraction (tests/golden/biwi_synth.npz), then one epoch of train() with

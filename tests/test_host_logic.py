@@ -71,6 +71,48 @@ def test_packed_adam_equals_torch_adam_and_reference_state_dict():
         assert torch.equal(flat2[a:a + k].view(s), p.detach())
 
 
+def test_packed_adam_loads_reference_state_with_gradientless_parameters():
+    """The unmodified reference trains with use_social=False (train.py:83): its generator optimizer never sees a
+    gradient for the attention / feature-embedder parameters, so torch Adam stores NO state for them
+    (train.py:659: `pred_optimizer` has entries 8..21 only).  Loading such a dict must not raise; the
+    missing slices keep zero moments and the shared step counter comes from the entries that exist."""
+    torch.manual_seed(1)
+    offs, n = _packed(SHAPES)
+    flat, gflat = torch.randn(n), torch.zeros(n)
+    ref = [torch.nn.Parameter(flat[a:a + k].view(s).clone()) for a, k, s in offs]
+    opt = torch.optim.Adam(ref, lr=1e-3, betas=(0.9, 0.999))
+    dead = {0, 3}                                      # parameters without gradients
+    for it in range(3):
+        for i, ((a, k, s), p) in enumerate(zip(offs, ref)):
+            p.grad = None if i in dead else torch.randn(s)
+        opt.step()
+    rd = opt.state_dict()
+    assert sorted(rd["state"]) == [1, 2, 4]
+    for a, k, s in offs:
+        flat[a:a + k] = ref[offs.index((a, k, s))].detach().reshape(-1)
+    pa = PackedAdam(flat, gflat, offs, 1e-3)
+    pa.load_state_dict(rd)
+    assert pa.t == 3
+    for i, (a, k, s) in enumerate(offs):
+        if i in dead:
+            assert float(pa.m[a:a + k].abs().max()) == 0.0 and float(pa.v[a:a + k].abs().max()) == 0.0
+        else:
+            assert torch.equal(pa.m[a:a + k].view(s), rd["state"][i]["exp_avg"])
+    # string keys (a checkpoint that went through json / older torch) load the same way
+    pb = PackedAdam(flat.clone(), gflat.clone(), offs, 1e-3)
+    pb.load_state_dict({"state": {str(k): v for k, v in rd["state"].items()}, "param_groups": rd["param_groups"]})
+    assert pb.t == 3 and torch.equal(pb.m, pa.m) and torch.equal(pb.v, pa.v)
+    # the live parameters continue exactly like the reference optimizer
+    for i, ((a, k, s), p) in enumerate(zip(offs, ref)):
+        g = torch.randn(s)
+        p.grad = None if i in dead else g.clone()
+        gflat[a:a + k] = 0 if i in dead else g.reshape(-1)
+    opt.step()
+    pa.step()
+    for i, ((a, k, s), p) in enumerate(zip(offs, ref)):
+        assert torch.equal(flat[a:a + k].view(s), p.detach()), i
+
+
 def test_scene_index_small_and_large_scenes():
     sizes = [3, 1, 70, 64, 130]
     ends = np.cumsum(sizes)

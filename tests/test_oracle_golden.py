@@ -211,3 +211,32 @@ def test_five_toy_epochs_track_the_reference():
         tol = 1e-5 * 10 ** ep
         assert abs(ade - float(g["ade.%d" % ep])) < tol and abs(fde - float(g["fde.%d" % ep])) < tol, (ep, ade, fde)
         assert_close(np.asarray(losses), g["losses.%d" % ep], 1e-4 * 10 ** ep, 1e-6, "MSE terms of epoch %d" % (ep + 1))
+
+
+def test_oracle_fixed_variety_term_reduces_to_l2_for_one_sample_and_is_a_minimum():
+    """The oracle's `use_variety_loss="fixed"` (best-of-K L2, NOT reference behaviour; the as-written branch is pinned
+    by the `variety` golden above): with K = 1 it is exactly the L2 term (same generator gradients as
+    use_l2_loss=True), and with K > 1 the reported value is the mean of the per-agent minima."""
+    import sw_oracle as O
+    t = O.synth_dataset(6, [3, 1, 4, 2, 2, 2], 8, 12, seed=5)
+    data = O.load_and_normalise(t["obsvs"], t["preds"], t["batches"])
+    B, sb = 10, data["the_batches"][:4]
+    grads = []
+    for kw in (dict(use_l2_loss=True), dict(use_variety_loss="fixed", variety_k=1)):
+        torch.manual_seed(0)
+        orc = O.SocialWaysOracle(12, use_social=True, **kw)
+        torch.manual_seed(1)
+        noise, rec = torch.rand(B, 32), {}
+        orc.train_step(data["obsv"][:B], data["pred"][:B], sb, 0.05, 0.95, noise, data["ss"], record=rec,
+                       variety_noise=torch.zeros(0, 32))
+        grads.append(rec["g_grads"])
+    for k in grads[0]:
+        assert torch.allclose(grads[0][k], grads[1][k], rtol=1e-5, atol=1e-9), k
+    torch.manual_seed(0)
+    orc = O.SocialWaysOracle(12, use_social=True, use_variety_loss="fixed", variety_k=4)
+    torch.manual_seed(1)
+    noise, vn, rec = torch.rand(B, 32), torch.rand(3 * B, 32), {}
+    orc.train_step(data["obsv"][:B], data["pred"][:B], sb, 0.05, 0.95, noise, data["ss"], record=rec, variety_noise=vn)
+    l2 = rec["variety_l2"]
+    assert l2.shape == (4, B) and abs(float(l2.min(0)[0].mean()) - rec["variety"]) < 1e-7
+    assert (rec["variety_kmin"] == l2.argmin(0)).all() and len(set(rec["variety_kmin"].tolist())) > 1
