@@ -71,8 +71,10 @@ import sw_oracle  # noqa: E402  (synthetic track generator only, so inputs are t
 _counter = [0]
 
 
-def import_reference(dataset, batch_size, seed=0, use_social=False):
-    """Import /root/reference/train.py on CPU (SURVEY.md §8c recipe)."""
+def import_reference(dataset, batch_size, seed=0, use_social=False, epochs=0, checkpoint_from=None):
+    """Import /root/reference/train.py on CPU (SURVEY.md §8c recipe).  `epochs` > 0 lets the module-level loop of
+    train.py:646-668 run (training, its own torch.save at epoch 50, its own test() every 5 epochs);
+    `checkpoint_from` = a .pt the reference wrote earlier, placed where train.py:56,622 looks for it."""
     torch.Tensor.cuda = lambda self, *a, **k: self
     nn.Module.cuda = lambda self, *a, **k: self
     time.clock = time.perf_counter
@@ -80,9 +82,12 @@ def import_reference(dataset, batch_size, seed=0, use_social=False):
     work = os.path.join(root, "work")
     os.makedirs(work)
     np.savez(os.path.join(root, "hotel-8-12.npz"), **dataset)
+    os.makedirs(os.path.join(root, "trained_models"))
+    if checkpoint_from is not None:
+        shutil.copy(checkpoint_from, os.path.join(root, "trained_models", "socialWays-hotel.pt"))
     old_cwd, old_argv, old_path = os.getcwd(), sys.argv, list(sys.path)
     os.chdir(work)
-    sys.argv = ["train.py", "--epochs", "0", "--batch-size", str(batch_size)]
+    sys.argv = ["train.py", "--epochs", str(epochs), "--batch-size", str(batch_size)]
     sys.path.insert(0, REF)
     for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
         del sys.modules[k]
@@ -94,7 +99,8 @@ def import_reference(dataset, batch_size, seed=0, use_social=False):
     with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
         spec.loader.exec_module(m)
     sys.argv, sys.path = old_argv, old_path
-    m.epoch = 1
+    if epochs == 0:
+        m.epoch = 1
     m.use_social = use_social
     m._root = root
 
@@ -387,6 +393,69 @@ def multi_epoch_case(dataset, n_epochs=5, batch_size=64, seed=0):
     return out
 
 
+def ref_checkpoint_case(dataset, batch_size=64, seed=0):
+    """A checkpoint the UNMODIFIED reference writes itself, and the reference resuming from it.
+      1. train.py runs as it ships (use_social hard-coded False, train.py:83) for 50 epochs; at epoch 50 its own
+         torch.save (train.py:651-663) writes ../trained_models/socialWays-hotel.pt.  Stored: the 5 state_dicts and
+         BOTH Adam state dicts exactly as found in that file - the generator optimizer holds state for parameter
+         indices 8..21 only (attention / feature_embedder never receive gradients without the social block).
+      2. a second import finds that file, so train.py:622-634 loads it (start_epoch 51); one more train() call from
+         there is recorded: the 9 MSE terms per step, every RNG draw, ADE/FDE = the resumed epoch 51."""
+    m = import_reference(dataset, batch_size, seed, False, epochs=50)
+    pt = os.path.join(m._root, "trained_models", "socialWays-hotel.pt")
+    assert os.path.isfile(pt), "the reference did not write its checkpoint"
+    ck = torch.load(pt, weights_only=False)
+    out = dict(threads=torch.get_num_threads(), batch_size=batch_size, epoch=int(ck["epoch"]))
+    for name in ("attentioner_dict", "feature_embedder_dict", "encoder_dict", "decoder_dict", "D_dict"):
+        for k, v in ck[name].items():
+            out["ck.%s.%s" % (name, k)] = v.detach().numpy()
+    for name in ("pred_optimizer", "D_optimizer"):
+        sd = ck[name]
+        grp = sd["param_groups"][0]
+        out["ck.%s.params" % name] = np.asarray(grp["params"], np.int64)
+        out["ck.%s.hyper" % name] = np.asarray([grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"], grp["weight_decay"]],
+                                               np.float64)
+        out["ck.%s.present" % name] = np.asarray(sorted(sd["state"].keys()), np.int64)
+        for i, st in sd["state"].items():
+            out["ck.%s.%d.step" % (name, i)] = np.float64(float(st["step"]))
+            out["ck.%s.%d.exp_avg" % (name, i)] = st["exp_avg"].numpy()
+            out["ck.%s.%d.exp_avg_sq" % (name, i)] = st["exp_avg_sq"].numpy()
+    tmp = tempfile.mkdtemp(prefix="swck_")
+    keep = os.path.join(tmp, "ck.pt")
+    shutil.copy(pt, keep)
+    m._cleanup()
+    # --- resume: a differently seeded process (its fresh init must be overwritten by the file)
+    m2 = import_reference(dataset, batch_size, seed + 123, False, epochs=50, checkpoint_from=keep)
+    assert m2.start_epoch == 51
+    m2.epoch = 51
+    rec = Recorder(m2)
+    torch.manual_seed(seed + 7)
+    np.random.seed(seed + 7)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m2.train()
+    rec.close()
+    n_steps = len(rec.g_grads)
+    per = 3 * (m2.n_unrolling_steps + 1) + 3
+    calls_per_step = 2 * (m2.n_unrolling_steps + 1) + 1
+    preds_per_step = (m2.n_unrolling_steps + 1) + 1
+    ade = fde = 0.0
+    for s in range(n_steps):
+        pred_hat = rec.predicts[s * preds_per_step + preds_per_step - 1]
+        pred = rec.d_calls[s * calls_per_step + 1][1][:, :, :2]
+        err = torch.pow((pred_hat[:, :, :2] - pred) / m2.ss, 2).sum(dim=2).sqrt()
+        ade += err.sum().item() / m2.n_next
+        fde += err[:, -1].sum().item()
+    out["resume.ade"], out["resume.fde"] = ade / m2.n_train_samples, fde / m2.n_train_samples
+    out["resume.losses"] = np.asarray(rec.mse, np.float64).reshape(n_steps, per)
+    out["resume.uniform"] = np.asarray(rec.uniform, np.float64).reshape(n_steps, 2)
+    for s in range(n_steps):
+        out["resume.noise.%d" % s] = rec.noise[s].numpy()
+    out.update(flat_state(m2, "resume.w1."))
+    m2._cleanup()
+    shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 VARIANTS = {
     "l2": dict(use_l2_loss=True),
     "variety": dict(use_variety_loss=True),
@@ -510,6 +579,8 @@ def main():
         save("syn_big_on", out)
     if only is None or "toy_multi" in only:
         save("toy_multi", multi_epoch_case(toy_dataset(768, 8, 3)))
+    if only is None or "ref_checkpoint" in only:
+        save("ref_checkpoint", ref_checkpoint_case(toy_dataset(768, 8, 3)))
     if only is None or "biwi_synth" in only:
         save("biwi_synth", biwi_case())
     if only is None or "toy_stats" in only:

@@ -344,22 +344,22 @@ class SocialWaysTrainer:
             return part
         return part.sum(1, dtype=torch.float64)
 
-    def step_many(self, batches, sub_batches, ss=1.0, global_B=None, out=None):
+    def step_many(self, batches, sub_batches, ss=1.0, global_B=None, out=None, global_row0=0):
         """K consecutive training steps on K packed batches of the SAME scene layout in ONE graph launch:
         `batches` = [(obsv, pred, zeros_val, ones_val, noise), ...].  Exactly the K `step()` calls in order (same
         kernels, same results); what it saves is the gap between two graph launches (~13 us, the system-scope
         fence at the end of a hipGraph) on K-1 of the K steps.  Returns the list of the K step results."""
         self._resolve_collectives()
         if not self.use_graph or len(batches) == 1 or self.use_variety_loss:
-            return [self.step(o, p, sub_batches, zv, ov, nz, ss, global_B, out) for o, p, zv, ov, nz in batches]
+            return [self.step(o, p, sub_batches, zv, ov, nz, ss, global_B, out, global_row0) for o, p, zv, ov, nz in batches]
         B = batches[0][0].shape[0]
         Bg = float(global_B if global_B is not None else B)
-        self._row0 = 0
+        self._row0 = int(global_row0)
         scenes = ops.SceneIndex.get(sub_batches, B, self.device)
         self._graphs_current()
         key = self._graph_key(scenes, batches[0][0].shape[1], ss, Bg, len(batches))
         if key not in self._graphs and len(self._graphs) >= self.max_graphs:
-            return [self.step(o, p, sub_batches, zv, ov, nz, ss, global_B, out) for o, p, zv, ov, nz in batches]
+            return [self.step(o, p, sub_batches, zv, ov, nz, ss, global_B, out, global_row0) for o, p, zv, ov, nz in batches]
         parts = self._step_graph(batches, sub_batches, float(ss), Bg)
         return parts if out is False else [q.sum(1, dtype=torch.float64) for q in parts]
 
@@ -588,7 +588,8 @@ class SocialWaysTrainer:
         def flush():
             nonlocal pend, pend_key
             if pend:
-                outs.extend(self.step_many([p[0] for p in pend], pend[0][1], data.ss))
+                outs.extend(self.step_many([p[0] for p in pend], pend[0][1], data.ss, global_B=pend[0][2],
+                                           global_row0=pend[0][3]))
                 pend, pend_key = [], None
         for a, b, sb in data.packed_steps(batch_size):
             bs = b - a
@@ -602,27 +603,27 @@ class SocialWaysTrainer:
             if self.use_variety_loss == "fixed":      # z of the extra samples, drawn for the whole packed batch
                 vn = torch.rand(self.variety_k - 1, bs, self.noise_len)
             sizes.append((bs, len(sb)))
-            if self.world > 1:
+            r0, r1, sbl = 0, bs, sb
+            if self.world > 1:      # this rank's scene-aligned shard of the packed batch (z / label noise: global draws, sliced)
                 lo, hi = shard_scenes(sb, self.world)[self.rank]
-                if hi > lo:
-                    r0, r1 = int(sb[lo, 0]), int(sb[hi - 1, 1])
-                    out = self.step(data.obsv[a + r0:a + r1], data.pred[a + r0:a + r1], sb[lo:hi] - r0, zv, ov,
-                                    noise[r0:r1], data.ss, global_B=bs, global_row0=r0,
-                                    variety_noise=None if vn is None else vn[:, r0:r1].reshape(-1, self.noise_len))
-                else:
-                    out = self._empty_step()
-                outs.append(out)
-                continue
+                if hi <= lo:        # no scene for this rank: it still takes part in the step's three all-reduces
+                    flush()
+                    outs.append(self._empty_step())
+                    continue
+                r0, r1 = int(sb[lo, 0]), int(sb[hi - 1, 1])
+                sbl = sb[lo:hi] - r0
+            item = (data.obsv[a + r0:a + r1], data.pred[a + r0:a + r1], zv, ov, noise[r0:r1])
             if vn is not None:        # the folded K-sample step is not graph-captured: one step() per packed batch
                 flush()
-                outs.append(self.step(data.obsv[a:b], data.pred[a:b], sb, zv, ov, noise, data.ss,
-                                      variety_noise=vn.reshape(-1, self.noise_len)))
+                outs.append(self.step(*item[:2], sbl, zv, ov, item[4], data.ss, global_B=bs, global_row0=r0,
+                                      variety_noise=vn[:, r0:r1].reshape(-1, self.noise_len)))
                 continue
-            key = (bs, np.asarray(sb).tobytes())
+            # consecutive packed batches with the same local layout share one graph launch (step_many)
+            key = (bs, r0, np.asarray(sbl).tobytes())
             if key != pend_key or len(pend) == self.STEPS_PER_LAUNCH:
                 flush()
                 pend_key = key
-            pend.append(((data.obsv[a:b], data.pred[a:b], zv, ov, noise), sb))
+            pend.append((item, sbl, bs, r0))
         flush()
         allo = torch.stack(outs)
         self._allreduce(allo)

@@ -58,3 +58,24 @@ def variant_expected_losses(g, name):
     v = np.asarray(g[name + ".losses"])
     n = 3 * int(g[name + ".n_d_updates"]) + 3
     return v[:n], v[n:]
+
+
+def reference_checkpoint(g):
+    """The checkpoint dict the unmodified reference wrote (tests/golden/ref_checkpoint.npz, train.py:651-663) rebuilt
+    from its arrays: 5 state_dicts + both torch.optim.Adam state dicts (entries only where the reference had them)."""
+    ck = {"epoch": int(g["epoch"])}
+    for name in ("attentioner_dict", "feature_embedder_dict", "encoder_dict", "decoder_dict", "D_dict"):
+        pre = "ck.%s." % name
+        ck[name] = {k[len(pre):]: torch.from_numpy(np.array(g[k])) for k in g.files if k.startswith(pre)}
+    for name in ("pred_optimizer", "D_optimizer"):
+        lr, b1, b2, eps, wd = [float(x) for x in g["ck.%s.hyper" % name]]
+        state = {}
+        for i in g["ck.%s.present" % name].tolist():
+            state[i] = {"step": torch.tensor(float(g["ck.%s.%d.step" % (name, i)])),
+                        "exp_avg": torch.from_numpy(np.array(g["ck.%s.%d.exp_avg" % (name, i)])),
+                        "exp_avg_sq": torch.from_numpy(np.array(g["ck.%s.%d.exp_avg_sq" % (name, i)]))}
+        ck[name] = {"state": state, "param_groups": [dict(lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, amsgrad=False,
+                                                          maximize=False, foreach=None, capturable=False,
+                                                          differentiable=False, fused=None,
+                                                          params=g["ck.%s.params" % name].tolist())]}
+    return ck

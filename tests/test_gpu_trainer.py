@@ -189,16 +189,57 @@ def test_checkpoint_roundtrip_reference_format(tmp_path):
     assert_close(o1[2], o2[2], 1e-6, 1e-8, "resumed run reproduces the next epoch")
 
 
-def _dp_worker(rank, world, port, ret):
+def test_resume_from_the_checkpoint_the_reference_wrote(tmp_path):
+    """Checkpoint interchange for real (train.py:622-634, 651-663): tests/golden/ref_checkpoint.npz holds the file the
+    unmodified reference saved after 50 toy epochs - 5 state_dicts + both Adam dicts, the generator's with state for
+    parameter indices 8..21 only (use_social is hard-coded False there) - and the epoch the reference itself ran after
+    loading it.  The HIP trainer loads the same contents (also through an actual .pt file) and reproduces epoch 51."""
+    import socialways_amd as sw
+    from _util import reference_checkpoint
+    g, toy = golden("ref_checkpoint"), golden("toy_768_8_3")
+    data = sw.SceneDataset(toy["obsvs"], toy["preds"], toy["batches"], device="cuda:0")
+    ck = reference_checkpoint(g)
+    path = tmp_path / "socialWays-hotel.pt"
+    torch.save(ck, str(path))
+    torch.manual_seed(11)
+    tr = sw.SocialWaysTrainer(2, use_social=False, device="cuda:0")
+    assert tr.load_checkpoint(str(path)) == 51
+    assert tr.predictor_optimizer.t == 500 and tr.D_optimizer.t == 1000
+    draws = iter([(float(u[0]), float(u[1]), torch.from_numpy(g["resume.noise.%d" % s])) for s, u in enumerate(g["resume.uniform"])])
+    ade, fde, losses, sizes = tr.train_epoch(data, int(g["batch_size"]), draw=lambda bs: next(draws))
+    assert_close(losses, g["resume.losses"], 5e-5, 1e-6, "epoch 51 MSE terms")
+    assert abs(ade - float(g["resume.ade"])) < 1e-4 and abs(fde - float(g["resume.fde"])) < 1e-4
+    # weights after the resumed epoch: Adam far from its first steps (t = 500 / 1000), so elementwise agreement is tight
+    for name, mod in (("encoder", tr.G.encoder), ("decoder", tr.G.decoder), ("D", tr.D)):
+        for k, v in mod.state_dict().items():
+            assert_close(v.cpu(), g["resume.w1.%s.%s" % (name, k)], 1e-4, 2e-5, "w1.%s.%s" % (name, k))
+    # ... and what we save is loadable by torch.optim.Adam over the reference's parameter list (round trip)
+    sd = tr.checkpoint()["pred_optimizer"]
+    assert sd["param_groups"][0]["params"] == list(range(22))
+    assert_close(sd["state"][8]["exp_avg"].cpu().shape, ck["pred_optimizer"]["state"][8]["exp_avg"].shape, 0, 0)
+
+
+def _dp_worker(rank, world, port, ret, backend="gloo", collectives=None):
     import os
     import torch.distributed as dist
     import socialways_amd as sw
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks share cuda:0: plumbing, not speed
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.pop("SW_GRAPH_COLLECTIVES", None)
+    if collectives is not None:
+        os.environ["SW_GRAPH_COLLECTIVES"] = collectives
+    if backend == "nccl":                 # RCCL: every rank on its OWN device
+        torch.cuda.set_device(rank)
+        dev = "cuda:%d" % rank
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        torch.manual_seed(1000 + rank)    # deliberately different seeds: construction broadcasts rank 0's replica
+    else:
+        dev = "cuda:0"
+        dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks share cuda:0: plumbing, not speed
     g = golden("syn_ragged_on")
     ds = dataset_from(g)
-    data = sw.SceneDataset(ds["obsvs"], ds["preds"], ds["batches"], device="cuda:0")
-    tr = sw.SocialWaysTrainer(12, use_social=True, device="cuda:0", process_group=dist.group.WORLD)
+    data = sw.SceneDataset(ds["obsvs"], ds["preds"], ds["batches"], device=dev)
+    tr = sw.SocialWaysTrainer(12, use_social=True, device=dev, process_group=dist.group.WORLD)
     tr.load_checkpoint(as_checkpoint(state_from(g, "w0.")))
     B = int(g["step_agents"][0])
     ade, fde, losses, sizes = tr.train_epoch(data, B, draw=lambda bs: (float(g["uniform"][0, 0]), float(g["uniform"][0, 1]),
@@ -240,6 +281,30 @@ def test_two_rank_data_parallel_step_equals_reference():
     for zv, ov in draws:
         ade, fde, losses, sizes = tr.train_epoch(data, B, draw=lambda bs: (zv, ov, torch.from_numpy(g["noise.0"])))
     assert_close(np.asarray(ret[0][4]), losses[0], 2e-4, 1e-6, "fifth step, 2 ranks vs 1")
+
+
+@pytest.mark.parametrize("collectives", ["0", "1", None])
+def test_rccl_two_devices_data_parallel_equals_reference(collectives):
+    """RCCL over xGMI with 2 ranks on 2 DISTINCT devices (skipped on a 1-GPU box): the scene-sharded epoch with
+    3 gradient all-reduces per step reproduces the reference's single-process losses, replicas stay bit-identical,
+    in both collective forms (graph segments around eager all-reduces = "0", all-reduces recorded in the step
+    graph = "1") and with the start-up probe choosing (None)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (RCCL ranks on distinct devices)")
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_dp_worker, args=(2, port, ret, "nccl", collectives), nprocs=2, join=True)
+    g = golden("syn_ragged_on")
+    for r in (0, 1):
+        assert_close(np.asarray(ret[r][0]), g["losses"][0], 5e-5, 1e-6, "rank %d losses" % r)
+        assert abs(ret[r][1] - float(g["ade"])) < 1e-5
+    assert ret[0][2] == ret[1][2] and ret[0][3] == ret[1][3], "replicas diverged"
+    assert ret[0][5] == ret[1][5] and (collectives is None or ret[0][5] is (collectives == "1"))
 
 
 def _rccl_worker(rank, world, port, ret, mode):

@@ -240,3 +240,26 @@ def test_oracle_fixed_variety_term_reduces_to_l2_for_one_sample_and_is_a_minimum
     l2 = rec["variety_l2"]
     assert l2.shape == (4, B) and abs(float(l2.min(0)[0].mean()) - rec["variety"]) < 1e-7
     assert (rec["variety_kmin"] == l2.argmin(0)).all() and len(set(rec["variety_kmin"].tolist())) > 1
+
+
+def test_oracle_resumes_from_the_checkpoint_the_reference_wrote():
+    """tests/golden/ref_checkpoint.npz: the unmodified reference trained 50 toy epochs, saved its checkpoint itself
+    (train.py:651-663), a second reference process loaded it (train.py:622-634) and trained epoch 51.  The oracle,
+    loaded from the same file contents incl. both Adam dicts (generator state present for indices 8..21 only),
+    reproduces that epoch."""
+    import sw_oracle as O
+    from _util import reference_checkpoint
+    g = golden("ref_checkpoint")
+    toy = golden("toy_768_8_3")
+    data = O.load_and_normalise(toy["obsvs"], toy["preds"], toy["batches"])
+    ck = reference_checkpoint(g)
+    assert sorted(ck["pred_optimizer"]["state"]) == list(range(8, 22)) and len(ck["D_optimizer"]["state"]) == 20
+    torch.manual_seed(5)
+    orc = O.SocialWaysOracle(2, use_social=False)
+    orc.load_state(ck)
+    orc.predictor_optimizer.load_state_dict(ck["pred_optimizer"])
+    orc.D_optimizer.load_state_dict(ck["D_optimizer"])
+    draws = iter([(float(u[0]), float(u[1]), torch.from_numpy(g["resume.noise.%d" % s])) for s, u in enumerate(g["resume.uniform"])])
+    ade, fde, losses, _ = orc.train_epoch(data, int(g["batch_size"]), draw=lambda bs: next(draws))
+    assert_close(np.asarray(losses), g["resume.losses"], 2e-5, 1e-7, "epoch 51 MSE terms")
+    assert abs(ade - float(g["resume.ade"])) < 1e-5 and abs(fde - float(g["resume.fde"])) < 1e-5
