@@ -51,6 +51,15 @@ enum {
 };
 
 int sw_version(void);
+/* Tiling of the time-unrolled kernels: 0 = chosen by batch size (default; currently always the 16-agent workgroups
+ * on v_mfma_f32_16x16x4_f32 - see DESIGN.md for the measurements), 1 = 16-agent tiles always, 2 = 8-agent workgroups
+ * on v_mfma_f32_4x4x1_16B_f32 where a kernel has them (encoder forward, decode forward; 256 workgroups at the metric
+ * shape).  Results of the two tilings differ in summation order only.  Environment SW_TILE_MODE sets the start value. */
+int sw_set_tile_mode(int mode);
+int sw_get_tile_mode(void);
+/* 1 if a batch of B agents currently runs on 8-agent tiles.  Callers size per-tile partial buffers (ADE/FDE and loss
+ * sums: one triple per tile) for ceil(B/8) tiles and do not hand auxiliary work to launches that fill the chip.   */
+int sw_serial_narrow(int B);
 const char* sw_last_error(void);
 
 /* Packed-weight layout: number of floats of group `grp` and the float offset of its `idx`-th
@@ -98,6 +107,12 @@ int sw_social_pool_fwd(const float* obsv /*[B,To,2]*/, int To, const float* h /*
                        const float* emb_w, const float* att_w, float* S_out /*[B,64]*/,
                        float* attn /*[B,64] softmax weights (row i, column j_local) or NULL*/,
                        const int* big_blocks /*or NULL*/, int NB, float* wh_ws, float* ml /*or NULL*/, void* stream);
+/* the same with an auxiliary copy aux_dst[0..aux_n) = aux_src[0..aux_n) (floats, aux_n % 4 == 0) done by extra
+ * workgroups of the launch (the captured training step pulls z out of its pinned host slot here)          */
+int sw_social_pool_fwd_aux(const float* obsv, int To, const float* h, const int* scene_off, int S, int B, int Amax,
+                           const float* emb_w, const float* att_w, float* S_out, float* attn, const int* big_blocks,
+                           int NB, float* wh_ws, float* ml, const float* aux_src, float* aux_dst, long long aux_n,
+                           void* stream);
 /* dense SocialFeatures (train.py:229-241) for the reference's module-level API on small batches */
 int sw_social_features(const float* x4_last /*[B,4]*/, int B, float* feat /*[B,B,3]*/, void* stream);
 /* EmbedSocialFeatures.forward on R rows of 3 features -> [R,64]; AttentionPooling.forward on a

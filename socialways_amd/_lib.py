@@ -22,6 +22,9 @@ _vp, _i, _f, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longl
 PROTOTYPES = {
     "sw_version": (_i, []),
     "sw_last_error": (ctypes.c_char_p, []),
+    "sw_set_tile_mode": (_i, [_i]),
+    "sw_get_tile_mode": (_i, []),
+    "sw_serial_narrow": (_i, [_i]),
     "sw_param_count": (_i, [_i, _i]),
     "sw_param_offset": (_i, [_i, _i, _i]),
     "sw_param_tensors": (_i, [_i]),
@@ -31,6 +34,7 @@ PROTOTYPES = {
     "sw_enc_lstm_fwd_aux": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _ll, _vp]),
     "sw_enc_lstm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "sw_social_pool_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "sw_social_pool_fwd_aux": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _ll, _vp]),
     "sw_social_features": (_i, [_vp, _i, _vp, _vp]),
     "sw_embed_features": (_i, [_vp, _ll, _vp, _vp, _vp]),
     "sw_attention_pool_dense": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),

@@ -292,6 +292,9 @@ __host__ __device__ inline GDelta gdelta_layout(int B, int To, int Tp) {
   return g;
 }
 
+// tiling choice of the serial kernels (sw_misc.hip: sw_set_tile_mode / SW_TILE_MODE)
+bool sw_narrow_tiles(int B);
+
 // host-side error plumbing ---------------------------------------------------------------------
 void sw_set_error(const char* what, hipError_t e);
 #define SW_CHECK_LAUNCH(name)                         \

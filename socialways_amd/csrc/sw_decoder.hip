@@ -519,6 +519,11 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
   }
 }
 
+int sw_dec_rollout_fwd8_launch(const float* obsv, int To, const float* z, const float* S_pool, const float* hT,
+                               const float* cT, const float* enc_w, const float* dec_w, int B, int Tp, float* pred4,
+                               float* h_end, float* c_end, float* gsave, const float* gt, float inv_ss, float* ade_part,
+                               hipStream_t stream);
+
 static int set_lds(const void* fn, int bytes) {
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) {
@@ -537,6 +542,11 @@ extern "C" int sw_dec_rollout_fwd_aux(const float* obsv, int To, const float* z,
   if (ade_part && !gt) return SW_EARG;
   if ((d_w != nullptr) != (dsave != nullptr)) return SW_EARG;
   if (B == 0) return SW_OK;
+  // 8-agent tiles (sw_decoder8.hip) fill the chip themselves: no idle workgroups for the discriminator's observation
+  // LSTM, so a caller that hands it over (d_w) gets the 16-agent kernel
+  if (!d_w && sw_narrow_tiles(B))
+    return sw_dec_rollout_fwd8_launch(obsv, To, z, S_pool, hT, cT, enc_w, dec_w, B, Tp, pred4, h_end, c_end, gsave, gt, inv_ss,
+                                      ade_part, (hipStream_t)stream);
   static bool attr = false;
   if (!attr) {
     if (int rc = set_lds((const void*)dec_rollout_fwd_kernel, FwdLds::total * 4)) return rc;

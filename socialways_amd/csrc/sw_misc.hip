@@ -2,6 +2,7 @@
 // deferred weight-gradient batch, the LSGAN/InfoGAN loss kernel and the ADE/FDE reduction.
 #include "../../include/socialways_hip.h"
 #include "sw_common.h"
+#include <stdlib.h>
 #include "sw_wgrad.h"
 #include <stdio.h>
 #include <string.h>
@@ -11,7 +12,35 @@ void sw_set_error(const char* what, hipError_t e) {
   snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
 }
 extern "C" const char* sw_last_error(void) { return g_err; }
-extern "C" int sw_version(void) { return 1; }
+extern "C" int sw_version(void) { return 2; }
+
+// Tiling of the serial (time-unrolled) kernels: 0 = by batch size, 1 = always 16-agent tiles (v_mfma_f32_16x16x4),
+// 2 = 8-agent tiles (v_mfma_f32_4x4x1_16B) where a kernel has them (encoder forward, decode forward).  Measured on
+// MI355X: the 8-agent kernels halve the matrix work per workgroup but are instruction-issue bound (an
+// 8-cycle MFMA hides no VALU / memory instruction, and one weight row per lane means dword instead of dwordx4 loads
+// and stores), and on full-chip launches they lose the idle CUs other work rides in - they do not win at any
+// BASELINE shape yet, so mode 0 picks them for no batch size (SW_NARROW_MAX_B, default 0).  SW_TILE_MODE sets the
+// start-up value; tests force both tilings.
+bool sw_narrow_tiles(int B);
+static int g_tile_mode = -1;
+extern "C" int sw_set_tile_mode(int mode) {
+  if (mode < 0 || mode > 2) return SW_EARG;
+  g_tile_mode = mode;
+  return SW_OK;
+}
+extern "C" int sw_get_tile_mode(void) {
+  if (g_tile_mode < 0) {
+    const char* e = getenv("SW_TILE_MODE");
+    g_tile_mode = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0;
+  }
+  return g_tile_mode;
+}
+extern "C" int sw_serial_narrow(int B) { return sw_narrow_tiles(B) ? 1 : 0; }
+bool sw_narrow_tiles(int B) {
+  const int m = sw_get_tile_mode();
+  static const int max_b = getenv("SW_NARROW_MAX_B") ? atoi(getenv("SW_NARROW_MAX_B")) : 0;
+  return m == 2 || (m == 0 && B <= max_b);
+}
 
 size_t sw_dsave_floats(int B, int To, int Tp, int nb);
 size_t sw_ddelta_floats(int B, int To, int Tp, int nb);

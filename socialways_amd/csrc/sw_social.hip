@@ -208,7 +208,16 @@ __device__ __forceinline__ void scene_softmax_pool(float* smem, const SocL& Ls, 
 __global__ __launch_bounds__(SW_THREADS) void social_pool_fwd_kernel(
     const float* __restrict__ obsv, int To, const float* __restrict__ h, const int* __restrict__ scene_off,
     const float* __restrict__ emb_w, const float* __restrict__ att_w, float* __restrict__ S_out,
-    float* __restrict__ attn, int a16) {
+    float* __restrict__ attn, int a16, int S, const float* __restrict__ aux_src, float* __restrict__ aux_dst, long long aux_n) {
+  // Workgroups beyond the scenes only copy aux_src -> aux_dst (the training step pulls z out of its pinned host slot
+  // here: this launch is light - small scenes use a few KB of LDS each - and the decode launch behind it is the
+  // first consumer of z)
+  if ((int)blockIdx.x >= S) {
+    const long long n4 = aux_n >> 2, stride = (long long)(gridDim.x - S) * SW_THREADS;
+    for (long long i = (long long)(blockIdx.x - S) * SW_THREADS + threadIdx.x; i < n4; i += stride)
+      st4(aux_dst + 4 * i, ld4(aux_src + 4 * i));
+    return;
+  }
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SocL Ls = soc_lds(a16);
   const int sa = Ls.sa;
@@ -1277,10 +1286,12 @@ extern "C" int sw_social_features(const float* x4_last, int B, float* feat, void
   return SW_OK;
 }
 
-extern "C" int sw_social_pool_fwd(const float* obsv, int To, const float* h, const int* scene_off, int S, int B,
-                                  int Amax, const float* emb_w, const float* att_w, float* S_out, float* attn,
-                                  const int* big_blocks, int NB, float* wh_ws, float* ml, void* stream) {
+extern "C" int sw_social_pool_fwd_aux(const float* obsv, int To, const float* h, const int* scene_off, int S, int B,
+                                      int Amax, const float* emb_w, const float* att_w, float* S_out, float* attn,
+                                      const int* big_blocks, int NB, float* wh_ws, float* ml, const float* aux_src,
+                                      float* aux_dst, long long aux_n, void* stream) {
   if (!obsv || !h || !scene_off || !emb_w || !att_w || !S_out || S < 0 || B < 0 || To < 2 || NB < 0) return SW_EARG;
+  if (aux_n < 0 || (aux_n & 3) || (aux_n > 0 && (!aux_src || !aux_dst))) return SW_EARG;
   if (NB > 0 && (!big_blocks || !wh_ws)) return SW_EARG;
   if (Amax > SW_AMAX) return SW_ESHAPE;      // Amax = largest scene handled by the one-workgroup-per-scene kernel
   if (S == 0 || B == 0) return SW_OK;
@@ -1290,8 +1301,10 @@ extern "C" int sw_social_pool_fwd(const float* obsv, int To, const float* h, con
     attr = true;
   }
   const int a16 = Amax < 16 ? 16 : ((Amax + 15) & ~15);
-  hipLaunchKernelGGL(social_pool_fwd_kernel, dim3(S), dim3(SW_THREADS), soc_lds(a16).fwd_total * 4, (hipStream_t)stream,
-                     obsv, To, h, scene_off, emb_w, att_w, S_out, attn, a16);
+  int extra = aux_n > 0 ? (int)((aux_n / 4 + SW_THREADS - 1) / SW_THREADS) : 0;
+  if (extra > 64) extra = 64;
+  hipLaunchKernelGGL(social_pool_fwd_kernel, dim3(S + extra), dim3(SW_THREADS), soc_lds(a16).fwd_total * 4, (hipStream_t)stream,
+                     obsv, To, h, scene_off, emb_w, att_w, S_out, attn, a16, S, aux_src, aux_dst, aux_n);
   SW_CHECK_LAUNCH("social_pool_fwd_kernel");
   if (NB > 0) {   // scenes above SW_AMAX agents
     hipLaunchKernelGGL(social_wh_kernel, dim3(NB), dim3(SW_THREADS), 0, (hipStream_t)stream, h, scene_off, big_blocks, att_w,
@@ -1302,6 +1315,13 @@ extern "C" int sw_social_pool_fwd(const float* obsv, int To, const float* h, con
     SW_CHECK_LAUNCH("social_big_fwd_kernel");
   }
   return SW_OK;
+}
+
+extern "C" int sw_social_pool_fwd(const float* obsv, int To, const float* h, const int* scene_off, int S, int B,
+                                  int Amax, const float* emb_w, const float* att_w, float* S_out, float* attn,
+                                  const int* big_blocks, int NB, float* wh_ws, float* ml, void* stream) {
+  return sw_social_pool_fwd_aux(obsv, To, h, scene_off, S, B, Amax, emb_w, att_w, S_out, attn, big_blocks, NB, wh_ws, ml,
+                                nullptr, nullptr, 0, stream);
 }
 
 extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, const int* scene_off,

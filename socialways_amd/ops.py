@@ -142,9 +142,13 @@ def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_soc
         gsave = ws.get(tag + ".gsave", nfl) if ws is not None else torch.empty(nfl, device=dev)
     # act rows live at offset 0 of gsave, x4s right behind (sw_common.h:gsave_layout)
     x4s_off = (To + n_next - 1) * B * 384
+    # z is first read by the decode launch: with the social block on, the (light) social launch in front of it pulls
+    # it from the pinned slot, else the encoder launch does
+    z_in_enc = noise_src if not use_social else None
+    z_in_soc = noise_src if use_social else None
     L.call("sw_enc_lstm_fwd_aux", L.ptr(obsv), 0, L.ptr(enc_w), None, None, B, To, L.ptr(hT), L.ptr(cT), None,
            L.ptr(gsave), (gsave.data_ptr() + 4 * x4s_off) if save else None, 0,
-           noise_src, L.ptr(noise) if noise_src else None, noise.numel() if noise_src else 0, st)
+           z_in_enc, L.ptr(noise) if z_in_enc else None, noise.numel() if z_in_enc else 0, st)
     attn = wh = ml = None
     if use_social:
         S = torch.empty(B, 64, device=dev)
@@ -152,8 +156,9 @@ def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_soc
         if scenes.NB:          # scenes above AMAX agents: W h + b per agent and the softmax statistics of every row
             wh = torch.empty(B, 64, device=dev)
             ml = torch.empty(B, 2, device=dev) if save else None
-        L.call("sw_social_pool_fwd", L.ptr(obsv), To, L.ptr(hT), L.ptr(scenes.scene_off), scenes.S, B, scenes.amax,
-               L.ptr(emb_w), L.ptr(att_w), L.ptr(S), L.ptr(attn), L.ptr(scenes.big_blocks), scenes.NB, L.ptr(wh), L.ptr(ml), st)
+        L.call("sw_social_pool_fwd_aux", L.ptr(obsv), To, L.ptr(hT), L.ptr(scenes.scene_off), scenes.S, B, scenes.amax,
+               L.ptr(emb_w), L.ptr(att_w), L.ptr(S), L.ptr(attn), L.ptr(scenes.big_blocks), scenes.NB, L.ptr(wh), L.ptr(ml),
+               z_in_soc, L.ptr(noise) if z_in_soc else None, noise.numel() if z_in_soc else 0, st)
     else:
         S = torch.zeros(B, 64, device=dev)                                   # train.py:413
     L.call("sw_dec_rollout_fwd_aux", L.ptr(obsv), To, L.ptr(noise), L.ptr(S), L.ptr(hT), L.ptr(cT), L.ptr(enc_w),
@@ -217,7 +222,7 @@ D_OBS_MAX_TILES = 128      # the decode launch has idle CUs for the D observatio
 def d_obs_buffer(ws, B, To, Tp, nb=2, tag="d"):
     """The save buffer disc_forward(tag, nb branches) will use, or None when the decode launch has no idle CUs to
     precompute the observation LSTM in (gen_forward(d_obs=...) / disc_forward(save_lstm=2))."""
-    if (B + 15) // 16 > D_OBS_MAX_TILES:
+    if (B + 15) // 16 > D_OBS_MAX_TILES or L.load().sw_serial_narrow(B):    # 8-agent tiles fill the chip themselves
         return None
     return ws.get(tag + ".dsave", L.workspace_floats(L.WS_DSAVE, B, To, Tp, nb))
 

@@ -334,7 +334,7 @@ class SocialWaysTrainer:
             if self._graph_key(scenes, obsv.shape[1], ss, Bg, 1) in self._graphs or len(self._graphs) < self.max_graphs:
                 part = self._step_graph([(obsv, pred, zeros_val, ones_val, noise)], sub_batches, float(ss), Bg)[0]
         if part is None:
-            part = torch.zeros(self.n_unrolling_steps + 3, (B + 15) // 16, 3, device=dev)
+            part = torch.zeros(self.n_unrolling_steps + 3, (B + 7) // 8, 3, device=dev)     # one triple per (8- or 16-agent) tile
             scenes = ops.SceneIndex.get(sub_batches, B, dev)
             noise = noise.to(dev, non_blocking=True).contiguous()
             # label-noise scalars of train.py:471-472 live in device memory: [zeros_val, ones_val]
@@ -377,7 +377,7 @@ class SocialWaysTrainer:
                 pred=torch.empty(B, Tp, 2, device=dev), pred4=torch.empty(B, Tp, 4, device=dev),
                 targets=torch.empty(4, device=dev), noise=torch.empty(B, self.noise_len, device=dev),
                 steps=torch.zeros(self.n_unrolling_steps + 2, device=dev),   # Adam step indices of the U+1 D updates, the G update
-                outs=[torch.zeros(self.n_unrolling_steps + 3, (B + 15) // 16, 3, device=dev) for _ in range(K)],
+                outs=[torch.zeros(self.n_unrolling_steps + 3, (B + 7) // 8, 3, device=dev) for _ in range(K)],
                 slots=[[torch.zeros(HDR + B * self.noise_len, dtype=torch.float32).pin_memory() for _ in range(K)]
                        for _ in range(2)],
                 done=[torch.cuda.Event(), torch.cuda.Event()], keep=[None, None])

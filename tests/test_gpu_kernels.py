@@ -42,7 +42,7 @@ def cmp_grads(got, g, prefix, rtol, atol_rel):
 
 
 @pytest.mark.parametrize("case", ["syn_s16a8_off", "syn_s16a8_on", "syn_ragged_on", "syn_big_on"])
-def test_predict_forward(case):
+def test_predict_forward(case, tile_mode):
     g = golden(case)
     G, D, dev = _models(g, 12, bool(g["use_social"]))
     data, obsv, pred, sb, noise = _step_inputs(g)
@@ -52,7 +52,7 @@ def test_predict_forward(case):
 
 
 @pytest.mark.parametrize("case", ["syn_s16a8_on", "syn_ragged_on"])
-def test_disc_forward(case):
+def test_disc_forward(case, tile_mode):
     import socialways_amd as sw
     g = golden(case)
     G, D, dev = _models(g, 12, True)
@@ -70,7 +70,7 @@ def test_disc_forward(case):
 
 
 @pytest.mark.parametrize("case", ["syn_s16a8_off", "syn_s16a8_on", "syn_ragged_on", "syn_big_on"])
-def test_predict_backward(case):
+def test_predict_backward(case, tile_mode):
     """dL/dpred_hat of the reference's G phase pushed through the HIP backward: every generator
     gradient must match the reference's autograd."""
     g = golden(case)
@@ -87,7 +87,7 @@ def test_predict_backward(case):
 
 
 @pytest.mark.parametrize("case", ["syn_s16a8_on", "syn_ragged_on"])
-def test_disc_backward_first_update(case):
+def test_disc_backward_first_update(case, tile_mode):
     """D update u=0 of train.py:476-496 through autograd on the HIP Function: d_loss = fake + real +
     0.5 info; gradients vs the reference's."""
     import socialways_amd as sw
@@ -189,7 +189,20 @@ def test_loss_and_ade_reductions_any_batch_size(B):
 def test_disc_observation_lstm_precomputed_by_the_decode_launch(B):
     """sw_dec_rollout_fwd_aux runs the discriminator's observation LSTM in idle workgroups of the decode launch;
     sw_disc_fwd(save_lstm=2) then reads the rows: labels, codes and the whole save buffer must equal the plain
-    sw_disc_fwd(save_lstm=1) bit for bit, and the rollout itself is unchanged."""
+    sw_disc_fwd(save_lstm=1) bit for bit, and the rollout itself is unchanged.  (A feature of the 16-agent tiling,
+    which leaves CUs idle at these sizes; 8-agent tiles fill the chip and ops.d_obs_buffer then declines.)"""
+    import socialways_amd as sw
+    from socialways_amd import ops, _lib as L
+    L.load().sw_set_tile_mode(2)
+    assert ops.d_obs_buffer(ops.Workspaces(torch.device("cuda:0")), B, 8, 12) is None
+    L.load().sw_set_tile_mode(1)
+    try:
+        _d_obs_case(B)
+    finally:
+        L.load().sw_set_tile_mode(0)
+
+
+def _d_obs_case(B):
     import socialways_amd as sw
     from socialways_amd import ops, _lib as L
     dev = torch.device("cuda:0")
