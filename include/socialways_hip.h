@@ -57,6 +57,15 @@ int sw_version(void);
  * shape).  Results of the two tilings differ in summation order only.  Environment SW_TILE_MODE sets the start value. */
 int sw_set_tile_mode(int mode);
 int sw_get_tile_mode(void);
+/* Co-scheduled weight gradients ("riders"): while a backward kernel runs its 16-agent tiles on at most half of the CUs
+ * (B <= 2048), the spare workgroups of the same launch run the deferred weight-gradient GEMM jobs as soon as the rows
+ * they need are published.  The hand-off between workgroups goes through UNCACHED device memory: with riding on, the
+ * caller must keep the delta workspaces (SW_WS_GDELTA, SW_WS_DDELTA) in memory obtained from sw_uc_alloc.
+ * sw_set_cosched(0 / 1); environment SW_COSCHED sets the start value (default 0).                                     */
+int sw_set_cosched(int on);
+int sw_get_cosched(void);
+void* sw_uc_alloc(size_t bytes);     /* hipExtMallocWithFlags(hipDeviceMallocUncached); NULL on failure */
+void sw_uc_free(void* p);
 /* 1 if a batch of B agents currently runs on 8-agent tiles.  Callers size per-tile partial buffers (ADE/FDE and loss
  * sums: one triple per tile) for ceil(B/8) tiles and do not hand auxiliary work to launches that fill the chip.   */
 int sw_serial_narrow(int B);

@@ -25,6 +25,10 @@ PROTOTYPES = {
     "sw_set_tile_mode": (_i, [_i]),
     "sw_get_tile_mode": (_i, []),
     "sw_serial_narrow": (_i, [_i]),
+    "sw_set_cosched": (_i, [_i]),
+    "sw_get_cosched": (_i, []),
+    "sw_uc_alloc": (_vp, [ctypes.c_size_t]),
+    "sw_uc_free": (None, [_vp]),
     "sw_param_count": (_i, [_i, _i]),
     "sw_param_offset": (_i, [_i, _i, _i]),
     "sw_param_tensors": (_i, [_i]),

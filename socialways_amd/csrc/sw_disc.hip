@@ -8,6 +8,7 @@
 #include "../../include/socialways_hip.h"
 #include "sw_lstm_dev.h"
 #include "sw_wgrad.h"
+#include "sw_wgrad_dev.h"
 #include <type_traits>
 #ifdef SW_PHASE_STAMPS
 __device__ long long sw_disc_stamps[16];
@@ -426,8 +427,15 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
     const float* __restrict__ d_w, const float* __restrict__ dsave, const float* __restrict__ dlabel_a,
     const float* __restrict__ dlabel_b, const float* __restrict__ dcode_a, const float* __restrict__ dcode_b, int nb,
     int B, int To, int Tp, int want_w, float* __restrict__ ddelta, float* __restrict__ dpred_a,
-    float* __restrict__ dpred_b, DiscLoss gl) {
+    float* __restrict__ dpred_b, DiscLoss gl, WgBatch wbatch, WgRide ride) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // Workgroups beyond the agent tiles are RIDERS (sw_wgrad_dev.h): they run the weight-gradient jobs of this very
+  // pass while the tiles compute - rows of the heads (event 0), then of BPTT step t (event To - t) as they are published
+  if ((int)blockIdx.x >= (B + SW_TILE - 1) / SW_TILE) {
+    wg_ride(wbatch, ride, (int)blockIdx.x - (B + SW_TILE - 1) / SW_TILE, smem);
+    return;
+  }
+  const bool riding = ride.nriders > 0;
   float* dgbuf = smem;  // [2][16][260]
   const HeadLdsB L = head_lds_b(Tp, 2 * 16 * SW_GLD);
   const swp::Disc O = swp::disc(Tp);
@@ -587,7 +595,9 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
     st4(smem + L.do1 + ln * LD32 + m0 + 4 * lg, acc);
     if (live) st4(ddelta + dd.do1 + (size_t)b * 32 + m0 + 4 * lg, acc);
   }
+  if (riding) wg_drain();                        // every row of the heads is in memory ...
   sw_barrier();
+  if (riding) wg_signal(ride.cnt + 0);           // ... for all four waves: event 0
   f32x4 dh = {0.f, 0.f, 0.f, 0.f}, dc = {0.f, 0.f, 0.f, 0.f};
   dh = tile_mm_rt(smem + L.of0T + (u0 + ln) * LD32 + 4 * lg, smem + L.do1 + ln * LD32 + 4 * lg, 2, dh);
   LstmWT WT;
@@ -629,6 +639,8 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
     dgg -= dgg_step;
     SW_STAMP(12);
     sw_barrier();
+    // behind this barrier every wave has drained the rows of the PREVIOUS step (wg_drain at its end): event To - (t+1)
+    if (riding && t + 1 < To) wg_signal(ride.cnt + (To - (t + 1)));
     SW_STAMP(13);
     if constexpr (decltype(nx)::value) dh = lstm_dh_prev(WT, &dgbuf[(t & 1) * 16 * SW_GLD + ln * SW_GLD + 4 * lg]);
     if constexpr (decltype(pf)::value) {
@@ -637,11 +649,16 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
       ct = nct;
       cprev = ncp;
     }
+    if (riding) wg_drain();                        // the dgates rows of step t (stored in front of the barrier above)
     SW_STAMP(14);
   };
   for (int t = To - 1; t >= 2; --t) step(t, T_{}, T_{}, T_{});
   if (To > 1) step(1, T_{}, F_{}, T_{});
   step(0, F_{}, F_{}, F_{});
+  if (riding) {                                    // the rows of step 0: event To
+    sw_barrier();
+    wg_signal(ride.cnt + To);
+  }
   SW_STAMP(11);
 }
 
@@ -727,31 +744,57 @@ static int disc_bwd_impl(const float* d_w, const float* dsave, const float* cons
     attr = lds;
   }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(disc_bwd_kernel, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS), lds, st, d_w, dsave,
+  const int tiles = (B + SW_TILE - 1) / SW_TILE;
+  WgBatch wb;
+  WgRide ride;
+  if (d_d_w) {
+    const swp::Disc O = swp::disc(Tp);
+    const DSave ds = dsave_layout(B, To, Tp, nb);
+    const DDelta dd = ddelta_layout(B, To, Tp, nb);
+    const int R = nb * B, K4 = 4 * Tp;
+    int rc_add = 0;
+    // LSTM: dW_hh over rows t >= 1 against h_{t-1}; dW_ih / biases over all rows against x4
+    rc_add |= wg_add_tail(wb, ddelta + dd.dgates, 256, dsave + ds.act + 320 - (ptrdiff_t)B * 384, 384, To * B, 256, 64,
+                          d_d_w + O.whh, 64, dsave + ds.x4s, 4, 4, d_d_w + O.wih, 4, B /*h_{t-1}: rows t >= 1*/,
+                          d_d_w + O.bih, d_d_w + O.bhh, 0);
+    rc_add |= wg_add(wb, ddelta + dd.do1, 32, dsave + ds.act + (size_t)(To - 1) * B * 384 + 320, 384, B, 32, 64, d_d_w + O.of0w,
+           64, d_d_w + O.of0b, nullptr, 0);
+    rc_add |= wg_add(wb, ddelta + dd.docode, 32, dsave + ds.o1, 32, B, 32, 32, d_d_w + O.of1w, 32, d_d_w + O.of1b, nullptr, 0);
+    rc_add |= wg_add(wb, ddelta + dd.dq1, 32, dsave + ds.px, K4, R, 32, K4, d_d_w + O.pe0w, K4, d_d_w + O.pe0b, nullptr, 0);
+    rc_add |= wg_add(wb, ddelta + dd.dpcode, 32, dsave + ds.q1, 32, R, 32, 32, d_d_w + O.pe1w, 32, d_d_w + O.pe1b, nullptr, 0);
+    rc_add |= wg_add(wb, ddelta + dd.dc1, 32, dsave + ds.both, 64, R, 32, 64, d_d_w + O.cl0w, 64, d_d_w + O.cl0b, nullptr, 0);
+    rc_add |= wg_add(wb, ddelta + dd.dlab, 4, dsave + ds.c1, 32, R, 1, 32, d_d_w + O.cl1w, 32, d_d_w + O.cl1b, nullptr, 0);
+    rc_add |= wg_add(wb, ddelta + dd.dl1, 32, dsave + ds.both, 64, R, 32, 64, d_d_w + O.la0w, 64, d_d_w + O.la0b, nullptr, 0);
+    rc_add |= wg_add(wb, ddelta + dd.dcod, 4, dsave + ds.l1, 32, R, 2, 32, d_d_w + O.la1w, 32, d_d_w + O.la1b, nullptr, 0);
+    if (rc_add) return SW_ESHAPE;
+    // Riders: with at most half of the CUs busy on tiles, the other workgroups of the launch run these jobs while the
+    // BPTT proceeds (the caller keeps ddelta in uncached memory: sw_set_cosched)
+    const int nriders = (wg_cosched() && tiles <= 128 && To + 1 < SW_RIDE_SLOTS) ? 256 - tiles : 0;
+    if (nriders > 0) {
+      if (wg_finalize_for(wb, 2 * nriders) > SW_WG_WS_FLOATS) return SW_ESHAPE;
+      struct Need : WgNeed {
+        const float* dg; int B, To;
+        int operator()(const WgProblem& P, int rbeg, int rend) const override {
+          if (P.delta != dg) return 0;                    // heads: event 0
+          return To - rbeg / B;                           // BPTT runs t = To-1 .. 0: the job's EARLIEST step completes last
+        }
+      } need;
+      need.dg = ddelta + dd.dgates; need.B = B; need.To = To;
+      const unsigned long long key = ((unsigned long long)B << 24) ^ ((unsigned long long)To << 16) ^ ((unsigned long long)Tp << 8) ^ (unsigned long long)nb;
+      if (int rc = wg_ride_setup(wb, ride, 0, key, nriders, (unsigned)tiles, To + 1, wgrad_ws, need)) return rc;
+      lds = lds > SW_WG_RED_FLOATS * 4 ? lds : SW_WG_RED_FLOATS * 4;
+      if (attr < lds) {
+        if (int rc = set_lds((const void*)disc_bwd_kernel, lds)) return rc;
+        attr = lds;
+      }
+    }
+  }
+  hipLaunchKernelGGL(disc_bwd_kernel, dim3(tiles + ride.nriders), dim3(SW_THREADS), lds, st, d_w, dsave,
                      dlabel[0], nb > 1 ? dlabel[1] : nullptr, dcode[0], nb > 1 ? dcode[1] : nullptr, nb, B, To, Tp,
-                     d_d_w ? 1 : 0, ddelta, dpred4 ? dpred4[0] : nullptr, (dpred4 && nb > 1) ? dpred4[1] : nullptr, gl);
+                     d_d_w ? 1 : 0, ddelta, dpred4 ? dpred4[0] : nullptr, (dpred4 && nb > 1) ? dpred4[1] : nullptr, gl, wb, ride);
   SW_CHECK_LAUNCH("disc_bwd_kernel");
   if (!d_d_w) return SW_OK;
-  const swp::Disc O = swp::disc(Tp);
-  const DSave ds = dsave_layout(B, To, Tp, nb);
-  const DDelta dd = ddelta_layout(B, To, Tp, nb);
-  const int R = nb * B, K4 = 4 * Tp;
-  WgBatch wb;
-  int rc_add = 0;
-  // LSTM: dW_hh over rows t >= 1 against h_{t-1}; dW_ih / biases over all rows against x4
-  rc_add |= wg_add_tail(wb, ddelta + dd.dgates, 256, dsave + ds.act + 320 - (ptrdiff_t)B * 384, 384, To * B, 256, 64,
-                        d_d_w + O.whh, 64, dsave + ds.x4s, 4, 4, d_d_w + O.wih, 4, B /*h_{t-1}: rows t >= 1*/,
-                        d_d_w + O.bih, d_d_w + O.bhh, 0);
-  rc_add |= wg_add(wb, ddelta + dd.do1, 32, dsave + ds.act + (size_t)(To - 1) * B * 384 + 320, 384, B, 32, 64, d_d_w + O.of0w,
-         64, d_d_w + O.of0b, nullptr, 0);
-  rc_add |= wg_add(wb, ddelta + dd.docode, 32, dsave + ds.o1, 32, B, 32, 32, d_d_w + O.of1w, 32, d_d_w + O.of1b, nullptr, 0);
-  rc_add |= wg_add(wb, ddelta + dd.dq1, 32, dsave + ds.px, K4, R, 32, K4, d_d_w + O.pe0w, K4, d_d_w + O.pe0b, nullptr, 0);
-  rc_add |= wg_add(wb, ddelta + dd.dpcode, 32, dsave + ds.q1, 32, R, 32, 32, d_d_w + O.pe1w, 32, d_d_w + O.pe1b, nullptr, 0);
-  rc_add |= wg_add(wb, ddelta + dd.dc1, 32, dsave + ds.both, 64, R, 32, 64, d_d_w + O.cl0w, 64, d_d_w + O.cl0b, nullptr, 0);
-  rc_add |= wg_add(wb, ddelta + dd.dlab, 4, dsave + ds.c1, 32, R, 1, 32, d_d_w + O.cl1w, 32, d_d_w + O.cl1b, nullptr, 0);
-  rc_add |= wg_add(wb, ddelta + dd.dl1, 32, dsave + ds.both, 64, R, 32, 64, d_d_w + O.la0w, 64, d_d_w + O.la0b, nullptr, 0);
-  rc_add |= wg_add(wb, ddelta + dd.dcod, 4, dsave + ds.l1, 32, R, 2, 32, d_d_w + O.la1w, 32, d_d_w + O.la1b, nullptr, 0);
-  if (rc_add) return SW_ESHAPE;
+  if (ride.nriders > 0) return wg_reduce_launch(wb, wgrad_ws, st);
   return wg_launch(wb, wgrad_ws, st);
 }
 

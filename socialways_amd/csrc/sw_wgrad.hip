@@ -16,12 +16,7 @@
 #include "../../include/socialways_hip.h"
 #include "sw_common.h"
 #include "sw_wgrad.h"
-#ifndef SW_WG_DEPTH
-#define SW_WG_DEPTH 4
-#endif
-#ifndef SW_WG_DEPTH5
-#define SW_WG_DEPTH5 2
-#endif
+#include "sw_wgrad_dev.h"
 #include <stdlib.h>
 
 // One wave = one job: a 64 x 64 output block (4 x 4 MFMA tiles, 16 accumulators) of one column block
@@ -34,144 +29,9 @@
 // this wave's 64x64 block): loads are unconditional from clamped addresses and masked by a 0/1
 // factor, so the hot loop is NI+KT loads, a few multiplies and NI*KT MFMAs - no exec-mask branches,
 // no accumulator shuffling through control flow.
-#define SW_WG_RLD 69   // LDS row stride of a wave's 64 x (<= 69) block: 64 act columns + tail segment + ones
-template <int NI, int KT>
-__device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const float* __restrict__ abase, int ldd, int lda,
-                                       int rbeg, int rend, int rmax, const int* acol, const float* amask,
-                                       const int* bcol, const float* bmask, const float* bone, int lg, int ln,
-                                       float* __restrict__ mine, const float* __restrict__ abase2, int lda2, int row0) {
-  f32x4 acc[NI][KT];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) acc[i][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  constexpr int DEPTH = KT == 5 ? SW_WG_DEPTH5 : SW_WG_DEPTH;  // 4-row groups in flight (swept on the GPU: 4 / 2)
-  // The pipeline registers hold the RAW loaded values; row masks / the ones column are applied when a group is
-  // consumed.  (Arithmetic attached to the load sits in front of the loop's back edge, so every load of a body
-  // iteration had to complete inside it: the compiler drained the pipeline - s_waitcnt vmcnt(0) - once per DEPTH
-  // groups.)
-  float a[DEPTH][NI], b[DEPTH][KT];
-  auto load = [&](int r0, float* av, float* bv) {
-    const int rc = min(r0 + lg, rmax);
-    const float* dr = dbase + (size_t)rc * ldd;
-    const float* ar = abase + (size_t)max(rc, row0) * lda;     // rows below row0 have no `act` operand
-#pragma unroll
-    for (int i = 0; i < NI; ++i) av[i] = dr[acol[i]];
-#pragma unroll
-    for (int kt = 0; kt < (KT < 5 ? KT : 4); ++kt) bv[kt] = ar[bcol[kt]];
-    if (KT == 5) bv[4] = (abase2 + (size_t)rc * lda2)[bcol[4]];   // tail segment | ones
-  };
-#pragma unroll
-  for (int q = 0; q < DEPTH - 1; ++q) load(rbeg + 4 * q, a[q], b[q]);
-  for (int r = rbeg; r < rend; r += 4 * DEPTH) {
-#pragma unroll
-    for (int q = 0; q < DEPTH; ++q) {
-      load(r + 4 * (q + DEPTH - 1), a[(q + DEPTH - 1) % DEPTH], b[(q + DEPTH - 1) % DEPTH]);
-      asm volatile("" ::: "memory");   // the loads are issued HERE (DEPTH - 1 groups ahead), not sunk to their uses
-#pragma unroll
-      for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(a[q][i]));   // ... and group q is first touched here
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt) asm volatile("" : "+v"(b[q][kt]));
-      const int rr = r + 4 * q + lg;
-      const float rs = rr < rend ? 1.0f : 0.0f;
-      const float rs0 = rr >= row0 ? rs : 0.0f;
-      float av[NI], bv[KT];
-#pragma unroll
-      for (int i = 0; i < NI; ++i) av[i] = a[q][i] * (amask[i] * rs);
-#pragma unroll
-      for (int kt = 0; kt < (KT < 5 ? KT : 4); ++kt) bv[kt] = fmaf(b[q][kt], bmask[kt], bone[kt]) * (bone[kt] > 0.f ? rs : rs0);
-      if (KT == 5) bv[4] = fmaf(b[q][4], bmask[4], bone[4]) * rs;
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) acc[i][kt] = SW_MFMA(av[i], bv[kt], acc[i][kt]);
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (kt < 4 || ln < SW_WG_RLD - 64) mine[(i * 16 + 4 * lg + r) * SW_WG_RLD + kt * 16 + ln] = acc[i][kt][r];
-    }
-  }
-}
-
-// One wave = one job: a 64 x 64 output block (NI x KT MFMA tiles) of one column block of one problem
-// over one row slice.  Operands come straight from global memory in MFMA layout (A: delta[r0+lg][n0+16i+ln],
-// B: act[r0+lg][16kt+ln], 64 B contiguous per 16 lanes), software pipelined 5 four-row groups ahead; no
-// LDS in the loop, no barriers - every wave streams independently, 3 waves per SIMD.  The 4 waves of a
-// workgroup take 4 consecutive row slices of the same block and sum them through LDS at the end.
 __global__ __launch_bounds__(SW_THREADS, 2) void wgrad_partial_kernel(WgBatch batch, float* __restrict__ ws) {
-  __shared__ __attribute__((aligned(16))) float red[4][64 * SW_WG_RLD];   // per-wave 64 x <=69 block, summed before the store
-  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
-  const int job = blockIdx.x;            // one workgroup = 4 consecutive row slices of one output block
-  int p = 0;
-#pragma unroll 1
-  while (p + 1 < batch.np && job >= batch.job0s[p + 1]) ++p;
-  const WgProblem& P = batch.p[p];
-  const int j = job - P.job0;
-  const int NB = (P.N + 63) >> 6;       // 64-row output blocks
-  const int sg = j / NB, nb = j - sg * NB;
-  const int s = sg * 4 + wave;          // this wave's row slice (may be empty)
-  const int N = P.N, K = P.K, Kc = P.K + P.K2 + P.ones;
-  const int n0 = nb * 64;
-  const int NI = min(4, (N - n0 + 15) >> 4), KT = (Kc + 15) >> 4;
-  const int nsub = P.nsplit * 4;
-  const int rows_per = (((P.R + nsub - 1) / nsub) + 3) & ~3;
-  const int rbeg = min(P.R, s * rows_per);
-  const int rend = min(P.R, rbeg + rows_per);
-  int acol[4], bcol[5];
-  float amask[4], bmask[5], bone[5];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int n = n0 + 16 * i + ln, k = 16 * i + ln;
-    acol[i] = min(n, N - 1);
-    amask[i] = n < N ? 1.0f : 0.0f;
-    bcol[i] = min(k, max(K - 1, 0));
-    bmask[i] = k < K ? 1.0f : 0.0f;
-    bone[i] = (P.ones && k == K + P.K2) ? 1.0f : 0.0f;
-  }
-  {  // k tile 4 exists only with a tail segment (K == 64): columns of act2, then the ones column
-    const int c = ln;
-    bcol[4] = min(c, max(P.K2 - 1, 0));
-    bmask[4] = c < P.K2 ? 1.0f : 0.0f;
-    bone[4] = (P.ones && c == P.K2) ? 1.0f : 0.0f;
-  }
-  float* mine = red[wave];
-#define WG_CASE(ni, kt)                                                                                          \
-  case ni * 8 + kt:                                                                                              \
-    wg_run<ni, kt>(P.delta, P.act, P.ldd, P.lda, rbeg, rend, P.R - 1, acol, amask, bcol, bmask, bone, lg, ln, mine, \
-                   P.act2 ? P.act2 : P.delta, P.act2 ? P.lda2 : P.ldd, P.row0);                                  \
-    break;
-  switch (NI * 8 + KT) {
-    WG_CASE(1, 1) WG_CASE(1, 2) WG_CASE(1, 3) WG_CASE(1, 4) WG_CASE(1, 5)
-    WG_CASE(2, 1) WG_CASE(2, 2) WG_CASE(2, 3) WG_CASE(2, 4) WG_CASE(2, 5)
-    WG_CASE(3, 1) WG_CASE(3, 2) WG_CASE(3, 3) WG_CASE(3, 4) WG_CASE(3, 5)
-    WG_CASE(4, 1) WG_CASE(4, 2) WG_CASE(4, 3) WG_CASE(4, 4) WG_CASE(4, 5)
-  }
-#undef WG_CASE
-  sw_barrier();
-  // one partial per workgroup (4 row slices summed): ws[ws_off + (sg*N + n)*Kc + k]
-  float* out = ws + P.ws_off + (size_t)sg * N * Kc;
-  const int rows = min(64, N - n0), cols = min(SW_WG_RLD, Kc);
-  // element e = rr * cols + cc walks the block row-major; (rr, cc) advance incrementally (one division per thread)
-  const int dq = SW_THREADS / cols, dr = SW_THREADS - dq * cols;
-  int rr = threadIdx.x / cols, cc = threadIdx.x - rr * cols;
-  for (int e = threadIdx.x; e < rows * cols; e += SW_THREADS) {
-    const int o = rr * SW_WG_RLD + cc;
-    const float v = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
-    out[(size_t)(n0 + rr) * Kc + cc] = v;
-    cc += dr;
-    rr += dq;
-    if (cc >= cols) {
-      cc -= cols;
-      ++rr;
-    }
-  }
+  __shared__ __attribute__((aligned(16))) float red[SW_WG_RED_FLOATS];   // per-wave 64 x <=69 blocks, summed before the store
+  wg_job(batch, ws, blockIdx.x, red);
 }
 
 // out element e of problem p = sum over slices.  A wave owns SW_WG_REL consecutive elements (lanes el = lane %
@@ -223,6 +83,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgBatch batch, const 
 }
 
 // host side -------------------------------------------------------------------------------------
+static bool wg_shape_ok(int N, int K) {   // every 64-column block of delta / act must split into whole lane vectors
+  for (int n0 = 0; n0 < N; n0 += 64)
+    if (!wg_tiles(N - n0 < 64 ? N - n0 : 64, false)) return false;
+  return K == 0 || wg_tiles(K, true) != 0;
+}
+
 int wg_add(WgBatch& b, const float* delta, int ldd, const float* act, int lda, int R, int N, int K, float* dW,
            int ldw, float* db, float* db2, int accumulate) {
   if (N > 256 || (ldd & 3) || (lda & 3)) return SW_ESHAPE;
@@ -239,8 +105,9 @@ int wg_add(WgBatch& b, const float* delta, int ldd, const float* act, int lda, i
     P.accumulate = accumulate;
     P.pre = 0;
     P.act2 = nullptr; P.dW2 = nullptr; P.lda2 = P.ldw2 = P.K2 = P.row0 = 0;
+    if (!wg_shape_ok(N, P.K)) return SW_ESHAPE;
     P.nbn = (N + 15) / 16;
-    P.nbk = (c1 - c0 + 15) / 16;
+    P.nbk = (P.K > 0 ? wg_tiles(P.K, true) : 1) + (has_ones ? 1 : 0);
   }
   return SW_OK;
 }
@@ -254,6 +121,7 @@ int wg_add_tail(WgBatch& b, const float* delta, int ldd, const float* act, int l
   P.delta = delta; P.ldd = ldd; P.act = act; P.lda = lda; P.R = R; P.N = N; P.K = K; P.ones = db ? 1 : 0;
   P.dW = dW; P.ldw = ldw; P.db = db; P.db2 = db ? db2 : nullptr; P.accumulate = accumulate; P.pre = 0;
   P.act2 = act2; P.lda2 = lda2; P.K2 = K2; P.dW2 = dW2; P.ldw2 = ldw2; P.row0 = row0;
+  if (!wg_shape_ok(N, K)) return SW_ESHAPE;
   P.nbn = (N + 15) / 16;
   P.nbk = 5;
   return SW_OK;
@@ -293,6 +161,14 @@ double wg_total_work(const WgBatch& b) {
   return w;
 }
 
+static double g_force_maxwg = 0.0;
+size_t wg_finalize_for(WgBatch& b, int max_wgs) {
+  g_force_maxwg = max_wgs;
+  const size_t r = wg_finalize(b);
+  g_force_maxwg = 0.0;
+  return r;
+}
+
 size_t wg_finalize(WgBatch& b) {
   // ~1024 workgroups = 4096 wave-jobs per launch (4 per SIMD), equal cost each
   const double total = wg_total_work(b) + 1.0;
@@ -305,7 +181,7 @@ size_t wg_finalize(WgBatch& b) {
   // full pipeline (swept: 512 -> 63 us, 448 -> 72, 576 -> 78, 1024 -> 69 for the generator pass at m1) - unless the
   // batch is so large that a second round still leaves each wave several grains of work (dense crowds: better balance)
   static const double maxwg_env = getenv("SW_WG_MAXWG") ? atof(getenv("SW_WG_MAXWG")) : 0.0;
-  const double maxwg = maxwg_env > 0.0 ? maxwg_env : (target >= 4096.0 ? 1024.0 : 512.0);
+  const double maxwg = g_force_maxwg > 0.0 ? g_force_maxwg : maxwg_env > 0.0 ? maxwg_env : (target >= 4096.0 ? 1024.0 : 512.0);
   if (target > maxwg) target = maxwg;
   size_t ws = 0;
   int job = 0, out = 0;
@@ -354,6 +230,95 @@ int wg_launch(WgBatch& b, float* ws, hipStream_t stream) {
   size_t need = wg_finalize(b);
   if (need > SW_WG_WS_FLOATS) return SW_ESHAPE;
   return wg_launch_finalized(b, ws, stream);
+}
+
+int wg_reduce_launch(WgBatch& b, float* ws, hipStream_t stream) {
+  if (b.total_out == 0) return SW_OK;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((b.total_out * SW_WG_RSUB + 255) / 256), dim3(256), 0, stream, b, ws);
+  SW_CHECK_LAUNCH("wgrad_reduce_kernel");
+  return SW_OK;
+}
+
+// ---- riders (host side) ------------------------------------------------------------------------------------------
+#include <algorithm>
+#include <map>
+#include <vector>
+static int g_cosched = -1;
+extern "C" int sw_set_cosched(int on) {
+  g_cosched = on ? 1 : 0;
+  return SW_OK;
+}
+extern "C" int sw_get_cosched(void) {
+  if (g_cosched < 0) {
+    const char* e = getenv("SW_COSCHED");
+    g_cosched = (e && e[0] == '1') ? 1 : 0;
+  }
+  return g_cosched;
+}
+bool wg_cosched() { return sw_get_cosched() != 0; }
+extern "C" void* sw_uc_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipExtMallocWithFlags(&p, bytes ? bytes : 4, hipDeviceMallocUncached) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+extern "C" void sw_uc_free(void* p) {
+  if (p) (void)hipFree(p);
+}
+int wg_ride_setup(const WgBatch& b, WgRide& ride, int kind, unsigned long long key, int nriders, unsigned target,
+                  int nevents, float* ws, const WgNeed& need, int job_lo, int job_hi) {
+  static unsigned* counters = nullptr;
+  static std::map<unsigned long long, int*> lists;
+  ride = WgRide();
+  if (nriders <= 0 || b.total_jobs <= 0 || nevents >= SW_RIDE_SLOTS || kind < 0 || kind > 2) return SW_OK;
+  if (!counters) {
+    counters = (unsigned*)sw_uc_alloc(3 * SW_RIDE_SLOTS * sizeof(unsigned));
+    if (!counters || hipMemset(counters, 0, 3 * SW_RIDE_SLOTS * sizeof(unsigned)) != hipSuccess) {
+      sw_set_error("rider counters (hipExtMallocWithFlags uncached)", hipGetLastError());
+      return SW_EHIP;
+    }
+  }
+  if (job_hi < 0) job_hi = b.total_jobs;
+  std::vector<std::pair<int, int>> jobs;   // (event, job)
+  for (int pi = 0; pi < b.np; ++pi) {
+    const WgProblem& P = b.p[pi];
+    if (P.pre) continue;
+    const int NB = (P.N + 63) / 64, nsub = P.nsplit * 4;
+    const int rows_per = (((P.R + nsub - 1) / nsub) + 3) & ~3;
+    for (int sg = 0; sg < P.nsplit; ++sg) {
+      const int rbeg = std::min(P.R, sg * 4 * rows_per), rend = std::min(P.R, (sg * 4 + 4) * rows_per);
+      const int ev = need(P, rbeg, rend);
+      for (int nb = 0; nb < NB; ++nb) {
+        const int job = P.job0 + sg * NB + nb;
+        if (job >= job_lo && job < job_hi) jobs.emplace_back(ev, job);
+      }
+    }
+  }
+  std::stable_sort(jobs.begin(), jobs.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first < y.first; });
+  key = key * 4 + (unsigned long long)kind;
+  int*& list = lists[key];
+  const size_t cap = 4096;
+  if (jobs.size() > cap) return SW_ESHAPE;
+  if (!list) {
+    if (hipHostMalloc((void**)&list, cap * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+      sw_set_error("rider job list (hipHostMalloc)", hipGetLastError());
+      return SW_EHIP;
+    }
+  }
+  static const int dbg = getenv("SW_RIDE_DEBUG") ? atoi(getenv("SW_RIDE_DEBUG")) : 0;   // timing experiments only (wrong results)
+  if (dbg == 1) jobs.clear();                                   // producers publish, riders idle
+  if (dbg == 2) for (auto& j : jobs) j.first = -1;              // riders never wait
+  for (size_t i = 0; i < jobs.size(); ++i) list[i] = jobs[i].second | ((jobs[i].first + 1) << 20);
+  ride.order = list;
+  ride.cnt = counters + kind * SW_RIDE_SLOTS;
+  ride.ws = ws;
+  ride.njobs = (int)jobs.size();
+  ride.nriders = nriders;
+  ride.nevents = nevents;
+  ride.target = target;
+  return SW_OK;
 }
 
 int wg_launch_finalized(WgBatch& b, float* ws, hipStream_t stream) {

@@ -1,0 +1,251 @@
+// sw_wgrad_dev.h - device code of the grouped split-K weight-gradient GEMM (see sw_wgrad.hip): the per-job body, shared by
+// wgrad_partial_kernel and by the serial kernels whose spare workgroups RIDE along (run jobs while the kernel computes).
+#pragma once
+#include "sw_common.h"
+#include "sw_wgrad.h"
+#ifndef SW_WG_DEPTH
+#define SW_WG_DEPTH 4
+#endif
+#ifndef SW_WG_DEPTH5
+#define SW_WG_DEPTH5 2
+#endif
+#ifndef SW_RIDE_DSCALE
+#define SW_RIDE_DSCALE 2
+#endif
+
+#define SW_WG_RLD 69   // LDS row stride of a wave's 64 x (<= 69) block: 64 act columns + tail segment + ones
+
+// NV consecutive floats as ONE vector load (dword / dwordx2 / dwordx3 / dwordx4)
+template <int NV>
+__device__ __forceinline__ void wg_ldv(float (&v)[NV], const float* p) {
+  if constexpr (NV == 4) {
+    const f32x4 q = *reinterpret_cast<const f32x4*>(p);
+    v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+  } else if constexpr (NV == 3) {
+    struct __attribute__((packed, aligned(4))) P3 { float a, b, c; };
+    const P3 q = *reinterpret_cast<const P3*>(p);
+    v[0] = q.a; v[1] = q.b; v[2] = q.c;
+  } else if constexpr (NV == 2) {
+    const float2 q = *reinterpret_cast<const float2*>(p);
+    v[0] = q.x; v[1] = q.y;
+  } else {
+    v[0] = p[0];
+  }
+}
+
+// Tiles per lane vector: the smallest t with 16 t >= n and n % t == 0 (every lane's vector is then wholly live or wholly
+// dead: no partial lane), t in {1, 2, 4} for delta columns, {1, 2, 3, 4} for act columns; 0 = no such t (the host
+// rejects the problem: SW_ESHAPE - cannot happen for the layer widths of this model, all multiples of 4 or <= 16)
+__host__ __device__ inline int wg_tiles(int n, bool allow3) {
+  if (n <= 16) return 1;
+  for (int t = (n + 15) >> 4; t <= 4; ++t)
+    if ((t != 3 || allow3) && n % t == 0) return t;
+  return 0;
+}
+
+// One wave = one job: a 64 x (<= 69) output block of one column block of one problem over one row slice, accumulated
+// in NA x (KR + XT) MFMA tiles.  MFMA K dimension = rows (4 per instruction: lane group lg = row r0 + lg).
+//
+// Operand loads are VECTOR loads: lane ln fetches the NA consecutive delta columns n0 + NA ln .. and the KR consecutive
+// act columns KR ln .. of its row - a 16-lane group reads one contiguous 64 NA / 64 KR-byte piece of the row - and
+// feeds component i to MFMA tile i.  Tile i therefore covers the columns {NA m + i}: a permutation of the output rows /
+// columns among the tiles, undone where the block is written out (`mine`).  (Round 1 loaded one dword per tile and
+// lane: 9 load instructions of 64-byte pieces per 20 MFMAs; the waves waited 58 % of their cycles.)  The summation
+// order of every output element - its rows, 4 per MFMA, in slice order - is unchanged: bit-identical results.
+//   NA = min(4, tiles of 16 delta columns in this block), KR = tiles of real act columns (1..4),
+//   XT = 1: one more k-tile holding the tail segment (act2, K2 columns) and / or the ones column at lanes ln = 0..
+// Branch-free streaming body: loads are unconditional from clamped addresses and masked by 0/1 factors; the pipeline
+// registers hold RAW loaded values (arithmetic attached to a load would sit in front of the loop's back edge and
+// drain the pipeline once per DEPTH groups).
+template <int NA, int KR, int XT, int DSCALE = 1>
+__device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const float* __restrict__ abase, int ldd, int lda,
+                                       int rbeg, int rend, int rmax, int acol, const float (&amask)[4], int bcol,
+                                       const float (&bmask)[4], int xcol, float xmask, float xone, int lg, int ln,
+                                       float* __restrict__ mine, const float* __restrict__ abase2, int lda2, int row0,
+                                       int xoff) {
+  constexpr int KT = KR + XT;
+  f32x4 acc[NA][KT];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) acc[i][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // 4-row groups in flight (swept on the GPU: 4 / 2 for the stand-alone launch at 8 waves per CU); riders have one
+  // workgroup per CU and the whole register file: DSCALE times deeper
+  constexpr int DEPTH = (KT == 5 ? SW_WG_DEPTH5 : SW_WG_DEPTH) * DSCALE;
+  float a[DEPTH][NA], b[DEPTH][KT];
+  auto load = [&](int r0, float (&av)[NA], float (&bv)[KT]) {
+    const int rc = min(r0 + lg, rmax);
+    float bt[KR];
+    wg_ldv<NA>(av, dbase + (size_t)rc * ldd + acol);
+    wg_ldv<KR>(bt, abase + (size_t)max(rc, row0) * lda + bcol);     // rows below row0 have no `act` operand
+#pragma unroll
+    for (int kt = 0; kt < KR; ++kt) bv[kt] = bt[kt];
+    if constexpr (XT) bv[KR] = (abase2 + (size_t)rc * lda2)[xcol];   // tail segment | ones
+  };
+#pragma unroll
+  for (int q = 0; q < DEPTH - 1; ++q) load(rbeg + 4 * q, a[q], b[q]);
+  for (int r = rbeg; r < rend; r += 4 * DEPTH) {
+#pragma unroll
+    for (int q = 0; q < DEPTH; ++q) {
+      load(r + 4 * (q + DEPTH - 1), a[(q + DEPTH - 1) % DEPTH], b[(q + DEPTH - 1) % DEPTH]);
+      asm volatile("" ::: "memory");   // the loads are issued HERE (DEPTH - 1 groups ahead), not sunk to their uses
+#pragma unroll
+      for (int i = 0; i < NA; ++i) asm volatile("" : "+v"(a[q][i]));   // ... and group q is first touched here
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) asm volatile("" : "+v"(b[q][kt]));
+      const int rr = r + 4 * q + lg;
+      const float rs = rr < rend ? 1.0f : 0.0f;
+      const float rs0 = rr >= row0 ? rs : 0.0f;
+      float av[NA], bv[KT];
+#pragma unroll
+      for (int i = 0; i < NA; ++i) av[i] = a[q][i] * (amask[i] * rs);
+#pragma unroll
+      for (int kt = 0; kt < KR; ++kt) bv[kt] = b[q][kt] * (bmask[kt] * rs0);
+      if constexpr (XT) bv[KR] = fmaf(b[q][KR], xmask, xone) * rs;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) acc[i][kt] = SW_MFMA(av[i], bv[kt], acc[i][kt]);
+      }
+    }
+  }
+  // tile (i, kt) element (m = 4 lg + r, n = ln)  =  output row NA m + i, act column KR n + kt (extra tile: xoff + n)
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int orow = NA * (4 * lg + r) + i;
+        if (kt < KR) {
+          if (KR * ln + kt < xoff) mine[orow * SW_WG_RLD + KR * ln + kt] = acc[i][kt][r];      // xoff = K: live columns only
+        } else if (xoff + ln < SW_WG_RLD) {
+          mine[orow * SW_WG_RLD + xoff + ln] = acc[i][kt][r];
+        }
+      }
+    }
+  }
+}
+
+// One workgroup-job = 4 waves = 4 consecutive row slices of one output block (summed through LDS at the end); every
+// wave streams independently (no LDS, no barriers in the loop).  `red` = 4 x 64 x SW_WG_RLD floats of LDS.
+#define SW_WG_RED_FLOATS (4 * 64 * SW_WG_RLD)
+template <int DSCALE = 1>
+__device__ __forceinline__ void wg_job(const WgBatch& batch, float* __restrict__ ws, int job, float* red) {
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  int p = 0;
+#pragma unroll 1
+  while (p + 1 < batch.np && job >= batch.job0s[p + 1]) ++p;
+  const WgProblem& P = batch.p[p];
+  const int j = job - P.job0;
+  const int NB = (P.N + 63) >> 6;       // 64-row output blocks
+  const int sg = j / NB, nb = j - sg * NB;
+  const int s = sg * 4 + wave;          // this wave's row slice (may be empty)
+  const int N = P.N, K = P.K, Kc = P.K + P.K2 + P.ones;
+  const int n0 = nb * 64;
+  const int Nb = min(64, N - n0);                       // live delta columns of this block
+  const int NA = wg_tiles(Nb, false);                   // delta tiles
+  const int KR = K > 0 ? wg_tiles(K, true) : 1;         // real act tiles (a block with only the ones column: one masked tile)
+  const int XT = (P.K2 + P.ones) > 0 ? 1 : 0;
+  const int nsub = P.nsplit * 4;
+  const int rows_per = (((P.R + nsub - 1) / nsub) + 3) & ~3;
+  const int rbeg = min(P.R, s * rows_per);
+  const int rend = min(P.R, rbeg + rows_per);
+  // the lane's NA delta columns n0 + NA ln + i and KR act columns KR ln + kt; bases clamped into the row, dead
+  // components masked
+  const int acol = n0 + max(0, min(NA * ln, Nb - NA));
+  const int bcol = max(0, min(KR * ln, K - KR));
+  float amask[4], bmask[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    amask[i] = (NA * ln + i < Nb && acol == n0 + NA * ln) ? 1.0f : 0.0f;
+    bmask[i] = (KR * ln + i < K && bcol == KR * ln) ? 1.0f : 0.0f;
+  }
+  // extra tile: columns of act2 (K2), then the ones column
+  const int xcol = min(ln, max(P.K2 - 1, 0));
+  const float xmask = ln < P.K2 ? 1.0f : 0.0f;
+  const float xone = (P.ones && ln == P.K2) ? 1.0f : 0.0f;
+  float* mine = red + wave * 64 * SW_WG_RLD;
+#define WG_CASE(na, kr, xt)                                                                                        \
+  case na * 16 + kr * 2 + xt:                                                                                      \
+    wg_run<na, kr, xt, DSCALE>(P.delta, P.act, P.ldd, P.lda, rbeg, rend, P.R - 1, acol, amask, bcol, bmask, xcol, xmask, xone, lg, \
+                       ln, mine, P.act2 ? P.act2 : P.delta, P.act2 ? P.lda2 : P.ldd, P.row0, K);                    \
+    break;
+  switch (NA * 16 + KR * 2 + XT) {
+    WG_CASE(1, 1, 0) WG_CASE(1, 2, 0) WG_CASE(1, 3, 0) WG_CASE(1, 4, 0)
+    WG_CASE(1, 1, 1) WG_CASE(1, 2, 1) WG_CASE(1, 3, 1) WG_CASE(1, 4, 1)
+    WG_CASE(2, 1, 0) WG_CASE(2, 2, 0) WG_CASE(2, 3, 0) WG_CASE(2, 4, 0)
+    WG_CASE(2, 1, 1) WG_CASE(2, 2, 1) WG_CASE(2, 3, 1) WG_CASE(2, 4, 1)
+    WG_CASE(4, 1, 0) WG_CASE(4, 2, 0) WG_CASE(4, 3, 0) WG_CASE(4, 4, 0)
+    WG_CASE(4, 1, 1) WG_CASE(4, 2, 1) WG_CASE(4, 3, 1) WG_CASE(4, 4, 1)
+  }
+#undef WG_CASE
+  sw_barrier();
+  // one partial per workgroup (4 row slices summed): ws[ws_off + (sg*N + n)*Kc + k]
+  float* out = ws + P.ws_off + (size_t)sg * N * Kc;
+  const int rows = min(64, N - n0), cols = min(SW_WG_RLD, Kc);
+  // element e = rr * cols + cc walks the block row-major; (rr, cc) advance incrementally (one division per thread)
+  const int dq = SW_THREADS / cols, dr = SW_THREADS - dq * cols;
+  int rr = threadIdx.x / cols, cc = threadIdx.x - rr * cols;
+  const float* r0 = red, *r1 = red + 64 * SW_WG_RLD, *r2 = red + 2 * 64 * SW_WG_RLD, *r3 = red + 3 * 64 * SW_WG_RLD;
+  for (int e = threadIdx.x; e < rows * cols; e += SW_THREADS) {
+    const int o = rr * SW_WG_RLD + cc;
+    const float v = (r0[o] + r1[o]) + (r2[o] + r3[o]);
+    out[(size_t)(n0 + rr) * Kc + cc] = v;
+    cc += dr;
+    rr += dq;
+    if (cc >= cols) {
+      cc -= cols;
+      ++rr;
+    }
+  }
+}
+
+// ---- riders ------------------------------------------------------------------------------------------------------
+// Spare workgroups of a serial (BPTT) launch run weight-gradient jobs WHILE the launch computes: the tile workgroups
+// publish "rows of event e are in memory" (their delta rows live in UNCACHED device memory: plain stores,
+// s_waitcnt vmcnt(0), one relaxed device-scope increment per wave - tools/mb/uc_handoff.hip: no stale read in 2.5 M
+// checked values, 8 cycles of waiting per step), a rider waits for the event its next job needs.  Riders never block
+// tile workgroups, the launch holds at most one workgroup per CU in total, tile workgroups come first in the grid.
+// Publishing an event costs ONE atomic per workgroup (512 waves incrementing one counter serialise at ~12 ns each, and
+// the next publish of a wave waits for its previous atomic: measured +42 us on a 27 us kernel): every wave drains its
+// own stores (wg_drain) in front of a workgroup barrier the kernel has anyway, one lane signals behind it (wg_signal).
+__device__ __forceinline__ void wg_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wg_signal(unsigned* cnt_e) {
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt_e, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wg_ride(const WgBatch& batch, const WgRide& ride, int rider, float* red) {
+  __shared__ int s_packed;
+  for (int k = rider; k < ride.njobs; k += ride.nriders) {
+    if (threadIdx.x == 0) {
+      const int packed = ride.order[k];                // job | (event + 1) << 20, event + 1 == 0: ready at launch
+      const int ev = (packed >> 20) - 1;
+      if (ev >= 0) {
+        int spins = 0;
+        while (__hip_atomic_load(ride.cnt + ev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ride.target) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1 << 24)) break;              // ~seconds: a lost producer must not hang the device
+        }
+      }
+      s_packed = packed & 0xfffff;
+    }
+    __syncthreads();
+    const int job = s_packed;
+    wg_job<SW_RIDE_DSCALE>(batch, ride.ws, job, red);
+    __syncthreads();
+  }
+  // the last rider to leave re-arms the counters for the next launch (every event it could reset is complete: it
+  // has run its jobs, and every other rider has left)
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(ride.cnt + SW_RIDE_SLOTS - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (unsigned)ride.nriders - 1) {
+      for (int e = 0; e < ride.nevents; ++e) {         // (an event no job waited for may still be filling up)
+        int spins = 0;
+        while (__hip_atomic_load(ride.cnt + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ride.target && ++spins < (1 << 24))
+          __builtin_amdgcn_s_sleep(8);
+      }
+      for (int i = 0; i < SW_RIDE_SLOTS; ++i) __hip_atomic_store(ride.cnt + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
