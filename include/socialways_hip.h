@@ -218,6 +218,18 @@ int sw_disc_bwd_gan(const float* d_w, const float* dsave, const float* const* la
                     float* loss_part /*[ceil(B/16)][3] or NULL: per-tile sums {(label_0-t0)^2, (code_0-z)^2,
                                        (label_1-t1)^2}, the reported MSE terms; column 2 untouched if nb == 1*/,
                     void* stream);
+/* The same with the discriminator's Adam update (train.py:384-385: lr, betas, eps; no weight decay) applied by the
+ * kernel that finishes the gradients: every discriminator parameter is an output of that reduction, so its thread
+ * updates exp_avg, exp_avg_sq and the weight right there - operation for operation torch's fused Adam
+ * (fused_adam_utils.cuh) - and the optimizer's own launch disappears.  adam_w must be d_w (the packed weights the pass
+ * just read: all of its readers are behind kernel boundaries), adam_m / adam_v the packed moments, adam_step a device
+ * scalar holding the 1-based index of this update.  adam_w = NULL: plain sw_disc_bwd_gan.  Single process only: data
+ * parallel ranks all-reduce the gradients between this call and their optimizer step.                             */
+int sw_disc_bwd_gan_adam(const float* d_w, const float* dsave, const float* const* label, const float* const* code,
+                         const float* targets, int t0, int t1, const float* z, float g_label, float g_code, int nb,
+                         int B, int To, int Tp, float* ddelta, float* d_d_w, float* const* dpred4, float* wgrad_ws,
+                         float* loss_part, float* adam_w, float* adam_m, float* adam_v, const float* adam_step,
+                         double lr, double beta1, double beta2, double eps, void* stream);
 
 /* ---- generator phase in one launch (train.py:510-523, 538): D forward on (obsv, pred_hat) fused with the backward of
  *      its prediction heads: dpred4 = d(g_loss)/d(pred_hat) with g_loss = mse(label, targets[t_idx]) +

@@ -729,7 +729,7 @@ extern "C" int sw_disc_dpred(const float* obsv, int To, int x_mode, const float*
 
 static int disc_bwd_impl(const float* d_w, const float* dsave, const float* const* dlabel, const float* const* dcode,
                          int nb, int B, int To, int Tp, float* ddelta, float* d_d_w, float* const* dpred4,
-                         float* wgrad_ws, void* stream, DiscLoss gl) {
+                         float* wgrad_ws, void* stream, DiscLoss gl, const WgAdam& adam = WgAdam()) {
   if (!d_w || !dsave || !dlabel || !dcode || nb < 1 || nb > SW_DISC_MAXB || B < 0 || To < 1 || Tp < 1) return SW_EARG;
   for (int k = 0; k < nb; ++k)
     if (!dlabel[k] || !dcode[k]) return SW_EARG;
@@ -794,8 +794,8 @@ static int disc_bwd_impl(const float* d_w, const float* dsave, const float* cons
                      d_d_w ? 1 : 0, ddelta, dpred4 ? dpred4[0] : nullptr, (dpred4 && nb > 1) ? dpred4[1] : nullptr, gl, wb, ride);
   SW_CHECK_LAUNCH("disc_bwd_kernel");
   if (!d_d_w) return SW_OK;
-  if (ride.nriders > 0) return wg_reduce_launch(wb, wgrad_ws, st);
-  return wg_launch(wb, wgrad_ws, st);
+  if (ride.nriders > 0) return wg_reduce_launch_adam(wb, wgrad_ws, adam, st);
+  return wg_launch_adam(wb, wgrad_ws, adam, st);
 }
 
 extern "C" int sw_disc_bwd(const float* d_w, const float* dsave, const float* const* dlabel,
@@ -807,11 +807,26 @@ extern "C" int sw_disc_bwd(const float* d_w, const float* dsave, const float* co
   return disc_bwd_impl(d_w, dsave, dlabel, dcode, nb, B, To, Tp, ddelta, d_d_w, dpred4, wgrad_ws, stream, gl);
 }
 
+extern "C" int sw_disc_bwd_gan_adam(const float* d_w, const float* dsave, const float* const* label,
+                                    const float* const* code, const float* targets, int t0, int t1, const float* z,
+                                    float g_label, float g_code, int nb, int B, int To, int Tp, float* ddelta,
+                                    float* d_d_w, float* const* dpred4, float* wgrad_ws, float* loss_part,
+                                    float* adam_w, float* adam_m, float* adam_v, const float* adam_step, double lr,
+                                    double beta1, double beta2, double eps, void* stream) {
+  if (!targets || !z || t0 < 0 || t1 < 0) return SW_EARG;
+  if (adam_w && (!adam_m || !adam_v || !adam_step || !d_d_w || adam_w != d_w)) return SW_EARG;
+  DiscLoss gl{targets, z, t0, t1, g_label, g_code, 1, loss_part};
+  WgAdam ad;
+  if (adam_w) {
+    ad.w = adam_w; ad.m = adam_m; ad.v = adam_v; ad.g0 = d_d_w; ad.step = adam_step;
+    ad.lr = lr; ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps;
+  }
+  return disc_bwd_impl(d_w, dsave, label, code, nb, B, To, Tp, ddelta, d_d_w, dpred4, wgrad_ws, stream, gl, ad);
+}
 extern "C" int sw_disc_bwd_gan(const float* d_w, const float* dsave, const float* const* label,
                                const float* const* code, const float* targets, int t0, int t1, const float* z,
                                float g_label, float g_code, int nb, int B, int To, int Tp, float* ddelta,
                                float* d_d_w, float* const* dpred4, float* wgrad_ws, float* loss_part, void* stream) {
-  if (!targets || !z || t0 < 0 || t1 < 0) return SW_EARG;
-  DiscLoss gl{targets, z, t0, t1, g_label, g_code, 1, loss_part};
-  return disc_bwd_impl(d_w, dsave, label, code, nb, B, To, Tp, ddelta, d_d_w, dpred4, wgrad_ws, stream, gl);
+  return sw_disc_bwd_gan_adam(d_w, dsave, label, code, targets, t0, t1, z, g_label, g_code, nb, B, To, Tp, ddelta, d_d_w,
+                              dpred4, wgrad_ws, loss_part, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, stream);
 }

@@ -35,6 +35,21 @@ struct WgBatch {
   size_t top_reserved = 0;   // floats handed out from the TOP of the workspace to precomputed-partial problems
 };
 
+// ---- Adam fused into the reduction: the thread that produces the final value of a gradient element also applies the
+// update to its weight (torch's fused Adam, aten/src/ATen/native/cuda/fused_adam_utils.cuh, restated operation by
+// operation incl. its float / double mix).  Valid when every parameter of the optimizer is an output of this very
+// reduction (the discriminator pass) and no all-reduce sits between gradient and update (single process).
+struct WgAdam {
+  float* w = nullptr;          // packed weights; m, v: packed Adam moments; all indexed like the packed gradient buffer g0
+  float* m = nullptr;
+  float* v = nullptr;
+  const float* g0 = nullptr;
+  const float* step = nullptr; // device scalar: 1-based index of this update (float, like torch's state step)
+  double lr = 0, beta1 = 0, beta2 = 0, eps = 0;
+};
+int wg_reduce_launch_adam(WgBatch& b, float* ws, const WgAdam& ad, hipStream_t stream);
+int wg_launch_adam(WgBatch& b, float* ws, const WgAdam& ad, hipStream_t stream);
+
 // ---- riders: weight-gradient jobs run by the spare workgroups of a serial launch (sw_wgrad_dev.h) ----------------
 #define SW_RIDE_SLOTS 48      // event counters per host kernel; the last one counts riders that have left
 struct WgRide {

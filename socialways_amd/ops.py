@@ -329,7 +329,7 @@ def disc_dpred(d_w, obsv, pred_hat, targets, t_idx, z, g_label, g_code, loss_par
 
 
 def disc_backward_gan(d_w, ctx, labels, codes, targets, t_idx, z, g_label, g_code, d_d_w=None, want_dpred=(), ws=None,
-                      tag="d", loss_part=None):
+                      tag="d", loss_part=None, adam=None):
     """disc_backward with the LSGAN / InfoGAN loss gradients formed inside the kernel from the forward
     outputs `labels` / `codes` (targets = device [2] label-noise scalars, t_idx = target index per branch).
     loss_part (ceil(B/16),3): receives the per-tile sums of the squared errors (the reported MSE terms)."""
@@ -346,6 +346,12 @@ def disc_backward_gan(d_w, ctx, labels, codes, targets, t_idx, z, g_label, g_cod
     cp, _k2 = L.ptr_array(codes)
     dp, _k3 = L.ptr_array(dpreds)
     t0, t1 = (list(t_idx) + [0])[:2]
+    if adam is not None:      # (m, v, step scalar, lr, beta1, beta2, eps): the update rides in the gradient reduction
+        m, v, step, lr, b1, b2, eps = adam
+        L.call("sw_disc_bwd_gan_adam", L.ptr(d_w), L.ptr(ctx.dsave), lp, cp, L.ptr(targets), t0, t1, L.ptr(z), g_label, g_code,
+               nb, B, To, Tp, L.ptr(ddelta), L.ptr(d_d_w), dp, L.ptr(wgrad), L.ptr(loss_part), L.ptr(d_w), L.ptr(m), L.ptr(v),
+               L.ptr(step), float(lr), float(b1), float(b2), float(eps), L.stream())
+        return dpreds
     L.call("sw_disc_bwd_gan", L.ptr(d_w), L.ptr(ctx.dsave), lp, cp, L.ptr(targets), t0, t1, L.ptr(z), g_label, g_code, nb,
            B, To, Tp, L.ptr(ddelta), L.ptr(d_d_w), dp, L.ptr(wgrad), L.ptr(loss_part), L.stream())
     return dpreds

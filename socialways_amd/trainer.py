@@ -69,6 +69,16 @@ class PackedAdam:
                            lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], weight_decay=g["weight_decay"],
                            eps=g["eps"], maximize=False, grad_scale=None, found_inf=None)
 
+    def fused_args(self, step_tensor=None):
+        """(m, v, step scalar, lr, beta1, beta2, eps) for a kernel that applies this update itself
+        (sw_disc_bwd_gan_adam) - the bookkeeping of `step()` without the launch."""
+        if step_tensor is None:
+            self.t += 1
+            self.step_t.fill_(float(self.t))
+            step_tensor = self.step_t
+        g = self.group
+        return (self.m, self.v, step_tensor, g["lr"], g["betas"][0], g["betas"][1], g["eps"])
+
     def zero_grad(self, set_to_none=False):
         for t in self.gs:
             t.zero_()
@@ -143,6 +153,7 @@ class SocialWaysTrainer:
         self.max_graphs = 8
         self._graphs = {}
         self._force_dist = os.environ.get("SW_FORCE_DIST", "") == "1"   # 1-rank group still runs the collectives (tests)
+        self._fuse_d_adam = os.environ.get("SW_FUSE_D_ADAM", "1") == "1"  # D's Adam inside the gradient reduction (world 1)
         # Data parallel: are the RCCL all-reduces recorded INSIDE the step graph (one launch for K steps) or run
         # eagerly between graph segments (3 segment boundaries per step)?  SW_GRAPH_COLLECTIVES=1 / 0 decides;
         # unset = probe once (a small captured all-reduce replayed twice and checked on every rank) and use the
@@ -526,11 +537,16 @@ class SocialWaysTrainer:
             labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat, pred4], save=True, ws=ws,
                                                    save_lstm=2 if (u == 0 and d_pre is not None) else 1,
                                                    w_snapshot=backup if u == 1 else None)
-            # the loss gradients AND the reported loss sums (per-tile partials) are formed inside the backward kernel
+            # the loss gradients AND the reported loss sums (per-tile partials) are formed inside the backward kernel;
+            # in a single process (no all-reduce between gradient and update) D's Adam step rides in the kernel that
+            # finishes the gradients
+            fuse = self._fuse_d_adam and isinstance(self.D_optimizer, PackedAdam) and not (self.world > 1 or self._force_dist)
             ops.disc_backward_gan(D._flat, dctx, labels, codes, targets, (0, 1), noise, g_label, g_code, d_gflat, (), ws=ws,
-                                  loss_part=out[u])
+                                  loss_part=out[u],
+                                  adam=self.D_optimizer.fused_args(None if steps is None else steps[u]) if fuse else None)
             yield d_gflat
-            self.D_optimizer.step() if steps is None else self.D_optimizer.step(steps[u])
+            if not fuse:
+                self.D_optimizer.step() if steps is None else self.D_optimizer.step(steps[u])
         # ---- generator update (train.py:503-539) ----------------------------------------------------
         # D forward on the prediction + backward of its heads down to d(g_loss)/d(pred_hat), one launch, nothing saved
         dpred = ops.disc_dpred(D._flat, obsv, pred_hat, targets, 1, noise, g_label, g_code, loss_part=out[U + 1])
