@@ -230,3 +230,34 @@ def _d_obs_case(B):
         assert torch.equal(x, y)
     n = L.workspace_floats(L.WS_DSAVE, B, 8, 12, 2)
     assert torch.equal(ctx_a.dsave[:n], ctx_b.dsave[:n])
+
+
+@pytest.mark.parametrize("B", [40, 1024])
+def test_riders_reproduce_the_deferred_weight_gradients(B):
+    """sw_set_cosched(1): the weight-gradient jobs of a discriminator pass run in spare workgroups of the disc_bwd launch
+    itself, fed through uncached memory as the BPTT publishes its rows (opt-in experiment).  Same
+    gradients as the deferred launch (different row slicing: summation order only), repeatable bit for bit."""
+    import socialways_amd as sw
+    from socialways_amd import ops, _lib as L
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B)
+    D = sw.Discriminator(12, 64, 2, device=dev)
+    obsv = torch.randn(B, 8, 2, device=dev).cumsum(1) * 0.1
+    fake, real = torch.randn(B, 12, 4, device=dev) * 0.1, torch.randn(B, 12, 4, device=dev) * 0.1
+    z = torch.rand(B, 32, device=dev)
+    targets = torch.tensor([0.05, 0.95], device=dev)
+    grads = []
+    for mode in (0, 1, 1):
+        L.load().sw_set_cosched(mode)
+        try:
+            ws = ops.Workspaces(dev)
+            labels, codes, ctx = ops.disc_forward(D._flat, obsv, [fake, real], save=True, ws=ws)
+            g = torch.zeros_like(D._flat)
+            part = torch.zeros((B + 7) // 8, 3, device=dev)
+            ops.disc_backward_gan(D._flat, ctx, labels, codes, targets, (0, 1), z, 1.0 / B, 0.25 / B, g, (), ws=ws, loss_part=part)
+            torch.cuda.synchronize()
+            grads.append(g.clone())
+        finally:
+            L.load().sw_set_cosched(0)
+    assert torch.equal(grads[1], grads[2])
+    assert_close(grads[1].cpu(), grads[0].cpu(), 2e-5, 2e-6 * float(grads[0].abs().max()), "riders vs deferred launch")

@@ -29,5 +29,17 @@ for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
     out[name] = {"kernel": k, "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
                  "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
+# identity of the kernel sources this pass was taken with: bench.py reports `roofline.traffic` only while they match
+import glob, hashlib, os, subprocess
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+h = hashlib.sha256()
+for f in sorted(glob.glob(os.path.join(root, "socialways_amd", "csrc", "*.h*"))):
+    h.update(open(f, "rb").read())
+try:
+    commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+except Exception:
+    commit = os.environ.get("SW_COMMIT", "unknown")
+out["_meta"] = {"kernel_src_sha16": h.hexdigest()[:16], "commit": commit,
+                "units": "FETCH_SIZE / WRITE_SIZE in KiB; hbm_bytes_per_launch = (2 FETCH + WRITE) * 1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md)"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
