@@ -287,6 +287,20 @@ int sw_stage_step(const float* slot, int B, int To, int Tp, float* obsv_dst /*[B
                   float* pred4_dst /*[B,Tp,4]*/, float* targets_dst /*[2]*/, float* z_dst /*[B,32]*/,
                   float* steps_dst /*[n_d_updates+1] or NULL*/, int n_d_updates, void* stream);
 
+/* ---- derived weight images of the generator.  Every workgroup of the encoder / decode launches needs the composed input
+ *      matrix W_ih W_embed (train.py:266-268: no non-linearity between embed and the LSTM), fc4 . fc3 and - in the
+ *      backward pass - the transposed decoder matrices.  sw_gen_images derives them ONCE into img (sw_gen_image_floats()
+ *      floats) and REGISTERS them for (enc_w, dec_w): until the registration is dropped, sw_enc_lstm_fwd*,
+ *      sw_dec_rollout_fwd*, sw_dec_rollout_bwd* called with these weight buffers copy the images instead of deriving
+ *      them per workgroup (same values bit for bit).  The images are valid while the weights are unchanged: the caller
+ *      drops the registration - sw_gen_images(NULL, NULL, NULL, NULL) - before it updates them.
+ *      sw_stage_step_img = sw_stage_step whose launch derives and registers the images as well (no extra launch).   */
+int sw_gen_image_floats(void);
+int sw_gen_images(const float* enc_w, const float* dec_w, float* img, void* stream);
+int sw_stage_step_img(const float* slot, int B, int To, int Tp, float* obsv_dst, float* pred_dst, float* pred4_dst,
+                      float* targets_dst, float* z_dst, float* steps_dst, int n_d_updates, const float* enc_w,
+                      const float* dec_w, float* img, void* stream);
+
 /* ---- ADE/FDE partial sums of train.py:546-551:
  *      out[3] = { sum_{b,t} err / Tp, sum_b err[:, -1], sum_{b,t} err^2 },  err = |(p_hat - p) / ss|   */
 int sw_ade_fde(const float* pred4 /*[B,Tp,4]*/, const float* gt /*[B,Tp,2]*/, int B, int Tp, float inv_ss,

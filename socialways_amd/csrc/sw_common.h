@@ -292,6 +292,25 @@ __host__ __device__ inline GDelta gdelta_layout(int B, int To, int Tp) {
   return g;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Derived images of the generator's weights (sw_gen_images, sw_misc.hip): what every workgroup of the encoder / decode
+// launches used to derive for itself in its prologue - the composed input matrix W_ih W_embed (256 uncoalesced row reads
+// + 80 K MACs per workgroup), fc4 . fc3, and the TRANSPOSED, zero-padded decoder matrices of the backward pass (scalar
+// LDS scatter with 8-way bank conflicts) - computed ONCE per step by a few workgroups of the staging launch.  The
+// prologues then copy them with coalesced 16-byte loads (dec_rollout_bwd: 9.9 -> ~3 us).  Layout in floats:
+// ---------------------------------------------------------------------------------------------
+namespace swimg {
+constexpr int WX = 0;                    // [256][4]   W_ih W_embed
+constexpr int BX = 1024;                 // [256]      W_ih b_embed + b_ih + b_hh
+constexpr int W43 = 1280;                // [2][80] | b43[2]   fc4 . fc3, fc4 b3 + b4
+constexpr int W43T = W43 + 176;          // [80][20]   (fc4 . fc3)^T, columns >= 2 zero
+constexpr int W1HT = W43T + 80 * 20;     // [64][164]  fc1.0.weight[:, :64]^T, columns >= 160 zero
+constexpr int W2T = W1HT + 64 * 164;     // [160][84]  fc1.2.weight^T, columns >= 80 zero
+constexpr int N = W2T + 160 * 84;
+}  // namespace swimg
+// the images registered for (enc_w, dec_w) by the current step, or null (sw_gen_images)
+const float* sw_gen_images_for(const float* enc_w, const float* dec_w);
+
 // tiling choice of the serial kernels (sw_misc.hip: sw_set_tile_mode / SW_TILE_MODE)
 bool sw_narrow_tiles(int B);
 

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
     const float* __restrict__ dec_w, int B, int Tp, float* __restrict__ pred4, float* __restrict__ h_end,
     float* __restrict__ c_end, float* __restrict__ gsave, const float* __restrict__ gt, float inv_ss,
     float* __restrict__ ade_part, const float* __restrict__ dobs_w, float* __restrict__ dobs_act,
-    float* __restrict__ dobs_x4s) {
+    float* __restrict__ dobs_x4s, const float* __restrict__ gimg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // Workgroups beyond the agent tiles (only launched while the rollout leaves CUs idle): the observation LSTM of
   // the discriminator's first pass of this step - it does not depend on the generator - with the rows disc_bwd needs
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
   f32x4 r1[11], r2[13], r3[4];
   stage_w_load<11>(r1, LD64, 160, dec_w + swp::DEC_W1, 160, 160, 64);
   stage_w_load<13>(r2, LD160, 80, dec_w + swp::DEC_W2, 160, 80, 160);
-  stage_w_load<4>(r3, LD80, 40, dec_w + swp::DEC_W3, 80, 40, 80);
+  if (!gimg) stage_w_load<4>(r3, LD80, 40, dec_w + swp::DEC_W3, 80, 40, 80);
   f32x4 c = ld4(cT + (size_t)b * 64 + u0 + 4 * lg);
   f32x4 h = ld4(hT + (size_t)b * 64 + u0 + 4 * lg);
   float szv[6];
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
   // composed per workgroup after the staging barrier (like W_ih . W_embed of the encoder): one layer less on the
   // serial chain of every decode step; a3 itself is never needed (its weight gradients are recovered from
   // dv^T [a2 | 1], sw_misc.hip).
-  stage_w_store<4>(r3, smem + FwdLds::W3tmp, LD80, 40);
+  if (!gimg) stage_w_store<4>(r3, smem + FwdLds::W3tmp, LD80, 40);
 #pragma unroll
   for (int q = 0; q < 6; ++q) {
     const int i = threadIdx.x + q * SW_THREADS, a = i / 96, cc = i - a * 96;
@@ -125,6 +125,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
   for (int i = threadIdx.x; i < 144; i += blockDim.x) {
     float v = 0.f;
     if (i < 80) v = dec_w[swp::DEC_B2 + i];
+    else if (i >= 128 && i < 130 && gimg) v = gimg[swimg::W43 + 160 + (i - 128)];
     else if (i >= 128 && i < 130) {
       const int c = i - 128;
       v = dec_w[swp::DEC_B4 + c];
@@ -136,14 +137,21 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
     }
     bbuf[i] = v;
   }
-  lstm_prep_rows(enc_w + swp::ENC_EMB_W, enc_w + swp::ENC_EMB_B, enc_w + swp::ENC_WIH, enc_w + swp::ENC_BIH,
-                 enc_w + swp::ENC_BHH, true, wx_lds, bx_lds);
+  if (gimg) {   // composed input matrix and fc4 . fc3 of this step: derived once by the staging launch (swimg)
+    st4(wx_lds + 4 * threadIdx.x, ld4(gimg + swimg::WX + 4 * threadIdx.x));
+    bx_lds[threadIdx.x] = gimg[swimg::BX + threadIdx.x];
+  } else {
+    lstm_prep_rows(enc_w + swp::ENC_EMB_W, enc_w + swp::ENC_EMB_B, enc_w + swp::ENC_WIH, enc_w + swp::ENC_BIH,
+                   enc_w + swp::ENC_BHH, true, wx_lds, bx_lds);
+  }
   st4(&hbuf[ln * LD64 + u0 + 4 * lg], h);
   sw_barrier();
   lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
   for (int i = threadIdx.x; i < 16 * LD80; i += blockDim.x)        // zero padding around the two live rows
     if (i >= 2 * LD80 || i % LD80 >= 80) W43[i] = 0.f;
-  if (threadIdx.x < 160) {   // W43 = W4 W3 from the staged fc3 image: one output per thread, 4 independent partial sums
+  if (gimg) {
+    if (threadIdx.x < 160) W43[(threadIdx.x / 80) * LD80 + threadIdx.x % 80] = gimg[swimg::W43 + threadIdx.x];
+  } else if (threadIdx.x < 160) {   // W43 = W4 W3 from the staged fc3 image: one output per thread, 4 independent partial sums
     const int c = threadIdx.x / 80, k = threadIdx.x - c * 80;
     const float* w4 = dec_w + swp::DEC_W4 + c * 40;
     const float* w3 = smem + FwdLds::W3tmp + k;
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
     const float* __restrict__ dpred4, const float* __restrict__ enc_w, const float* __restrict__ dec_w,
     const float* __restrict__ gsave, int B, int To, int Tp, float* __restrict__ gdelta,
     float* __restrict__ dhT, float* __restrict__ dcT, float* __restrict__ dS_pool, const float* __restrict__ aux_src,
-    float* __restrict__ aux_dst, const float* __restrict__ aux_mask, long long aux_n) {
+    float* __restrict__ aux_dst, const float* __restrict__ aux_mask, long long aux_n, const float* __restrict__ gimg) {
   // Workgroups beyond the agent tiles run an auxiliary masked copy dst[i] = mask[i] > 0 ? src[i] : dst[i]
   // (the training step's D.load(backup), train.py:541-542, on CUs this latency-bound launch leaves idle)
   {
@@ -311,8 +319,37 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
 
   // ---- prologue: transposed decoder weights into LDS, composed Wx^T, W_hh^T into registers ---
   // All global loads of the prologue are issued before anything waits on them (one L2 round trip, not one per matrix)
+#ifdef SW_PHASE_STAMPS
+  long long _tprev = clock64();
+#endif
   LstmWT WT;
   lstm_load_wT(WT, enc_w + swp::ENC_WHH, u0, ln, lg);
+  if (gimg) {
+    // The transposed, zero-padded images of this step were derived once by the staging launch (swimg, sw_common.h):
+    // a straight coalesced copy - [64][164] | [160][84] | [80][20] = 25 536 floats, 25 float4 per thread - instead of
+    // scalar LDS scatters (8-way bank conflicts) and 80 K MACs of composition per workgroup (9.9 -> ~3 us of prologue)
+    f32x4 q[25];
+    constexpr int n1 = 64 * LD160 / 4, n2 = 160 * LD80 / 4, n3 = 80 * LD2 / 4;
+    static_assert(BwdLds::W2T == BwdLds::W1hT + 64 * LD160 && BwdLds::W43T == BwdLds::W2T + 160 * LD80, "images are contiguous in LDS");
+    static_assert(swimg::W2T == swimg::W1HT + 64 * LD160, "... and in the image buffer");
+#pragma unroll
+    for (int j = 0; j < 25; ++j) {
+      const int f = threadIdx.x + SW_THREADS * j;
+      const float* src = f < n1 + n2 ? gimg + swimg::W1HT + 4 * f : gimg + swimg::W43T + 4 * (f - n1 - n2);
+      q[j] = f < n1 + n2 + n3 ? ld4(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const f32x4 wxq = ld4(gimg + swimg::WX + 4 * threadIdx.x);
+#pragma unroll
+    for (int j = 0; j < 25; ++j) {
+      const int f = threadIdx.x + SW_THREADS * j;
+      if (f < n1 + n2 + n3) st4(smem + BwdLds::W1hT + 4 * f, q[j]);
+    }
+    st4(wx_lds + 4 * threadIdx.x, wxq);
+    for (int i = threadIdx.x; i < 16 * LD2; i += blockDim.x) dvbuf[i] = 0.f;
+    sw_barrier();
+    SW_STAMP(5);
+    SW_STAMP(6);
+  } else {
   f32x4 r1[10], r2[13], r3[4];
   stage_wT_load<10>(r1, dec_w + swp::DEC_W1, 160, 160, 64);
   stage_wT_load<13>(r2, dec_w + swp::DEC_W2, 160, 80, 160);
@@ -320,6 +357,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
   const f32x4 w4v = threadIdx.x < 20 ? ld4(dec_w + swp::DEC_W4 + 4 * threadIdx.x) : f32x4{0.f, 0.f, 0.f, 0.f};
   stage_zero(smem, BwdLds::dgbuf);  // transposed images are zero padded
   sw_barrier();
+  SW_STAMP(5);
   stage_wT_store<10>(r1, W1hT, LD160, 160, 64);
   stage_wT_store<13>(r2, W2T, LD80, 80, 160);
   stage_w_store<4>(r3, smem + BwdLds::W3tmp, LD80, 40);
@@ -328,6 +366,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
                  enc_w + swp::ENC_BHH, true, wx_lds, bx_lds);
   for (int i = threadIdx.x; i < 16 * LD2; i += blockDim.x) dvbuf[i] = 0.f;
   sw_barrier();
+  SW_STAMP(6);
   // Wx^T slice of this wave's K-quarter as A operands: row c = ln (< 4 live), k = 64*wave + 16j + 4lg + r
   if (threadIdx.x < 160) {   // W43^T from the staged fc3 image (see the forward kernel): one output per thread,
     const int c = threadIdx.x / 80, k = threadIdx.x - c * 80;   // 4 independent partial sums (the zero padding is already there)
@@ -343,6 +382,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
     }
     W43T[k * LD2 + c] = (v0 + v1) + (v2 + v3);
   }
+  }   // legacy prologue
   f32x4 wxT[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -350,6 +390,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
     for (int r = 0; r < 4; ++r) wxT[j][r] = ln < 4 ? wx_lds[(64 * wave + 16 * j + 4 * lg + r) * 4 + ln] : 0.f;
   }
   sw_barrier();
+  SW_STAMP(2);
 
   f32x4 dh = {0.f, 0.f, 0.f, 0.f}, dc = {0.f, 0.f, 0.f, 0.f};
   f32x4 du[3];
@@ -358,9 +399,6 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
   // per-agent running gradient w.r.t. the position (lanes lg==0 of wave 0)
   float dpx = 0.f, dpy = 0.f;
 
-#ifdef SW_PHASE_STAMPS
-  long long _tprev = clock64();
-#endif
   // Everything an iteration reads from HBM/L2 (saved LSTM rows, saved a1 / a2 tiles, the upstream gradient) is
   // fetched ONE ITERATION AHEAD, and the loop body has no conditional memory operation: clamped tile indices
   // instead of `mt < n ? load : 0`, the first / last iteration peeled instead of `if (i < Tp - 1)`, stores of the
@@ -559,7 +597,7 @@ extern "C" int sw_dec_rollout_fwd_aux(const float* obsv, int To, const float* z,
   float* x4s = dsave ? dsave + (size_t)To * B * 384 : nullptr;
   hipLaunchKernelGGL(dec_rollout_fwd_kernel, dim3(d_w ? 2 * tiles : tiles), dim3(SW_THREADS), FwdLds::total * 4,
                      (hipStream_t)stream, obsv, To, z, S_pool, hT, cT, enc_w, dec_w, B, Tp, pred4, h_end, c_end, gsave, gt,
-                     inv_ss, ade_part, d_w, act, x4s);
+                     inv_ss, ade_part, d_w, act, x4s, sw_gen_images_for(enc_w, dec_w));
   SW_CHECK_LAUNCH("dec_rollout_fwd_kernel");
   return SW_OK;
 }
@@ -589,7 +627,8 @@ extern "C" int sw_dec_rollout_bwd_aux(const float* dpred4, const float* enc_w, c
   int extra = aux_n > 0 ? (int)((aux_n + SW_THREADS - 1) / SW_THREADS) : 0;
   if (extra > 64) extra = 64;
   hipLaunchKernelGGL(dec_rollout_bwd_kernel, dim3(tiles + extra), dim3(SW_THREADS), BwdLds::total * 4, (hipStream_t)stream,
-                     dpred4, enc_w, dec_w, gsave, B, To, Tp, gdelta, dhT, dcT, dS_pool, aux_src, aux_dst, aux_mask, aux_n);
+                     dpred4, enc_w, dec_w, gsave, B, To, Tp, gdelta, dhT, dcT, dS_pool, aux_src, aux_dst, aux_mask, aux_n,
+                     sw_gen_images_for(enc_w, dec_w));
   SW_CHECK_LAUNCH("dec_rollout_bwd_kernel");
   return SW_OK;
 }

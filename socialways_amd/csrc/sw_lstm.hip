@@ -17,7 +17,7 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ enc_w, const float* __restrict__ h0,
     const float* __restrict__ c0, int B, int T, float* __restrict__ hT, float* __restrict__ cT,
     float* __restrict__ y, float* __restrict__ act, float* __restrict__ x4s, int t0, const float* __restrict__ aux_src,
-    float* __restrict__ aux_dst, long long aux_n) {
+    float* __restrict__ aux_dst, long long aux_n, const float* __restrict__ gimg) {
   // Workgroups beyond the agent tiles only copy aux_src -> aux_dst (the training step pulls z out of its pinned
   // host slot here: 128 tiles leave half of the CUs idle for the whole latency-bound kernel, the PCIe read is free)
   const int tiles = (B + SW_TILE - 1) / SW_TILE;
@@ -37,8 +37,13 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
   LstmW W;
   lstm_load_whh(W, enc_w + swp::ENC_WHH, u0, ln, lg);
 
-  lstm_prep_rows(enc_w + swp::ENC_EMB_W, enc_w + swp::ENC_EMB_B, enc_w + swp::ENC_WIH, enc_w + swp::ENC_BIH,
-                 enc_w + swp::ENC_BHH, true, wx_lds, bx_lds);
+  if (gimg) {   // composed input matrix of this step: derived once by the staging launch (swimg, sw_common.h)
+    st4(wx_lds + 4 * threadIdx.x, ld4(gimg + swimg::WX + 4 * threadIdx.x));
+    bx_lds[threadIdx.x] = gimg[swimg::BX + threadIdx.x];
+  } else {
+    lstm_prep_rows(enc_w + swp::ENC_EMB_W, enc_w + swp::ENC_EMB_B, enc_w + swp::ENC_WIH, enc_w + swp::ENC_BIH,
+                   enc_w + swp::ENC_BHH, true, wx_lds, bx_lds);
+  }
   // initial state
   f32x4 c = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};
   if (h0) h = ld4(h0 + (size_t)b * 64 + u0 + 4 * lg);
@@ -295,6 +300,7 @@ extern "C" int sw_enc_lstm_fwd_aux(const float* x, int x_mode, const float* enc_
   if (x_mode == 0 && T < 2) return SW_ESHAPE;  // the observation velocity rule needs 2 points
   if (B == 0) return SW_OK;
   const bool narrow = sw_narrow_tiles(B);
+  const float* gimg = sw_gen_images_for(enc_w, nullptr);
   const int tiles = narrow ? (B + SW8_TILE - 1) / SW8_TILE : (B + SW_TILE - 1) / SW_TILE;
   int extra = aux_n > 0 ? (int)((aux_n / 4 + SW_THREADS - 1) / SW_THREADS) : 0;
   if (extra > 64) extra = 64;
@@ -312,7 +318,7 @@ extern "C" int sw_enc_lstm_fwd_aux(const float* x, int x_mode, const float* enc_
                        x, enc_w, h0, c0, B, T, hT, cT, y, act, x4s, t0, aux_src, aux_dst, aux_n);                   \
   } else                                                                                                            \
     hipLaunchKernelGGL((enc_lstm_fwd_kernel<XM, A, Y_, X4>), dim3(tiles + extra), dim3(SW_THREADS), 0, (hipStream_t)stream, \
-                       x, enc_w, h0, c0, B, T, hT, cT, y, act, x4s, t0, aux_src, aux_dst, aux_n)
+                       x, enc_w, h0, c0, B, T, hT, cT, y, act, x4s, t0, aux_src, aux_dst, aux_n, gimg)
   switch ((x_mode ? 8 : 0) | (act ? 4 : 0) | (y ? 2 : 0) | (x4s ? 1 : 0)) {
     case 0: SW_ENC_FWD(0, false, false, false); break;
     case 1: SW_ENC_FWD(0, false, false, true); break;

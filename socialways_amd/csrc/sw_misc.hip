@@ -2,6 +2,7 @@
 // deferred weight-gradient batch, the LSGAN/InfoGAN loss kernel and the ADE/FDE reduction.
 #include "../../include/socialways_hip.h"
 #include "sw_common.h"
+#include "sw_lstm_dev.h"
 #include <stdlib.h>
 #include "sw_wgrad.h"
 #include <stdio.h>
@@ -499,6 +500,82 @@ extern "C" int sw_traj_dist(const float* a, const float* b, int Na, int Nb, int 
   return SW_OK;
 }
 
+// ---- derived weight images of the generator (swimg, sw_common.h) ---------------------------------------------------
+#define SW_IMG_BLOCKS 32
+__device__ __forceinline__ void gen_images_block(const float* __restrict__ enc_w, const float* __restrict__ dec_w,
+                                                 float* __restrict__ img, int blk) {
+  using namespace swp;
+  if (blk == 0) {          // composed input matrix: the very code the kernels ran per workgroup (bit-identical values)
+    lstm_prep_rows(enc_w + ENC_EMB_W, enc_w + ENC_EMB_B, enc_w + ENC_WIH, enc_w + ENC_BIH, enc_w + ENC_BHH, true,
+                   img + swimg::WX, img + swimg::BX);
+    return;
+  }
+  if (blk == 1) {          // fc4 . fc3 and its transpose: same partial-sum order as dec_rollout_fwd / bwd had
+    const int t = threadIdx.x;
+    if (t < 160) {
+      const int c = t / 80, k = t - c * 80;
+      const float* w4 = dec_w + DEC_W4 + c * 40;
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+#pragma unroll
+      for (int m = 0; m < 40; m += 4) {
+        v0 = fmaf(w4[m], dec_w[DEC_W3 + m * 80 + k], v0);
+        v1 = fmaf(w4[m + 1], dec_w[DEC_W3 + (m + 1) * 80 + k], v1);
+        v2 = fmaf(w4[m + 2], dec_w[DEC_W3 + (m + 2) * 80 + k], v2);
+        v3 = fmaf(w4[m + 3], dec_w[DEC_W3 + (m + 3) * 80 + k], v3);
+      }
+      const float v = (v0 + v1) + (v2 + v3);
+      img[swimg::W43 + c * 80 + k] = v;
+      img[swimg::W43T + k * 20 + c] = v;
+    } else if (t < 162) {
+      const int c = t - 160;
+      float v = dec_w[DEC_B4 + c];
+#pragma unroll
+      for (int m = 0; m < 40; m += 4) {   // the order dec_rollout_fwd uses (bit-identical b43)
+        const f32x4 w = ld4(dec_w + DEC_W4 + c * 40 + m), bb = ld4(dec_w + DEC_B3 + m);
+        v = fmaf(w[0], bb[0], fmaf(w[1], bb[1], fmaf(w[2], bb[2], fmaf(w[3], bb[3], v))));
+      }
+      img[swimg::W43 + 160 + c] = v;
+    }
+    for (int i = t; i < 80 * 20; i += 256)      // zero padding of the transposed image (columns >= 2)
+      if (i % 20 >= 2) img[swimg::W43T + i] = 0.f;
+    return;
+  }
+  // transposed, zero-padded decoder matrices: element i of [64][164] + [160][84]
+  const int n1 = 64 * 164, n2 = 160 * 84;
+  for (int i = (blk - 2) * 256 + threadIdx.x; i < n1 + n2; i += (SW_IMG_BLOCKS - 2) * 256) {
+    if (i < n1) {
+      const int k = i / 164, m = i - k * 164;                       // W1hT[k][m] = fc1.0.weight[m][k]
+      img[swimg::W1HT + i] = m < 160 ? dec_w[DEC_W1 + m * 160 + k] : 0.f;
+    } else {
+      const int j = i - n1, k = j / 84, m = j - k * 84;              // W2T[k][m] = fc1.2.weight[m][k]
+      img[swimg::W2T + j] = m < 80 ? dec_w[DEC_W2 + m * 160 + k] : 0.f;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void gen_images_kernel(const float* __restrict__ enc_w, const float* __restrict__ dec_w,
+                                                          float* __restrict__ img) {
+  gen_images_block(enc_w, dec_w, img, blockIdx.x);
+}
+static const float *g_img_enc = nullptr, *g_img_dec = nullptr, *g_img = nullptr;
+const float* sw_gen_images_for(const float* enc_w, const float* dec_w) {   // dec_w null: the encoder part alone
+  return (g_img && enc_w == g_img_enc && (!dec_w || dec_w == g_img_dec)) ? g_img : nullptr;
+}
+extern "C" int sw_gen_image_floats(void) { return swimg::N; }
+static void gen_images_register(const float* enc_w, const float* dec_w, const float* img) {
+  g_img_enc = enc_w; g_img_dec = dec_w; g_img = img;
+}
+extern "C" int sw_gen_images(const float* enc_w, const float* dec_w, float* img, void* stream) {
+  if (!img) {                       // unregister: the weights are about to change (or have changed)
+    gen_images_register(nullptr, nullptr, nullptr);
+    return SW_OK;
+  }
+  if (!enc_w || !dec_w) return SW_EARG;
+  hipLaunchKernelGGL(gen_images_kernel, dim3(SW_IMG_BLOCKS), dim3(256), 0, (hipStream_t)stream, enc_w, dec_w, img);
+  SW_CHECK_LAUNCH("gen_images_kernel");
+  gen_images_register(enc_w, dec_w, img);
+  return SW_OK;
+}
+
 // ---- one-kernel input staging of a hipGraph-replayed training step ---------------------------------
 // `slot` is a host-pinned (device-mapped) buffer the host fills before every replay, 4-byte words:
 //   [0,1] device pointer of obsv (B,To,2)   [2,3] device pointer of pred (B,Tp,2)
@@ -511,11 +588,18 @@ __global__ __launch_bounds__(256) void stage_step_kernel(const float* __restrict
                                                           float* __restrict__ obsv_dst, float* __restrict__ pred_dst,
                                                           float* __restrict__ pred4_dst, float* __restrict__ targets_dst,
                                                           float* __restrict__ z_dst, float* __restrict__ steps_dst,
-                                                          int n_d_updates) {
+                                                          int n_d_updates, const float* __restrict__ enc_w,
+                                                          const float* __restrict__ dec_w, float* __restrict__ img,
+                                                          int img_blocks) {
+  // the last img_blocks workgroups derive the generator's weight images of this step (sw_gen_images)
+  if ((int)blockIdx.x >= (int)gridDim.x - img_blocks) {
+    gen_images_block(enc_w, dec_w, img, (int)blockIdx.x - ((int)gridDim.x - img_blocks));
+    return;
+  }
   const unsigned long long* ptrs = reinterpret_cast<const unsigned long long*>(slot);
   const float* obsv = reinterpret_cast<const float*>(ptrs[0]);
   const float* pred = reinterpret_cast<const float*>(ptrs[1]);
-  const int gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+  const int gid = blockIdx.x * 256 + threadIdx.x, gsz = ((int)gridDim.x - img_blocks) * 256;
   if (z_dst)
     for (int i = gid; i < B * SW_Z / 4; i += gsz) st4(z_dst + 4 * (size_t)i, ld4(slot + 8 + 4 * (size_t)i));
   if (gid < 2) targets_dst[gid] = slot[4 + gid];
@@ -531,17 +615,26 @@ __global__ __launch_bounds__(256) void stage_step_kernel(const float* __restrict
     st4(pred4_dst + 4 * (size_t)k, f32x4{p.x, p.y, p.x - q.x, p.y - q.y});
   }
 }
-extern "C" int sw_stage_step(const float* slot, int B, int To, int Tp, float* obsv_dst, float* pred_dst,
-                             float* pred4_dst, float* targets_dst, float* z_dst, float* steps_dst, int n_d_updates,
-                             void* stream) {
+extern "C" int sw_stage_step_img(const float* slot, int B, int To, int Tp, float* obsv_dst, float* pred_dst,
+                                 float* pred4_dst, float* targets_dst, float* z_dst, float* steps_dst, int n_d_updates,
+                                 const float* enc_w, const float* dec_w, float* img, void* stream) {
   if (!slot || !obsv_dst || !pred_dst || !pred4_dst || !targets_dst || B < 1 || To < 2 || Tp < 1 ||
       n_d_updates < 0 || n_d_updates > 254)
     return SW_EARG;
+  if (img && (!enc_w || !dec_w)) return SW_EARG;
   int n = z_dst ? B * SW_Z / 4 : B * (To > Tp ? To : Tp);
   int blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(stage_step_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slot, B, To, Tp, obsv_dst,
-                     pred_dst, pred4_dst, targets_dst, z_dst, steps_dst, n_d_updates);
+  const int ib = img ? SW_IMG_BLOCKS : 0;
+  hipLaunchKernelGGL(stage_step_kernel, dim3(blocks + ib), dim3(256), 0, (hipStream_t)stream, slot, B, To, Tp, obsv_dst,
+                     pred_dst, pred4_dst, targets_dst, z_dst, steps_dst, n_d_updates, enc_w, dec_w, img, ib);
   SW_CHECK_LAUNCH("stage_step_kernel");
+  if (img) gen_images_register(enc_w, dec_w, img);
   return SW_OK;
+}
+extern "C" int sw_stage_step(const float* slot, int B, int To, int Tp, float* obsv_dst, float* pred_dst,
+                             float* pred4_dst, float* targets_dst, float* z_dst, float* steps_dst, int n_d_updates,
+                             void* stream) {
+  return sw_stage_step_img(slot, B, To, Tp, obsv_dst, pred_dst, pred4_dst, targets_dst, z_dst, steps_dst, n_d_updates, nullptr,
+                           nullptr, nullptr, stream);
 }

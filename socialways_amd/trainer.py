@@ -179,6 +179,10 @@ class SocialWaysTrainer:
             self.sync_replicas()
         self.ws = ops.Workspaces(self.device)
         self._ws_version = 0
+        # derived images of the generator's weights (composed input matrix, fc4 . fc3, transposed decoder matrices):
+        # computed once per step by the staging launch instead of by every workgroup of four launches (sw_gen_images)
+        self._gimg = (torch.empty(L.load().sw_gen_image_floats(), device=self.device)
+                      if self.device.type == "cuda" and os.environ.get("SW_GEN_IMAGES", "1") == "1" else None)
         self._lin_mask = None
         self._lin_maskf = None
         self._noise_src = None
@@ -415,9 +419,9 @@ class SocialWaysTrainer:
 
         def stage(kk, j):
             slot = st["slots"][kk][j]
-            L.call("sw_stage_step", slot.data_ptr(), B, To, Tp, L.ptr(st["obsv"]), L.ptr(st["pred"]),
+            L.call("sw_stage_step_img", slot.data_ptr(), B, To, Tp, L.ptr(st["obsv"]), L.ptr(st["pred"]),
                    L.ptr(st["pred4"]), L.ptr(st["targets"]), None, L.ptr(st["steps"]), self.n_unrolling_steps + 1,
-                   L.stream())
+                   L.ptr(self.G.encoder._flat), L.ptr(self.G.decoder._flat), L.ptr(self._gimg), L.stream())
             self._noise_src = slot.data_ptr() + 4 * HDR        # z: pulled by idle workgroups of the encoder launch
 
         def args(j):
@@ -500,6 +504,22 @@ class SocialWaysTrainer:
         # this runtime - more than any of the small kernels that could be overlapped (measured).
         if pre is not None:
             pre()
+        elif self._gimg is not None:     # eager step without a staging launch: derive the weight images here
+            L.call("sw_gen_images", L.ptr(G.encoder._flat), L.ptr(G.decoder._flat), L.ptr(self._gimg), L.stream())
+        try:
+            yield from self._step_body(obsv, pred, pred4, scenes, targets, noise, ss, Bg, out, steps)
+        finally:
+            if self._gimg is not None:   # the generator's Adam step follows / has run: the images are stale
+                L.call("sw_gen_images", None, None, None, None)
+
+    def _step_body(self, obsv, pred, pred4, scenes, targets, noise, ss, Bg, out, steps):
+        G, D = self.G, self.D
+        B, Tp = obsv.shape[0], self.n_next
+        dev = self.device
+        ws = self.ws
+        U = self.n_unrolling_steps
+        g_label = 1.0 / Bg
+        g_code = (self.loss_info_w if self.use_info_loss else 0.0) / (2.0 * Bg)
         noise_src, self._noise_src = self._noise_src, None      # set by the staging of this step (graph / warm-up path)
         if pred4 is None:          # real future as 4-d (train.py:470); the observation stays 2-d: kernels form (p, v) on the fly
             pred4 = torch.empty(B, Tp, 4, device=dev)
