@@ -175,14 +175,19 @@ class Leg:
         o, p, zv, ov, noise = self.draw(i)
         self.last = self.tr.step(o, p, self.sb, zv, ov, noise, self.data.ss, global_B=self.Bg, out=False)
 
-    def run_steps(self, i0, n):
-        """n training steps, KG per graph launch where possible (identical work: see SocialWaysTrainer.step_many)."""
+    def run_steps(self, i0, n, cold=False):
+        """n training steps, KG per graph launch where possible (identical work: see SocialWaysTrainer.step_many).
+        `cold`: the GPU is idle (right behind a fence).  The host needs ~0.15 ms per step to draw z and fill the slot, so
+        a KG-step launch reaches an idle GPU ~0.6 ms late; starting with single-step launches gets the GPU going after
+        one step's preparation and the later, larger launches are prepared while it works."""
         i, KG, tr = i0, self.KG, self.tr
+        ramp = [1, 1, 2] if cold and KG >= 4 and n >= 8 else []
         while i < i0 + n:
-            if KG > 1 and tr.use_graph and i + KG <= i0 + n:
-                self.last = tr.step_many([self.draw(i + j) for j in range(KG)], self.sb, self.data.ss, global_B=self.Bg,
+            k = ramp.pop(0) if ramp else KG
+            if k > 1 and tr.use_graph and i + k <= i0 + n:
+                self.last = tr.step_many([self.draw(i + j) for j in range(k)], self.sb, self.data.ss, global_B=self.Bg,
                                          out=False)[-1]
-                i += KG
+                i += k
             else:
                 self.one_step(i)
                 i += 1
@@ -193,12 +198,14 @@ class Leg:
         for rep in range(3):
             if self.KG > 1:
                 self.run_steps(0, self.KG)
+                self.last = self.tr.step_many([self.draw(j) for j in range(2)], self.sb, self.data.ss, global_B=self.Bg,
+                                              out=False)[-1]     # the 2-step launch of the ramp-up
             self.one_step(rep)
 
     def timed(self, fence, i0, steps):
         fence()
         t0 = time.perf_counter()
-        self.run_steps(i0, steps)
+        self.run_steps(i0, steps, cold=True)
         fence()
         return time.perf_counter() - t0
 
