@@ -123,22 +123,23 @@ static bool wg_shape_ok(int N, int K) {   // every 64-column block of delta / ac
 int wg_add(WgBatch& b, const float* delta, int ldd, const float* act, int lda, int R, int N, int K, float* dW,
            int ldw, float* db, float* db2, int accumulate) {
   if (N > 256 || (ldd & 3) || (lda & 3)) return SW_ESHAPE;
-  const int total = K + (db ? 1 : 0);  // act columns incl. the ones column
-  for (int c0 = 0; c0 < total; c0 += 64) {
+  // column blocks of <= 64 REAL act columns; the ones column (bias gradient) rides with the last block on the VALU
+  // (it used to open a block of its own whenever K was a multiple of 64: every delta row read again for a row sum)
+  if (K < 1) return SW_ESHAPE;
+  for (int c0 = 0; c0 < K; c0 += 64) {
     if (b.np >= SW_WG_MAXP) return SW_ESHAPE;
-    const int c1 = c0 + 64 < total ? c0 + 64 : total;
-    const bool has_ones = db && c1 == total;
+    const int c1 = c0 + 64 < K ? c0 + 64 : K;
+    const bool has_ones = db && c1 == K;
     WgProblem& P = b.p[b.np++];
-    // a block that holds only the ones column multiplies no act column: keep its (masked) loads in bounds
-    P.delta = delta; P.ldd = ldd; P.act = (has_ones && c1 - c0 == 1) ? act : act + c0; P.lda = lda;
-    P.R = R; P.N = N; P.K = (c1 - c0) - (has_ones ? 1 : 0); P.ones = has_ones ? 1 : 0;
+    P.delta = delta; P.ldd = ldd; P.act = act + c0; P.lda = lda;
+    P.R = R; P.N = N; P.K = c1 - c0; P.ones = has_ones ? 1 : 0;
     P.dW = dW + c0; P.ldw = ldw; P.db = has_ones ? db : nullptr; P.db2 = has_ones ? db2 : nullptr;
     P.accumulate = accumulate;
     P.pre = 0;
     P.act2 = nullptr; P.dW2 = nullptr; P.lda2 = P.ldw2 = P.K2 = P.row0 = 0;
     if (!wg_shape_ok(N, P.K)) return SW_ESHAPE;
     P.nbn = (N + 15) / 16;
-    P.nbk = (P.K > 0 ? wg_tiles(P.K, true) : 1) + (has_ones ? 1 : 0);
+    P.nbk = P.K > 0 ? wg_tiles(P.K, true) : 1;     // the ones column costs no matrix tile (VALU)
   }
   return SW_OK;
 }
@@ -146,15 +147,15 @@ int wg_add(WgBatch& b, const float* delta, int ldd, const float* act, int lda, i
 int wg_add_tail(WgBatch& b, const float* delta, int ldd, const float* act, int lda, int R, int N, int K, float* dW,
                 int ldw, const float* act2, int lda2, int K2, float* dW2, int ldw2, int row0, float* db, float* db2,
                 int accumulate) {
-  if (N > 256 || (ldd & 3) || (lda & 3) || K != 64 || K2 < 1 || K2 + (db ? 1 : 0) > SW_WG_RLD - 64 || b.np >= SW_WG_MAXP)
-    return SW_ESHAPE;
+  if (N > 256 || (ldd & 3) || (lda & 3) || (lda2 & 3) || K != 64 || K2 != 4 || b.np >= SW_WG_MAXP)   // the tail runs on the
+    return SW_ESHAPE;                                                                                  // VALU: 4 columns, float4 rows
   WgProblem& P = b.p[b.np++];
   P.delta = delta; P.ldd = ldd; P.act = act; P.lda = lda; P.R = R; P.N = N; P.K = K; P.ones = db ? 1 : 0;
   P.dW = dW; P.ldw = ldw; P.db = db; P.db2 = db ? db2 : nullptr; P.accumulate = accumulate; P.pre = 0;
   P.act2 = act2; P.lda2 = lda2; P.K2 = K2; P.dW2 = dW2; P.ldw2 = ldw2; P.row0 = row0;
   if (!wg_shape_ok(N, K)) return SW_ESHAPE;
   P.nbn = (N + 15) / 16;
-  P.nbk = 5;
+  P.nbk = 4;
   return SW_OK;
 }
 

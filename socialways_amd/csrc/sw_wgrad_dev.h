@@ -9,6 +9,9 @@
 #ifndef SW_WG_DEPTH5
 #define SW_WG_DEPTH5 2
 #endif
+#ifndef SW_WG_DEPTH_TAIL
+#define SW_WG_DEPTH_TAIL SW_WG_DEPTH
+#endif
 #ifndef SW_RIDE_DSCALE
 #define SW_RIDE_DSCALE 2
 #endif
@@ -57,43 +60,51 @@ __host__ __device__ inline int wg_tiles(int n, bool allow3) {
 // Branch-free streaming body: loads are unconditional from clamped addresses and masked by 0/1 factors; the pipeline
 // registers hold RAW loaded values (arithmetic attached to a load would sit in front of the loop's back edge and
 // drain the pipeline once per DEPTH groups).
-template <int NA, int KR, int XT, int DSCALE = 1>
+template <int NA, int KR, int K2, int ONES, int DSCALE = 1>
 __device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const float* __restrict__ abase, int ldd, int lda,
                                        int rbeg, int rend, int rmax, int acol, const float (&amask)[4], int bcol,
-                                       const float (&bmask)[4], int xcol, float xmask, float xone, int lg, int ln,
-                                       float* __restrict__ mine, const float* __restrict__ abase2, int lda2, int row0,
-                                       int xoff) {
-  constexpr int KT = KR + XT;
+                                       const float (&bmask)[4], int lg, int ln, float* __restrict__ mine,
+                                       const float* __restrict__ abase2, int lda2, int row0, int xoff) {
+  constexpr int KT = KR, XC = K2 + ONES;
   f32x4 acc[NA][KT];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) acc[i][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  // 4-row groups in flight (swept on the GPU: 4 / 2 for the stand-alone launch at 8 waves per CU); riders have one
-  // workgroup per CU and the whole register file: DSCALE times deeper
-  constexpr int DEPTH = (KT == 5 ? SW_WG_DEPTH5 : SW_WG_DEPTH) * DSCALE;
-  float a[DEPTH][NA], b[DEPTH][KT];
-  auto load = [&](int r0, float (&av)[NA], float (&bv)[KT]) {
-    const int rc = min(r0 + lg, rmax);
-    float bt[KR];
-    wg_ldv<NA>(av, dbase + (size_t)rc * ldd + acol);
-    wg_ldv<KR>(bt, abase + (size_t)max(rc, row0) * lda + bcol);     // rows below row0 have no `act` operand
+  // The tail segment (K2 = 4 columns of act2: the LSTM's x_t) and the ones column (bias gradient) do NOT get an MFMA
+  // tile of their own - it would carry 5 (or 1) useful columns of 16, a fifth of the LSTM problem's matrix work -:
+  // the lane that holds delta[row][n] multiplies it with the row's 4 x values / adds it up on the VALU, which runs
+  // beside the matrix pipe; the per-row-group partial sums meet in two lane shuffles at the end of the slice.
+  float xacc[NA][XC > 0 ? XC : 1];
 #pragma unroll
-    for (int kt = 0; kt < KR; ++kt) bv[kt] = bt[kt];
-    if constexpr (XT) bv[KR] = (abase2 + (size_t)rc * lda2)[xcol];   // tail segment | ones
+  for (int i = 0; i < NA; ++i) {
+#pragma unroll
+    for (int c = 0; c < (XC > 0 ? XC : 1); ++c) xacc[i][c] = 0.f;
+  }
+  // 4-row groups in flight (swept on the GPU for the stand-alone launch at 8 waves per CU); riders have one workgroup
+  // per CU and the whole register file: DSCALE times deeper
+  constexpr int DEPTH = (K2 > 0 ? SW_WG_DEPTH_TAIL : SW_WG_DEPTH) * DSCALE;
+  float a[DEPTH][NA], b[DEPTH][KT];
+  f32x4 xq[DEPTH];
+  auto load = [&](int r0, float (&av)[NA], float (&bv)[KT], f32x4& xv) {
+    const int rc = min(r0 + lg, rmax);
+    wg_ldv<NA>(av, dbase + (size_t)rc * ldd + acol);
+    wg_ldv<KR>(bv, abase + (size_t)max(rc, row0) * lda + bcol);     // rows below row0 have no `act` operand
+    if constexpr (K2 > 0) xv = ld4(abase2 + (size_t)rc * lda2);      // the row's tail columns (same address for 16 lanes)
   };
 #pragma unroll
-  for (int q = 0; q < DEPTH - 1; ++q) load(rbeg + 4 * q, a[q], b[q]);
+  for (int q = 0; q < DEPTH - 1; ++q) load(rbeg + 4 * q, a[q], b[q], xq[q]);
   for (int r = rbeg; r < rend; r += 4 * DEPTH) {
 #pragma unroll
     for (int q = 0; q < DEPTH; ++q) {
-      load(r + 4 * (q + DEPTH - 1), a[(q + DEPTH - 1) % DEPTH], b[(q + DEPTH - 1) % DEPTH]);
+      load(r + 4 * (q + DEPTH - 1), a[(q + DEPTH - 1) % DEPTH], b[(q + DEPTH - 1) % DEPTH], xq[(q + DEPTH - 1) % DEPTH]);
       asm volatile("" ::: "memory");   // the loads are issued HERE (DEPTH - 1 groups ahead), not sunk to their uses
 #pragma unroll
       for (int i = 0; i < NA; ++i) asm volatile("" : "+v"(a[q][i]));   // ... and group q is first touched here
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) asm volatile("" : "+v"(b[q][kt]));
+      if constexpr (K2 > 0) asm volatile("" : "+v"(xq[q]));
       const int rr = r + 4 * q + lg;
       const float rs = rr < rend ? 1.0f : 0.0f;
       const float rs0 = rr >= row0 ? rs : 0.0f;
@@ -102,15 +113,22 @@ __device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const fl
       for (int i = 0; i < NA; ++i) av[i] = a[q][i] * (amask[i] * rs);
 #pragma unroll
       for (int kt = 0; kt < KR; ++kt) bv[kt] = b[q][kt] * (bmask[kt] * rs0);
-      if constexpr (XT) bv[KR] = fmaf(b[q][KR], xmask, xone) * rs;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) acc[i][kt] = SW_MFMA(av[i], bv[kt], acc[i][kt]);
       }
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        if constexpr (K2 > 0) {
+#pragma unroll
+          for (int c = 0; c < K2; ++c) xacc[i][c] = fmaf(av[i], xq[q][c], xacc[i][c]);
+        }
+        if constexpr (ONES) xacc[i][K2] += av[i];
+      }
     }
   }
-  // tile (i, kt) element (m = 4 lg + r, n = ln)  =  output row NA m + i, act column KR n + kt (extra tile: xoff + n)
+  // tile (i, kt) element (m = 4 lg + r, n = ln)  =  output row NA m + i, act column KR n + kt
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
 #pragma unroll
@@ -118,11 +136,20 @@ __device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const fl
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int orow = NA * (4 * lg + r) + i;
-        if (kt < KR) {
-          if (KR * ln + kt < xoff) mine[orow * SW_WG_RLD + KR * ln + kt] = acc[i][kt][r];      // xoff = K: live columns only
-        } else if (xoff + ln < SW_WG_RLD) {
-          mine[orow * SW_WG_RLD + xoff + ln] = acc[i][kt][r];
-        }
+        if (KR * ln + kt < xoff) mine[orow * SW_WG_RLD + KR * ln + kt] = acc[i][kt][r];      // xoff = K: live columns only
+      }
+    }
+  }
+  // extra columns xoff + c of output row NA ln + i: sum of the four row groups (lanes ln, ln + 16, ln + 32, ln + 48)
+  if constexpr (XC > 0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+#pragma unroll
+      for (int c = 0; c < XC; ++c) {
+        float v = xacc[i][c];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lg == 0) mine[(NA * ln + i) * SW_WG_RLD + xoff + c] = v;
       }
     }
   }
@@ -147,7 +174,6 @@ __device__ __forceinline__ void wg_job(const WgBatch& batch, float* __restrict__
   const int Nb = min(64, N - n0);                       // live delta columns of this block
   const int NA = wg_tiles(Nb, false);                   // delta tiles
   const int KR = K > 0 ? wg_tiles(K, true) : 1;         // real act tiles (a block with only the ones column: one masked tile)
-  const int XT = (P.K2 + P.ones) > 0 ? 1 : 0;
   const int nsub = P.nsplit * 4;
   const int rows_per = (((P.R + nsub - 1) / nsub) + 3) & ~3;
   const int rbeg = min(P.R, s * rows_per);
@@ -162,24 +188,21 @@ __device__ __forceinline__ void wg_job(const WgBatch& batch, float* __restrict__
     amask[i] = (NA * ln + i < Nb && acol == n0 + NA * ln) ? 1.0f : 0.0f;
     bmask[i] = (KR * ln + i < K && bcol == KR * ln) ? 1.0f : 0.0f;
   }
-  // extra tile: columns of act2 (K2), then the ones column
-  const int xcol = min(ln, max(P.K2 - 1, 0));
-  const float xmask = ln < P.K2 ? 1.0f : 0.0f;
-  const float xone = (P.ones && ln == P.K2) ? 1.0f : 0.0f;
   float* mine = red + wave * 64 * SW_WG_RLD;
-#define WG_CASE(na, kr, xt)                                                                                        \
-  case na * 16 + kr * 2 + xt:                                                                                      \
-    wg_run<na, kr, xt, DSCALE>(P.delta, P.act, P.ldd, P.lda, rbeg, rend, P.R - 1, acol, amask, bcol, bmask, xcol, xmask, xone, lg, \
-                       ln, mine, P.act2 ? P.act2 : P.delta, P.act2 ? P.lda2 : P.ldd, P.row0, K);                    \
+  // extra columns on the VALU: a tail segment of exactly 4 columns (K2; only next to K = 64) and / or the ones column
+#define WG_CASE(na, kr, k2, on)                                                                                     \
+  case ((na * 8 + kr) * 2 + (k2 ? 1 : 0)) * 2 + on:                                                                 \
+    wg_run<na, kr, k2, on, DSCALE>(P.delta, P.act, P.ldd, P.lda, rbeg, rend, P.R - 1, acol, amask, bcol, bmask, lg, ln,  \
+                                   mine, P.act2 ? P.act2 : P.delta, P.act2 ? P.lda2 : P.ldd, P.row0, K);            \
     break;
-  switch (NA * 16 + KR * 2 + XT) {
-    WG_CASE(1, 1, 0) WG_CASE(1, 2, 0) WG_CASE(1, 3, 0) WG_CASE(1, 4, 0)
-    WG_CASE(1, 1, 1) WG_CASE(1, 2, 1) WG_CASE(1, 3, 1) WG_CASE(1, 4, 1)
-    WG_CASE(2, 1, 0) WG_CASE(2, 2, 0) WG_CASE(2, 3, 0) WG_CASE(2, 4, 0)
-    WG_CASE(2, 1, 1) WG_CASE(2, 2, 1) WG_CASE(2, 3, 1) WG_CASE(2, 4, 1)
-    WG_CASE(4, 1, 0) WG_CASE(4, 2, 0) WG_CASE(4, 3, 0) WG_CASE(4, 4, 0)
-    WG_CASE(4, 1, 1) WG_CASE(4, 2, 1) WG_CASE(4, 3, 1) WG_CASE(4, 4, 1)
+#define WG_CASES(na)                                                                                                \
+  WG_CASE(na, 1, 0, 0) WG_CASE(na, 2, 0, 0) WG_CASE(na, 3, 0, 0) WG_CASE(na, 4, 0, 0)                               \
+  WG_CASE(na, 1, 0, 1) WG_CASE(na, 2, 0, 1) WG_CASE(na, 3, 0, 1) WG_CASE(na, 4, 0, 1)                               \
+  WG_CASE(na, 4, 4, 0) WG_CASE(na, 4, 4, 1)
+  switch (((NA * 8 + KR) * 2 + (P.K2 ? 1 : 0)) * 2 + (P.ones ? 1 : 0)) {
+    WG_CASES(1) WG_CASES(2) WG_CASES(4)
   }
+#undef WG_CASES
 #undef WG_CASE
   sw_barrier();
   // one partial per workgroup (4 row slices summed): ws[ws_off + (sg*N + n)*Kc + k]
