@@ -190,6 +190,20 @@ int sw_gen_wgrad(const float* enc_w, const float* dec_w, const float* gsave, con
                  float* wgrad_ws, float* tmp /*[2048]*/,
                  sw_wgrad_batch* pending /*or NULL: problems deferred by sw_social_pool_bwd join this launch*/,
                  void* stream);
+/* sw_gen_wgrad(part 0) that ALSO applies the generator's Adam update (train.py:539 `predictor_optimizer.step()`,
+ * torch's fused Adam restated like sw_disc_bwd_gan_adam): every generator gradient is finished either by the
+ * reduction of the grouped GEMM or by the composition kernel behind it, and the thread that finishes an element
+ * updates exp_avg / exp_avg_sq / the weight.  adam_w / adam_m / adam_v / adam_g = the packed weight, moment and
+ * gradient buffers of the WHOLE generator (adam_n floats each, one layout; enc_w, dec_w, d_enc_w, d_dec_w and the
+ * pending problems' outputs point into them); adam_step = device scalar, 1-based index of the update.  Needs
+ * the weight images of this step (sw_gen_images / sw_stage_step_img: the compositions read their step-start
+ * snapshot while live weights are overwritten), else SW_EARG.  Single process only: a data-parallel job
+ * all-reduces between gradient and update.                                                                */
+int sw_gen_wgrad_adam(const float* enc_w, const float* dec_w, const float* gsave, const float* gdelta,
+                      const float* z, const float* S_pool, int B, int To, int Tp, float* d_enc_w, float* d_dec_w,
+                      float* wgrad_ws, float* tmp /*[2048]*/, sw_wgrad_batch* pending /*or NULL*/, float* adam_w,
+                      float* adam_m, float* adam_v, const float* adam_g, long long adam_n, const float* adam_step,
+                      double lr, double beta1, double beta2, double eps, void* stream);
 
 /* ---- Discriminator.forward (train.py:294-309) for nb prediction branches sharing one
  *      observation encoding (fake / real of the same batch) ----------------------------------- */

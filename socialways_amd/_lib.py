@@ -49,6 +49,8 @@ PROTOTYPES = {
     "sw_dec_rollout_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sw_dec_rollout_bwd_aux": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
     "sw_gen_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "sw_gen_wgrad_adam": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               ctypes.c_longlong, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp]),
     "sw_wgrad_batch_new": (_vp, []),
     "sw_wgrad_batch_free": (None, [_vp]),
     "sw_disc_fwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),

@@ -306,7 +306,16 @@ constexpr int W43 = 1280;                // [2][80] | b43[2]   fc4 . fc3, fc4 b3
 constexpr int W43T = W43 + 176;          // [80][20]   (fc4 . fc3)^T, columns >= 2 zero
 constexpr int W1HT = W43T + 80 * 20;     // [64][164]  fc1.0.weight[:, :64]^T, columns >= 160 zero
 constexpr int W2T = W1HT + 64 * 164;     // [160][84]  fc1.2.weight^T, columns >= 80 zero
-constexpr int N = W2T + 160 * 84;
+// SNAPSHOT of the raw weights the composed maps are made of, as they were when this step started: the kernel that
+// back-propagates through the compositions AND applies the generator's Adam step (sw_gen_wgrad_adam) reads these
+// while it overwrites the live weights
+constexpr int RAW_WIH = W2T + 160 * 84;  // [256][64]  encoder LSTM weight_ih
+constexpr int RAW_WE = RAW_WIH + 16384;  // [64][4]    embed weight
+constexpr int RAW_BE = RAW_WE + 256;     // [64]       embed bias
+constexpr int RAW_W3 = RAW_BE + 64;      // [40][80]   fc3 weight
+constexpr int RAW_B3 = RAW_W3 + 3200;    // [40]       fc3 bias
+constexpr int RAW_W4 = RAW_B3 + 40;      // [2][40]    fc4 weight
+constexpr int N = RAW_W4 + 80;
 }  // namespace swimg
 // the images registered for (enc_w, dec_w) by the current step, or null (sw_gen_images)
 const float* sw_gen_images_for(const float* enc_w, const float* dec_w);

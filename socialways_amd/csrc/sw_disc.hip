@@ -795,7 +795,8 @@ static int disc_bwd_impl(const float* d_w, const float* dsave, const float* cons
   SW_CHECK_LAUNCH("disc_bwd_kernel");
   if (!d_d_w) return SW_OK;
   if (ride.nriders > 0) return wg_reduce_launch_adam(wb, wgrad_ws, adam, st);
-  return wg_launch_adam(wb, wgrad_ws, adam, st);
+  WgAdam ad = adam;
+  return wg_launch_adam(wb, wgrad_ws, ad, st);
 }
 
 extern "C" int sw_disc_bwd(const float* d_w, const float* dsave, const float* const* dlabel,

@@ -121,39 +121,50 @@ extern "C" size_t sw_workspace_floats(int ws_id, int B, int To, int Tp, int nb, 
 // (v = W43 a2 + b43, sw_decoder.hip); their four gradients follow from M = dv^T a2 (2 x 80) and s = sum dv (2):
 //   dW3 = W4^T M,  db3 = W4^T s,  dW4 = M W3^T + s b3^T,  db4 = s        (exactly autograd's values, reassociated)
 #define SW_DEC_COMPOSE_BLOCKS 13   // 3322 outputs
+// With `ad.w` set the thread that forms a gradient element also applies the generator's Adam update to its weight
+// (wg_adam1); the compositions then read the weights from `snap` - the step-start snapshot inside the image buffer
+// (swimg::RAW_*) - because other workgroups of this launch are overwriting the live ones.
 __global__ __launch_bounds__(256) void enc_compose_bwd_kernel(const float* __restrict__ enc_w,
                                                               const float* __restrict__ dWx,
                                                               const float* __restrict__ dbx,
                                                               float* __restrict__ d_enc_w,
                                                               const float* __restrict__ dec_w,
                                                               const float* __restrict__ Ms,
-                                                              float* __restrict__ d_dec_w) {
+                                                              float* __restrict__ d_dec_w, WgAdam ad,
+                                                              const float* __restrict__ snap) {
   using namespace swp;
+  float bc1 = 1.f, bc2s = 1.f;
+  if (ad.w) wg_adam_bc(ad, bc1, bc2s);
+  auto put = [&](float* dst, float g) {
+    *dst = g;
+    if (ad.w) wg_adam1(ad, bc1, bc2s, dst, g);
+  };
   if (blockIdx.x >= 128) {
     const int o = (blockIdx.x - 128) * 256 + threadIdx.x;
     const float* M = Ms;            // [2][80]
     const float* sv = Ms + 160;     // [2]
-    const float* W3 = dec_w + DEC_W3;
-    const float* W4 = dec_w + DEC_W4;
+    const float* W3 = snap ? snap + swimg::RAW_W3 : dec_w + DEC_W3;
+    const float* W4 = snap ? snap + swimg::RAW_W4 : dec_w + DEC_W4;
+    const float* b3 = snap ? snap + swimg::RAW_B3 : dec_w + DEC_B3;
     if (o < 3200) {                 // dW3[m][k]
       const int m = o / 80, k = o - m * 80;
-      d_dec_w[DEC_W3 + o] = fmaf(W4[m], M[k], W4[40 + m] * M[80 + k]);
+      put(d_dec_w + DEC_W3 + o, fmaf(W4[m], M[k], W4[40 + m] * M[80 + k]));
     } else if (o < 3240) {          // db3[m]
       const int m = o - 3200;
-      d_dec_w[DEC_B3 + m] = fmaf(W4[m], sv[0], W4[40 + m] * sv[1]);
+      put(d_dec_w + DEC_B3 + m, fmaf(W4[m], sv[0], W4[40 + m] * sv[1]));
     } else if (o < 3320) {          // dW4[c][m]
       const int c = (o - 3240) / 40, m = (o - 3240) - c * 40;
-      float v = sv[c] * dec_w[DEC_B3 + m];
+      float v = sv[c] * b3[m];
       for (int k = 0; k < 80; ++k) v = fmaf(M[c * 80 + k], W3[m * 80 + k], v);
-      d_dec_w[DEC_W4 + c * 40 + m] = v;
+      put(d_dec_w + DEC_W4 + c * 40 + m, v);
     } else if (o < 3322) {          // db4[c]
-      d_dec_w[DEC_B4 + (o - 3320)] = sv[o - 3320];
+      put(d_dec_w + DEC_B4 + (o - 3320), sv[o - 3320]);
     }
     return;
   }
-  const float* We = enc_w + ENC_EMB_W;
-  const float* be = enc_w + ENC_EMB_B;
-  const float* Wih = enc_w + ENC_WIH;
+  const float* We = snap ? snap + swimg::RAW_WE : enc_w + ENC_EMB_W;
+  const float* be = snap ? snap + swimg::RAW_BE : enc_w + ENC_EMB_B;
+  const float* Wih = snap ? snap + swimg::RAW_WIH : enc_w + ENC_WIH;
   const int t = threadIdx.x;
   if (blockIdx.x < 64) {  // dWih[row][e] = sum_c dWx[row][c] We[e][c] + dbx[row] be[e]; 256 elements per block
     int i = blockIdx.x * 256 + t;
@@ -161,10 +172,10 @@ __global__ __launch_bounds__(256) void enc_compose_bwd_kernel(const float* __res
     f32x4 g = ld4(dWx + row * 4), w = ld4(We + e * 4);
     float v = dbx[row] * be[e];
     v = fmaf(g[0], w[0], v); v = fmaf(g[1], w[1], v); v = fmaf(g[2], w[2], v); v = fmaf(g[3], w[3], v);
-    d_enc_w[ENC_WIH + i] = v;
+    put(d_enc_w + ENC_WIH + i, v);
     if (blockIdx.x == 0) {
-      d_enc_w[ENC_BIH + t] = dbx[t];
-      d_enc_w[ENC_BHH + t] = dbx[t];
+      put(d_enc_w + ENC_BIH + t, dbx[t]);
+      put(d_enc_w + ENC_BHH + t, dbx[t]);
     }
     return;
   }
@@ -183,8 +194,8 @@ __global__ __launch_bounds__(256) void enc_compose_bwd_kernel(const float* __res
     }
     __syncthreads();
   }
-  if (t < 4) d_enc_w[ENC_EMB_W + e * 4 + t] = red[t][0];
-  if (t == 4) d_enc_w[ENC_EMB_B + e] = red[4][0];
+  if (t < 4) put(d_enc_w + ENC_EMB_W + e * 4 + t, red[t][0]);
+  if (t == 4) put(d_enc_w + ENC_EMB_B + e, red[4][0]);
 }
 
 // part 0: everything.  part 1: what is available right after dec_rollout_bwd (all decoder problems +
@@ -192,9 +203,10 @@ __global__ __launch_bounds__(256) void enc_compose_bwd_kernel(const float* __res
 // (after enc_lstm_bwd), accumulated on top of part 1, then the composed-input-matrix back-propagation.
 // Parts 1 and 2 may run on different streams (different partial workspaces `wgrad_ws`); `tmp` holds
 // the 256x4 + 256 composed-matrix gradient between them.
-extern "C" int sw_gen_wgrad(const float* enc_w, const float* dec_w, const float* gsave, const float* gdelta, const float* z,
-                            const float* S_pool, int B, int To, int Tp, float* d_enc_w, float* d_dec_w, int part,
-                            float* wgrad_ws, float* tmp, sw_wgrad_batch* pending, void* stream) {
+static int gen_wgrad_impl(const float* enc_w, const float* dec_w, const float* gsave, const float* gdelta, const float* z,
+                          const float* S_pool, int B, int To, int Tp, float* d_enc_w, float* d_dec_w, int part,
+                          float* wgrad_ws, float* tmp, sw_wgrad_batch* pending, void* stream, WgAdam ad,
+                          const float* snap) {
   if (!enc_w || !dec_w || !gsave || !gdelta || !z || !S_pool || !d_enc_w || !d_dec_w || !wgrad_ws || !tmp || B < 1 || To < 2 ||
       Tp < 1 || part < 0 || part > 2)
     return SW_EARG;
@@ -235,13 +247,43 @@ extern "C" int sw_gen_wgrad(const float* enc_w, const float* dec_w, const float*
     rc_add |= wg_add(wb, gdelta + gd.dv, 4, gsave + gs.a2, 80, Tp * B, 2, 80, dM, 80, dM + 160, nullptr, 0);
   }
   if (rc_add) return SW_ESHAPE;
-  if (int rc = wg_launch(wb, wgrad_ws, st)) return rc;
+  if (int rc = ad.w ? wg_launch_adam(wb, wgrad_ws, ad, st) : wg_launch(wb, wgrad_ws, st)) return rc;
   if (part != 1) {
     hipLaunchKernelGGL(enc_compose_bwd_kernel, dim3(128 + SW_DEC_COMPOSE_BLOCKS), dim3(256), 0, st, enc_w, dWx, dbx, d_enc_w,
-                       dec_w, dM, d_dec_w);
+                       dec_w, dM, d_dec_w, ad, snap);
     SW_CHECK_LAUNCH("enc_compose_bwd_kernel");
   }
   return SW_OK;
+}
+extern "C" int sw_gen_wgrad(const float* enc_w, const float* dec_w, const float* gsave, const float* gdelta, const float* z,
+                            const float* S_pool, int B, int To, int Tp, float* d_enc_w, float* d_dec_w, int part,
+                            float* wgrad_ws, float* tmp, sw_wgrad_batch* pending, void* stream) {
+  return gen_wgrad_impl(enc_w, dec_w, gsave, gdelta, z, S_pool, B, To, Tp, d_enc_w, d_dec_w, part, wgrad_ws, tmp, pending,
+                        stream, WgAdam(), nullptr);
+}
+// sw_gen_wgrad(part 0) that also applies the generator's Adam update: every generator parameter's gradient is finished
+// either by the reduction of the grouped GEMM or by the composition kernel behind it, and the thread that finishes an
+// element updates exp_avg / exp_avg_sq / the weight in the packed buffers (adam_w / adam_m / adam_v, laid out like the
+// packed gradient buffer adam_g of adam_n floats that d_enc_w, d_dec_w and the pending problems' outputs point into).
+// Needs the weight images of this step (sw_gen_images / sw_stage_step_img): the composition reads their snapshot.
+extern "C" int sw_gen_wgrad_adam(const float* enc_w, const float* dec_w, const float* gsave, const float* gdelta,
+                                 const float* z, const float* S_pool, int B, int To, int Tp, float* d_enc_w, float* d_dec_w,
+                                 float* wgrad_ws, float* tmp, sw_wgrad_batch* pending, float* adam_w, float* adam_m,
+                                 float* adam_v, const float* adam_g, long long adam_n, const float* adam_step, double lr,
+                                 double beta1, double beta2, double eps, void* stream) {
+  if (!adam_w || !adam_m || !adam_v || !adam_g || !adam_step || adam_n < 1 || !enc_w || !dec_w || !d_enc_w || !d_dec_w)
+    return SW_EARG;
+  // weights and gradients must share one layout
+  if (enc_w - adam_w != d_enc_w - adam_g || dec_w - adam_w != d_dec_w - adam_g || enc_w < adam_w ||
+      dec_w + swp::DEC_N > adam_w + adam_n || enc_w + swp::ENC_N > adam_w + adam_n || dec_w < adam_w)
+    return SW_EARG;
+  const float* img = sw_gen_images_for(enc_w, dec_w);
+  if (!img) return SW_EARG;
+  WgAdam ad;
+  ad.w = adam_w; ad.m = adam_m; ad.v = adam_v; ad.g0 = adam_g; ad.step = adam_step; ad.n = (size_t)adam_n;
+  ad.lr = lr; ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps;
+  return gen_wgrad_impl(enc_w, dec_w, gsave, gdelta, z, S_pool, B, To, Tp, d_enc_w, d_dec_w, 0, wgrad_ws, tmp, pending, stream,
+                        ad, img);
 }
 
 // ---- losses (train.py:484-494, 512-523) ---------------------------------------------------------
@@ -550,6 +592,17 @@ __device__ __forceinline__ void gen_images_block(const float* __restrict__ enc_w
       const int j = i - n1, k = j / 84, m = j - k * 84;              // W2T[k][m] = fc1.2.weight[m][k]
       img[swimg::W2T + j] = m < 80 ? dec_w[DEC_W2 + m * 160 + k] : 0.f;
     }
+  }
+  // snapshot of the raw weights behind the compositions (swimg::RAW_*), float4 granularity
+  for (int i = (blk - 2) * 256 + threadIdx.x; i < (swimg::N - swimg::RAW_WIH) / 4; i += (SW_IMG_BLOCKS - 2) * 256) {
+    const int o = swimg::RAW_WIH + 4 * i;
+    const float* src = o < swimg::RAW_WE   ? enc_w + ENC_WIH + (o - swimg::RAW_WIH)
+                       : o < swimg::RAW_BE ? enc_w + ENC_EMB_W + (o - swimg::RAW_WE)
+                       : o < swimg::RAW_W3 ? enc_w + ENC_EMB_B + (o - swimg::RAW_BE)
+                       : o < swimg::RAW_B3 ? dec_w + DEC_W3 + (o - swimg::RAW_W3)
+                       : o < swimg::RAW_W4 ? dec_w + DEC_B3 + (o - swimg::RAW_B3)
+                                           : dec_w + DEC_W4 + (o - swimg::RAW_W4);
+    st4(img + o, ld4(src));
   }
 }
 __global__ __launch_bounds__(256) void gen_images_kernel(const float* __restrict__ enc_w, const float* __restrict__ dec_w,

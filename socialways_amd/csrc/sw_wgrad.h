@@ -46,9 +46,65 @@ struct WgAdam {
   const float* g0 = nullptr;
   const float* step = nullptr; // device scalar: 1-based index of this update (float, like torch's state step)
   double lr = 0, beta1 = 0, beta2 = 0, eps = 0;
+  size_t n = ~(size_t)0;       // floats in the packed buffers: gradient outputs outside [g0, g0 + n) are scratch, not parameters
+  const float* bc = nullptr;   // {bias_correction1, sqrt(bias_correction2)} of this update if some earlier kernel of the
+                               // sequence has computed them (wg_launch_adam: the GEMM launch), else every wave does
 };
+// bias corrections of the update whose 1-based index sits in *step (torch: 1 - beta^step in double, then float)
+__device__ __forceinline__ void wg_adam_bc_compute(const float* step, double beta1, double beta2, float& bc1, float& bc2s) {
+  const float st = *step;
+  bc1 = (float)(1 - pow(beta1, (double)st));
+  bc2s = (float)sqrt(1 - pow(beta2, (double)st));
+}
+__device__ __forceinline__ void wg_adam_bc(const WgAdam& A, float& bc1, float& bc2s) {
+  // two double-precision pow() cost a kernel of this size 2-3 us (measured: wgrad_reduce 7.2 -> 10.2 us): they are
+  // computed ONCE, by one thread of the GEMM launch in front, wherever there is one
+  if (A.bc) {
+    bc1 = A.bc[0];
+    bc2s = A.bc[1];
+    return;
+  }
+  wg_adam_bc_compute(A.step, A.beta1, A.beta2, bc1, bc2s);
+}
+// The update in two halves so that a caller can issue the three state loads BEFORE the work that produces the
+// gradient (their round trip then hides under it): wg_adam_pre() loads, wg_adam_fin() computes and stores.
+struct WgAdamPre {
+  size_t i;
+  float m, v, w;
+};
+__device__ __forceinline__ WgAdamPre wg_adam_pre(const WgAdam& A, const float* gptr) {
+  WgAdamPre s;
+  s.i = (size_t)(gptr - A.g0);
+  if (s.i >= A.n) {          // scratch output, not a parameter
+    s.i = ~(size_t)0;
+    s.m = s.v = s.w = 0.f;
+    return s;
+  }
+  s.m = A.m[s.i];
+  s.v = A.v[s.i];
+  s.w = A.w[s.i];
+  return s;
+}
+__device__ __forceinline__ void wg_adam_fin(const WgAdam& A, const WgAdamPre& s, float bc1, float bc2s, float grad) {
+  if (s.i == ~(size_t)0) return;
+  // double arithmetic, rounded on assignment.  exp_avg as a lerp, m + (1 - beta1) (g - m): of the candidate forms this
+  // is the one that agrees with torch._fused_adam_ of this build on 99.8 % of random inputs bit for bit, exp_avg_sq
+  // below on 100 % (tools/dbg/adam_probe.py); the remaining last-bit differences are fused-multiply-add placement
+  const float m = (float)((double)s.m + (1 - A.beta1) * ((double)grad - (double)s.m));
+  const float v = (float)(A.beta2 * s.v + (1 - A.beta2) * grad * grad);
+  const float step_size = (float)(A.lr / bc1);
+  const float denom = (float)((sqrtf(v) / bc2s) + A.eps);
+  A.m[s.i] = m;
+  A.v[s.i] = v;
+  A.w[s.i] = s.w - step_size * m / denom;
+}
+__device__ __forceinline__ void wg_adam1(const WgAdam& A, float bc1, float bc2s, const float* gptr, float grad) {
+  wg_adam_fin(A, wg_adam_pre(A, gptr), bc1, bc2s, grad);
+}
 int wg_reduce_launch_adam(WgBatch& b, float* ws, const WgAdam& ad, hipStream_t stream);
-int wg_launch_adam(WgBatch& b, float* ws, const WgAdam& ad, hipStream_t stream);
+// GEMM + reduction; `ad` comes back with `bc` set when the GEMM launch computed the bias corrections (kernels that
+// follow in the same stream - the composition back-propagation - may use them)
+int wg_launch_adam(WgBatch& b, float* ws, WgAdam& ad, hipStream_t stream);
 
 // ---- riders: weight-gradient jobs run by the spare workgroups of a serial launch (sw_wgrad_dev.h) ----------------
 #define SW_RIDE_SLOTS 48      // event counters per host kernel; the last one counts riders that have left

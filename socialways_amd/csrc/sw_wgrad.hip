@@ -29,9 +29,39 @@
 // this wave's 64x64 block): loads are unconditional from clamped addresses and masked by a 0/1
 // factor, so the hot loop is NI+KT loads, a few multiplies and NI*KT MFMAs - no exec-mask branches,
 // no accumulator shuffling through control flow.
-__global__ __launch_bounds__(SW_THREADS, 2) void wgrad_partial_kernel(WgBatch batch, float* __restrict__ ws) {
+__global__ __launch_bounds__(SW_THREADS, 2) void wgrad_partial_kernel(WgBatch batch, float* __restrict__ ws,
+                                                                      const float* __restrict__ adam_step, double beta1,
+                                                                      double beta2, float* __restrict__ bc_out) {
   __shared__ __attribute__((aligned(16))) float red[SW_WG_RED_FLOATS];   // per-wave 64 x <=69 blocks, summed before the store
+  // Adam's bias corrections for the reduction that follows (it applies the update): one extra workgroup, no job delayed
+  if ((int)blockIdx.x >= batch.total_jobs) {
+    if (threadIdx.x == 0) {
+      float bc1, bc2s;
+      wg_adam_bc_compute(adam_step, beta1, beta2, bc1, bc2s);
+      bc_out[0] = bc1;
+      bc_out[1] = bc2s;
+    }
+    return;
+  }
   wg_job(batch, ws, blockIdx.x, red);
+}
+// scratch for those two floats: a ring of slots per device (launches of one stream are ordered; 64 slots cover
+// concurrent streams)
+__device__ float g_wg_bc[2 * 64];
+static float* wg_bc_slot() {
+  static float* base[32] = {};
+  static unsigned next = 0;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+  if (!base[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wg_bc)) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    base[dev] = (float*)p;
+  }
+  return base[dev] + 2 * (next++ % 64);
 }
 
 // out element e of problem p = sum over slices.  A wave owns SW_WG_REL consecutive elements (lanes el = lane %
@@ -41,21 +71,6 @@ __global__ __launch_bounds__(SW_THREADS, 2) void wgrad_partial_kernel(WgBatch ba
 #define SW_WG_RSUB 4
 #endif
 #define SW_WG_REL (64 / SW_WG_RSUB)
-__device__ __forceinline__ void wg_adam1(const WgAdam& A, float bc1, float bc2s, const float* gptr, float grad) {
-  const size_t i = (size_t)(gptr - A.g0);
-  float m = A.m[i], v = A.v[i], w = A.w[i];
-  // double arithmetic, rounded on assignment.  exp_avg as a lerp, m + (1 - beta1) (g - m): of the candidate forms this
-  // is the one that agrees with torch._fused_adam_ of this build on 99.8 % of random inputs bit for bit, exp_avg_sq
-  // below on 100 % (tools/dbg/adam_probe.py); the remaining last-bit differences are fused-multiply-add placement
-  m = (float)((double)m + (1 - A.beta1) * ((double)grad - (double)m));
-  v = (float)(A.beta2 * v + (1 - A.beta2) * grad * grad);
-  const float step_size = (float)(A.lr / bc1);
-  const float denom = (float)((sqrtf(v) / bc2s) + A.eps);
-  w -= step_size * m / denom;
-  A.m[i] = m;
-  A.v[i] = v;
-  A.w[i] = w;
-}
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgBatch batch, const float* __restrict__ ws, WgAdam ad) {
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int lane = gid & 63, el = lane % SW_WG_REL, sub = lane / SW_WG_REL;
@@ -70,6 +85,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgBatch batch, const 
   const int Kc = P.K + P.K2 + P.ones;
   const size_t stride = (size_t)P.N * Kc;
   const float* src = ws + P.ws_off + e;
+  // destination(s) of this element; with the fused Adam update their optimizer state is fetched now, under the sums
+  const int n = e / Kc, k = e - n * Kc;
+  float* dst = k < P.K ? P.dW + (size_t)n * P.ldw + k : k < P.K + P.K2 ? P.dW2 + (size_t)n * P.ldw2 + (k - P.K) : P.db + n;
+  float* dst2 = (k >= P.K + P.K2 && P.db2) ? P.db2 + n : nullptr;   // LSTM b_ih / b_hh share their gradient
+  WgAdamPre a1 = {}, a2 = {};
+  float old1 = 0.f, old2 = 0.f;
+  if (ad.w) {
+    a1 = wg_adam_pre(ad, dst);
+    if (dst2) a2 = wg_adam_pre(ad, dst2);
+  }
+  if (P.accumulate) {
+    old1 = *dst;
+    if (dst2) old2 = *dst2;
+  }
   float s = 0.f;
   float s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int q = sub;
@@ -84,32 +113,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgBatch batch, const 
 #pragma unroll
   for (int o = SW_WG_REL; o < 64; o <<= 1) s += __shfl_xor(s, o);
   float bc1 = 1.f, bc2s = 1.f;
-  if (ad.w) {   // bias corrections of this update (wave-uniform; computed here so that graph and eager steps share the code)
-    const float st = *ad.step;
-    bc1 = (float)(1 - pow(ad.beta1, (double)st));
-    bc2s = (float)sqrt(1 - pow(ad.beta2, (double)st));
-  }
+  if (ad.w) wg_adam_bc(ad, bc1, bc2s);   // wave-uniform; computed here so that graph and eager steps share the code
   if (!live || sub != 0) return;
-  int n = e / Kc, k = e - n * Kc;
-  if (k < P.K) {
-    float* dst = P.dW + (size_t)n * P.ldw + k;
-    const float g = P.accumulate ? *dst + s : s;
-    *dst = g;
-    if (ad.w) wg_adam1(ad, bc1, bc2s, dst, g);
-  } else if (k < P.K + P.K2) {
-    float* dst = P.dW2 + (size_t)n * P.ldw2 + (k - P.K);
-    const float g = P.accumulate ? *dst + s : s;
-    *dst = g;
-    if (ad.w) wg_adam1(ad, bc1, bc2s, dst, g);
-  } else {
-    const float g = P.accumulate ? P.db[n] + s : s;
-    P.db[n] = g;
-    if (ad.w) wg_adam1(ad, bc1, bc2s, P.db + n, g);
-    if (P.db2) {   // LSTM b_ih / b_hh share their gradient
-      const float g2 = P.accumulate ? P.db2[n] + s : s;
-      P.db2[n] = g2;
-      if (ad.w) wg_adam1(ad, bc1, bc2s, P.db2 + n, g2);
-    }
+  const float g = P.accumulate ? old1 + s : s;
+  *dst = g;
+  if (ad.w) wg_adam_fin(ad, a1, bc1, bc2s, g);
+  if (dst2) {
+    const float g2 = P.accumulate ? old2 + s : s;
+    *dst2 = g2;
+    if (ad.w) wg_adam_fin(ad, a2, bc1, bc2s, g2);
   }
 }
 
@@ -271,14 +283,18 @@ int wg_reduce_launch_adam(WgBatch& b, float* ws, const WgAdam& ad, hipStream_t s
   return SW_OK;
 }
 int wg_reduce_launch(WgBatch& b, float* ws, hipStream_t stream) { return wg_reduce_launch_adam(b, ws, WgAdam(), stream); }
-int wg_launch_adam(WgBatch& b, float* ws, const WgAdam& ad, hipStream_t stream) {
+int wg_launch_adam(WgBatch& b, float* ws, WgAdam& ad, hipStream_t stream) {
   if (b.np == 0) return SW_OK;
   size_t need = wg_finalize(b);
   if (need > SW_WG_WS_FLOATS) return SW_ESHAPE;
   if (b.total_out == 0) return SW_OK;
+  ad.bc = nullptr;
   if (b.total_jobs > 0) {
-    hipLaunchKernelGGL(wgrad_partial_kernel, dim3(b.total_jobs), dim3(SW_THREADS), 0, stream, b, ws);
+    float* bc = ad.w ? wg_bc_slot() : nullptr;
+    hipLaunchKernelGGL(wgrad_partial_kernel, dim3(b.total_jobs + (bc ? 1 : 0)), dim3(SW_THREADS), 0, stream, b, ws, ad.step,
+                       ad.beta1, ad.beta2, bc);
     SW_CHECK_LAUNCH("wgrad_partial_kernel");
+    ad.bc = bc;
   }
   return wg_reduce_launch_adam(b, ws, ad, stream);
 }
@@ -368,7 +384,8 @@ int wg_ride_setup(const WgBatch& b, WgRide& ride, int kind, unsigned long long k
 int wg_launch_finalized(WgBatch& b, float* ws, hipStream_t stream) {
   if (b.total_out == 0) return SW_OK;
   if (b.total_jobs > 0) {
-    hipLaunchKernelGGL(wgrad_partial_kernel, dim3(b.total_jobs), dim3(SW_THREADS), 0, stream, b, ws);
+    hipLaunchKernelGGL(wgrad_partial_kernel, dim3(b.total_jobs), dim3(SW_THREADS), 0, stream, b, ws, (const float*)nullptr,
+                       0.0, 0.0, (float*)nullptr);
     SW_CHECK_LAUNCH("wgrad_partial_kernel");
   }
   return wg_reduce_launch(b, ws, stream);

@@ -210,12 +210,14 @@ def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_soc
     return pred4, ctx
 
 
-def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d_dec, ws=None, tag="g", aux=None):
+def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d_dec, ws=None, tag="g", aux=None, adam=None):
     """Backward of predict(): decode BPTT -> social block -> obs BPTT -> ONE grouped weight-gradient GEMM launch
     (the social block's problems ride in it).  d_* are the packed gradient buffers (overwritten).
     aux = (src, dst, mask): masked copy dst = mask > 0 ? src : dst done by idle workgroups of the decode BPTT
     launch.  (Running part of the weight GEMMs on a side stream under the BPTT was measured slower: it takes
-    CUs from the latency-bound chain and every cross-stream edge of a captured graph costs 5-10 us.)"""
+    CUs from the latency-bound chain and every cross-stream edge of a captured graph costs 5-10 us.)
+    adam = (w_all, g_all, m, v, step scalar, lr, beta1, beta2, eps): the kernels that finish the gradients also apply
+    the generator's Adam update (sw_gen_wgrad_adam; the four weight / gradient buffers are views of w_all / g_all)."""
     dev = dpred4.device
     ws = ws or default_ws(dev)
     B, To, Tp = ctx.B, ctx.To, ctx.Tp
@@ -244,6 +246,12 @@ def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d
         d_att.zero_()
     L.call("sw_enc_lstm_bwd", L.ptr(enc_w), L.ptr(ctx.gsave), None, L.ptr(dhT), L.ptr(dcT), None, B, To, 0,
            L.ptr(gdelta), None, None, L.stream())
+    if adam is not None:
+        w_all, g_all, m, v, step, lr, b1, b2, eps = adam
+        L.call("sw_gen_wgrad_adam", L.ptr(enc_w), L.ptr(dec_w), L.ptr(ctx.gsave), L.ptr(gdelta), L.ptr(ctx.noise), L.ptr(ctx.S),
+               B, To, Tp, L.ptr(d_enc), L.ptr(d_dec), L.ptr(wgrad), L.ptr(tmp), pending, L.ptr(w_all), L.ptr(m), L.ptr(v),
+               L.ptr(g_all), w_all.numel(), L.ptr(step), lr, b1, b2, eps, L.stream())
+        return
     L.call("sw_gen_wgrad", L.ptr(enc_w), L.ptr(dec_w), L.ptr(ctx.gsave), L.ptr(gdelta), L.ptr(ctx.noise), L.ptr(ctx.S), B, To, Tp,
            L.ptr(d_enc), L.ptr(d_dec), 0, L.ptr(wgrad), L.ptr(tmp), pending, L.stream())
 

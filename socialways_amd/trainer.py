@@ -154,6 +154,7 @@ class SocialWaysTrainer:
         self._graphs = {}
         self._force_dist = os.environ.get("SW_FORCE_DIST", "") == "1"   # 1-rank group still runs the collectives (tests)
         self._fuse_d_adam = os.environ.get("SW_FUSE_D_ADAM", "1") == "1"  # D's Adam inside the gradient reduction (world 1)
+        self._fuse_g_adam = os.environ.get("SW_FUSE_G_ADAM", "1") == "1"  # ... and the generator's (needs the weight images)
         # Data parallel: are the RCCL all-reduces recorded INSIDE the step graph (one launch for K steps) or run
         # eagerly between graph segments (3 segment boundaries per step)?  SW_GRAPH_COLLECTIVES=1 / 0 decides;
         # unset = probe once (a small captured all-reduce replayed twice and checked on every rank) and use the
@@ -590,10 +591,22 @@ class SocialWaysTrainer:
                 self._lin_maskf = D.linear_mask().float().contiguous()
             restore = (backup[:D._flat.numel()], D._flat, self._lin_maskf)
         G.grad_views()
+        # Single process: the generator's Adam step rides in the two kernels that finish its gradients (the reduction of
+        # the grouped GEMM and the composition back-propagation; the latter reads the step-start weight snapshot of the
+        # image buffer).  Without social problems in the launch the attention / embedder weights would miss their
+        # (zero-gradient) update: torch's kernel then.
+        fuse = (self._fuse_g_adam and self._gimg is not None and isinstance(self.predictor_optimizer, PackedAdam)
+                and not (self.world > 1 or self._force_dist)
+                and (not G.use_social or gctx.scenes.P > 0 or gctx.scenes.NB > 0))
+        adam = None
+        if fuse:
+            opt = self.predictor_optimizer
+            adam = (G._flat_all, G._gflat_all) + opt.fused_args(None if steps is None else steps[U + 1])
         ops.gen_backward(enc._flat, emb._flat, att._flat, dec._flat, gctx, dpred, enc._gflat, emb._gflat, att._gflat,
-                         dec._gflat, ws=ws, aux=restore, tag="gv" if KV > 1 else "g")
+                         dec._gflat, ws=ws, aux=restore, tag="gv" if KV > 1 else "g", adam=adam)
         yield G._gflat_all
-        self.predictor_optimizer.step() if steps is None else self.predictor_optimizer.step(steps[U + 1])
+        if not fuse:
+            self.predictor_optimizer.step() if steps is None else self.predictor_optimizer.step(steps[U + 1])
         self.last_pred_hat = pred_hat
         self.last_pred_hat_k = pred_hat_k if KV > 1 else None
 

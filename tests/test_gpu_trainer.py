@@ -189,9 +189,9 @@ def test_checkpoint_roundtrip_reference_format(tmp_path):
     assert_close(o1[2], o2[2], 1e-6, 1e-8, "resumed run reproduces the next epoch")
 
 
-def test_discriminator_adam_inside_the_gradient_reduction_equals_torch_adam():
-    """Single-process default: D's Adam update is applied by the kernel that finishes D's gradients
-    (sw_disc_bwd_gan_adam) instead of a torch launch.  Against the same trainer with torch's fused Adam: identical
+def test_adam_inside_the_gradient_reduction_equals_torch_adam():
+    """Single-process default: the Adam updates of D and of the generator are applied by the kernels that finish their
+    gradients (sw_disc_bwd_gan_adam, sw_gen_wgrad_adam) instead of torch launches.  Against the same trainer with torch's fused Adam: identical
     gradients; weights and moments agree to the last bits (different fused-multiply-add placement only) over several
     steps, eager and hipGraph-replayed."""
     import socialways_amd as sw
@@ -202,18 +202,22 @@ def test_discriminator_adam_inside_the_gradient_reduction_equals_torch_adam():
     for fuse, graph in ((True, True), (True, False), (False, False)):
         torch.manual_seed(0)
         tr = sw.SocialWaysTrainer(12, use_social=True, device="cuda:0", use_graph=graph)
-        tr._fuse_d_adam = fuse
+        tr._fuse_d_adam = tr._fuse_g_adam = fuse
         gen = torch.Generator().manual_seed(5)
         for i in range(5):
             out = tr.step(data.obsv[:B], data.pred[:B], sb, 0.01 * i, 0.9, torch.rand(B, 32, generator=gen), data.ss)
-        res.append((tr.D._flat.clone(), tr.D_optimizer.m.clone(), tr.D_optimizer.v.clone(), out.clone(), tr.D_optimizer.t))
-    assert all(torch.equal(a, b) for a, b in zip(res[0][:4], res[1][:4])), "graph replay == eager with the fused update"
-    assert res[0][4] == res[2][4] == 10
-    for name, a, b in zip(("weights", "exp_avg", "exp_avg_sq"), res[1][:3], res[2][:3]):
+        res.append((tr.D._flat.clone(), tr.D_optimizer.m.clone(), tr.D_optimizer.v.clone(), tr.G._flat_all.clone(),
+                    tr.predictor_optimizer.m.clone(), tr.predictor_optimizer.v.clone(), out.clone(),
+                    tr.D_optimizer.t, tr.predictor_optimizer.t))
+    assert all(torch.equal(a, b) for a, b in zip(res[0][:7], res[1][:7])), "graph replay == eager with the fused update"
+    assert res[0][7] == res[2][7] == 10 and res[0][8] == res[2][8] == 5
+    names = ("D weights", "D exp_avg", "D exp_avg_sq", "G weights", "G exp_avg", "G exp_avg_sq")
+    for name, a, b in zip(names, res[1][:6], res[2][:6]):
         err = (a - b).abs()
         tol = 1e-7 + 2e-5 * b.abs()
         assert bool((err <= tol).all()), "%s: max err %.3e" % (name, err.max().item())
-    assert_close(res[1][3].cpu(), res[2][3].cpu(), 1e-5, 1e-7, "loss sums of the fifth step")
+    assert float((res[1][4] != 0).float().mean()) > 0.9, "the generator's moments were updated by the fused path"
+    assert_close(res[1][6].cpu(), res[2][6].cpu(), 1e-5, 1e-7, "loss sums of the fifth step")
 
 
 def test_resume_from_the_checkpoint_the_reference_wrote(tmp_path):
@@ -353,7 +357,7 @@ def _rccl_worker(rank, world, port, ret, mode):
     for pg in (dist.group.WORLD, None):
         torch.manual_seed(0)
         tr = sw.SocialWaysTrainer(12, use_social=True, device="cuda:0", process_group=pg)
-        tr._fuse_d_adam = False       # like with like: the data-parallel path keeps torch's Adam behind the all-reduce (the
+        tr._fuse_d_adam = tr._fuse_g_adam = False       # like with like: the data-parallel path keeps torch's Adam behind the all-reduce (the
         if pg is None:                # single-process default applies D's update inside the gradient reduction: last-bit differences)
             tr._force_dist = False
         elif mode == "probe_fails":       # an all-reduce that cannot be recorded: the probe must clean up and fall back
