@@ -315,7 +315,14 @@ constexpr int RAW_BE = RAW_WE + 256;     // [64]       embed bias
 constexpr int RAW_W3 = RAW_BE + 64;      // [40][80]   fc3 weight
 constexpr int RAW_B3 = RAW_W3 + 3200;    // [40]       fc3 bias
 constexpr int RAW_W4 = RAW_B3 + 40;      // [2][40]    fc4 weight
-constexpr int N = RAW_W4 + 80;
+// MFMA A-OPERAND images: float4 q of lane l of k-step j of 16-row tile t of a matrix = W[16 t + (l & 15)][c0 + 16 j +
+// 4 (l >> 4) .. + 3] at OP_x + ((t KJ + j) 64 + l) 4 - a wave's operand load is 1 KB of consecutive memory instead of
+// 16 rows x 4 pieces (64 cache-line accesses per instruction)
+constexpr int OP_WHH = RAW_W4 + 80;      // encoder LSTM weight_hh [256][64]: 16 tiles, KJ 4 (tile = 4 gate + wave)
+constexpr int OP_W1H = OP_WHH + 16384;   // fc1.0.weight[:, 0:64]:   10 tiles, KJ 4
+constexpr int OP_W1SZ = OP_W1H + 10240;  // fc1.0.weight[:, 64:160]: 10 tiles, KJ 6
+constexpr int OP_W2 = OP_W1SZ + 15360;   // fc1.2.weight [80][160]:   5 tiles, KJ 10
+constexpr int N = OP_W2 + 12800;
 }  // namespace swimg
 // the images registered for (enc_w, dec_w) by the current step, or null (sw_gen_images)
 const float* sw_gen_images_for(const float* enc_w, const float* dec_w);

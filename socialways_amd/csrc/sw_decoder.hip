@@ -22,24 +22,6 @@ constexpr int LD40 = sw_ld(40);    // 52
 constexpr int LD96 = sw_ld(96);    // 100
 constexpr int LD2 = sw_ld(2);      // 20
 
-// forward LDS carve (floats)
-struct FwdLds {
-  static constexpr int W1h = 0;                        // [160][68]
-  static constexpr int W2 = W1h + 160 * LD64;          // [80][164]
-  static constexpr int W43 = W2 + 80 * LD160;          // [16][84]   fc4 . fc3 composed (2 x 80), rows >= 2 zero
-  static constexpr int W3tmp = W43 + 16 * LD80;        // [40][84]   fc3 weight, prologue only (operand of the composition)
-  static constexpr int hbuf = W3tmp + 40 * LD80;       // [2][16][68]
-  static constexpr int ubuf = hbuf + 2 * 16 * LD64;    // [16][164]
-  static constexpr int a1buf = ubuf + 16 * LD160;      // [16][164]  (prologue: [S|z] tile [16][100])
-  static constexpr int a2buf = a1buf + 16 * LD160;     // [16][84]   (prologue: wx_lds, bx_lds)
-  static constexpr int a3buf = a2buf + 16 * LD80;      // [16][52]   (prologue alias only)
-  static constexpr int xbuf = a3buf + 16 * LD40;       // [16][4]
-  static constexpr int bbuf = xbuf + 64;               // b2[80] | - | b43[16]
-  static constexpr int total = bbuf + 144;
-};
-static_assert(16 * LD80 + 16 * LD40 >= 1280, "prologue alias");
-static_assert(FwdLds::total * 4 <= 163840, "LDS budget");
-
 // backward LDS carve
 struct BwdLds {
   static constexpr int W1hT = 0;                       // [64][164]   W1hT[m][k] = W1[k][m], m < 64
@@ -55,6 +37,54 @@ struct BwdLds {
   static constexpr int total = dxpart + 256;
 };
 static_assert(BwdLds::total * 4 <= 163840, "LDS budget");
+}  // namespace
+
+#ifdef SW_PHASE_STAMPS
+__device__ long long sw_stamps[16];
+#define SW_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); long long _t = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) sw_stamps[k] += _t - _tprev; _tprev = _t; __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int sw_debug_stamps(long long* out, int reset) {
+  if (reset) { long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(sw_stamps), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sw_stamps), 16 * sizeof(long long));
+}
+#else
+#define SW_STAMP(k)
+#endif
+// Forward.  EVERY weight of the decode step lives in registers (A operands of the MFMAs: ~220 of the 512 VGPRs + AGPRs a
+// wave owns at one wave per SIMD), loaded once from global memory in operand layout; LDS holds activations only
+// (31 KB).  Round 2 had the 110 KB of decoder weights in LDS: every layer then began with a burst of ds_read_b128 for
+// its weight tiles (112 KB per step through a 128 B/clk port shared by the four waves) before its first MFMA could
+// issue.  The layers are also cut so that the four waves carry equal MFMA counts:
+//   layer 1 (160 x 64):  wave w owns row tiles 2w, 2w+1 and ONE K-half of tile 8 + (w >> 1)        (40 MFMAs each; was 48/32)
+//   layer 2 (80 x 160):  wave w owns row tile w and 3 / 3 / 2 / 2 of the 10 k-steps of tile 4       (52/52/48/48; was 80/40)
+//   fc4 . fc3 (2 x 80):  every wave for itself (20), then its 16 hidden units of the LSTM step       (68)
+// The K-split tiles leave PARTIAL sums in LDS; the consumer of the layer (every wave reads the whole activation row as
+// its B operand anyway) adds the partials, the bias and applies the LeakyReLU while loading.
+namespace {
+struct FwdLds {
+  static constexpr int LD128 = sw_ld(128);  // 132
+  static constexpr int LD32 = sw_ld(32);    // 36
+  static constexpr int LD16 = sw_ld(16);    // 20
+  static constexpr int hbuf = 0;                        // [2][16][68]
+  static constexpr int a1buf = hbuf + 2 * 16 * LD64;    // [16][132]  a1[:, :128]            (prologue: [S|z] tile [16][100])
+  static constexpr int p1 = a1buf + 16 * LD128;         // [2][16][36] K-halves of z1[:, 128:160] (u in half 0)
+  static constexpr int a2buf = p1 + 2 * 16 * LD32;      // [16][68]   a2[:, :64]             (prologue: wx | bx | W43, 1456 floats)
+  static constexpr int q2 = a2buf + 16 * LD64;          // [4][16][20] K-quarters of z2[:, 64:80] (no bias)
+  static constexpr int total = q2 + 4 * 16 * LD16;
+};
+static_assert(16 * FwdLds::LD128 >= 16 * LD96, "prologue alias [S|z]");
+static_assert(16 * LD64 + 4 * 16 * FwdLds::LD16 >= 1280 + 176, "prologue alias wx | bx | W43");
+static_assert(FwdLds::total >= 2 * 16 * SW_HLD + 1280, "LDS of the observation-LSTM workgroups");
+
+// the k-steps J0 .. J0+NJ-1 of layer 2's tile 4 (rows 64..79): acc += W2[64 + ln][16 j + 4 lg + r] a1[ln][16 j + 4 lg + r]
+template <int J0, int NJ>
+__device__ __forceinline__ f32x4 fwd_l2_part(const f32x4 (&w2p)[3], const f32x4 (&b1)[10]) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = SW_MFMA(w2p[jj][r], b1[J0 + jj][r], acc);
+  return acc;
+}
 }  // namespace
 
 __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
@@ -73,17 +103,16 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
                        (int)(blockIdx.x * SW_TILE) - ((B + SW_TILE - 1) / SW_TILE) * SW_TILE, dobs_act, dobs_x4s);
     return;
   }
-  float* W1h = smem + FwdLds::W1h;
-  float* W2 = smem + FwdLds::W2;
-  float* W43 = smem + FwdLds::W43;
+  constexpr int LD128 = FwdLds::LD128, LD32 = FwdLds::LD32, LD16 = FwdLds::LD16;
   float* hbuf = smem + FwdLds::hbuf;
-  float* ubuf = smem + FwdLds::ubuf;
   float* a1buf = smem + FwdLds::a1buf;
+  float* p1 = smem + FwdLds::p1;
   float* a2buf = smem + FwdLds::a2buf;
-  float* bbuf = smem + FwdLds::bbuf;
-  float* szbuf = a1buf;           // prologue alias
-  float* wx_lds = a2buf;          // prologue alias (1024)
-  float* bx_lds = a2buf + 1024;   // prologue alias (256)
+  float* q2 = smem + FwdLds::q2;
+  float* szbuf = a1buf;            // prologue alias [16][100]
+  float* wx_lds = a2buf;           // prologue alias (1024)
+  float* bx_lds = a2buf + 1024;    // prologue alias (256)
+  float* w43_lds = a2buf + 1280;   // prologue alias: [2][80] | b43[2] when no image buffer is registered
 
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
   const int u0 = wave * 16;
@@ -91,93 +120,181 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
   const int b = min(a0 + ln, B - 1);
   const bool live = (a0 + ln) < B;
   const GSave gs = gsave_layout(B, To, Tp);
+  // this wave's share of the layers (see above)
+  const int m1a = 32 * wave, m1b = m1a + 16;              // layer-1 row tiles it owns outright
+  const int hf = wave & 1, t1p = wave >> 1;               // ... and K-half hf of tile 8 + t1p (rows 128 + 16 t1p ..)
+  const int m2 = 16 * wave;                               // layer-2 row tile; of tile 4 the k-steps J0 ..
+  const int J0 = wave < 2 ? 3 * wave : 2 + 2 * wave;      // {0,1,2} {3,4,5} {6,7} {8,9}
 
-  // ---- prologue: stage decoder weights, compose the LSTM input matrix, build u ----------------
+  // ---- prologue: every weight into registers, straight from global memory in A-operand layout ------------------
+  // ALL global loads of the prologue are issued before anything waits on one of them: one L2 round trip (bounded by
+  // the ~200 KB a workgroup pulls in), not one per matrix.
+#ifdef SW_PHASE_STAMPS
+  long long _tprev = clock64();
+#endif
   LstmW W;
-  lstm_load_whh(W, enc_w + swp::ENC_WHH, u0, ln, lg);   // global loads in flight during the LDS staging
-  // all global loads of the prologue are issued before anything waits on them (one L2 round trip, not one per matrix)
-  f32x4 r1[11], r2[13], r3[4];
-  stage_w_load<11>(r1, LD64, 160, dec_w + swp::DEC_W1, 160, 160, 64);
-  stage_w_load<13>(r2, LD160, 80, dec_w + swp::DEC_W2, 160, 80, 160);
-  if (!gimg) stage_w_load<4>(r3, LD80, 40, dec_w + swp::DEC_W3, 80, 40, 80);
+  f32x4 w1a[4], w1b[4], w1p[2], w2f[10], w2p[3];
+  f32x4 wu[3][6], ua, ub, up;    // W1[:, 64:160] rows of this wave's layer-1 tiles: operands of u (below), prologue only
+  const int m1p = 128 + 16 * t1p;
+  if (gimg) {
+    // operand-layout images of this step (swimg::OP_*): the float4 of (row tile, k-step, lane) is one contiguous
+    // 16-byte piece, so a wave's load instruction reads 1 KB of consecutive memory.  The row-per-lane loads of the
+    // fallback below touch 64 cache lines per instruction - 95 of them kept the four waves' address units busy for
+    // ~6.5 us (cycle stamps)
+    auto op = [&](int base, int KJ, int tile, int j) { return ld4(gimg + base + (((size_t)tile * KJ + j) * 64 + lane) * 4); };
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) W.whh[g][j] = op(swimg::OP_WHH, 4, 4 * g + wave, j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w1a[j] = op(swimg::OP_W1H, 4, 2 * wave, j);
+      w1b[j] = op(swimg::OP_W1H, 4, 2 * wave + 1, j);
+    }
+    w1p[0] = op(swimg::OP_W1H, 4, 8 + t1p, 2 * hf);
+    w1p[1] = op(swimg::OP_W1H, 4, 8 + t1p, 2 * hf + 1);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) w2f[j] = op(swimg::OP_W2, 10, wave, j);
+    w2p[0] = op(swimg::OP_W2, 10, 4, J0);
+    w2p[1] = op(swimg::OP_W2, 10, 4, J0 + 1);
+    w2p[2] = op(swimg::OP_W2, 10, 4, J0 + (wave < 2 ? 2 : 1));   // waves 2, 3 have two k-steps: the third set is unused
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      wu[0][j] = op(swimg::OP_W1SZ, 6, 2 * wave, j);
+      wu[1][j] = op(swimg::OP_W1SZ, 6, 2 * wave + 1, j);
+      wu[2][j] = op(swimg::OP_W1SZ, 6, 8 + t1p, j);
+    }
+  } else {
+    lstm_load_whh(W, enc_w + swp::ENC_WHH, u0, ln, lg);
+    const float* ra = dec_w + swp::DEC_W1 + (size_t)(m1a + ln) * 160 + 4 * lg;
+    const float* rp = dec_w + swp::DEC_W1 + (size_t)(m1p + ln) * 160 + 4 * lg;
+    const float* r2 = dec_w + swp::DEC_W2 + (size_t)(m2 + ln) * 160 + 4 * lg;
+    const float* rq = dec_w + swp::DEC_W2 + (size_t)(64 + ln) * 160 + 16 * J0 + 4 * lg;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w1a[j] = ld4(ra + 16 * j);
+      w1b[j] = ld4(ra + 16 * 160 + 16 * j);
+    }
+    w1p[0] = ld4(rp + 32 * hf);
+    w1p[1] = ld4(rp + 32 * hf + 16);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) w2f[j] = ld4(r2 + 16 * j);
+    w2p[0] = ld4(rq);
+    w2p[1] = ld4(rq + 16);
+    w2p[2] = ld4(rq + (wave < 2 ? 32 : 16));
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      wu[0][j] = ld4(ra + 64 + 16 * j);
+      wu[1][j] = ld4(ra + 16 * 160 + 64 + 16 * j);
+      wu[2][j] = ld4(rp + 64 + 16 * j);
+    }
+  }
+  ua = ld4(dec_w + swp::DEC_B1 + m1a + 4 * lg);
+  ub = ld4(dec_w + swp::DEC_B1 + m1b + 4 * lg);
+  up = ld4(dec_w + swp::DEC_B1 + m1p + 4 * lg);
+  const f32x4 b2f = ld4(dec_w + swp::DEC_B2 + m2 + 4 * lg), b2p = ld4(dec_w + swp::DEC_B2 + 64 + 4 * lg);
   f32x4 c = ld4(cT + (size_t)b * 64 + u0 + 4 * lg);
   f32x4 h = ld4(hT + (size_t)b * 64 + u0 + 4 * lg);
-  float szv[6];
-#pragma unroll
-  for (int q = 0; q < 6; ++q) {
-    const int i = threadIdx.x + q * SW_THREADS, a = i / 96, cc = i - a * 96;
-    const int bb = min(a0 + a, B - 1);
-    szv[q] = cc < 64 ? (S_pool ? S_pool[(size_t)bb * 64 + cc] : 0.f) : z[(size_t)bb * 32 + cc - 64];
-  }
-  stage_w_store<11>(r1, W1h, LD64, 160);
-  stage_w_store<13>(r2, W2, LD160, 80);
-  // fc3 (80 -> 40) has NO activation in front of fc4 (40 -> 2) (train.py:327-330): the two are ONE 2 x 80 map
-  //   v = W4 (W3 a2 + b3) + b4 = W43 a2 + b43
-  // composed per workgroup after the staging barrier (like W_ih . W_embed of the encoder): one layer less on the
-  // serial chain of every decode step; a3 itself is never needed (its weight gradients are recovered from
-  // dv^T [a2 | 1], sw_misc.hip).
-  if (!gimg) stage_w_store<4>(r3, smem + FwdLds::W3tmp, LD80, 40);
-#pragma unroll
-  for (int q = 0; q < 6; ++q) {
-    const int i = threadIdx.x + q * SW_THREADS, a = i / 96, cc = i - a * 96;
-    szbuf[a * LD96 + cc] = szv[q];
-  }
-  for (int i = threadIdx.x; i < 144; i += blockDim.x) {
-    float v = 0.f;
-    if (i < 80) v = dec_w[swp::DEC_B2 + i];
-    else if (i >= 128 && i < 130 && gimg) v = gimg[swimg::W43 + 160 + (i - 128)];
-    else if (i >= 128 && i < 130) {
-      const int c = i - 128;
-      v = dec_w[swp::DEC_B4 + c];
-#pragma unroll
-      for (int m = 0; m < 40; m += 4) {
-        const f32x4 w = ld4(dec_w + swp::DEC_W4 + c * 40 + m), bb = ld4(dec_w + swp::DEC_B3 + m);
-        v = fmaf(w[0], bb[0], fmaf(w[1], bb[1], fmaf(w[2], bb[2], fmaf(w[3], bb[3], v))));
-      }
-    }
-    bbuf[i] = v;
-  }
-  if (gimg) {   // composed input matrix and fc4 . fc3 of this step: derived once by the staging launch (swimg)
-    st4(wx_lds + 4 * threadIdx.x, ld4(gimg + swimg::WX + 4 * threadIdx.x));
-    bx_lds[threadIdx.x] = gimg[swimg::BX + threadIdx.x];
-  } else {
-    lstm_prep_rows(enc_w + swp::ENC_EMB_W, enc_w + swp::ENC_EMB_B, enc_w + swp::ENC_WIH, enc_w + swp::ENC_BIH,
-                   enc_w + swp::ENC_BHH, true, wx_lds, bx_lds);
-  }
-  st4(&hbuf[ln * LD64 + u0 + 4 * lg], h);
-  sw_barrier();
-  lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
-  for (int i = threadIdx.x; i < 16 * LD80; i += blockDim.x)        // zero padding around the two live rows
-    if (i >= 2 * LD80 || i % LD80 >= 80) W43[i] = 0.f;
-  if (gimg) {
-    if (threadIdx.x < 160) W43[(threadIdx.x / 80) * LD80 + threadIdx.x % 80] = gimg[swimg::W43 + threadIdx.x];
-  } else if (threadIdx.x < 160) {   // W43 = W4 W3 from the staged fc3 image: one output per thread, 4 independent partial sums
-    const int c = threadIdx.x / 80, k = threadIdx.x - c * 80;
-    const float* w4 = dec_w + swp::DEC_W4 + c * 40;
-    const float* w3 = smem + FwdLds::W3tmp + k;
-    f32x4 wv[10];
-#pragma unroll
-    for (int q = 0; q < 10; ++q) wv[q] = ld4(w4 + 4 * q);
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-#pragma unroll
-    for (int q = 0; q < 10; ++q) {
-      v0 = fmaf(wv[q][0], w3[(4 * q) * LD80], v0);
-      v1 = fmaf(wv[q][1], w3[(4 * q + 1) * LD80], v1);
-      v2 = fmaf(wv[q][2], w3[(4 * q + 2) * LD80], v2);
-      v3 = fmaf(wv[q][3], w3[(4 * q + 3) * LD80], v3);
-    }
-    W43[c * LD80 + k] = (v0 + v1) + (v2 + v3);
-  }
-  for (int mt = wave; mt < 10; mt += 4) {
-    int m0 = mt * 16;
-    f32x4 acc = ld4(dec_w + swp::DEC_B1 + m0 + 4 * lg);
-    acc = tile_mm<6>(dec_w + swp::DEC_W1 + (size_t)(m0 + ln) * 160 + 64 + 4 * lg, &szbuf[ln * LD96 + 4 * lg], acc);
-    st4(&ubuf[ln * LD160 + m0 + 4 * lg], acc);
-  }
   // running position of agent ln (every lane keeps a copy)
   float px = obsv[((size_t)b * To + To - 1) * 2 + 0];
   float py = obsv[((size_t)b * To + To - 1) * 2 + 1];
-  sw_barrier();  // szbuf / wx_lds aliases are dead from here on
+  // [S | z] tile: both sources are read unconditionally from clamped addresses and selected afterwards - a load under a
+  // lane-dependent branch makes the compiler wait for EVERYTHING in flight right behind it (six serial round trips here)
+  float szs[6], szz[6];
+  {
+    const float* sp = S_pool ? S_pool : z;     // no social block: any readable address, the value is discarded
+    const int sld = S_pool ? 64 : 32;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int i = threadIdx.x + q * SW_THREADS, a = i / 96, cc = i - a * 96;
+      const int bb = min(a0 + a, B - 1);
+      szs[q] = sp[(size_t)bb * sld + min(cc, sld - 1)];
+      szz[q] = z[(size_t)bb * 32 + max(cc - 64, 0)];
+    }
+  }
+  // fc3 (80 -> 40) has NO activation in front of fc4 (40 -> 2) (train.py:327-330): the two are ONE 2 x 80 map
+  //   v = W4 (W3 a2 + b3) + b4 = W43 a2 + b43
+  // (one layer less on the serial chain of every decode step; a3 itself is never needed: its weight gradients are
+  // recovered from dv^T [a2 | 1], sw_misc.hip).  W43 and the composed LSTM input matrix come from the image buffer of
+  // this step when one is registered (swimg: straight into operand registers), else they are derived here through LDS
+  // with the very same arithmetic.
+  f32x4 w43[5], b43i = {0.f, 0.f, 0.f, 0.f};   // A operand: rows 0, 1 live, the other 14 rows of the tile zero; bias in C layout
+  if (gimg) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      W.wx[g] = gimg[swimg::WX + (g * 64 + u0 + ln) * 4 + lg];
+      W.bias[g] = ld4(gimg + swimg::BX + g * 64 + u0 + 4 * lg);
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) w43[j] = ld4(gimg + swimg::W43 + (ln & 1) * 80 + 16 * j + 4 * lg);
+    b43i[0] = gimg[swimg::W43 + 160];
+    b43i[1] = gimg[swimg::W43 + 161];
+  } else {
+    lstm_prep_rows(enc_w + swp::ENC_EMB_W, enc_w + swp::ENC_EMB_B, enc_w + swp::ENC_WIH, enc_w + swp::ENC_BIH,
+                   enc_w + swp::ENC_BHH, true, wx_lds, bx_lds);
+    const int t = threadIdx.x;
+    if (t < 160) {
+      const int cc = t / 80, k = t - cc * 80;
+      const float* w4 = dec_w + swp::DEC_W4 + cc * 40;
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+#pragma unroll
+      for (int m = 0; m < 40; m += 4) {
+        v0 = fmaf(w4[m], dec_w[swp::DEC_W3 + m * 80 + k], v0);
+        v1 = fmaf(w4[m + 1], dec_w[swp::DEC_W3 + (m + 1) * 80 + k], v1);
+        v2 = fmaf(w4[m + 2], dec_w[swp::DEC_W3 + (m + 2) * 80 + k], v2);
+        v3 = fmaf(w4[m + 3], dec_w[swp::DEC_W3 + (m + 3) * 80 + k], v3);
+      }
+      w43_lds[t] = (v0 + v1) + (v2 + v3);
+    } else if (t < 162) {
+      const int cc = t - 160;
+      float v = dec_w[swp::DEC_B4 + cc];
+#pragma unroll
+      for (int m = 0; m < 40; m += 4) {
+        const f32x4 w = ld4(dec_w + swp::DEC_W4 + cc * 40 + m), bb = ld4(dec_w + swp::DEC_B3 + m);
+        v = fmaf(w[0], bb[0], fmaf(w[1], bb[1], fmaf(w[2], bb[2], fmaf(w[3], bb[3], v))));
+      }
+      w43_lds[t] = v;
+    }
+  }
+  SW_STAMP(13);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const int i = threadIdx.x + q * SW_THREADS, a = i / 96, cc = i - a * 96;
+    szbuf[a * LD96 + cc] = cc < 64 ? (S_pool ? szs[q] : 0.f) : szz[q];
+  }
+  st4(&hbuf[ln * LD64 + u0 + 4 * lg], h);
+  sw_barrier();
+  SW_STAMP(14);
+  if (!gimg) {
+    lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) w43[j] = ld4(w43_lds + (ln & 1) * 80 + 16 * j + 4 * lg);
+    b43i[0] = w43_lds[160];
+    b43i[1] = w43_lds[161];
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+    if (ln >= 2) w43[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (lg != 0) b43i[0] = b43i[1] = 0.f;
+  // u = W1[:, 64:160] [S; z] + b1 is constant over the steps (train.py:411,421): it is the initial accumulator of
+  // this wave's layer-1 tiles (K-half 0 carries it for the split tiles)
+  {
+    f32x4 bz[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) bz[j] = ld4(&szbuf[ln * LD96 + 16 * j + 4 * lg]);
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ua = SW_MFMA(wu[0][j][r], bz[j][r], ua);
+        ub = SW_MFMA(wu[1][j][r], bz[j][r], ub);
+        up = SW_MFMA(wu[2][j][r], bz[j][r], up);
+      }
+    if (hf != 0) up = f32x4{0.f, 0.f, 0.f, 0.f};   // K-half 1 of the split tile starts from zero
+  }
+  SW_STAMP(15);
+  sw_barrier();  // the prologue aliases are dead from here on
+  SW_STAMP(8);
 
   // displacement-error sums of this tile (train.py:546-551), lanes lg == 0 of wave 0
   float e_sum = 0.f, e_last = 0.f, e_sq = 0.f;
@@ -186,38 +303,102 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
   for (int i = 0; i < Tp; ++i) {
     float2 gti = {0.f, 0.f};
     if (ade_lane) gti = *reinterpret_cast<const float2*>(gt + ((size_t)b * Tp + i) * 2);   // in flight under the layers
-    // ---- layer 1: a1 = lrelu(W1h h + u) -----------------------------------------------------
-    for (int mt = wave; mt < 10; mt += 4) {
-      int m0 = mt * 16;
-      f32x4 acc = ld4(&ubuf[ln * LD160 + m0 + 4 * lg]);
-      acc = tile_mm<4>(&W1h[(m0 + ln) * LD64 + 4 * lg], &hbuf[cur * 16 * LD64 + ln * LD64 + 4 * lg], acc);
+    const float* hrow = &hbuf[cur * 16 * LD64 + ln * LD64 + 4 * lg];
+    // ---- layer 1: z1 = W1h h + u ; a1 = lrelu(z1) --------------------------------------------------
+    {
+      f32x4 bh[4], bp[2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu(acc[r]);
-      st4(&a1buf[ln * LD160 + m0 + 4 * lg], acc);
-      if (gsave && live) st4(gsave + gs.a1 + ((size_t)i * B + b) * 160 + m0 + 4 * lg, acc);
+      for (int j = 0; j < 4; ++j) bh[j] = ld4(hrow + 16 * j);
+      bp[0] = ld4(hrow + 32 * hf);
+      bp[1] = ld4(hrow + 32 * hf + 16);
+      f32x4 acc_a = ua, acc_b = ub, acc_p = up;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc_a = SW_MFMA(w1a[j][r], bh[j][r], acc_a);
+          acc_b = SW_MFMA(w1b[j][r], bh[j][r], acc_b);
+          if (j < 2) acc_p = SW_MFMA(w1p[j][r], bp[j][r], acc_p);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc_a[r] = sw_lrelu(acc_a[r]);
+        acc_b[r] = sw_lrelu(acc_b[r]);
+      }
+      st4(&a1buf[ln * LD128 + m1a + 4 * lg], acc_a);
+      st4(&a1buf[ln * LD128 + m1b + 4 * lg], acc_b);
+      st4(&p1[hf * 16 * LD32 + ln * LD32 + 16 * t1p + 4 * lg], acc_p);
+      if (gsave && live) {
+        float* row = gsave + gs.a1 + ((size_t)i * B + b) * 160 + 4 * lg;
+        st4(row + m1a, acc_a);
+        st4(row + m1b, acc_b);
+      }
     }
     sw_barrier();
-    // ---- layer 2: a2 = lrelu(W2 a1 + b2) ----------------------------------------------------
-    for (int mt = wave; mt < 5; mt += 4) {
-      int m0 = mt * 16;
-      f32x4 acc = ld4(&bbuf[m0 + 4 * lg]);
-      acc = tile_mm<10>(&W2[(m0 + ln) * LD160 + 4 * lg], &a1buf[ln * LD160 + 4 * lg], acc);
+    SW_STAMP(9);
+    // ---- layer 2: a2 = lrelu(W2 a1 + b2) ----------------------------------------------------------
+    {
+      f32x4 b1[10];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b1[j] = ld4(&a1buf[ln * LD128 + 16 * j + 4 * lg]);
+#pragma unroll
+      for (int j = 8; j < 10; ++j) {     // the K-split tiles of layer 1: sum of the halves, then the LeakyReLU
+        const f32x4 s = ld4(&p1[ln * LD32 + 16 * (j - 8) + 4 * lg]) + ld4(&p1[16 * LD32 + ln * LD32 + 16 * (j - 8) + 4 * lg]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b1[j][r] = sw_lrelu(s[r]);
+      }
+      if (gsave && live && wave >= 2)    // ... whose rows of the save buffer waves 2 and 3 write
+        st4(gsave + gs.a1 + ((size_t)i * B + b) * 160 + 128 + 16 * (wave - 2) + 4 * lg, wave == 2 ? b1[8] : b1[9]);
+      f32x4 acc = b2f, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        acc = SW_MFMA(w2f[j][0], b1[j][0], acc);
+        acc1 = SW_MFMA(w2f[j][1], b1[j][1], acc1);
+        acc = SW_MFMA(w2f[j][2], b1[j][2], acc);
+        acc1 = SW_MFMA(w2f[j][3], b1[j][3], acc1);
+      }
+      f32x4 accq;
+      if (wave == 0) accq = fwd_l2_part<0, 3>(w2p, b1);
+      else if (wave == 1) accq = fwd_l2_part<3, 3>(w2p, b1);
+      else if (wave == 2) accq = fwd_l2_part<6, 2>(w2p, b1);
+      else accq = fwd_l2_part<8, 2>(w2p, b1);
+      acc = acc + acc1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu(acc[r]);
-      st4(&a2buf[ln * LD80 + m0 + 4 * lg], acc);
-      if (gsave && live) st4(gsave + gs.a2 + ((size_t)i * B + b) * 80 + m0 + 4 * lg, acc);
+      st4(&a2buf[ln * LD64 + m2 + 4 * lg], acc);
+      st4(&q2[wave * 16 * LD16 + ln * LD16 + 4 * lg], accq);
+      if (gsave && live) st4(gsave + gs.a2 + ((size_t)i * B + b) * 80 + m2 + 4 * lg, acc);
     }
     sw_barrier();
+    SW_STAMP(10);
     // ---- layers 3+4 composed (v = W43 a2 + b43 ; p += v) and the re-fed encoder step (train.py:422-430) ----
     // Every wave computes the 2-row map itself (20 MFMAs) and keeps its own copy of the running position, so
     // the LSTM step needs no barrier / LDS hop for its input.
     {
-      f32x4 acc = ld4(&bbuf[128 + 4 * lg]);
-      acc = tile_mm<5>(&W43[ln * LD80 + 4 * lg], &a2buf[ln * LD80 + 4 * lg], acc);
+      f32x4 b2v[5];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b2v[j] = ld4(&a2buf[ln * LD64 + 16 * j + 4 * lg]);
+      {
+        const float* q = &q2[ln * LD16 + 4 * lg];
+        const f32x4 s = ((b2p + ld4(q)) + ld4(q + 16 * LD16)) + (ld4(q + 2 * 16 * LD16) + ld4(q + 3 * 16 * LD16));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b2v[4][r] = sw_lrelu(s[r]);
+      }
+      if (gsave && live && wave == 1) st4(gsave + gs.a2 + ((size_t)i * B + b) * 80 + 64 + 4 * lg, b2v[4]);
+      f32x4 acc = b43i, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        acc = SW_MFMA(w43[j][0], b2v[j][0], acc);
+        acc1 = SW_MFMA(w43[j][1], b2v[j][1], acc1);
+        acc = SW_MFMA(w43[j][2], b2v[j][2], acc);
+        acc1 = SW_MFMA(w43[j][3], b2v[j][3], acc1);
+      }
+      acc = acc + acc1;
       // rows 0,1 (= v_x, v_y of agent ln) sit in the lg == 0 lanes; every lane fetches its agent's pair
       float vx = __shfl(acc[0], ln), vy = __shfl(acc[1], ln);
       px += vx;
       py += vy;
+      SW_STAMP(11);
       if (ade_lane && live) {
         float dx = (px - gti.x) * inv_ss, dy = (py - gti.y) * inv_ss;
         float q = dx * dx + dy * dy;
@@ -234,7 +415,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
       if (i < Tp - 1 || h_end) {  // the step after the last decode is dead compute (train.py:430)
         float xb = lg == 0 ? px : (lg == 1 ? py : (lg == 2 ? vx : vy));
         f32x4 gate[4];
-        lstm_cell(W, xb, &hbuf[cur * 16 * LD64 + ln * LD64 + 4 * lg], gate, c, h);
+        lstm_cell(W, xb, hrow, gate, c, h);
         st4(&hbuf[(cur ^ 1) * 16 * LD64 + ln * LD64 + u0 + 4 * lg], h);
         if (gsave && live && i < Tp - 1) {
           float* row = gsave + gs.act + ((size_t)(To + i) * B + b) * 384 + u0 + 4 * lg;
@@ -246,6 +427,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
         cur ^= 1;
       }
       sw_barrier();
+      SW_STAMP(12);
     }
   }
   if (h_end && live) {
@@ -268,16 +450,6 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-#ifdef SW_PHASE_STAMPS
-__device__ long long sw_stamps[8];
-#define SW_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); long long _t = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) sw_stamps[k] += _t - _tprev; _tprev = _t; __builtin_amdgcn_sched_barrier(0); } while (0)
-extern "C" int sw_debug_stamps(long long* out, int reset) {
-  if (reset) { long long z[8] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(sw_stamps), z, sizeof(z)); }
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sw_stamps), 8 * sizeof(long long));
-}
-#else
-#define SW_STAMP(k)
-#endif
 // Backward of the decode loop.  Propagates data gradients only; every weight gradient is a
 // deferred GEMM over the time-major delta / activation rows written here (sw_wgrad.hip).
 // ---------------------------------------------------------------------------------------------
@@ -590,7 +762,6 @@ extern "C" int sw_dec_rollout_fwd_aux(const float* obsv, int To, const float* z,
     if (int rc = set_lds((const void*)dec_rollout_fwd_kernel, FwdLds::total * 4)) return rc;
     attr = true;
   }
-  static_assert(FwdLds::total >= 2 * 16 * SW_HLD + 1280, "LDS of the observation-LSTM workgroups");
   const int tiles = (B + SW_TILE - 1) / SW_TILE;
   // rows of the D observation LSTM inside the save buffer of sw_disc_fwd (independent of its branch count)
   float* act = dsave;

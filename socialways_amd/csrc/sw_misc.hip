@@ -543,7 +543,7 @@ extern "C" int sw_traj_dist(const float* a, const float* b, int Na, int Nb, int 
 }
 
 // ---- derived weight images of the generator (swimg, sw_common.h) ---------------------------------------------------
-#define SW_IMG_BLOCKS 32
+#define SW_IMG_BLOCKS 64
 __device__ __forceinline__ void gen_images_block(const float* __restrict__ enc_w, const float* __restrict__ dec_w,
                                                  float* __restrict__ img, int blk) {
   using namespace swp;
@@ -594,7 +594,7 @@ __device__ __forceinline__ void gen_images_block(const float* __restrict__ enc_w
     }
   }
   // snapshot of the raw weights behind the compositions (swimg::RAW_*), float4 granularity
-  for (int i = (blk - 2) * 256 + threadIdx.x; i < (swimg::N - swimg::RAW_WIH) / 4; i += (SW_IMG_BLOCKS - 2) * 256) {
+  for (int i = (blk - 2) * 256 + threadIdx.x; i < (swimg::OP_WHH - swimg::RAW_WIH) / 4; i += (SW_IMG_BLOCKS - 2) * 256) {
     const int o = swimg::RAW_WIH + 4 * i;
     const float* src = o < swimg::RAW_WE   ? enc_w + ENC_WIH + (o - swimg::RAW_WIH)
                        : o < swimg::RAW_BE ? enc_w + ENC_EMB_W + (o - swimg::RAW_WE)
@@ -604,6 +604,18 @@ __device__ __forceinline__ void gen_images_block(const float* __restrict__ enc_w
                                            : dec_w + DEC_W4 + (o - swimg::RAW_W4);
     st4(img + o, ld4(src));
   }
+  // MFMA A-operand images (swimg::OP_*)
+  const int nth = (SW_IMG_BLOCKS - 2) * 256, tid = (blk - 2) * 256 + threadIdx.x;
+  auto op_image = [&](int dst0, const float* W, int ldw, int c0, int KJ, int ntile) {
+    for (int f = tid; f < ntile * KJ * 64; f += nth) {
+      const int t = f / (KJ * 64), rem = f - t * (KJ * 64), j = rem >> 6, l = rem & 63;
+      st4(img + dst0 + 4 * (size_t)f, ld4(W + (size_t)(16 * t + (l & 15)) * ldw + c0 + 16 * j + 4 * (l >> 4)));
+    }
+  };
+  op_image(swimg::OP_WHH, enc_w + ENC_WHH, 64, 0, 4, 16);
+  op_image(swimg::OP_W1H, dec_w + DEC_W1, 160, 0, 4, 10);
+  op_image(swimg::OP_W1SZ, dec_w + DEC_W1, 160, 64, 6, 10);
+  op_image(swimg::OP_W2, dec_w + DEC_W2, 160, 0, 10, 5);
 }
 __global__ __launch_bounds__(256) void gen_images_kernel(const float* __restrict__ enc_w, const float* __restrict__ dec_w,
                                                           float* __restrict__ img) {

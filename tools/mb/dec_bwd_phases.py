@@ -40,7 +40,7 @@ for _ in range(N):
     run()
 e1.record()
 torch.cuda.synchronize()
-out = (ctypes.c_longlong * 8)()
+out = (ctypes.c_longlong * 16)()
 lib.sw_debug_stamps(out, 0)
 pro = {5: "prologue: W_hh^T loads issued, LDS zeroed, barrier", 6: "prologue: weight staging + input-matrix rows, barrier",
        2: "prologue: W43^T / Wx^T composition, barrier"}
