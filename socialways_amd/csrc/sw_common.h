@@ -297,32 +297,34 @@ __host__ __device__ inline GDelta gdelta_layout(int B, int To, int Tp) {
 // launches used to derive for itself in its prologue - the composed input matrix W_ih W_embed (256 uncoalesced row reads
 // + 80 K MACs per workgroup), fc4 . fc3, and the TRANSPOSED, zero-padded decoder matrices of the backward pass (scalar
 // LDS scatter with 8-way bank conflicts) - computed ONCE per step by a few workgroups of the staging launch.  The
-// prologues then copy them with coalesced 16-byte loads (dec_rollout_bwd: 9.9 -> ~3 us).  Layout in floats:
+// prologues then load them with coalesced 16-byte loads.  Layout in floats:
 // ---------------------------------------------------------------------------------------------
 namespace swimg {
 constexpr int WX = 0;                    // [256][4]   W_ih W_embed
 constexpr int BX = 1024;                 // [256]      W_ih b_embed + b_ih + b_hh
-constexpr int W43 = 1280;                // [2][80] | b43[2]   fc4 . fc3, fc4 b3 + b4
-constexpr int W43T = W43 + 176;          // [80][20]   (fc4 . fc3)^T, columns >= 2 zero
-constexpr int W1HT = W43T + 80 * 20;     // [64][164]  fc1.0.weight[:, :64]^T, columns >= 160 zero
-constexpr int W2T = W1HT + 64 * 164;     // [160][84]  fc1.2.weight^T, columns >= 80 zero
+constexpr int W43 = 1280;                // [2][80] | b43[2]   fc4 . fc3, fc4 b3 + b4   (176 floats reserved)
 // SNAPSHOT of the raw weights the composed maps are made of, as they were when this step started: the kernel that
 // back-propagates through the compositions AND applies the generator's Adam step (sw_gen_wgrad_adam) reads these
 // while it overwrites the live weights
-constexpr int RAW_WIH = W2T + 160 * 84;  // [256][64]  encoder LSTM weight_ih
+constexpr int RAW_WIH = W43 + 176;       // [256][64]  encoder LSTM weight_ih
 constexpr int RAW_WE = RAW_WIH + 16384;  // [64][4]    embed weight
 constexpr int RAW_BE = RAW_WE + 256;     // [64]       embed bias
 constexpr int RAW_W3 = RAW_BE + 64;      // [40][80]   fc3 weight
 constexpr int RAW_B3 = RAW_W3 + 3200;    // [40]       fc3 bias
 constexpr int RAW_W4 = RAW_B3 + 40;      // [2][40]    fc4 weight
-// MFMA A-OPERAND images: float4 q of lane l of k-step j of 16-row tile t of a matrix = W[16 t + (l & 15)][c0 + 16 j +
-// 4 (l >> 4) .. + 3] at OP_x + ((t KJ + j) 64 + l) 4 - a wave's operand load is 1 KB of consecutive memory instead of
-// 16 rows x 4 pieces (64 cache-line accesses per instruction)
-constexpr int OP_WHH = RAW_W4 + 80;      // encoder LSTM weight_hh [256][64]: 16 tiles, KJ 4 (tile = 4 gate + wave)
+constexpr int RAW_END = RAW_W4 + 80;
+// MFMA A-OPERAND images of a matrix M [rows][K]: float4 q of lane l of k-step j of 16-row tile t =
+// M[16 t + (l & 15)][16 j + 4 (l >> 4) .. + 3] at OP_x + ((t KJ + j) 64 + l) 4 - a wave's operand load is 1 KB of
+// consecutive memory instead of 16 rows x 4 pieces (64 cache-line accesses per instruction).  The backward kernels
+// use the TRANSPOSED matrices (M = W^T).
+constexpr int OP_WHH = RAW_END;          // encoder LSTM weight_hh [256][64]: 16 tiles, KJ 4 (tile = 4 gate + wave)
 constexpr int OP_W1H = OP_WHH + 16384;   // fc1.0.weight[:, 0:64]:   10 tiles, KJ 4
 constexpr int OP_W1SZ = OP_W1H + 10240;  // fc1.0.weight[:, 64:160]: 10 tiles, KJ 6
 constexpr int OP_W2 = OP_W1SZ + 15360;   // fc1.2.weight [80][160]:   5 tiles, KJ 10
-constexpr int N = OP_W2 + 12800;
+constexpr int OP_WHHT = OP_W2 + 12800;   // weight_hh^T [64][256]:    4 tiles, KJ 16
+constexpr int OP_W2T = OP_WHHT + 16384;  // fc1.2.weight^T [160][80]: 10 tiles, KJ 5
+constexpr int OP_W1HT = OP_W2T + 12800;  // fc1.0.weight[:, 0:64]^T [64][160]: 4 tiles, KJ 10
+constexpr int N = OP_W1HT + 10240;
 }  // namespace swimg
 // the images registered for (enc_w, dec_w) by the current step, or null (sw_gen_images)
 const float* sw_gen_images_for(const float* enc_w, const float* dec_w);

@@ -18,25 +18,8 @@ namespace {
 constexpr int LD64 = sw_ld(64);    // 68
 constexpr int LD160 = sw_ld(160);  // 164
 constexpr int LD80 = sw_ld(80);    // 84
-constexpr int LD40 = sw_ld(40);    // 52
 constexpr int LD96 = sw_ld(96);    // 100
-constexpr int LD2 = sw_ld(2);      // 20
 
-// backward LDS carve
-struct BwdLds {
-  static constexpr int W1hT = 0;                       // [64][164]   W1hT[m][k] = W1[k][m], m < 64
-  static constexpr int W2T = W1hT + 64 * LD160;        // [160][84]
-  static constexpr int W43T = W2T + 160 * LD80;        // [80][20]    (fc4 . fc3)^T: W43T[k][c] = W43[c][k], cols >= 2 zero
-  static constexpr int W3tmp = W43T + 80 * LD2;        // [40][84]    fc3 weight, prologue only
-  static constexpr int dgbuf = W3tmp + 40 * LD80;      // [16][260]
-  static constexpr int dz1buf = dgbuf + 16 * SW_GLD;   // [16][164]
-  static constexpr int dz2buf = dz1buf + 16 * LD160;   // [16][84]
-  static constexpr int da3buf = dz2buf + 16 * LD80;    // [16][52]
-  static constexpr int dvbuf = da3buf + 16 * LD40;     // [16][20]
-  static constexpr int dxpart = dvbuf + 16 * LD2;      // [4 waves][16][4]
-  static constexpr int total = dxpart + 256;
-};
-static_assert(BwdLds::total * 4 <= 163840, "LDS budget");
 }  // namespace
 
 #ifdef SW_PHASE_STAMPS
@@ -142,10 +125,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
     // fallback below touch 64 cache lines per instruction - 95 of them kept the four waves' address units busy for
     // ~6.5 us (cycle stamps)
     auto op = [&](int base, int KJ, int tile, int j) { return ld4(gimg + base + (((size_t)tile * KJ + j) * 64 + lane) * 4); };
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) W.whh[g][j] = op(swimg::OP_WHH, 4, 4 * g + wave, j);
+    lstm_load_img(W, gimg, wave, lane);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       w1a[j] = op(swimg::OP_W1H, 4, 2 * wave, j);
@@ -220,11 +200,6 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
   // with the very same arithmetic.
   f32x4 w43[5], b43i = {0.f, 0.f, 0.f, 0.f};   // A operand: rows 0, 1 live, the other 14 rows of the tile zero; bias in C layout
   if (gimg) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      W.wx[g] = gimg[swimg::WX + (g * 64 + u0 + ln) * 4 + lg];
-      W.bias[g] = ld4(gimg + swimg::BX + g * 64 + u0 + 4 * lg);
-    }
 #pragma unroll
     for (int j = 0; j < 5; ++j) w43[j] = ld4(gimg + swimg::W43 + (ln & 1) * 80 + 16 * j + 4 * lg);
     b43i[0] = gimg[swimg::W43 + 160];
@@ -452,7 +427,28 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
 // ---------------------------------------------------------------------------------------------
 // Backward of the decode loop.  Propagates data gradients only; every weight gradient is a
 // deferred GEMM over the time-major delta / activation rows written here (sw_wgrad.hip).
+//
+// Like the forward kernel every weight (transposed) lives in registers as MFMA A operands - W_hh^T, Wx^T, W2^T,
+// W1h^T, (fc4 . fc3)^T: ~180 registers per lane - loaded from the operand-layout images of the step, and LDS holds
+// delta tiles only.  Work per wave and decode step: dh_prev = W_hh^T dgates (64 MFMAs) + its K-quarter of dx4 (16);
+// dz2 (2 tiles x 2); dz1 = W2^T dz2 with row tiles 2w, 2w+1 outright and K-part (3 or 2 of 5 k-steps) of tile
+// 8 + (w >> 1) (52 / 48; was 60 with tile 9 repeated by the waves that would have idled); dh += W1h^T dz1 (40).  The
+// consumer of dz1 adds the partial sums of the split tiles and applies LeakyReLU' while loading its B operand.
 // ---------------------------------------------------------------------------------------------
+namespace {
+struct BwdLds {
+  static constexpr int LD128 = sw_ld(128);  // 132
+  static constexpr int LD16 = sw_ld(16);    // 20
+  static constexpr int dgbuf = 0;                         // [16][260]  (prologue without images: wx | bx | W43; epilogue: du [16][164])
+  static constexpr int dz1buf = dgbuf + 16 * SW_GLD;      // [16][132]  dz1[:, :128]
+  static constexpr int pz1 = dz1buf + 16 * LD128;         // [4][16][20] K-parts of (W2^T dz2)[:, 128:160]: slot 2 (tile - 8) + part
+  static constexpr int dz2buf = pz1 + 4 * 16 * LD16;      // [16][84]
+  static constexpr int dxpart = dz2buf + 16 * LD80;       // [4 waves][16][4]
+  static constexpr int total = dxpart + 256;
+};
+static_assert(16 * SW_GLD >= 16 * LD160 && 16 * SW_GLD >= 1280 + 176, "aliases of dgbuf");
+}  // namespace
+
 __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
     const float* __restrict__ dpred4, const float* __restrict__ enc_w, const float* __restrict__ dec_w,
     const float* __restrict__ gsave, int B, int To, int Tp, float* __restrict__ gdelta,
@@ -470,16 +466,15 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
     }
   }
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* W1hT = smem + BwdLds::W1hT;
-  float* W2T = smem + BwdLds::W2T;
-  float* W43T = smem + BwdLds::W43T;
+  constexpr int LD128 = BwdLds::LD128, LD16 = BwdLds::LD16;
   float* dgbuf = smem + BwdLds::dgbuf;
   float* dz1buf = smem + BwdLds::dz1buf;
+  float* pz1 = smem + BwdLds::pz1;
   float* dz2buf = smem + BwdLds::dz2buf;
-  float* dvbuf = smem + BwdLds::dvbuf;
   float* dxpart = smem + BwdLds::dxpart;
-  float* wx_lds = dz1buf;          // prologue alias (1024)
-  float* bx_lds = dz1buf + 1024;   // prologue alias (256)
+  float* wx_lds = dgbuf;            // prologue alias (1024), only without an image buffer
+  float* bx_lds = dgbuf + 1024;     // prologue alias (256)
+  float* w43_lds = dgbuf + 1280;    // prologue alias [2][80]
 
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
   const int u0 = wave * 16;
@@ -488,100 +483,118 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
   const bool live = (a0 + ln) < B;
   const GSave gs = gsave_layout(B, To, Tp);
   const GDelta gd = gdelta_layout(B, To, Tp);
+  const int hf = wave & 1, t1p = wave >> 1;     // of dz1's split tile 8 + t1p this wave sums k-steps {0,1,2} (hf 0) or {3,4}
+  const int m2q[2] = {min(wave, 4) * 16, 64};   // its dz2 row tiles: wave and 4 (every wave repeats tile 4: same values, same places)
 
-  // ---- prologue: transposed decoder weights into LDS, composed Wx^T, W_hh^T into registers ---
-  // All global loads of the prologue are issued before anything waits on them (one L2 round trip, not one per matrix)
+  // ---- prologue: every (transposed) weight into registers ------------------------------------------------------
 #ifdef SW_PHASE_STAMPS
   long long _tprev = clock64();
 #endif
   LstmWT WT;
-  lstm_load_wT(WT, enc_w + swp::ENC_WHH, u0, ln, lg);
+  f32x4 wxT[4], w2t[2][5], w2p[3], w1t[10];
+  float w43t[2][2];
   if (gimg) {
-    // The transposed, zero-padded images of this step were derived once by the staging launch (swimg, sw_common.h):
-    // a straight coalesced copy - [64][164] | [160][84] | [80][20] = 25 536 floats, 25 float4 per thread - instead of
-    // scalar LDS scatters (8-way bank conflicts) and 80 K MACs of composition per workgroup (9.9 -> ~3 us of prologue)
-    f32x4 q[25];
-    constexpr int n1 = 64 * LD160 / 4, n2 = 160 * LD80 / 4, n3 = 80 * LD2 / 4;
-    static_assert(BwdLds::W2T == BwdLds::W1hT + 64 * LD160 && BwdLds::W43T == BwdLds::W2T + 160 * LD80, "images are contiguous in LDS");
-    static_assert(swimg::W2T == swimg::W1HT + 64 * LD160, "... and in the image buffer");
+    auto op = [&](int base, int KJ, int tile, int j) { return ld4(gimg + base + (((size_t)tile * KJ + j) * 64 + lane) * 4); };
 #pragma unroll
-    for (int j = 0; j < 25; ++j) {
-      const int f = threadIdx.x + SW_THREADS * j;
-      const float* src = f < n1 + n2 ? gimg + swimg::W1HT + 4 * f : gimg + swimg::W43T + 4 * (f - n1 - n2);
-      q[j] = f < n1 + n2 + n3 ? ld4(src) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const f32x4 wxq = ld4(gimg + swimg::WX + 4 * threadIdx.x);
+    for (int j = 0; j < 16; ++j) WT.whhT[j] = op(swimg::OP_WHHT, 16, wave, j);
 #pragma unroll
-    for (int j = 0; j < 25; ++j) {
-      const int f = threadIdx.x + SW_THREADS * j;
-      if (f < n1 + n2 + n3) st4(smem + BwdLds::W1hT + 4 * f, q[j]);
+    for (int j = 0; j < 5; ++j) {
+      w2t[0][j] = op(swimg::OP_W2T, 5, 2 * wave, j);
+      w2t[1][j] = op(swimg::OP_W2T, 5, 2 * wave + 1, j);
     }
-    st4(wx_lds + 4 * threadIdx.x, wxq);
-    for (int i = threadIdx.x; i < 16 * LD2; i += blockDim.x) dvbuf[i] = 0.f;
-    sw_barrier();
-    SW_STAMP(5);
-    SW_STAMP(6);
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) w2p[jj] = op(swimg::OP_W2T, 5, 8 + t1p, hf ? 3 + min(jj, 1) : jj);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) w1t[j] = op(swimg::OP_W1HT, 10, wave, j);
+    // Wx^T slice of this wave's K-quarter as A operands: row c = ln (< 4 live), k = 64 wave + 16 j + 4 lg + r
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wxT[j][r] = gimg[swimg::WX + (64 * wave + 16 * j + 4 * lg + r) * 4 + (ln & 3)];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      w43t[q][0] = gimg[swimg::W43 + m2q[q] + ln];
+      w43t[q][1] = gimg[swimg::W43 + 80 + m2q[q] + ln];
+    }
   } else {
-  f32x4 r1[10], r2[13], r3[4];
-  stage_wT_load<10>(r1, dec_w + swp::DEC_W1, 160, 160, 64);
-  stage_wT_load<13>(r2, dec_w + swp::DEC_W2, 160, 80, 160);
-  stage_w_load<4>(r3, LD80, 40, dec_w + swp::DEC_W3, 80, 40, 80);   // operand of the fc4 . fc3 composition
-  const f32x4 w4v = threadIdx.x < 20 ? ld4(dec_w + swp::DEC_W4 + 4 * threadIdx.x) : f32x4{0.f, 0.f, 0.f, 0.f};
-  stage_zero(smem, BwdLds::dgbuf);  // transposed images are zero padded
-  sw_barrier();
-  SW_STAMP(5);
-  stage_wT_store<10>(r1, W1hT, LD160, 160, 64);
-  stage_wT_store<13>(r2, W2T, LD80, 80, 160);
-  stage_w_store<4>(r3, smem + BwdLds::W3tmp, LD80, 40);
-  if (threadIdx.x < 20) st4(dxpart + 4 * threadIdx.x, w4v);        // fc4 weight (2 x 40), prologue use of dxpart
-  lstm_prep_rows(enc_w + swp::ENC_EMB_W, enc_w + swp::ENC_EMB_B, enc_w + swp::ENC_WIH, enc_w + swp::ENC_BIH,
-                 enc_w + swp::ENC_BHH, true, wx_lds, bx_lds);
-  for (int i = threadIdx.x; i < 16 * LD2; i += blockDim.x) dvbuf[i] = 0.f;
-  sw_barrier();
-  SW_STAMP(6);
-  // Wx^T slice of this wave's K-quarter as A operands: row c = ln (< 4 live), k = 64*wave + 16j + 4lg + r
-  if (threadIdx.x < 160) {   // W43^T from the staged fc3 image (see the forward kernel): one output per thread,
-    const int c = threadIdx.x / 80, k = threadIdx.x - c * 80;   // 4 independent partial sums (the zero padding is already there)
-    const float* w4 = dxpart + c * 40;
-    const float* w3 = smem + BwdLds::W3tmp + k;
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    // no image buffer registered (stand-alone module calls): strided loads from the weights themselves, the composed
+    // maps derived here with the arithmetic of sw_gen_images
+    lstm_load_wT(WT, enc_w + swp::ENC_WHH, u0, ln, lg);
+    lstm_prep_rows(enc_w + swp::ENC_EMB_W, enc_w + swp::ENC_EMB_B, enc_w + swp::ENC_WIH, enc_w + swp::ENC_BIH,
+                   enc_w + swp::ENC_BHH, true, wx_lds, bx_lds);
+    {
+      const int t = threadIdx.x;
+      if (t < 160) {
+        const int cc = t / 80, k = t - cc * 80;
+        const float* w4 = dec_w + swp::DEC_W4 + cc * 40;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
 #pragma unroll
-    for (int m = 0; m < 40; m += 4) {
-      v0 = fmaf(w4[m], w3[m * LD80], v0);
-      v1 = fmaf(w4[m + 1], w3[(m + 1) * LD80], v1);
-      v2 = fmaf(w4[m + 2], w3[(m + 2) * LD80], v2);
-      v3 = fmaf(w4[m + 3], w3[(m + 3) * LD80], v3);
+        for (int m = 0; m < 40; m += 4) {
+          v0 = fmaf(w4[m], dec_w[swp::DEC_W3 + m * 80 + k], v0);
+          v1 = fmaf(w4[m + 1], dec_w[swp::DEC_W3 + (m + 1) * 80 + k], v1);
+          v2 = fmaf(w4[m + 2], dec_w[swp::DEC_W3 + (m + 2) * 80 + k], v2);
+          v3 = fmaf(w4[m + 3], dec_w[swp::DEC_W3 + (m + 3) * 80 + k], v3);
+        }
+        w43_lds[t] = (v0 + v1) + (v2 + v3);
+      }
     }
-    W43T[k * LD2 + c] = (v0 + v1) + (v2 + v3);
-  }
-  }   // legacy prologue
-  f32x4 wxT[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 5; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) wxT[j][r] = ln < 4 ? wx_lds[(64 * wave + 16 * j + 4 * lg + r) * 4 + ln] : 0.f;
+      for (int r = 0; r < 4; ++r) {
+        const float* col = dec_w + swp::DEC_W2 + (size_t)(16 * j + 4 * lg + r) * 160;
+        w2t[0][j][r] = col[32 * wave + ln];
+        w2t[1][j][r] = col[32 * wave + 16 + ln];
+      }
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        w2p[jj][r] = dec_w[swp::DEC_W2 + (size_t)(16 * (hf ? 3 + min(jj, 1) : jj) + 4 * lg + r) * 160 + 128 + 16 * t1p + ln];
+#pragma unroll
+    for (int j = 0; j < 10; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w1t[j][r] = dec_w[swp::DEC_W1 + (size_t)(16 * j + 4 * lg + r) * 160 + u0 + ln];
+    sw_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wxT[j][r] = wx_lds[(64 * wave + 16 * j + 4 * lg + r) * 4 + (ln & 3)];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      w43t[q][0] = w43_lds[m2q[q] + ln];
+      w43t[q][1] = w43_lds[80 + m2q[q] + ln];
+    }
   }
-  sw_barrier();
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (ln >= 4) wxT[j][r] = 0.f;
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    if (lg != 0) w43t[q][0] = w43t[q][1] = 0.f;
+  sw_barrier();   // the prologue aliases of dgbuf are dead
+  SW_STAMP(5);
+  SW_STAMP(6);
   SW_STAMP(2);
 
   f32x4 dh = {0.f, 0.f, 0.f, 0.f}, dc = {0.f, 0.f, 0.f, 0.f};
-  f32x4 du[3];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) du[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // per-agent running gradient w.r.t. the position (lanes lg==0 of wave 0)
+  f32x4 du_a = {0.f, 0.f, 0.f, 0.f}, du_b = du_a, du_s[2] = {du_a, du_a};   // sum over the steps of dz1: own tiles | split tiles 8, 9
+  // per-agent running gradient w.r.t. the position (every lane keeps a copy)
   float dpx = 0.f, dpy = 0.f;
 
   // Everything an iteration reads from HBM/L2 (saved LSTM rows, saved a1 / a2 tiles, the upstream gradient) is
   // fetched ONE ITERATION AHEAD, and the loop body has no conditional memory operation: clamped tile indices
   // instead of `mt < n ? load : 0`, the first / last iteration peeled instead of `if (i < Tp - 1)`, stores of the
-  // padding lanes of the last tile kept (exact replicas of agent B-1: every load is clamped to it).  With
-  // conditional loads or stores the compiler cannot count what is in flight and waits for EVERYTHING
-  // (s_waitcnt vmcnt(0)) where a loaded value is first used - here that was the top of every step.
+  // padding lanes of the last tile kept (exact replicas of agent B-1: every load is clamped to it), values that
+  // several waves hold stored by all of them.  With conditional loads or stores the compiler cannot count what is in
+  // flight and waits for EVERYTHING (s_waitcnt vmcnt(0)) where a loaded value is first used.
   using T_ = std::true_type;
   using F_ = std::false_type;
   struct Rows {
-    f32x4 gate[4], ct, cprev;   // LSTM step To + i (consumed x4_i)
-    f32x4 a2[2], a1[3], g4;     // decoder step i
+    f32x4 gate[4], ct, cprev;     // LSTM step To + i (consumed x4_i)
+    f32x4 a2[2], a1[2], a1s[2], g4;   // decoder step i: a2 tiles wave, 4; a1 tiles 2w, 2w+1; a1[:, 128:160] (every wave)
   };
   const float* act_b = gsave + gs.act + ((size_t)To * B + b) * 384 + u0 + 4 * lg;
   const float* a2_b = gsave + gs.a2 + (size_t)b * 80 + 4 * lg;
@@ -595,9 +608,11 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
       R.cprev = ld4(row - (size_t)B * 384 + 256);
     }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) R.a2[q] = ld4(a2_b + (size_t)i * B * 80 + min(wave + 4 * q, 4) * 16);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) R.a1[q] = ld4(a1_b + (size_t)i * B * 160 + min(wave + 4 * q, 9) * 16);
+    for (int q = 0; q < 2; ++q) {
+      R.a2[q] = ld4(a2_b + (size_t)i * B * 80 + m2q[q]);
+      R.a1[q] = ld4(a1_b + (size_t)i * B * 160 + 32 * wave + 16 * q);
+      R.a1s[q] = ld4(a1_b + (size_t)i * B * 160 + 128 + 16 * q);
+    }
     R.g4 = ld4(dpred4 + ((size_t)b * Tp + i) * 4);  // every wave keeps its own copy of the p/v gradient state
   };
   Rows R;
@@ -633,7 +648,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
       dx4 = ld4(&dxpart[ln * 4]) + ld4(&dxpart[(16 + ln) * 4]) + ld4(&dxpart[(32 + ln) * 4]) +
             ld4(&dxpart[(48 + ln) * 4]);
     }
-    // ---- decoder step i: dv (registers, every wave) -> da3 = W4^T dv ---------------------------
+    // ---- decoder step i: dv (registers, every wave) ------------------------------------------------
     const f32x4 g4 = R.g4;
     dpx += g4[0] + dx4[0];  // dL/dp_i  (p_i also feeds p_{i+1}: carried in dpx)
     dpy += g4[1] + dx4[1];
@@ -644,52 +659,90 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
       st4(gdelta + gd.dv + ((size_t)i * B + b) * 4, o);
     }
     // dz2 = (W43^T dv) * lrelu'(a2)   (80): fc3 and fc4 are one linear map, so d(a2) comes straight from dv
-    // (2 MFMAs per tile, B operand k = 4lg + r with only k = 0,1 live, straight from registers).  Waves without a
-    // second tile repeat tile 4 (same values to the same places): no wave-dependent trip count around the stores
+    // (2 MFMAs per tile, k = 4 lg + r with only k = 0, 1 live, both operands straight from registers)
 #pragma unroll
     for (int q2 = 0; q2 < 2; ++q2) {
-      const int m0 = min(wave + 4 * q2, 4) * 16;
-      f32x4 w = ld4(&W43T[(m0 + ln) * LD2 + 4 * lg]);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      acc = SW_MFMA(w[0], lg == 0 ? dvx : 0.f, acc);
-      acc = SW_MFMA(w[1], lg == 0 ? dvy : 0.f, acc);
-      f32x4 a2 = R.a2[q2];
+      acc = SW_MFMA(w43t[q2][0], lg == 0 ? dvx : 0.f, acc);
+      acc = SW_MFMA(w43t[q2][1], lg == 0 ? dvy : 0.f, acc);
+      const f32x4 a2 = R.a2[q2];
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(a2[r], acc[r]);
-      st4(&dz2buf[ln * LD80 + m0 + 4 * lg], acc);
-      st4(gdelta + gd.dz2 + ((size_t)i * B + b) * 80 + m0 + 4 * lg, acc);
+      st4(&dz2buf[ln * LD80 + m2q[q2] + 4 * lg], acc);
+      st4(gdelta + gd.dz2 + ((size_t)i * B + b) * 80 + m2q[q2] + 4 * lg, acc);
     }
     sw_barrier();
     SW_STAMP(3);
-    // dz1 = (W2^T dz2) * lrelu'(a1)   (160); waves 2, 3 repeat tile 9 as their third (they would idle at the barrier)
+    // dz1 = (W2^T dz2) * lrelu'(a1)   (160): row tiles 2w, 2w+1 and this wave's K-part of the split tile
     {
+      f32x4 b2[5];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int mt = wave + 4 * q;
-        const int m0 = min(mt, 9) * 16;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = tile_mm<5>(&W2T[(m0 + ln) * LD80 + 4 * lg], &dz2buf[ln * LD80 + 4 * lg], acc);
-        f32x4 a1 = R.a1[q];
+      for (int j = 0; j < 5; ++j) b2[j] = ld4(&dz2buf[ln * LD80 + 16 * j + 4 * lg]);
+      f32x4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = acc_a, acc_p = acc_a;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(a1[r], acc[r]);
-        st4(&dz1buf[ln * LD160 + m0 + 4 * lg], acc);
-        st4(gdelta + gd.dz1 + ((size_t)i * B + b) * 160 + m0 + 4 * lg, acc);
-        if (mt < 10) du[q] += acc;
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc_a = SW_MFMA(w2t[0][j][r], b2[j][r], acc_a);
+          acc_b = SW_MFMA(w2t[1][j][r], b2[j][r], acc_b);
+        }
+      if (hf == 0) {
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc_p = SW_MFMA(w2p[jj][r], b2[jj][r], acc_p);
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc_p = SW_MFMA(w2p[jj][r], b2[3 + jj][r], acc_p);
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc_a[r] = sw_lrelu_grad(R.a1[0][r], acc_a[r]);
+        acc_b[r] = sw_lrelu_grad(R.a1[1][r], acc_b[r]);
+      }
+      st4(&dz1buf[ln * LD128 + 32 * wave + 4 * lg], acc_a);
+      st4(&dz1buf[ln * LD128 + 32 * wave + 16 + 4 * lg], acc_b);
+      st4(&pz1[(2 * t1p + hf) * 16 * LD16 + ln * LD16 + 4 * lg], acc_p);
+      float* row = gdelta + gd.dz1 + ((size_t)i * B + b) * 160 + 32 * wave + 4 * lg;
+      st4(row, acc_a);
+      st4(row + 16, acc_b);
+      du_a += acc_a;
+      du_b += acc_b;
     }
     sw_barrier();
     SW_STAMP(4);
     // dh_{To+i-1} += W1h^T dz1   (wave w owns units 16w.. : same layout as dh)
     {
-      f32x4 acc = decltype(lstm)::value ? dh : f32x4{0.f, 0.f, 0.f, 0.f};
-      acc = tile_mm<10>(&W1hT[(u0 + ln) * LD160 + 4 * lg], &dz1buf[ln * LD160 + 4 * lg], acc);
-      dh = acc;
+      f32x4 b1[10];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b1[j] = ld4(&dz1buf[ln * LD128 + 16 * j + 4 * lg]);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {   // the split tiles: sum of the K-parts, then LeakyReLU' - every wave, and every wave
+        const float* pp = &pz1[2 * q * 16 * LD16 + ln * LD16 + 4 * lg];   // stores them (the same values to the same places)
+        f32x4 v = ld4(pp) + ld4(pp + 16 * LD16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = sw_lrelu_grad(R.a1s[q][r], v[r]);
+        b1[8 + q] = v;
+        st4(gdelta + gd.dz1 + ((size_t)i * B + b) * 160 + 128 + 16 * q + 4 * lg, v);
+        du_s[q] += v;
+      }
+      f32x4 acc = decltype(lstm)::value ? dh : f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        acc = SW_MFMA(w1t[j][0], b1[j][0], acc);
+        acc1 = SW_MFMA(w1t[j][1], b1[j][1], acc1);
+        acc = SW_MFMA(w1t[j][2], b1[j][2], acc);
+        acc1 = SW_MFMA(w1t[j][3], b1[j][3], acc1);
+      }
+      dh = acc + acc1;
     }
-    // (next iteration's first LDS writes are to dgbuf/dvbuf, whose readers are behind barriers)
+    // (next iteration's first LDS writes are to dgbuf, whose readers are behind barriers)
     if constexpr (decltype(pf)::value) {
       // the prefetched rows are not touched before the products above have been issued
       asm volatile("" : "+v"(N.gate[0]), "+v"(N.gate[1]), "+v"(N.gate[2]), "+v"(N.gate[3]), "+v"(N.ct), "+v"(N.cprev));
-      asm volatile("" : "+v"(N.a2[0]), "+v"(N.a2[1]), "+v"(N.a1[0]), "+v"(N.a1[1]), "+v"(N.a1[2]), "+v"(N.g4));
+      asm volatile("" : "+v"(N.a2[0]), "+v"(N.a2[1]), "+v"(N.a1[0]), "+v"(N.a1[1]), "+v"(N.a1s[0]), "+v"(N.a1s[1]), "+v"(N.g4));
       R = N;
     }
   };
@@ -706,13 +759,18 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
     st4(dcT + (size_t)b * 64 + u0 + 4 * lg, dc);
   }
   sw_barrier();
+  float* dub = dgbuf;   // [16][164]
   {
-    int q = 0;
-    for (int mt = wave; mt < 10; mt += 4, ++q) {
-      int m0 = mt * 16;
-      f32x4 v = q == 0 ? du[0] : (q == 1 ? du[1] : du[2]);
-      st4(&dz1buf[ln * LD160 + m0 + 4 * lg], v);
-      if (live) st4(gdelta + gd.du + (size_t)b * 160 + m0 + 4 * lg, v);
+    st4(&dub[ln * LD160 + 32 * wave + 4 * lg], du_a);
+    st4(&dub[ln * LD160 + 32 * wave + 16 + 4 * lg], du_b);
+    st4(&dub[ln * LD160 + 128 + 4 * lg], du_s[0]);      // every wave holds the split tiles' sums
+    st4(&dub[ln * LD160 + 144 + 4 * lg], du_s[1]);
+    if (live) {
+      float* row = gdelta + gd.du + (size_t)b * 160 + 4 * lg;
+      st4(row + 32 * wave, du_a);
+      st4(row + 32 * wave + 16, du_b);
+      st4(row + 128, du_s[0]);
+      st4(row + 144, du_s[1]);
     }
   }
   sw_barrier();
@@ -721,7 +779,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
     const float* w1 = dec_w + swp::DEC_W1 + 64 + u0 + ln;  // column 64+unit of fc1.0.weight
 #pragma unroll
     for (int j = 0; j < 10; ++j) {
-      f32x4 bb = ld4(&dz1buf[ln * LD160 + 16 * j + 4 * lg]);
+      f32x4 bb = ld4(&dub[ln * LD160 + 16 * j + 4 * lg]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc = SW_MFMA(w1[(size_t)(16 * j + 4 * lg + r) * 160], bb[r], acc);
     }

@@ -35,12 +35,10 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
   const int a0 = blockIdx.x * SW_TILE;
   const int b = min(a0 + ln, B - 1);
   LstmW W;
-  lstm_load_whh(W, enc_w + swp::ENC_WHH, u0, ln, lg);
-
-  if (gimg) {   // composed input matrix of this step: derived once by the staging launch (swimg, sw_common.h)
-    st4(wx_lds + 4 * threadIdx.x, ld4(gimg + swimg::WX + 4 * threadIdx.x));
-    bx_lds[threadIdx.x] = gimg[swimg::BX + threadIdx.x];
+  if (gimg) {   // weight images of this step, derived once by the staging launch (swimg, sw_common.h)
+    lstm_load_img(W, gimg, wave, lane);
   } else {
+    lstm_load_whh(W, enc_w + swp::ENC_WHH, u0, ln, lg);
     lstm_prep_rows(enc_w + swp::ENC_EMB_W, enc_w + swp::ENC_EMB_B, enc_w + swp::ENC_WIH, enc_w + swp::ENC_BIH,
                    enc_w + swp::ENC_BHH, true, wx_lds, bx_lds);
   }
@@ -50,7 +48,7 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
   if (c0) c = ld4(c0 + (size_t)b * 64 + u0 + 4 * lg);
   st4(&hbuf[0][ln * SW_HLD + u0 + 4 * lg], h);
   sw_barrier();
-  lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
+  if (!gimg) lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
 
   // the input of step t+1 is fetched while step t computes: its L2/HBM latency would otherwise sit in front of
   // the first MFMA of every step (the last step re-fetches its own input: no conditional load)

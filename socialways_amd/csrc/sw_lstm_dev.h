@@ -81,6 +81,20 @@ __device__ __forceinline__ void lstm_load_wx(LstmW& W, const float* wx_lds, cons
   }
 }
 
+// The generator's LSTM weights from the image buffer of the step (swimg, sw_common.h): W_hh as an operand-layout image
+// (a wave's load instruction = 1 KB of consecutive memory; the row-per-lane loads of lstm_load_whh touch 64 cache lines
+// per instruction), the composed input matrix and bias straight into their registers - no LDS staging, no barrier.
+__device__ __forceinline__ void lstm_load_img(LstmW& W, const float* __restrict__ gimg, int wave, int lane) {
+  const int ln = lane & 15, lg = lane >> 4, u0 = wave * 16;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) W.whh[g][j] = ld4(gimg + swimg::OP_WHH + ((((size_t)4 * g + wave) * 4 + j) * 64 + lane) * 4);
+    W.wx[g] = gimg[swimg::WX + (g * 64 + u0 + ln) * 4 + lg];
+    W.bias[g] = ld4(gimg + swimg::BX + g * 64 + u0 + 4 * lg);
+  }
+}
+
 // One cell step.  xb = x4[agent ln][component lg]; hrow = &h_lds[ln*SW_HLD + 4*lg] (previous h).
 // On return gate[] holds the post-activation gates i,f,g,o, c the new cell state, h the new h.
 __device__ __forceinline__ void lstm_cell(const LstmW& W, float xb, const float* hrow, f32x4 gate[4],

@@ -552,7 +552,7 @@ __device__ __forceinline__ void gen_images_block(const float* __restrict__ enc_w
                    img + swimg::WX, img + swimg::BX);
     return;
   }
-  if (blk == 1) {          // fc4 . fc3 and its transpose: same partial-sum order as dec_rollout_fwd / bwd had
+  if (blk == 1) {          // fc4 . fc3: same partial-sum order as the kernels' own fallback code
     const int t = threadIdx.x;
     if (t < 160) {
       const int c = t / 80, k = t - c * 80;
@@ -565,9 +565,7 @@ __device__ __forceinline__ void gen_images_block(const float* __restrict__ enc_w
         v2 = fmaf(w4[m + 2], dec_w[DEC_W3 + (m + 2) * 80 + k], v2);
         v3 = fmaf(w4[m + 3], dec_w[DEC_W3 + (m + 3) * 80 + k], v3);
       }
-      const float v = (v0 + v1) + (v2 + v3);
-      img[swimg::W43 + c * 80 + k] = v;
-      img[swimg::W43T + k * 20 + c] = v;
+      img[swimg::W43 + c * 80 + k] = (v0 + v1) + (v2 + v3);
     } else if (t < 162) {
       const int c = t - 160;
       float v = dec_w[DEC_B4 + c];
@@ -578,23 +576,11 @@ __device__ __forceinline__ void gen_images_block(const float* __restrict__ enc_w
       }
       img[swimg::W43 + 160 + c] = v;
     }
-    for (int i = t; i < 80 * 20; i += 256)      // zero padding of the transposed image (columns >= 2)
-      if (i % 20 >= 2) img[swimg::W43T + i] = 0.f;
     return;
   }
-  // transposed, zero-padded decoder matrices: element i of [64][164] + [160][84]
-  const int n1 = 64 * 164, n2 = 160 * 84;
-  for (int i = (blk - 2) * 256 + threadIdx.x; i < n1 + n2; i += (SW_IMG_BLOCKS - 2) * 256) {
-    if (i < n1) {
-      const int k = i / 164, m = i - k * 164;                       // W1hT[k][m] = fc1.0.weight[m][k]
-      img[swimg::W1HT + i] = m < 160 ? dec_w[DEC_W1 + m * 160 + k] : 0.f;
-    } else {
-      const int j = i - n1, k = j / 84, m = j - k * 84;              // W2T[k][m] = fc1.2.weight[m][k]
-      img[swimg::W2T + j] = m < 80 ? dec_w[DEC_W2 + m * 160 + k] : 0.f;
-    }
-  }
+  const int nth = (SW_IMG_BLOCKS - 2) * 256, tid = (blk - 2) * 256 + threadIdx.x;
   // snapshot of the raw weights behind the compositions (swimg::RAW_*), float4 granularity
-  for (int i = (blk - 2) * 256 + threadIdx.x; i < (swimg::OP_WHH - swimg::RAW_WIH) / 4; i += (SW_IMG_BLOCKS - 2) * 256) {
+  for (int i = tid; i < (swimg::RAW_END - swimg::RAW_WIH) / 4; i += nth) {
     const int o = swimg::RAW_WIH + 4 * i;
     const float* src = o < swimg::RAW_WE   ? enc_w + ENC_WIH + (o - swimg::RAW_WIH)
                        : o < swimg::RAW_BE ? enc_w + ENC_EMB_W + (o - swimg::RAW_WE)
@@ -604,18 +590,27 @@ __device__ __forceinline__ void gen_images_block(const float* __restrict__ enc_w
                                            : dec_w + DEC_W4 + (o - swimg::RAW_W4);
     st4(img + o, ld4(src));
   }
-  // MFMA A-operand images (swimg::OP_*)
-  const int nth = (SW_IMG_BLOCKS - 2) * 256, tid = (blk - 2) * 256 + threadIdx.x;
+  // MFMA A-operand images (swimg::OP_*) of W[rows][c0 + K] and of transposes M = W^T (M[m][k] = W[k][m])
   auto op_image = [&](int dst0, const float* W, int ldw, int c0, int KJ, int ntile) {
     for (int f = tid; f < ntile * KJ * 64; f += nth) {
       const int t = f / (KJ * 64), rem = f - t * (KJ * 64), j = rem >> 6, l = rem & 63;
       st4(img + dst0 + 4 * (size_t)f, ld4(W + (size_t)(16 * t + (l & 15)) * ldw + c0 + 16 * j + 4 * (l >> 4)));
     }
   };
+  auto op_image_T = [&](int dst0, const float* W, int ldw, int KJ, int ntile) {
+    for (int f = tid; f < ntile * KJ * 64; f += nth) {
+      const int t = f / (KJ * 64), rem = f - t * (KJ * 64), j = rem >> 6, l = rem & 63;
+      const float* col = W + (size_t)(16 * j + 4 * (l >> 4)) * ldw + 16 * t + (l & 15);
+      st4(img + dst0 + 4 * (size_t)f, f32x4{col[0], col[ldw], col[2 * ldw], col[3 * ldw]});
+    }
+  };
   op_image(swimg::OP_WHH, enc_w + ENC_WHH, 64, 0, 4, 16);
   op_image(swimg::OP_W1H, dec_w + DEC_W1, 160, 0, 4, 10);
   op_image(swimg::OP_W1SZ, dec_w + DEC_W1, 160, 64, 6, 10);
   op_image(swimg::OP_W2, dec_w + DEC_W2, 160, 0, 10, 5);
+  op_image_T(swimg::OP_WHHT, enc_w + ENC_WHH, 64, 16, 4);
+  op_image_T(swimg::OP_W2T, dec_w + DEC_W2, 160, 5, 10);
+  op_image_T(swimg::OP_W1HT, dec_w + DEC_W1, 160, 10, 4);
 }
 __global__ __launch_bounds__(256) void gen_images_kernel(const float* __restrict__ enc_w, const float* __restrict__ dec_w,
                                                           float* __restrict__ img) {
