@@ -1,6 +1,7 @@
 // sw_wgrad_dev.h - device code of the grouped split-K weight-gradient GEMM (see sw_wgrad.hip): the per-job body, shared by
 // wgrad_partial_kernel and by the serial kernels whose spare workgroups RIDE along (run jobs while the kernel computes).
 #pragma once
+#include <type_traits>
 #include "sw_common.h"
 #include "sw_wgrad.h"
 #ifndef SW_WG_DEPTH
@@ -62,8 +63,8 @@ __host__ __device__ inline int wg_tiles(int n, bool allow3) {
 // drain the pipeline once per DEPTH groups).
 template <int NA, int KR, int K2, int ONES, int DSCALE = 1>
 __device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const float* __restrict__ abase, int ldd, int lda,
-                                       int rbeg, int rend, int rmax, int acol, const float (&amask)[4], int bcol,
-                                       const float (&bmask)[4], int lg, int ln, float* __restrict__ mine,
+                                       int rbeg, int rend, int rmax, int acol, int bcol, int lg, int ln,
+                                       float* __restrict__ mine,
                                        const float* __restrict__ abase2, int lda2, int row0, int xoff) {
   constexpr int KT = KR, XC = K2 + ONES;
   f32x4 acc[NA][KT];
@@ -88,13 +89,22 @@ __device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const fl
   float a[DEPTH][NA], b[DEPTH][KT];
   f32x4 xq[DEPTH];
   auto load = [&](int r0, float (&av)[NA], float (&bv)[KT], f32x4& xv) {
+#ifdef SW_WG_EXP_NOMEM      // timing experiment: every group re-reads the slice's first rows (L1 hits)
+    const int rc = min(rbeg + lg + 0 * r0, rmax);
+#else
     const int rc = min(r0 + lg, rmax);
+#endif
     wg_ldv<NA>(av, dbase + (size_t)rc * ldd + acol);
     wg_ldv<KR>(bv, abase + (size_t)max(rc, row0) * lda + bcol);     // rows below row0 have no `act` operand
     if constexpr (K2 > 0) xv = ld4(abase2 + (size_t)rc * lda2);      // the row's tail columns (same address for 16 lanes)
   };
 #pragma unroll
   for (int q = 0; q < DEPTH - 1; ++q) load(rbeg + 4 * q, a[q], b[q], xq[q]);
+  // Row masks only (rows >= rend belong to the next slice; rows below row0 have no act operand - a zero delta row
+  // already kills its products).  There are no COLUMN masks: a lane beyond the block's live delta / act columns
+  // (clamped to the last live ones) only feeds output rows / columns that are never written out - an MFMA output
+  // element mixes nothing but its own row and column.  (Peeling the unmasked interior into a branch of its own was
+  // measured 1.8 x slower: memory operations under a branch cost the exact vmcnt bookkeeping, see DESIGN.md.)
   for (int r = rbeg; r < rend; r += 4 * DEPTH) {
 #pragma unroll
     for (int q = 0; q < DEPTH; ++q) {
@@ -107,16 +117,22 @@ __device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const fl
       if constexpr (K2 > 0) asm volatile("" : "+v"(xq[q]));
       const int rr = r + 4 * q + lg;
       const float rs = rr < rend ? 1.0f : 0.0f;
-      const float rs0 = rr >= row0 ? rs : 0.0f;
+      const float rs0 = rr >= row0 ? 1.0f : 0.0f;
       float av[NA], bv[KT];
 #pragma unroll
-      for (int i = 0; i < NA; ++i) av[i] = a[q][i] * (amask[i] * rs);
+      for (int i = 0; i < NA; ++i) av[i] = a[q][i] * rs;
 #pragma unroll
-      for (int kt = 0; kt < KR; ++kt) bv[kt] = b[q][kt] * (bmask[kt] * rs0);
+      for (int kt = 0; kt < KR; ++kt) bv[kt] = b[q][kt] * rs0;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) acc[i][kt] = SW_MFMA(av[i], bv[kt], acc[i][kt]);
+        for (int kt = 0; kt < KT; ++kt) {
+#ifdef SW_WG_EXP_NOMFMA     // timing experiment: one VALU op instead of the MFMA
+          acc[i][kt][0] = fmaf(av[i], bv[kt], acc[i][kt][0]);
+#else
+          acc[i][kt] = SW_MFMA(av[i], bv[kt], acc[i][kt]);
+#endif
+        }
       }
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
@@ -182,17 +198,11 @@ __device__ __forceinline__ void wg_job(const WgBatch& batch, float* __restrict__
   // components masked
   const int acol = n0 + max(0, min(NA * ln, Nb - NA));
   const int bcol = max(0, min(KR * ln, K - KR));
-  float amask[4], bmask[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    amask[i] = (NA * ln + i < Nb && acol == n0 + NA * ln) ? 1.0f : 0.0f;
-    bmask[i] = (KR * ln + i < K && bcol == KR * ln) ? 1.0f : 0.0f;
-  }
   float* mine = red + wave * 64 * SW_WG_RLD;
   // extra columns on the VALU: a tail segment of exactly 4 columns (K2; only next to K = 64) and / or the ones column
 #define WG_CASE(na, kr, k2, on)                                                                                     \
   case ((na * 8 + kr) * 2 + (k2 ? 1 : 0)) * 2 + on:                                                                 \
-    wg_run<na, kr, k2, on, DSCALE>(P.delta, P.act, P.ldd, P.lda, rbeg, rend, P.R - 1, acol, amask, bcol, bmask, lg, ln,  \
+    wg_run<na, kr, k2, on, DSCALE>(P.delta, P.act, P.ldd, P.lda, rbeg, rend, P.R - 1, acol, bcol, lg, ln,              \
                                    mine, P.act2 ? P.act2 : P.delta, P.act2 ? P.lda2 : P.ldd, P.row0, K);            \
     break;
 #define WG_CASES(na)                                                                                                \
