@@ -302,18 +302,23 @@ int sw_stage_step(const float* slot, int B, int To, int Tp, float* obsv_dst /*[B
                   float* steps_dst /*[n_d_updates+1] or NULL*/, int n_d_updates, void* stream);
 
 /* ---- derived weight images of the generator.  Every workgroup of the encoder / decode launches needs the composed input
- *      matrix W_ih W_embed (train.py:266-268: no non-linearity between embed and the LSTM), fc4 . fc3 and - in the
- *      backward pass - the transposed decoder matrices.  sw_gen_images derives them ONCE into img (sw_gen_image_floats()
- *      floats) and REGISTERS them for (enc_w, dec_w): until the registration is dropped, sw_enc_lstm_fwd*,
- *      sw_dec_rollout_fwd*, sw_dec_rollout_bwd* called with these weight buffers copy the images instead of deriving
- *      them per workgroup (same values bit for bit).  The images are valid while the weights are unchanged: the caller
- *      drops the registration - sw_gen_images(NULL, NULL, NULL, NULL) - before it updates them.
+ *      matrix W_ih W_embed (train.py:266-268: no non-linearity between embed and the LSTM), fc4 . fc3 and every weight
+ *      matrix (transposed in the backward pass) as MFMA A operands.  sw_gen_images derives them ONCE into img
+ *      (sw_gen_image_floats() floats) - the compositions, a step-start snapshot of the raw weights behind them, and
+ *      OPERAND-LAYOUT images (a wave's operand load = 1 KB of consecutive memory instead of 64 cache-line accesses) -
+ *      and REGISTERS them for (enc_w, dec_w) and, when given, for the social block's (emb_w, att_w): until the
+ *      registration is dropped, sw_enc_lstm_fwd*, sw_dec_rollout_fwd*, sw_dec_rollout_bwd*, sw_social_pool_fwd/bwd
+ *      called with these weight buffers load the images instead of deriving / gathering per workgroup (same values bit
+ *      for bit).  The images are valid while the weights are unchanged: the caller drops the registration -
+ *      sw_gen_images(NULL, NULL, NULL, NULL, NULL, NULL) - before it updates them.
  *      sw_stage_step_img = sw_stage_step whose launch derives and registers the images as well (no extra launch).   */
 int sw_gen_image_floats(void);
-int sw_gen_images(const float* enc_w, const float* dec_w, float* img, void* stream);
+int sw_gen_images(const float* enc_w, const float* dec_w, const float* emb_w /*or NULL*/, const float* att_w /*or NULL*/,
+                  float* img, void* stream);
 int sw_stage_step_img(const float* slot, int B, int To, int Tp, float* obsv_dst, float* pred_dst, float* pred4_dst,
                       float* targets_dst, float* z_dst, float* steps_dst, int n_d_updates, const float* enc_w,
-                      const float* dec_w, float* img, void* stream);
+                      const float* dec_w, const float* emb_w /*or NULL*/, const float* att_w /*or NULL*/, float* img,
+                      void* stream);
 
 /* ---- ADE/FDE partial sums of train.py:546-551:
  *      out[3] = { sum_{b,t} err / Tp, sum_b err[:, -1], sum_{b,t} err^2 },  err = |(p_hat - p) / ss|   */

@@ -324,10 +324,18 @@ constexpr int OP_W2 = OP_W1SZ + 15360;   // fc1.2.weight [80][160]:   5 tiles, K
 constexpr int OP_WHHT = OP_W2 + 12800;   // weight_hh^T [64][256]:    4 tiles, KJ 16
 constexpr int OP_W2T = OP_WHHT + 16384;  // fc1.2.weight^T [160][80]: 10 tiles, KJ 5
 constexpr int OP_W1HT = OP_W2T + 12800;  // fc1.0.weight[:, 0:64]^T [64][160]: 4 tiles, KJ 10
-constexpr int N = OP_W1HT + 10240;
+// the social block's weights (feature embedder fc.2 / fc.4, attention W), when registered with the images
+constexpr int OP_E1 = OP_W1HT + 10240;   // embedder fc.2.weight [64][32]:   4 tiles, KJ 2
+constexpr int OP_E2 = OP_E1 + 2048;      // embedder fc.4.weight [64][64]:   4 tiles, KJ 4
+constexpr int OP_E1T = OP_E2 + 4096;     // fc.2.weight^T [32][64]:          2 tiles, KJ 4
+constexpr int OP_E2T = OP_E1T + 2048;    // fc.4.weight^T [64][64]:          4 tiles, KJ 4
+constexpr int OP_ATT_T = OP_E2T + 4096;  // attention weight^T [64][64]:     4 tiles, KJ 4
+constexpr int N = OP_ATT_T + 4096;
 }  // namespace swimg
 // the images registered for (enc_w, dec_w) by the current step, or null (sw_gen_images)
 const float* sw_gen_images_for(const float* enc_w, const float* dec_w);
+// ... whose social part (swimg::OP_E*, OP_ATT_T) was derived from these embedder / attention weights, or null
+const float* sw_soc_images_for(const float* emb_w, const float* att_w);
 
 // tiling choice of the serial kernels (sw_misc.hip: sw_set_tile_mode / SW_TILE_MODE)
 bool sw_narrow_tiles(int B);

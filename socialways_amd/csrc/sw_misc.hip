@@ -545,6 +545,7 @@ extern "C" int sw_traj_dist(const float* a, const float* b, int Na, int Nb, int 
 // ---- derived weight images of the generator (swimg, sw_common.h) ---------------------------------------------------
 #define SW_IMG_BLOCKS 64
 __device__ __forceinline__ void gen_images_block(const float* __restrict__ enc_w, const float* __restrict__ dec_w,
+                                                 const float* __restrict__ emb_w, const float* __restrict__ att_w,
                                                  float* __restrict__ img, int blk) {
   using namespace swp;
   if (blk == 0) {          // composed input matrix: the very code the kernels ran per workgroup (bit-identical values)
@@ -611,28 +612,41 @@ __device__ __forceinline__ void gen_images_block(const float* __restrict__ enc_w
   op_image_T(swimg::OP_WHHT, enc_w + ENC_WHH, 64, 16, 4);
   op_image_T(swimg::OP_W2T, dec_w + DEC_W2, 160, 5, 10);
   op_image_T(swimg::OP_W1HT, dec_w + DEC_W1, 160, 10, 4);
+  if (emb_w) {
+    op_image(swimg::OP_E1, emb_w + EMB_W1, 32, 0, 2, 4);
+    op_image(swimg::OP_E2, emb_w + EMB_W2, 64, 0, 4, 4);
+    op_image_T(swimg::OP_E1T, emb_w + EMB_W1, 32, 4, 2);
+    op_image_T(swimg::OP_E2T, emb_w + EMB_W2, 64, 4, 4);
+    op_image_T(swimg::OP_ATT_T, att_w + ATT_W, 64, 4, 4);
+  }
 }
 __global__ __launch_bounds__(256) void gen_images_kernel(const float* __restrict__ enc_w, const float* __restrict__ dec_w,
+                                                          const float* __restrict__ emb_w, const float* __restrict__ att_w,
                                                           float* __restrict__ img) {
-  gen_images_block(enc_w, dec_w, img, blockIdx.x);
+  gen_images_block(enc_w, dec_w, emb_w, att_w, img, blockIdx.x);
 }
-static const float *g_img_enc = nullptr, *g_img_dec = nullptr, *g_img = nullptr;
+static const float *g_img_enc = nullptr, *g_img_dec = nullptr, *g_img_emb = nullptr, *g_img_att = nullptr, *g_img = nullptr;
+const float* sw_soc_images_for(const float* emb_w, const float* att_w) {
+  return (g_img && emb_w && emb_w == g_img_emb && att_w == g_img_att) ? g_img : nullptr;
+}
 const float* sw_gen_images_for(const float* enc_w, const float* dec_w) {   // dec_w null: the encoder part alone
   return (g_img && enc_w == g_img_enc && (!dec_w || dec_w == g_img_dec)) ? g_img : nullptr;
 }
 extern "C" int sw_gen_image_floats(void) { return swimg::N; }
-static void gen_images_register(const float* enc_w, const float* dec_w, const float* img) {
-  g_img_enc = enc_w; g_img_dec = dec_w; g_img = img;
+static void gen_images_register(const float* enc_w, const float* dec_w, const float* emb_w, const float* att_w,
+                                const float* img) {
+  g_img_enc = enc_w; g_img_dec = dec_w; g_img_emb = emb_w; g_img_att = att_w; g_img = img;
 }
-extern "C" int sw_gen_images(const float* enc_w, const float* dec_w, float* img, void* stream) {
+extern "C" int sw_gen_images(const float* enc_w, const float* dec_w, const float* emb_w, const float* att_w, float* img,
+                             void* stream) {
   if (!img) {                       // unregister: the weights are about to change (or have changed)
-    gen_images_register(nullptr, nullptr, nullptr);
+    gen_images_register(nullptr, nullptr, nullptr, nullptr, nullptr);
     return SW_OK;
   }
-  if (!enc_w || !dec_w) return SW_EARG;
-  hipLaunchKernelGGL(gen_images_kernel, dim3(SW_IMG_BLOCKS), dim3(256), 0, (hipStream_t)stream, enc_w, dec_w, img);
+  if (!enc_w || !dec_w || ((emb_w != nullptr) != (att_w != nullptr))) return SW_EARG;
+  hipLaunchKernelGGL(gen_images_kernel, dim3(SW_IMG_BLOCKS), dim3(256), 0, (hipStream_t)stream, enc_w, dec_w, emb_w, att_w, img);
   SW_CHECK_LAUNCH("gen_images_kernel");
-  gen_images_register(enc_w, dec_w, img);
+  gen_images_register(enc_w, dec_w, emb_w, att_w, img);
   return SW_OK;
 }
 
@@ -649,11 +663,12 @@ __global__ __launch_bounds__(256) void stage_step_kernel(const float* __restrict
                                                           float* __restrict__ pred4_dst, float* __restrict__ targets_dst,
                                                           float* __restrict__ z_dst, float* __restrict__ steps_dst,
                                                           int n_d_updates, const float* __restrict__ enc_w,
-                                                          const float* __restrict__ dec_w, float* __restrict__ img,
+                                                          const float* __restrict__ dec_w, const float* __restrict__ emb_w,
+                                                          const float* __restrict__ att_w, float* __restrict__ img,
                                                           int img_blocks) {
   // the last img_blocks workgroups derive the generator's weight images of this step (sw_gen_images)
   if ((int)blockIdx.x >= (int)gridDim.x - img_blocks) {
-    gen_images_block(enc_w, dec_w, img, (int)blockIdx.x - ((int)gridDim.x - img_blocks));
+    gen_images_block(enc_w, dec_w, emb_w, att_w, img, (int)blockIdx.x - ((int)gridDim.x - img_blocks));
     return;
   }
   const unsigned long long* ptrs = reinterpret_cast<const unsigned long long*>(slot);
@@ -677,24 +692,25 @@ __global__ __launch_bounds__(256) void stage_step_kernel(const float* __restrict
 }
 extern "C" int sw_stage_step_img(const float* slot, int B, int To, int Tp, float* obsv_dst, float* pred_dst,
                                  float* pred4_dst, float* targets_dst, float* z_dst, float* steps_dst, int n_d_updates,
-                                 const float* enc_w, const float* dec_w, float* img, void* stream) {
+                                 const float* enc_w, const float* dec_w, const float* emb_w, const float* att_w, float* img,
+                                 void* stream) {
   if (!slot || !obsv_dst || !pred_dst || !pred4_dst || !targets_dst || B < 1 || To < 2 || Tp < 1 ||
       n_d_updates < 0 || n_d_updates > 254)
     return SW_EARG;
-  if (img && (!enc_w || !dec_w)) return SW_EARG;
+  if (img && (!enc_w || !dec_w || ((emb_w != nullptr) != (att_w != nullptr)))) return SW_EARG;
   int n = z_dst ? B * SW_Z / 4 : B * (To > Tp ? To : Tp);
   int blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   const int ib = img ? SW_IMG_BLOCKS : 0;
   hipLaunchKernelGGL(stage_step_kernel, dim3(blocks + ib), dim3(256), 0, (hipStream_t)stream, slot, B, To, Tp, obsv_dst,
-                     pred_dst, pred4_dst, targets_dst, z_dst, steps_dst, n_d_updates, enc_w, dec_w, img, ib);
+                     pred_dst, pred4_dst, targets_dst, z_dst, steps_dst, n_d_updates, enc_w, dec_w, emb_w, att_w, img, ib);
   SW_CHECK_LAUNCH("stage_step_kernel");
-  if (img) gen_images_register(enc_w, dec_w, img);
+  if (img) gen_images_register(enc_w, dec_w, emb_w, att_w, img);
   return SW_OK;
 }
 extern "C" int sw_stage_step(const float* slot, int B, int To, int Tp, float* obsv_dst, float* pred_dst,
                              float* pred4_dst, float* targets_dst, float* z_dst, float* steps_dst, int n_d_updates,
                              void* stream) {
   return sw_stage_step_img(slot, B, To, Tp, obsv_dst, pred_dst, pred4_dst, targets_dst, z_dst, steps_dst, n_d_updates, nullptr,
-                           nullptr, nullptr, stream);
+                           nullptr, nullptr, nullptr, nullptr, stream);
 }

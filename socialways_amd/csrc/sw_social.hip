@@ -45,6 +45,17 @@ __device__ __forceinline__ void load_pair_w(PairW& W, const float* emb_w, int ln
   }
 }
 
+// the same from the operand-layout images of the step (swimg::OP_E1 / OP_E2): a wave's load = 1 KB of consecutive memory
+__device__ __forceinline__ void load_pair_w_img(PairW& W, const float* __restrict__ img, int lane) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) W.w1[mt][j] = ld4(img + swimg::OP_E1 + ((mt * 2 + j) * 64 + lane) * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) W.w2[mt][k] = ld4(img + swimg::OP_E2 + ((mt * 4 + k) * 64 + lane) * 4);
+  }
+}
+
 // [dist, bearing, dca] of the ordered pair (i, j): dp = p_i - p_j, dv = v_i - v_j (train.py:232-234);
 // eps placement as train.py:212,225.  The diagonal gives (0, 0, 0).
 __device__ __forceinline__ void pair_feat(f32x4 si, f32x4 sj, float& f0, float& f1, float& f2) {
@@ -208,7 +219,8 @@ __device__ __forceinline__ void scene_softmax_pool(float* smem, const SocL& Ls, 
 __global__ __launch_bounds__(SW_THREADS) void social_pool_fwd_kernel(
     const float* __restrict__ obsv, int To, const float* __restrict__ h, const int* __restrict__ scene_off,
     const float* __restrict__ emb_w, const float* __restrict__ att_w, float* __restrict__ S_out,
-    float* __restrict__ attn, int a16, int S, const float* __restrict__ aux_src, float* __restrict__ aux_dst, long long aux_n) {
+    float* __restrict__ attn, int a16, int S, const float* __restrict__ aux_src, float* __restrict__ aux_dst, long long aux_n,
+    const float* __restrict__ simg) {
   // Workgroups beyond the scenes only copy aux_src -> aux_dst (the training step pulls z out of its pinned host slot
   // here: this launch is light - small scenes use a few KB of LDS each - and the decode launch behind it is the
   // first consumer of z)
@@ -234,9 +246,10 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_fwd_kernel(
     return;
   }
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  PairW W;     // requested first: the weights arrive under the scene prologue
+  if (simg) load_pair_w_img(W, simg, lane);
+  else load_pair_w(W, emb_w, ln, lg);
   scene_prologue(smem, Ls, obsv, To, h, emb_w, att_w, s0, n);
-  PairW W;
-  load_pair_w(W, emb_w, ln, lg);
   const int P = n * n;
   for (int pt = wave; pt * 16 < P; pt += 4) {
     int p = min(pt * 16 + ln, P - 1);
@@ -695,7 +708,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_rows_kernel(
     const float* __restrict__ obsv, int To, const float* __restrict__ h, const int* __restrict__ scene_off,
     const long long* __restrict__ pair_off, const float* __restrict__ emb_w, const float* __restrict__ att_w,
     const float* __restrict__ attn, const float* __restrict__ dS, float* __restrict__ dh,
-    float* __restrict__ dwh_rows, PairRows pr, int a16) {
+    float* __restrict__ dwh_rows, PairRows pr, int a16, const float* __restrict__ simg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SocL Ls = soc_lds(a16);
   const int sa = Ls.sa;
@@ -721,26 +734,39 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_rows_kernel(
 #endif
   // the pair-MLP weights (registers, L2 latency) are requested first: they arrive under the scene prologue
   PairW W;
-  load_pair_w(W, emb_w, ln, lg);
   f32x4 w2T[4][4];  // fc.4.weight^T: [mt][mo][r] = W2[16mo + 4lg + r][16mt + ln]
   f32x4 w1T[2][4];  // fc.2.weight^T: [jt][mt][r] = W1[16mt + 4lg + r][16jt + ln]
+  f32x4 wT[4];      // attention W^T for the dh rows: W[k = 16kt + 4lg + r][u = 16 wave + ln]
+  if (simg) {       // operand-layout images of the step: every load instruction reads 1 KB of consecutive memory
+    load_pair_w_img(W, simg, lane);
 #pragma unroll
-  for (int mo = 0; mo < 4; ++mo) {
+    for (int mo = 0; mo < 4; ++mo) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float* row2 = emb_w + swp::EMB_W2 + (16 * mo + 4 * lg + r) * 64 + ln;
-      const float* row1 = emb_w + swp::EMB_W1 + (16 * mo + 4 * lg + r) * 32 + ln;
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) w2T[mt][mo][r] = row2[16 * mt];
-      w1T[0][mo][r] = row1[0];
-      w1T[1][mo][r] = row1[16];
+      for (int mt = 0; mt < 4; ++mt) w2T[mt][mo] = ld4(simg + swimg::OP_E2T + ((mt * 4 + mo) * 64 + lane) * 4);
+      w1T[0][mo] = ld4(simg + swimg::OP_E1T + ((0 * 4 + mo) * 64 + lane) * 4);
+      w1T[1][mo] = ld4(simg + swimg::OP_E1T + ((1 * 4 + mo) * 64 + lane) * 4);
     }
-  }
-  f32x4 wT[4];   // attention W^T for the dh rows: W[k = 16kt + 4lg + r][u = 16 wave + ln]
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt) {
+    for (int kt = 0; kt < 4; ++kt) wT[kt] = ld4(simg + swimg::OP_ATT_T + ((wave * 4 + kt) * 64 + lane) * 4);
+  } else {
+    load_pair_w(W, emb_w, ln, lg);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) wT[kt][r] = att_w[swp::ATT_W + (16 * kt + 4 * lg + r) * 64 + 16 * wave + ln];
+    for (int mo = 0; mo < 4; ++mo) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* row2 = emb_w + swp::EMB_W2 + (16 * mo + 4 * lg + r) * 64 + ln;
+        const float* row1 = emb_w + swp::EMB_W1 + (16 * mo + 4 * lg + r) * 32 + ln;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) w2T[mt][mo][r] = row2[16 * mt];
+        w1T[0][mo][r] = row1[0];
+        w1T[1][mo][r] = row1[16];
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wT[kt][r] = att_w[swp::ATT_W + (16 * kt + 4 * lg + r) * 64 + 16 * wave + ln];
+    }
   }
   scene_prologue(smem, Ls, obsv, To, h, emb_w, att_w, s0, n);
   for (int i = threadIdx.x; i < n * 16; i += blockDim.x) {
@@ -1304,7 +1330,8 @@ extern "C" int sw_social_pool_fwd_aux(const float* obsv, int To, const float* h,
   int extra = aux_n > 0 ? (int)((aux_n / 4 + SW_THREADS - 1) / SW_THREADS) : 0;
   if (extra > 64) extra = 64;
   hipLaunchKernelGGL(social_pool_fwd_kernel, dim3(S + extra), dim3(SW_THREADS), soc_lds(a16).fwd_total * 4, (hipStream_t)stream,
-                     obsv, To, h, scene_off, emb_w, att_w, S_out, attn, a16, S, aux_src, aux_dst, aux_n);
+                     obsv, To, h, scene_off, emb_w, att_w, S_out, attn, a16, S, aux_src, aux_dst, aux_n,
+                     sw_soc_images_for(emb_w, att_w));
   SW_CHECK_LAUNCH("social_pool_fwd_kernel");
   if (NB > 0) {   // scenes above SW_AMAX agents
     hipLaunchKernelGGL(social_wh_kernel, dim3(NB), dim3(SW_THREADS), 0, (hipStream_t)stream, h, scene_off, big_blocks, att_w,
@@ -1359,7 +1386,7 @@ extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, con
     }
     PairRows pr = pair_rows(pair_ws + (size_t)B * 64, P);
     hipLaunchKernelGGL(social_pool_bwd_rows_kernel, dim3(S), dim3(SW_THREADS), soc_lds(a16).bwd_total * 4, st, obsv, To, h,
-                       scene_off, pair_off, emb_w, att_w, attn, dS, dh, dwh_rows, pr, a16);
+                       scene_off, pair_off, emb_w, att_w, attn, dS, dh, dwh_rows, pr, a16, sw_soc_images_for(emb_w, att_w));
     SW_CHECK_LAUNCH("social_pool_bwd_rows_kernel");
     WgBatch wr_local;
     WgBatch& wr = defer ? *wg_pending(defer) : wr_local;

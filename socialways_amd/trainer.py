@@ -422,7 +422,8 @@ class SocialWaysTrainer:
             slot = st["slots"][kk][j]
             L.call("sw_stage_step_img", slot.data_ptr(), B, To, Tp, L.ptr(st["obsv"]), L.ptr(st["pred"]),
                    L.ptr(st["pred4"]), L.ptr(st["targets"]), None, L.ptr(st["steps"]), self.n_unrolling_steps + 1,
-                   L.ptr(self.G.encoder._flat), L.ptr(self.G.decoder._flat), L.ptr(self._gimg), L.stream())
+                   L.ptr(self.G.encoder._flat), L.ptr(self.G.decoder._flat), L.ptr(self.G.feature_embedder._flat),
+                   L.ptr(self.G.attention._flat), L.ptr(self._gimg), L.stream())
             self._noise_src = slot.data_ptr() + 4 * HDR        # z: pulled by idle workgroups of the encoder launch
 
         def args(j):
@@ -506,12 +507,13 @@ class SocialWaysTrainer:
         if pre is not None:
             pre()
         elif self._gimg is not None:     # eager step without a staging launch: derive the weight images here
-            L.call("sw_gen_images", L.ptr(G.encoder._flat), L.ptr(G.decoder._flat), L.ptr(self._gimg), L.stream())
+            L.call("sw_gen_images", L.ptr(G.encoder._flat), L.ptr(G.decoder._flat), L.ptr(G.feature_embedder._flat),
+                   L.ptr(G.attention._flat), L.ptr(self._gimg), L.stream())
         try:
             yield from self._step_body(obsv, pred, pred4, scenes, targets, noise, ss, Bg, out, steps)
         finally:
             if self._gimg is not None:   # the generator's Adam step follows / has run: the images are stale
-                L.call("sw_gen_images", None, None, None, None)
+                L.call("sw_gen_images", None, None, None, None, None, None)
 
     def _step_body(self, obsv, pred, pred4, scenes, targets, noise, ss, Bg, out, steps):
         G, D = self.G, self.D

@@ -28,7 +28,7 @@ run = lambda: L.call("sw_dec_rollout_bwd", L.ptr(dp), L.ptr(G.encoder._flat), L.
                      L.ptr(gdelta), L.ptr(dh), L.ptr(dc), L.ptr(dS), st)
 if os.environ.get("SW_GEN_IMAGES", "1") == "1":      # the trainer's default: weight images derived once per step
     gimg = torch.empty(lib.sw_gen_image_floats(), device=dev)
-    L.call("sw_gen_images", L.ptr(G.encoder._flat), L.ptr(G.decoder._flat), L.ptr(gimg), st)
+    L.call("sw_gen_images", L.ptr(G.encoder._flat), L.ptr(G.decoder._flat), None, None, L.ptr(gimg), st)
 for _ in range(3):
     run()
 torch.cuda.synchronize()

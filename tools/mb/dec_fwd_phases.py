@@ -24,7 +24,7 @@ run = lambda: L.call("sw_dec_rollout_fwd", L.ptr(obsv), To, L.ptr(z), L.ptr(S), 
                      L.ptr(G.decoder._flat), B, Tp, L.ptr(pred4), None, None, L.ptr(gsave) if save else None, None, 0.0, None, st)
 if os.environ.get("SW_GEN_IMAGES", "1") == "1":
     gimg = torch.empty(lib.sw_gen_image_floats(), device=dev)
-    L.call("sw_gen_images", L.ptr(G.encoder._flat), L.ptr(G.decoder._flat), L.ptr(gimg), st)
+    L.call("sw_gen_images", L.ptr(G.encoder._flat), L.ptr(G.decoder._flat), None, None, L.ptr(gimg), st)
 for _ in range(3):
     run()
 torch.cuda.synchronize()
