@@ -130,6 +130,40 @@ int sw_embed_features(const float* feat /*[R,3]*/, long long R, const float* emb
                       void* stream);
 int sw_attention_pool_dense(const float* f /*[B,B,64]*/, const float* h /*[B,64]*/, const int* scene_off,
                             int S, int B, const float* att_w, float* S_out /*[B,64]*/, void* stream);
+/* ---- backward passes of the STAND-ALONE sub-modules (the reference's modules are ordinary nn.Modules: a user may
+ *      compose AttentionPooling / EmbedSocialFeatures / EncoderLstm / DecoderFC differently from predict() and
+ *      back-propagate through them, train.py:153-189, 245-269, 320-335).  Not on the training step's path. ------- */
+/* y[r][n] (+)= bias[n] + sum_k x[r][k] w[k*w_rs + n*w_cs]  (w or w^T by the strides; bias may be NULL)              */
+int sw_rows_gemm(const float* x, int ldx, const float* w, int w_rs, int w_cs, const float* bias, long long R, int K, int N,
+                 float* y, int ldy, int accumulate, void* stream);
+/* dW[N][K] (+)= delta^T act, db[N] (+)= column sums of delta (db may be NULL): one problem of the grouped weight-gradient
+ * GEMM; wgrad_ws = sw_workspace_floats(SW_WS_WGRAD, ...) floats.  N <= 256; ldd, lda multiples of 4.               */
+int sw_linear_wgrad(const float* delta, int ldd, const float* act, int lda, int R, int N, int K, float* dW, int ldw,
+                    float* db, float* wgrad_ws, int accumulate, void* stream);
+/* EmbedSocialFeatures backward on R rows: recomputes the MLP, leaves rows = h2 [R,64] | dh2 [R,64] | h1 [R,32] | dh1 [R,32] |
+ * feat4 [R,4] (196 R floats) for sw_linear_wgrad (dout x h2, dh2 x h1, dh1 x feat4) and dfeat [R,3] (or NULL).        */
+int sw_embed_features_bwd(const float* feat /*[R,3]*/, long long R, const float* emb_w, const float* dout /*[R,64]*/,
+                          float* rows, float* dfeat, void* stream);
+/* AttentionPooling on a dense (B,B,64) embedding tensor, ANY scene size (one workgroup per agent): wh = W h + b [B,64]
+ * (sw_rows_gemm), attn [B,B] receives a_ij inside the scene blocks.  Backward: dsig [B,B] scratch, df [B,B,64] (or
+ * NULL; zero outside the scene blocks on entry), dwh [B,64] = dL/d(Wh), dh [B,64] = sum_i a_ij dS_i (the caller adds
+ * W^T dwh and forms dW, db from dwh and h).                                                                        */
+int sw_attention_dense_fwd(const float* f, const float* h, const float* wh, const int* scene_off, int S, int B, float* attn,
+                           float* S_out, void* stream);
+int sw_attention_dense_bwd(const float* f, const float* h, const float* wh, const float* attn, const float* dS,
+                           const int* scene_off, int S, int B, float* dsig, float* df, float* dwh, float* dh, void* stream);
+/* Weight gradients of EncoderLstm over T steps from state (h0 or NULL = zeros): act / x4s as sw_enc_lstm_fwd left them,
+ * dgates from sw_enc_lstm_bwd; tmp = 2048 floats.  Writes the whole packed gradient buffer d_enc_w.                 */
+int sw_enc_lstm_wgrad(const float* enc_w, const float* act, const float* x4s, const float* h0, const float* dgates, int B,
+                      int T, float* d_enc_w, float* wgrad_ws, float* tmp, void* stream);
+/* Weight gradients of DecoderFC on one batch = a Tp = 1 rollout (gsave / gdelta of sw_dec_rollout_fwd / _bwd called
+ * with this To and Tp = 1) with its inputs h, s (NULL = zeros), z; tmp = 2048 floats.  Writes the whole d_dec_w.   */
+int sw_dec_fc_wgrad(const float* dec_w, const float* gsave, const float* gdelta, const float* h, const float* s,
+                    const float* z, int B, int To, float* d_dec_w, float* wgrad_ws, float* tmp, void* stream);
+
+/* ... and dz [B,32] = dL/dz of that rollout (predict() never needs it: z is data, train.py:473)                    */
+int sw_dec_fc_dz(const float* dec_w, const float* gdelta, int B, int To, float* dz, void* stream);
+
 /* pair_off = int64[S+1] prefix sums of n_s^2 over scenes with n_s > 1 (single-agent scenes own no
  * pair rows), P = pair_off[S].  dh is accumulated into.  d_emb_w / d_att_w are overwritten.
  * pair_ws holds sw_workspace_floats(SW_WS_PAIRS, ...) floats.                                    */

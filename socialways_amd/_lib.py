@@ -51,6 +51,14 @@ PROTOTYPES = {
     "sw_gen_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "sw_gen_wgrad_adam": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                ctypes.c_longlong, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp]),
+    "sw_rows_gemm": (_i, [_vp, _i, _vp, _i, _i, _vp, ctypes.c_longlong, _i, _i, _vp, _i, _i, _vp]),
+    "sw_linear_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp]),
+    "sw_embed_features_bwd": (_i, [_vp, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp]),
+    "sw_attention_dense_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "sw_attention_dense_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "sw_enc_lstm_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "sw_dec_fc_dz": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "sw_dec_fc_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "sw_wgrad_batch_new": (_vp, []),
     "sw_wgrad_batch_free": (None, [_vp]),
     "sw_disc_fwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),

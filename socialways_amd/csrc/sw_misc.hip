@@ -124,14 +124,11 @@ extern "C" size_t sw_workspace_floats(int ws_id, int B, int To, int Tp, int nb, 
 // With `ad.w` set the thread that forms a gradient element also applies the generator's Adam update to its weight
 // (wg_adam1); the compositions then read the weights from `snap` - the step-start snapshot inside the image buffer
 // (swimg::RAW_*) - because other workgroups of this launch are overwriting the live ones.
-__global__ __launch_bounds__(256) void enc_compose_bwd_kernel(const float* __restrict__ enc_w,
-                                                              const float* __restrict__ dWx,
-                                                              const float* __restrict__ dbx,
-                                                              float* __restrict__ d_enc_w,
-                                                              const float* __restrict__ dec_w,
-                                                              const float* __restrict__ Ms,
-                                                              float* __restrict__ d_dec_w, WgAdam ad,
-                                                              const float* __restrict__ snap) {
+__device__ __forceinline__ void compose_bwd_block(const int blk, const float* __restrict__ enc_w,
+                                                  const float* __restrict__ dWx, const float* __restrict__ dbx,
+                                                  float* __restrict__ d_enc_w, const float* __restrict__ dec_w,
+                                                  const float* __restrict__ Ms, float* __restrict__ d_dec_w,
+                                                  const WgAdam& ad, const float* __restrict__ snap) {
   using namespace swp;
   float bc1 = 1.f, bc2s = 1.f;
   if (ad.w) wg_adam_bc(ad, bc1, bc2s);
@@ -139,8 +136,8 @@ __global__ __launch_bounds__(256) void enc_compose_bwd_kernel(const float* __res
     *dst = g;
     if (ad.w) wg_adam1(ad, bc1, bc2s, dst, g);
   };
-  if (blockIdx.x >= 128) {
-    const int o = (blockIdx.x - 128) * 256 + threadIdx.x;
+  if (blk >= 128) {
+    const int o = (blk - 128) * 256 + threadIdx.x;
     const float* M = Ms;            // [2][80]
     const float* sv = Ms + 160;     // [2]
     const float* W3 = snap ? snap + swimg::RAW_W3 : dec_w + DEC_W3;
@@ -166,14 +163,14 @@ __global__ __launch_bounds__(256) void enc_compose_bwd_kernel(const float* __res
   const float* be = snap ? snap + swimg::RAW_BE : enc_w + ENC_EMB_B;
   const float* Wih = snap ? snap + swimg::RAW_WIH : enc_w + ENC_WIH;
   const int t = threadIdx.x;
-  if (blockIdx.x < 64) {  // dWih[row][e] = sum_c dWx[row][c] We[e][c] + dbx[row] be[e]; 256 elements per block
-    int i = blockIdx.x * 256 + t;
+  if (blk < 64) {  // dWih[row][e] = sum_c dWx[row][c] We[e][c] + dbx[row] be[e]; 256 elements per block
+    int i = blk * 256 + t;
     int row = i >> 6, e = i & 63;
     f32x4 g = ld4(dWx + row * 4), w = ld4(We + e * 4);
     float v = dbx[row] * be[e];
     v = fmaf(g[0], w[0], v); v = fmaf(g[1], w[1], v); v = fmaf(g[2], w[2], v); v = fmaf(g[3], w[3], v);
     put(d_enc_w + ENC_WIH + i, v);
-    if (blockIdx.x == 0) {
+    if (blk == 0) {
       put(d_enc_w + ENC_BIH + t, dbx[t]);
       put(d_enc_w + ENC_BHH + t, dbx[t]);
     }
@@ -182,7 +179,7 @@ __global__ __launch_bounds__(256) void enc_compose_bwd_kernel(const float* __res
   // blocks 64..127: one embed unit e each; thread = gate row; dWe[e][c] = sum_row Wih[row][e] dWx[row][c],
   // dbe[e] = sum_row Wih[row][e] dbx[row]
   __shared__ float red[5][256];
-  const int e = blockIdx.x - 64;
+  const int e = blk - 64;
   float w = Wih[t * 64 + e];
   f32x4 g = ld4(dWx + t * 4);
   red[0][t] = w * g[0]; red[1][t] = w * g[1]; red[2][t] = w * g[2]; red[3][t] = w * g[3]; red[4][t] = w * dbx[t];
@@ -196,6 +193,24 @@ __global__ __launch_bounds__(256) void enc_compose_bwd_kernel(const float* __res
   }
   if (t < 4) put(d_enc_w + ENC_EMB_W + e * 4 + t, red[t][0]);
   if (t == 4) put(d_enc_w + ENC_EMB_B + e, red[4][0]);
+}
+
+__global__ __launch_bounds__(256) void enc_compose_bwd_kernel(const float* __restrict__ enc_w,
+                                                              const float* __restrict__ dWx,
+                                                              const float* __restrict__ dbx,
+                                                              float* __restrict__ d_enc_w,
+                                                              const float* __restrict__ dec_w,
+                                                              const float* __restrict__ Ms,
+                                                              float* __restrict__ d_dec_w, WgAdam ad,
+                                                              const float* __restrict__ snap) {
+  compose_bwd_block((int)blockIdx.x, enc_w, dWx, dbx, d_enc_w, dec_w, Ms, d_dec_w, ad, snap);
+}
+// one half on its own (blocks block0 ..): the stand-alone module backward passes below
+__global__ __launch_bounds__(256) void compose_bwd_part_kernel(const float* __restrict__ enc_w, const float* __restrict__ dWx,
+                                                               const float* __restrict__ dbx, float* __restrict__ d_enc_w,
+                                                               const float* __restrict__ dec_w, const float* __restrict__ Ms,
+                                                               float* __restrict__ d_dec_w, int block0) {
+  compose_bwd_block((int)blockIdx.x + block0, enc_w, dWx, dbx, d_enc_w, dec_w, Ms, d_dec_w, WgAdam(), nullptr);
 }
 
 // part 0: everything.  part 1: what is available right after dec_rollout_bwd (all decoder problems +
@@ -284,6 +299,59 @@ extern "C" int sw_gen_wgrad_adam(const float* enc_w, const float* dec_w, const f
   ad.lr = lr; ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps;
   return gen_wgrad_impl(enc_w, dec_w, gsave, gdelta, z, S_pool, B, To, Tp, d_enc_w, d_dec_w, 0, wgrad_ws, tmp, pending, stream,
                         ad, img);
+}
+
+// ---- weight gradients of the STAND-ALONE EncoderLstm / DecoderFC modules (model.py: _EncFn, _DecFn) ----------------
+// EncoderLstm over T steps from state (h0, c0): act [T][B][384] / x4s [T][B][4] as sw_enc_lstm_fwd left them, dgates
+// [T][B][256] from sw_enc_lstm_bwd; h0 NULL = zero initial state.  Writes every gradient of the packed encoder buffer.
+extern "C" int sw_enc_lstm_wgrad(const float* enc_w, const float* act, const float* x4s, const float* h0, const float* dgates,
+                                 int B, int T, float* d_enc_w, float* wgrad_ws, float* tmp, void* stream) {
+  if (!enc_w || !act || !x4s || !dgates || !d_enc_w || !wgrad_ws || !tmp || B < 1 || T < 1) return SW_EARG;
+  using namespace swp;
+  hipStream_t st = (hipStream_t)stream;
+  float* dWx = tmp;
+  float* dbx = tmp + 1024;
+  WgBatch wb;
+  // W_hh against h_{t-1} (rows t >= 1; row t - 1 of `act`) and the composed input matrix against x4 (all rows)
+  if (wg_add_tail(wb, dgates, 256, act - (ptrdiff_t)B * 384 + 320, 384, T * B, 256, 64, d_enc_w + ENC_WHH, 64, x4s, 4, 4, dWx, 4,
+                  B, dbx, nullptr, 0))
+    return SW_ESHAPE;
+  if (int rc = wg_launch(wb, wgrad_ws, st)) return rc;
+  if (h0) {   // ... and the first step against the given initial state
+    WgBatch w0;
+    if (wg_add(w0, dgates, 256, h0, 64, B, 256, 64, d_enc_w + ENC_WHH, 64, nullptr, nullptr, 1)) return SW_ESHAPE;
+    if (int rc = wg_launch(w0, wgrad_ws, st)) return rc;
+  }
+  hipLaunchKernelGGL(compose_bwd_part_kernel, dim3(128), dim3(256), 0, st, enc_w, dWx, dbx, d_enc_w, nullptr, nullptr, nullptr, 0);
+  SW_CHECK_LAUNCH("compose_bwd_part_kernel");
+  return SW_OK;
+}
+// DecoderFC on one batch (a Tp = 1 rollout: gsave / gdelta of sw_dec_rollout_fwd / _bwd with To, Tp = 1) with its
+// inputs h, s (NULL = zeros), z given explicitly.  Writes every gradient of the packed decoder buffer.
+extern "C" int sw_dec_fc_wgrad(const float* dec_w, const float* gsave, const float* gdelta, const float* h, const float* s,
+                               const float* z, int B, int To, float* d_dec_w, float* wgrad_ws, float* tmp, void* stream) {
+  if (!dec_w || !gsave || !gdelta || !h || !z || !d_dec_w || !wgrad_ws || !tmp || B < 1 || To < 2) return SW_EARG;
+  using namespace swp;
+  hipStream_t st = (hipStream_t)stream;
+  const GSave gs = gsave_layout(B, To, 1);
+  const GDelta gd = gdelta_layout(B, To, 1);
+  float* dM = tmp + 1280;
+  WgBatch wb;
+  int rc = 0;
+  rc |= wg_add(wb, gdelta + gd.dz1, 160, h, 64, B, 160, 64, d_dec_w + DEC_W1, 160, nullptr, nullptr, 0);
+  if (s) rc |= wg_add(wb, gdelta + gd.dz1, 160, s, 64, B, 160, 64, d_dec_w + DEC_W1 + 64, 160, nullptr, nullptr, 0);
+  rc |= wg_add(wb, gdelta + gd.dz1, 160, z, 32, B, 160, 32, d_dec_w + DEC_W1 + 128, 160, d_dec_w + DEC_B1, nullptr, 0);
+  rc |= wg_add(wb, gdelta + gd.dz2, 80, gsave + gs.a1, 160, B, 80, 160, d_dec_w + DEC_W2, 160, d_dec_w + DEC_B2, nullptr, 0);
+  rc |= wg_add(wb, gdelta + gd.dv, 4, gsave + gs.a2, 80, B, 2, 80, dM, 80, dM + 160, nullptr, 0);
+  if (rc) return SW_ESHAPE;
+  if (int r2 = wg_launch(wb, wgrad_ws, st)) return r2;
+  if (!s) {     // no pooled social vector: that block of fc1.0.weight has no gradient
+    if (hipMemset2DAsync(d_dec_w + DEC_W1 + 64, 160 * sizeof(float), 0, 64 * sizeof(float), 160, st) != hipSuccess) return SW_EHIP;
+  }
+  hipLaunchKernelGGL(compose_bwd_part_kernel, dim3(SW_DEC_COMPOSE_BLOCKS), dim3(256), 0, st, nullptr, nullptr, nullptr, nullptr,
+                     dec_w, dM, d_dec_w, 128);
+  SW_CHECK_LAUNCH("compose_bwd_part_kernel");
+  return SW_OK;
 }
 
 // ---- losses (train.py:484-494, 512-523) ---------------------------------------------------------

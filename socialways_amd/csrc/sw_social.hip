@@ -1273,6 +1273,127 @@ __global__ __launch_bounds__(SW_THREADS) void embed_features_kernel(const float*
   }
 }
 
+// Backward of EmbedSocialFeatures.forward on R rows (one wave per 16 rows): the MLP is recomputed on the matrix cores,
+// dout is back-propagated to the hidden layers; rows = h2 [R][64] | dh2 [R][64] | h1 [R][32] | dh1 [R][32] | feat4 [R][4]
+// are what the weight-gradient GEMMs contract over (sw_linear_wgrad: dout x h2, dh2 x h1, dh1 x feat4); dfeat [R][3]
+// (optional) = fc.0.weight^T dh1.
+__global__ __launch_bounds__(SW_THREADS) void embed_features_bwd_kernel(const float* __restrict__ feat, long long R,
+                                                                        const float* __restrict__ emb_w,
+                                                                        const float* __restrict__ dout,
+                                                                        float* __restrict__ rows, float* __restrict__ dfeat) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const SocL Ls = soc_lds(16);
+  const float* w0b = smem + Ls.w0b;
+  const float* b12 = smem + Ls.b12;
+  stage_pair_consts(smem, Ls, emb_w);
+  sw_barrier();
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  PairW W;
+  load_pair_w(W, emb_w, ln, lg);
+  f32x4 w2T[4][4], w1T[2][4];   // fc.4.weight^T, fc.2.weight^T as A operands (see social_pool_bwd_rows_kernel)
+#pragma unroll
+  for (int mo = 0; mo < 4; ++mo) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* row2 = emb_w + swp::EMB_W2 + (16 * mo + 4 * lg + r) * 64 + ln;
+      const float* row1 = emb_w + swp::EMB_W1 + (16 * mo + 4 * lg + r) * 32 + ln;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) w2T[mt][mo][r] = row2[16 * mt];
+      w1T[0][mo][r] = row1[0];
+      w1T[1][mo][r] = row1[16];
+    }
+  }
+  const long long r0 = ((long long)blockIdx.x * 4 + wave) * 16;
+  if (r0 >= R) return;
+  const bool valid = r0 + ln < R;
+  const long long row = valid ? r0 + ln : R - 1;
+  const float f0 = feat[row * 3], f1 = feat[row * 3 + 1], f2 = feat[row * 3 + 2];
+  f32x4 h1[2], h2[4], fo[4];
+  pair_l1(w0b, lg, f0, f1, f2, h1);
+  pair_l23(W, b12, b12 + 64, lg, h1, h2, fo);
+  f32x4 dz3[4], dh2[4], dh1[2];
+#pragma unroll
+  for (int mo = 0; mo < 4; ++mo) dz3[mo] = ld4(dout + row * 64 + 16 * mo + 4 * lg);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) dh2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) dh2[mt] = SW_MFMA(w2T[mt][mo][r], dz3[mo][r], dh2[mt]);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dh2[mt][r] = h2[mt][r] > 0.f ? dh2[mt][r] : 0.f;
+  dh1[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  dh1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      dh1[0] = SW_MFMA(w1T[0][mt][r], dh2[mt][r], dh1[0]);
+      dh1[1] = SW_MFMA(w1T[1][mt][r], dh2[mt][r], dh1[1]);
+    }
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dh1[jt][r] = h1[jt][r] > 0.f ? dh1[jt][r] : 0.f;
+  // fc.0.weight^T dh1: this lane's 8 hidden units, then the four lane groups of the row
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f32x4 w = ld4(w0b + (16 * jt + 4 * lg + r) * 4);
+      g0 = fmaf(w[0], dh1[jt][r], g0);
+      g1 = fmaf(w[1], dh1[jt][r], g1);
+      g2 = fmaf(w[2], dh1[jt][r], g2);
+    }
+  g0 += __shfl_xor(g0, 16); g0 += __shfl_xor(g0, 32);
+  g1 += __shfl_xor(g1, 16); g1 += __shfl_xor(g1, 32);
+  g2 += __shfl_xor(g2, 16); g2 += __shfl_xor(g2, 32);
+  if (valid) {
+    float* ph2 = rows;
+    float* pdh2 = ph2 + 64 * R;
+    float* ph1 = pdh2 + 64 * R;
+    float* pdh1 = ph1 + 32 * R;
+    float* pf4 = pdh1 + 32 * R;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      st4(ph2 + row * 64 + 16 * mt + 4 * lg, h2[mt]);
+      st4(pdh2 + row * 64 + 16 * mt + 4 * lg, dh2[mt]);
+    }
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      st4(ph1 + row * 32 + 16 * jt + 4 * lg, h1[jt]);
+      st4(pdh1 + row * 32 + 16 * jt + 4 * lg, dh1[jt]);
+    }
+    if (lg == 0) {
+      st4(pf4 + row * 4, f32x4{f0, f1, f2, 0.f});
+      if (dfeat) {
+        dfeat[row * 3] = g0;
+        dfeat[row * 3 + 1] = g1;
+        dfeat[row * 3 + 2] = g2;
+      }
+    }
+  }
+}
+extern "C" int sw_embed_features_bwd(const float* feat, long long R, const float* emb_w, const float* dout, float* rows,
+                                     float* dfeat, void* stream) {
+  if (!feat || !emb_w || !dout || !rows || R < 0) return SW_EARG;
+  if (R == 0) return SW_OK;
+  static bool attr = false;
+  if (!attr) {
+    if (int rc = set_lds((const void*)embed_features_bwd_kernel, soc_lds(16).fwd_total * 4)) return rc;
+    attr = true;
+  }
+  hipLaunchKernelGGL(embed_features_bwd_kernel, dim3((unsigned)((R + 63) / 64)), dim3(SW_THREADS), soc_lds(16).fwd_total * 4,
+                     (hipStream_t)stream, feat, R, emb_w, dout, rows, dfeat);
+  SW_CHECK_LAUNCH("embed_features_bwd_kernel");
+  return SW_OK;
+}
+
 extern "C" int sw_attention_pool_dense(const float* f, const float* h, const int* scene_off, int S, int B,
                                        const float* att_w, float* S_out, void* stream) {
   if (!f || !h || !scene_off || !att_w || !S_out || S < 0 || B < 0) return SW_EARG;

@@ -14,10 +14,12 @@ reference dicts.  All compute is the HIP library (socialways_amd/_lib.py); param
 module live in ONE packed buffer (the layout the C ABI reads) and the nn.Parameters are views of
 it, so state_dict()/load_state_dict()/torch.optim work unchanged.
 
-Differentiable entry points are the two functions train() differentiates: `predict()` /
-`Generator.forward` and `Discriminator.forward`.  The stand-alone sub-module forwards
-(`EncoderLstm`, `DecoderFC`, `EmbedSocialFeatures`, `AttentionPooling`, `SocialFeatures`) run the
-same kernels for inference / inspection and do not record autograd graphs.
+Differentiable entry points: the two functions train() differentiates - `predict()` / `Generator.forward` and
+`Discriminator.forward` (fused kernels) - and the stand-alone sub-modules `EncoderLstm`, `DecoderFC`,
+`EmbedSocialFeatures`, `AttentionPooling` (any scene size), which record autograd graphs of their own (`_EncFn`,
+`_DecFn`, `_EmbFn`, `_AttFn`: the same forward kernels plus their backward passes, csrc/sw_modules.hip) so that a model
+composed differently from predict() still trains.  `SocialFeatures` / `get_traj_4d` act on track data and carry no
+gradient.
 """
 import numpy as np
 import torch
@@ -125,6 +127,177 @@ def SocialFeatures(x, sub_batches):
     return feat
 
 
+def _wants_grad(module, *tensors):
+    return torch.is_grad_enabled() and (any(t.requires_grad for t in tensors if t is not None)
+                                        or any(p.requires_grad for p in module.parameters()))
+
+
+def _wgrad_ws(dev):
+    return ops.default_ws(dev).get("wgrad", L.workspace_floats(L.WS_WGRAD, 1, 2, 1))
+
+
+class _AttFn(torch.autograd.Function):
+    """AttentionPooling.forward on a dense (B,B,F) tensor (train.py:160-174), any scene size."""
+
+    @staticmethod
+    def forward(ctx, att, f, h, sc, *params):
+        B, dev = h.shape[0], h.device
+        w = att.packed()
+        f, h = f.contiguous(), h.contiguous()
+        wh = torch.empty(B, 64, device=dev)           # W h + b
+        L.call("sw_rows_gemm", L.ptr(h), 64, L.ptr(w), 1, 64, w.data_ptr() + 4 * 4096, B, 64, 64, L.ptr(wh), 64, 0, L.stream())
+        attn = torch.zeros(B, B, device=dev)
+        S = torch.empty(B, 64, device=dev)
+        L.call("sw_attention_dense_fwd", L.ptr(f), L.ptr(h), L.ptr(wh), L.ptr(sc.scene_off), sc.S, B, L.ptr(attn), L.ptr(S),
+               L.stream())
+        ctx.att, ctx.sc, ctx.need_f = att, sc, f.requires_grad
+        ctx.save_for_backward(f, h, wh, attn)
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        att, sc = ctx.att, ctx.sc
+        f, h, wh, attn = ctx.saved_tensors
+        B, dev = h.shape[0], h.device
+        w = att.packed()
+        dsig = torch.empty(B, B, device=dev)
+        df = torch.zeros(B, B, 64, device=dev) if ctx.need_f else None
+        dwh, dh = torch.empty(B, 64, device=dev), torch.empty(B, 64, device=dev)
+        L.call("sw_attention_dense_bwd", L.ptr(f), L.ptr(h), L.ptr(wh), L.ptr(attn), L.ptr(dS.contiguous()), L.ptr(sc.scene_off),
+               sc.S, B, L.ptr(dsig), L.ptr(df), L.ptr(dwh), L.ptr(dh), L.stream())
+        # dh += W^T dWh ; dW = dWh^T h ; db = sum dWh
+        L.call("sw_rows_gemm", L.ptr(dwh), 64, L.ptr(w), 64, 1, None, B, 64, 64, L.ptr(dh), 64, 1, L.stream())
+        gflat = torch.zeros_like(w)
+        L.call("sw_linear_wgrad", L.ptr(dwh), 64, L.ptr(h), 64, B, 64, 64, L.ptr(gflat), 64, gflat.data_ptr() + 4 * 4096,
+               L.ptr(_wgrad_ws(dev)), 0, L.stream())
+        return (None, df, dh, None) + tuple(att.split_grad(gflat))
+
+
+class _EmbFn(torch.autograd.Function):
+    """EmbedSocialFeatures.forward (train.py:185-189) on any (..., 3) feature tensor."""
+
+    @staticmethod
+    def forward(ctx, emb, x, *params):
+        x = x.contiguous()
+        R = x.numel() // 3
+        out = torch.empty(*x.shape[:-1], 64, device=x.device)
+        L.call("sw_embed_features", L.ptr(x), R, L.ptr(emb.packed()), L.ptr(out), L.stream())
+        ctx.emb, ctx.need_x = emb, x.requires_grad
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        emb = ctx.emb
+        (x,) = ctx.saved_tensors
+        dev = x.device
+        R = x.numel() // 3
+        if R >= 2 ** 31:
+            raise L.SocialWaysHipError("EmbedSocialFeatures backward: %d rows" % R)
+        w = emb.packed()
+        dout = dout.contiguous()
+        rows = torch.empty(196 * R, device=dev)
+        dx = torch.empty_like(x) if ctx.need_x else None
+        L.call("sw_embed_features_bwd", L.ptr(x), R, L.ptr(w), L.ptr(dout), L.ptr(rows), L.ptr(dx), L.stream())
+        h2, dh2, h1, dh1, f4 = (rows[a * R:b * R] for a, b in ((0, 64), (64, 128), (128, 160), (160, 192), (192, 196)))
+        gflat = torch.zeros_like(w)
+        off = [o for o, _ in emb._slices]      # fc.0.weight, fc.0.bias, fc.2.weight, fc.2.bias, fc.4.weight, fc.4.bias
+        ws, g0 = _wgrad_ws(dev), gflat.data_ptr()
+        for delta, ldd, act, lda, N, K, iw, ib in ((dout, 64, h2, 64, 64, 64, 4, 5), (dh2, 64, h1, 32, 64, 32, 2, 3),
+                                                   (dh1, 32, f4, 4, 32, 3, 0, 1)):
+            L.call("sw_linear_wgrad", L.ptr(delta), ldd, L.ptr(act), lda, R, N, K, g0 + 4 * off[iw], K, g0 + 4 * off[ib],
+                   L.ptr(ws), 0, L.stream())
+        return (None, dx) + tuple(emb.split_grad(gflat))
+
+
+class _EncFn(torch.autograd.Function):
+    """EncoderLstm.forward (train.py:262-269): embed + LSTM over T steps from the state (h0, c0)."""
+
+    @staticmethod
+    def forward(ctx, enc, x, h0, c0, *params):
+        B, T, dev = x.shape[0], x.shape[1], x.device
+        x, h0, c0 = x.contiguous(), h0.contiguous(), c0.contiguous()
+        hT, cT = torch.empty_like(h0), torch.empty_like(c0)
+        y = torch.empty(B, T, 64, device=dev)
+        act, x4s = torch.empty(T, B, 384, device=dev), torch.empty(T, B, 4, device=dev)
+        L.call("sw_enc_lstm_fwd", L.ptr(x), 1, L.ptr(enc.packed()), L.ptr(h0), L.ptr(c0), B, T, L.ptr(hT), L.ptr(cT), L.ptr(y),
+               L.ptr(act), L.ptr(x4s), 0, L.stream())
+        ctx.enc, ctx.need_x, ctx.need_state = enc, x.requires_grad, (h0.requires_grad or c0.requires_grad)
+        ctx.save_for_backward(act, x4s, h0, c0)
+        return y, hT, cT
+
+    @staticmethod
+    def backward(ctx, dy, dhT, dcT):
+        enc = ctx.enc
+        act, x4s, h0, c0 = ctx.saved_tensors
+        T, B, dev = act.shape[0], act.shape[1], act.device
+        w = enc.packed()
+        zeros = lambda: torch.zeros(B, 64, device=dev)
+        dhT = zeros() if dhT is None else dhT.contiguous()
+        dcT = zeros() if dcT is None else dcT.contiguous()
+        dy = None if dy is None else dy.contiguous()
+        dgates = torch.empty(T, B, 256, device=dev)
+        dh0, dc0 = torch.empty(B, 64, device=dev), torch.empty(B, 64, device=dev)
+        L.call("sw_enc_lstm_bwd", L.ptr(w), L.ptr(act), L.ptr(c0), L.ptr(dhT), L.ptr(dcT), L.ptr(dy), B, T, 0, L.ptr(dgates),
+               L.ptr(dh0), L.ptr(dc0), L.stream())
+        gflat = torch.zeros_like(w)
+        tmp = torch.empty(2048, device=dev)
+        L.call("sw_enc_lstm_wgrad", L.ptr(w), L.ptr(act), L.ptr(x4s), L.ptr(h0), L.ptr(dgates), B, T, L.ptr(gflat),
+               L.ptr(_wgrad_ws(dev)), L.ptr(tmp), L.stream())
+        dx = None
+        if ctx.need_x:     # dx_t = (W_ih W_embed)^T dgates_t: the composed 256 x 4 input matrix, then one small product
+            off = dict(zip(("embed.weight", "embed.bias", "lstm.weight_ih_l0"), [o for o, _ in enc._slices][:3]))
+            wx = torch.empty(256, 4, device=dev)
+            L.call("sw_rows_gemm", w.data_ptr() + 4 * off["lstm.weight_ih_l0"], 64, w.data_ptr() + 4 * off["embed.weight"], 4, 1,
+                   None, 256, 64, 4, L.ptr(wx), 4, 0, L.stream())
+            dxt = torch.empty(T, B, 4, device=dev)
+            L.call("sw_rows_gemm", L.ptr(dgates), 256, L.ptr(wx), 4, 1, None, T * B, 256, 4, L.ptr(dxt), 4, 0, L.stream())
+            dx = dxt.permute(1, 0, 2).contiguous()
+        return (None, dx, dh0 if ctx.need_state else None, dc0 if ctx.need_state else None) + tuple(enc.split_grad(gflat))
+
+
+class _DecFn(torch.autograd.Function):
+    """DecoderFC.forward (train.py:330-335) = one decode step of the rollout kernels (Tp = 1)."""
+    TO = 2
+
+    @staticmethod
+    def forward(ctx, dec, h, s, z, enc_w, *params):
+        B, dev = h.shape[0], h.device
+        h, s, z = h.contiguous(), s.contiguous(), z.contiguous()
+        zero_obs = torch.zeros(B, _DecFn.TO, 2, device=dev)
+        c = torch.zeros(B, 64, device=dev)
+        pred4 = torch.empty(B, 1, 4, device=dev)
+        gsave = torch.empty(L.workspace_floats(L.WS_GSAVE, B, _DecFn.TO, 1), device=dev)
+        L.call("sw_dec_rollout_fwd", L.ptr(zero_obs), _DecFn.TO, L.ptr(z), L.ptr(s), L.ptr(h), L.ptr(c), L.ptr(enc_w),
+               L.ptr(dec.packed()), B, 1, L.ptr(pred4), None, None, L.ptr(gsave), None, 0.0, None, L.stream())
+        ctx.dec, ctx.enc_w = dec, enc_w
+        ctx.need = (h.requires_grad, s.requires_grad, z.requires_grad)
+        ctx.save_for_backward(h, s, z, gsave)
+        return pred4[:, 0, 2:4].contiguous()
+
+    @staticmethod
+    def backward(ctx, dv):
+        dec = ctx.dec
+        h, s, z, gsave = ctx.saved_tensors
+        B, dev = h.shape[0], h.device
+        w = dec.packed()
+        dpred4 = torch.zeros(B, 1, 4, device=dev)
+        dpred4[:, 0, 2:4] = dv
+        gdelta = torch.empty(L.workspace_floats(L.WS_GDELTA, B, _DecFn.TO, 1), device=dev)
+        dh, dc, ds = (torch.empty(B, 64, device=dev) for _ in range(3))
+        L.call("sw_dec_rollout_bwd", L.ptr(dpred4), L.ptr(ctx.enc_w), L.ptr(w), L.ptr(gsave), B, _DecFn.TO, 1, L.ptr(gdelta),
+               L.ptr(dh), L.ptr(dc), L.ptr(ds), L.stream())
+        dz = None
+        if ctx.need[2]:
+            dz = torch.empty(B, 32, device=dev)
+            L.call("sw_dec_fc_dz", L.ptr(w), L.ptr(gdelta), B, _DecFn.TO, L.ptr(dz), L.stream())
+        gflat = torch.zeros_like(w)
+        tmp = torch.empty(2048, device=dev)
+        L.call("sw_dec_fc_wgrad", L.ptr(w), L.ptr(gsave), L.ptr(gdelta), L.ptr(h), L.ptr(s), L.ptr(z), B, _DecFn.TO, L.ptr(gflat),
+               L.ptr(_wgrad_ws(dev)), L.ptr(tmp), L.stream())
+        return (None, dh if ctx.need[0] else None, ds if ctx.need[1] else None, dz, None) + tuple(dec.split_grad(gflat))
+
+
 class AttentionPooling(_Packed):
     _GRP = L.GRP_ATT
 
@@ -143,11 +316,9 @@ class AttentionPooling(_Packed):
         L.require_gpu(h)
         B = h.shape[0]
         sc = _scene_index(sub_batches, B, h.device)
-        if sc.NB > 0:      # the dense stand-alone kernel stages one scene in LDS; predict() / the training step route
-            raise L.SocialWaysHipError(       # larger scenes through the row-block kernels and have no such limit
-                "AttentionPooling.forward (dense f) handles scenes of up to %d agents; got a scene of %d - use "
-                "predict() / Generator.forward, which has no scene-size limit" % (L.AMAX, int(sc.sizes.max())))
-        S = torch.empty(B, 64, device=h.device)
+        if _wants_grad(self, f, h) or sc.NB > 0:    # one workgroup per agent: any scene size, records an autograd graph
+            return _AttFn.apply(self, f, h, sc, *self.parameters())
+        S = torch.empty(B, 64, device=h.device)     # one workgroup per scene (<= 64 agents staged in LDS)
         L.call("sw_attention_pool_dense", L.ptr(f.contiguous()), L.ptr(h.contiguous()), L.ptr(sc.scene_off), sc.S, B,
                L.ptr(self.packed()), L.ptr(S), L.stream())
         return S
@@ -169,6 +340,8 @@ class EmbedSocialFeatures(_Packed):
 
     def forward(self, ftr_list, sub_batches):
         L.require_gpu(ftr_list)
+        if _wants_grad(self, ftr_list):
+            return _EmbFn.apply(self, ftr_list, *self.parameters())
         x = ftr_list.contiguous()
         R = x.numel() // 3
         out = torch.empty(*x.shape[:-1], 64, device=x.device)
@@ -201,8 +374,13 @@ class EncoderLstm(_Packed):
         bs = obsv.shape[0]
         x = obsv.reshape(bs, -1, 4).contiguous()
         T = x.shape[1]
-        h0 = self.lstm_h[0].reshape(bs, 64).contiguous()
-        c0 = self.lstm_h[1].reshape(bs, 64).contiguous()
+        h0 = self.lstm_h[0].reshape(bs, 64)
+        c0 = self.lstm_h[1].reshape(bs, 64)
+        if _wants_grad(self, x, h0, c0):
+            y, hT, cT = _EncFn.apply(self, x, h0, c0, *self.parameters())
+            self.lstm_h = (hT.view(1, bs, 64), cT.view(1, bs, 64))
+            return y
+        h0, c0 = h0.contiguous(), c0.contiguous()
         hT, cT = torch.empty_like(h0), torch.empty_like(c0)
         y = torch.empty(bs, T, 64, device=x.device)
         L.call("sw_enc_lstm_fwd", L.ptr(x), 1, L.ptr(self.packed()), L.ptr(h0), L.ptr(c0), bs, T, L.ptr(hT), L.ptr(cT),
@@ -234,6 +412,8 @@ class DecoderFC(_Packed):
         c = torch.zeros(B, 64, device=dev)
         pred4 = torch.empty(B, 1, 4, device=dev)
         enc_w = _encoder.packed() if _encoder is not None else torch.zeros(L.load().sw_param_count(L.GRP_ENC, 1), device=dev)
+        if _wants_grad(self, h, s, z):
+            return _DecFn.apply(self, h, s, z, enc_w, *self.parameters())
         L.call("sw_dec_rollout_fwd", L.ptr(zero_obs), 2, L.ptr(z.contiguous()), L.ptr(s.contiguous()),
                L.ptr(h.contiguous()), L.ptr(c), L.ptr(enc_w), L.ptr(self.packed()), B, 1, L.ptr(pred4), None, None, None,
                None, 0.0, None, L.stream())

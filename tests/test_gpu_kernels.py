@@ -126,8 +126,10 @@ def test_module_level_api_matches_reference_ops():
     assert_close(feats.cpu(), g["features"], 1e-5, 1e-6, "dense features")
     emb = fe(feats, sb)
     for s, (a, b) in enumerate(sb):
-        assert_close(emb[a:b, a:b].cpu(), g["emb.%d" % s], 1e-5, 2e-6, "emb block %d" % s)
-    assert_close(att(emb, h, sb).cpu(), g["S"], 1e-5, 2e-6, "S")
+        assert_close(emb[a:b, a:b].detach().cpu(), g["emb.%d" % s], 1e-5, 2e-6, "emb block %d" % s)
+    assert_close(att(emb, h, sb).detach().cpu(), g["S"], 1e-5, 2e-6, "S (autograd path: one workgroup per agent)")
+    with torch.no_grad():
+        assert_close(att(emb.detach(), h, sb).cpu(), g["S"], 1e-5, 2e-6, "S (no-grad path: one workgroup per scene)")
     # EncoderLstm stand-alone vs the oracle module, sequence then single step, state carried
     enc = sw.EncoderLstm(64, 1, device=dev)
     enc.load_state_dict(st["encoder"])
@@ -261,3 +263,100 @@ def test_riders_reproduce_the_deferred_weight_gradients(B):
             L.load().sw_set_cosched(0)
     assert torch.equal(grads[1], grads[2])
     assert_close(grads[1].cpu(), grads[0].cpu(), 2e-5, 2e-6 * float(grads[0].abs().max()), "riders vs deferred launch")
+
+
+def _grad_close(a, b, what, rel=2e-4):
+    """Gradient tensors: within `rel` of the reference tensor's largest entry (like the predict() gradient tests)."""
+    a, b = a.detach().cpu().double().numpy(), b.detach().cpu().double().numpy()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    tol = rel * max(float(np.abs(b).max()), 1e-6)
+    err = float(np.abs(a - b).max())
+    assert err <= tol, "%s: max|err| %.3e > %.3e (max|ref| %.3e)" % (what, err, tol, float(np.abs(b).max()))
+
+
+def _pair(hip_mod, oracle_mod):
+    oracle_mod.load_state_dict({k: v.detach().cpu().clone() for k, v in hip_mod.state_dict().items()})
+    return oracle_mod
+
+
+def _check_param_grads(hip_mod, oracle_mod, what):
+    for (name, p), (_, q) in zip(hip_mod.named_parameters(), oracle_mod.named_parameters()):
+        assert p.grad is not None, "%s.%s has no gradient" % (what, name)
+        _grad_close(p.grad, q.grad, "%s d/d%s" % (what, name))
+
+
+def test_standalone_social_modules_are_differentiable_any_scene_size():
+    """EmbedSocialFeatures and AttentionPooling called one by one on DENSE tensors, as a user who re-composes the
+    reference's modules would (train.py:153-189), with autograd: outputs, input gradients (dense f, h, features) and
+    every parameter gradient against the oracle modules under torch's CPU autograd.  Scenes of 5, 1, 70 (above the 64
+    agents one workgroup stages in LDS) and 24 agents."""
+    import socialways_amd as sw
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    sb = np.array([[0, 5], [5, 6], [6, 76], [76, 100]])
+    B = 100
+    fe, att = sw.EmbedSocialFeatures(3, 64, device=dev), sw.AttentionPooling(64, 64, device=dev)
+    ofe, oatt = _pair(fe, O.EmbedSocialFeatures(3, 64)), _pair(att, O.AttentionPooling(64, 64))
+    feats, h = torch.rand(B, B, 3) * 2 - 0.5, torch.randn(B, 64) * 0.5
+    wS, wE = torch.randn(B, 64), torch.randn(B, B, 64) * 0.01
+    outs = []
+    for fe_, att_, d in ((fe, att, dev), (ofe, oatt, torch.device("cpu"))):
+        x, hh = feats.to(d).requires_grad_(), h.to(d).requires_grad_()
+        emb = fe_(x, sb)
+        S = att_(emb, hh, sb)
+        ((S * wS.to(d)).sum() + (emb * wE.to(d)).sum()).backward()
+        outs.append((emb, S, x.grad, hh.grad))
+    (emb, S, dx, dh), (oemb, oS, odx, odh) = outs
+    assert_close(emb.detach().cpu(), oemb.detach(), 1e-5, 2e-6, "embedding")
+    assert_close(S.detach().cpu(), oS.detach(), 2e-5, 2e-6, "pooled S (scene of 70 agents included)")
+    _grad_close(dx, odx, "d/d features")
+    _grad_close(dh, odh, "d/d h")
+    _check_param_grads(fe, ofe, "feature_embedder")
+    _check_param_grads(att, oatt, "attention")
+    # the single-agent scene: S = 0 and nothing flows through it (train.py:165)
+    assert float(S[5].detach().abs().max()) == 0.0
+    # without autograd the same scenes go through the no-grad paths and give the same numbers
+    with torch.no_grad():
+        S2 = att(fe(feats.to(dev), sb), h.to(dev), sb)
+    assert_close(S2.cpu(), S.detach().cpu(), 1e-5, 1e-6, "no-grad path")
+
+
+def test_standalone_encoder_and_decoder_are_differentiable():
+    """EncoderLstm (a sequence, then one more step from the carried state - how predict() uses it, train.py:405,430) and
+    DecoderFC with autograd through the stand-alone modules: outputs, the gradients w.r.t. inputs and initial state and
+    every parameter gradient against the oracle modules on the CPU."""
+    import socialways_amd as sw
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    B, T = 37, 6
+    enc, dec = sw.EncoderLstm(64, 1, device=dev), sw.DecoderFC(160, device=dev)
+    oenc, odec = _pair(enc, O.EncoderLstm(64, 1)), _pair(dec, O.DecoderFC(160))
+    x, h0, c0 = torch.randn(B, T, 4) * 0.5, torch.randn(1, B, 64) * 0.3, torch.randn(1, B, 64) * 0.3
+    x1 = torch.randn(B, 4) * 0.5
+    w1, w2, w3 = torch.randn(B, T, 64), torch.randn(B, 1, 64), torch.randn(1, B, 64)
+    outs = []
+    for e_, d in ((enc, dev), (oenc, torch.device("cpu"))):
+        xs, x1s = x.to(d).requires_grad_(), x1.to(d).requires_grad_()
+        hs, cs = h0.to(d).requires_grad_(), c0.to(d).requires_grad_()
+        e_.init_lstm(hs, cs)
+        y = e_(xs)
+        y1 = e_(x1s)
+        ((y * w1.to(d)).sum() + (y1 * w2.to(d)).sum() + (e_.lstm_h[1] * w3.to(d)).sum()).backward()
+        outs.append((y, y1, xs.grad, x1s.grad, hs.grad, cs.grad))
+    for name, a, b in zip(("y", "y (one more step)"), outs[0][:2], outs[1][:2]):
+        assert_close(a.detach().cpu(), b.detach(), RT, AT, "encoder " + name)
+    for name, a, b in zip(("x", "x (one more step)", "h0", "c0"), outs[0][2:], outs[1][2:]):
+        _grad_close(a, b, "encoder d/d" + name)
+    _check_param_grads(enc, oenc, "encoder")
+    # DecoderFC
+    hh, s, z, wv = torch.randn(B, 64) * 0.5, torch.randn(B, 64) * 0.5, torch.rand(B, 32), torch.randn(B, 2)
+    outs = []
+    for d_, d in ((dec, dev), (odec, torch.device("cpu"))):
+        a, b, c = (t.to(d).requires_grad_() for t in (hh, s, z))
+        v = d_(a, b, c)
+        (v * wv.to(d)).sum().backward()
+        outs.append((v, a.grad, b.grad, c.grad))
+    assert_close(outs[0][0].detach().cpu(), outs[1][0].detach(), RT, AT, "decoder v")
+    for name, a, b in zip(("h", "s", "z"), outs[0][1:], outs[1][1:]):
+        _grad_close(a, b, "decoder d/d" + name)
+    _check_param_grads(dec, odec, "decoder")
