@@ -220,19 +220,15 @@ __global__ __launch_bounds__(SW_THREADS) void disc_fwd_kernel(
     stage_w_store<1>(s_cl1, smem + L.cl1, LD32, 16);
     stage_w_store<1>(s_la1, smem + L.la1, LD32, 16);
   }
-  {
-    int i = threadIdx.x;  // 256 = 8 x 32
-    int q = i >> 5, k = i & 31;
-    float v = 0.f;
-    if (q == 0) v = d_w[O.of0b + k];
-    else if (q == 1) v = d_w[O.of1b + k];
-    else if (q == 2) v = d_w[O.pe0b + k];
-    else if (q == 3) v = d_w[O.pe1b + k];
-    else if (q == 4) v = d_w[O.cl0b + k];
-    else if (q == 5) v = d_w[O.la0b + k];
-    else if (q == 6) v = k < 1 ? d_w[O.cl1b + k] : 0.f;
-    else v = k < 2 ? d_w[O.la1b + k] : 0.f;
-    smem[L.bias + i] = v;
+  {   // the eight bias vectors: ONE unconditional load per thread from a selected offset (eight loads under lane branches
+      // compiled to eight serial round trips, each behind an s_waitcnt vmcnt(0))
+    const int i = threadIdx.x;  // 256 = 8 x 32
+    const int q = i >> 5, k = i & 31;
+    const int boff = q == 0 ? O.of0b : q == 1 ? O.of1b : q == 2 ? O.pe0b : q == 3 ? O.pe1b : q == 4 ? O.cl0b
+                     : q == 5 ? O.la0b : q == 6 ? O.cl1b : O.la1b;
+    const int lim = q < 6 ? 32 : (q == 6 ? 1 : 2);
+    const float v = d_w[boff + min(k, lim - 1)];
+    smem[L.bias + i] = k < lim ? v : 0.f;
   }
   f32x4 c = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};  // h0 = c0 = 0 (train.py:296-297)
   if (!obs_pre) {
