@@ -137,6 +137,13 @@ __host__ __device__ inline SocL soc_lds(int a16) {
 __device__ __forceinline__ void scene_load_h_wh(float* smem, const SocL& Ls, const float* h, const float* att_w, int s0, int n) {
   float* hs = smem + Ls.hs;
   float* wh = smem + Ls.wh;
+  // the attention weights are requested first: they arrive together with the h rows (behind the barrier below they
+  // were a global round trip of their own)
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  f32x4 wr[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wr[j] = ld4(att_w + swp::ATT_W + (16 * wave + ln) * 64 + 16 * j + 4 * lg);
+  f32x4 bias = ld4(att_w + swp::ATT_B + 16 * wave + 4 * lg);
   for (int i = threadIdx.x; i < n * 16; i += blockDim.x) {
     int a = i >> 4, q = i & 15;
     st4(&hs[a * 68 + 4 * q], ld4(h + (size_t)(s0 + a) * 64 + 4 * q));
@@ -147,11 +154,6 @@ __device__ __forceinline__ void scene_load_h_wh(float* smem, const SocL& Ls, con
     st4(&hs[a * 68 + 4 * q], f32x4{0.f, 0.f, 0.f, 0.f});
   }
   sw_barrier();
-  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
-  f32x4 wr[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) wr[j] = ld4(att_w + swp::ATT_W + (16 * wave + ln) * 64 + 16 * j + 4 * lg);
-  f32x4 bias = ld4(att_w + swp::ATT_B + 16 * wave + 4 * lg);
   for (int at = 0; at < npad / 16; ++at) {
     f32x4 acc = tile_mm_reg<4>(wr, &hs[(16 * at + ln) * 68 + 4 * lg], bias);
     st4(&wh[(16 * at + ln) * 68 + 16 * wave + 4 * lg], acc);
