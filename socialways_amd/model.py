@@ -30,12 +30,90 @@ from . import ops
 
 
 # ------------------------------------------------------------------------------------------------
+def _ar(n, base=0):
+    return torch.arange(n, dtype=torch.long) + base
+
+
+def _gate_rows(H):
+    """LSTM gate rows (i, f, g, o blocks of H) inside the kernels' 4 x 64 layout."""
+    return torch.cat([_ar(H, 64 * g) for g in range(4)])
+
+
+def _check_hidden(H, what):
+    """The kernels are built for 64 hidden units (train.py's default `--hidden-size`).  Smaller networks run on them
+    EXACTLY, zero-padded: a padded unit has zero weights and biases, so it stays at 0 through every layer (lrelu(0) = 0,
+    an LSTM unit with zero pre-activations keeps c = h = 0), feeds nothing forward, and receives zero gradients."""
+    if H > 64 or H < 8 or H % 8:
+        raise L.SocialWaysHipError("%s: hidden size %d - the kernels hold 64 hidden units per layer in registers; sizes "
+                                   "8, 16, .. 64 are supported (smaller ones zero-padded), larger ones are not" % (what, H))
+
+
 class _Packed(nn.Module):
-    """Parameters as views of one packed fp32 buffer (C-ABI layout) plus a packed grad buffer."""
+    """Parameters as views of one packed fp32 buffer (C-ABI layout) plus a packed grad buffer.
+
+    With a hidden size below 64 the parameters have the KERNEL shapes (padded with zeros); `_true` lists, per parameter,
+    (true shape, index of the true entries inside the flattened padded tensor).  state_dict() / load_state_dict() speak
+    the reference's true shapes (hooks below), so checkpoints interchange with a reference run at that `--hidden-size`."""
     _GRP = None
+    _true = None
 
     def _tp(self):
         return 1
+
+    @staticmethod
+    def _idx(rows, cols=None, ncols=None):
+        return rows.clone() if cols is None else (rows[:, None] * ncols + cols[None, :]).reshape(-1)
+
+    def _adopt(self, true_mods, maps):
+        """Padded construction: `true_mods` were built first with the reference's shapes (they consumed the RNG exactly
+        like train.py:370-384 does), the kernel-shaped modules afterwards with the generator state restored; copy the
+        true entries into their padded places, zero everything else."""
+        true_params = [q for m in true_mods for q in m.parameters()]
+        mine = list(self.parameters())
+        assert len(true_params) == len(mine) == len(maps)
+        self._true = []
+        with torch.no_grad():
+            for p, q, idx in zip(mine, true_params, maps):
+                assert idx.numel() == q.numel() and int(idx.max()) < p.numel(), (tuple(p.shape), tuple(q.shape))
+                p.zero_()
+                p.view(-1)[idx] = q.reshape(-1)
+                self._true.append((tuple(q.shape), idx))
+        self._register_state_dict_hook(_Packed._shrink_hook)
+        self._register_load_state_dict_pre_hook(self._expand_hook)
+
+    @staticmethod
+    def _shrink_hook(module, state_dict, prefix, local_metadata):
+        for (name, p), (shape, idx) in zip(module.named_parameters(), module._true):
+            key = prefix + name
+            if key in state_dict:
+                state_dict[key] = state_dict[key].reshape(-1)[idx.to(state_dict[key].device)].view(shape).clone()
+
+    def _expand_hook(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for (name, p), (shape, idx) in zip(self.named_parameters(), self._true):
+            key = prefix + name
+            t = state_dict.get(key)
+            if t is not None and tuple(t.shape) == shape and tuple(p.shape) != shape:
+                full = torch.zeros(p.shape, dtype=t.dtype, device=t.device)
+                full.view(-1)[idx.to(t.device)] = t.reshape(-1)
+                state_dict[key] = full
+
+    def load_state_dict(self, state_dict, *a, **k):
+        return super().load_state_dict(dict(state_dict) if self._true is not None else state_dict, *a, **k)
+
+    def true_view(self, i, t):
+        """Parameter-shaped tensor `t` (a gradient, an optimizer moment) of parameter i in the reference's shape."""
+        if self._true is None:
+            return t
+        shape, idx = self._true[i]
+        return t.reshape(-1)[idx.to(t.device)].view(shape)
+
+    def pad_mask(self):
+        """1.0 on the live entries of the packed buffer, 0.0 on zero padding (all ones at 64 hidden units)."""
+        m = torch.ones_like(self._flat) if self._true is None else torch.zeros_like(self._flat)
+        if self._true is not None:
+            for (off, k), (shape, idx) in zip(self._slices, self._true):
+                m[off:off + k][idx.to(m.device)] = 1.0
+        return m
 
     def _move(self, device):
         """Parameters are initialised on the CPU generator exactly like the reference (which builds
@@ -303,17 +381,34 @@ class AttentionPooling(_Packed):
 
     def __init__(self, h_dim, f_dim, device=None):
         super().__init__()
-        if h_dim != 64 or f_dim != 64:
-            raise L.SocialWaysHipError("AttentionPooling kernels are built for h_dim = f_dim = 64")
+        if h_dim != f_dim:
+            raise L.SocialWaysHipError("AttentionPooling kernels are built for h_dim = f_dim")
+        _check_hidden(h_dim, "AttentionPooling")
         self.f_dim, self.h_dim = f_dim, h_dim
-        self.W = nn.Linear(h_dim, f_dim, bias=True)
-        self._pack()
+        H = h_dim
+        if H == 64:
+            self.W = nn.Linear(64, 64, bias=True)
+            self._pack()
+        else:
+            true = [nn.Linear(H, H, bias=True)]
+            st = torch.get_rng_state()
+            self.W = nn.Linear(64, 64, bias=True)
+            torch.set_rng_state(st)
+            self._pack()
+            self._adopt(true, [self._idx(_ar(H), _ar(H), 64), _ar(H)])
         self._move(device)
 
     def forward(self, f, h, sub_batches):
         """f: dense (B,B,F) pair embeddings (only in-scene blocks are read), h: (B,H).
         sigma_ij=<f_ij, W h_j>, sigma_ii:=-1000, softmax over the scene, S_i = sum_j a_ij h_j."""
         L.require_gpu(h)
+        B = h.shape[0]
+        if self.h_dim < 64:       # zero-padded to the kernels' 64 units (exact)
+            pad = 64 - self.h_dim
+            return self.forward_padded(nn.functional.pad(f, (0, pad)), nn.functional.pad(h, (0, pad)), sub_batches)[:, :self.h_dim]
+        return self.forward_padded(f, h, sub_batches)
+
+    def forward_padded(self, f, h, sub_batches):
         B = h.shape[0]
         sc = _scene_index(sub_batches, B, h.device)
         if _wants_grad(self, f, h) or sc.NB > 0:    # one workgroup per agent: any scene size, records an autograd graph
@@ -329,16 +424,29 @@ class EmbedSocialFeatures(_Packed):
 
     def __init__(self, input_size, hidden_size, device=None):
         super().__init__()
-        if input_size != 3 or hidden_size != 64:
-            raise L.SocialWaysHipError("EmbedSocialFeatures kernels are built for 3 -> 64")
+        if input_size != 3:
+            raise L.SocialWaysHipError("EmbedSocialFeatures kernels are built for 3 input features")
+        _check_hidden(hidden_size, "EmbedSocialFeatures")
         self.input_size, self.hidden_size = input_size, hidden_size
-        self.fc = nn.Sequential(nn.Linear(input_size, 32), nn.ReLU(),
-                                nn.Linear(32, 64), nn.ReLU(),
-                                nn.Linear(64, hidden_size))
-        self._pack()
+        H = hidden_size
+        make = lambda n: nn.Sequential(nn.Linear(input_size, 32), nn.ReLU(), nn.Linear(32, 64), nn.ReLU(), nn.Linear(64, n))
+        if H == 64:
+            self.fc = make(64)
+            self._pack()
+        else:
+            true = [make(H)]
+            st = torch.get_rng_state()
+            self.fc = make(64)
+            torch.set_rng_state(st)
+            self._pack()
+            self._adopt(true, [_ar(96), _ar(32), _ar(2048), _ar(64), self._idx(_ar(H), _ar(64), 64), _ar(H)])
         self._move(device)
 
     def forward(self, ftr_list, sub_batches):
+        out = self.forward_padded(ftr_list, sub_batches)
+        return out if self.hidden_size == 64 else out[..., :self.hidden_size]
+
+    def forward_padded(self, ftr_list, sub_batches):
         L.require_gpu(ftr_list)
         if _wants_grad(self, ftr_list):
             return _EmbFn.apply(self, ftr_list, *self.parameters())
@@ -355,13 +463,24 @@ class EncoderLstm(_Packed):
     def __init__(self, hidden_size, n_layers=2, device=None):
         self.hidden_size = hidden_size
         super().__init__()
-        if hidden_size != 64 or n_layers != 1:
-            raise L.SocialWaysHipError("EncoderLstm kernels are built for hidden_size=64, n_layers=1 "
-                                       "(train.py:77,82)")
-        self.embed = nn.Linear(4, hidden_size)
-        self.lstm = nn.LSTM(hidden_size, hidden_size, num_layers=n_layers, batch_first=True)
+        if n_layers != 1:
+            raise L.SocialWaysHipError("EncoderLstm kernels are built for n_layers=1 (train.py:82)")
+        _check_hidden(hidden_size, "EncoderLstm")
+        H = hidden_size
+        if H == 64:
+            self.embed = nn.Linear(4, 64)
+            self.lstm = nn.LSTM(64, 64, num_layers=1, batch_first=True)
+            self._pack()
+        else:
+            true = [nn.Linear(4, H), nn.LSTM(H, H, num_layers=1, batch_first=True)]
+            st = torch.get_rng_state()
+            self.embed = nn.Linear(4, 64)
+            self.lstm = nn.LSTM(64, 64, num_layers=1, batch_first=True)
+            torch.set_rng_state(st)
+            self._pack()
+            g = _gate_rows(H)
+            self._adopt(true, [self._idx(_ar(H), _ar(4), 4), _ar(H), self._idx(g, _ar(H), 64), self._idx(g, _ar(H), 64), g, g])
         self.lstm_h = []
-        self._pack()
         self._move(device)
 
     def init_lstm(self, h, c):
@@ -374,8 +493,17 @@ class EncoderLstm(_Packed):
         bs = obsv.shape[0]
         x = obsv.reshape(bs, -1, 4).contiguous()
         T = x.shape[1]
-        h0 = self.lstm_h[0].reshape(bs, 64)
-        c0 = self.lstm_h[1].reshape(bs, 64)
+        H = self.hidden_size
+        h0 = self.lstm_h[0].reshape(bs, H)
+        c0 = self.lstm_h[1].reshape(bs, H)
+        if H < 64:          # zero-padded to the kernels' 64 units (exact: padded units stay at 0)
+            h0, c0 = nn.functional.pad(h0, (0, 64 - H)), nn.functional.pad(c0, (0, 64 - H))
+            if _wants_grad(self, x, h0, c0):
+                y, hT, cT = _EncFn.apply(self, x, h0, c0, *self.parameters())
+            else:
+                y, hT, cT = self._forward_nograd(x, h0, c0)
+            self.lstm_h = (hT[:, :H].reshape(1, bs, H), cT[:, :H].reshape(1, bs, H))
+            return y[..., :H]
         if _wants_grad(self, x, h0, c0):
             y, hT, cT = _EncFn.apply(self, x, h0, c0, *self.parameters())
             self.lstm_h = (hT.view(1, bs, 64), cT.view(1, bs, 64))
@@ -388,24 +516,50 @@ class EncoderLstm(_Packed):
         self.lstm_h = (hT.view(1, bs, 64), cT.view(1, bs, 64))
         return y
 
+    def _forward_nograd(self, x, h0, c0):
+        bs, T = x.shape[0], x.shape[1]
+        h0, c0 = h0.contiguous(), c0.contiguous()
+        hT, cT = torch.empty_like(h0), torch.empty_like(c0)
+        y = torch.empty(bs, T, 64, device=x.device)
+        L.call("sw_enc_lstm_fwd", L.ptr(x), 1, L.ptr(self.packed()), L.ptr(h0), L.ptr(c0), bs, T, L.ptr(hT), L.ptr(cT),
+               L.ptr(y), None, None, 0, L.stream())
+        return y, hT, cT
+
 
 class DecoderFC(_Packed):
     _GRP = L.GRP_DEC
 
     def __init__(self, hidden_dim, device=None):
         super().__init__()
-        if hidden_dim != 160:
-            raise L.SocialWaysHipError("DecoderFC kernels are built for hidden_dim = 64+64+32 = 160")
-        self.fc1 = nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.LeakyReLU(0.2),
-                                 nn.Linear(hidden_dim, hidden_dim // 2), nn.LeakyReLU(0.2),
-                                 nn.Linear(hidden_dim // 2, hidden_dim // 4),
-                                 nn.Linear(hidden_dim // 4, 2))
-        self._pack()
+        if hidden_dim % 5 or (2 * hidden_dim) % 5:
+            raise L.SocialWaysHipError("DecoderFC: hidden_dim = 2.5 x hidden size (train.py:375), got %d" % hidden_dim)
+        H = 2 * hidden_dim // 5
+        _check_hidden(H, "DecoderFC")
+        self.hidden_size = H
+        make = lambda d: nn.Sequential(nn.Linear(d, d), nn.LeakyReLU(0.2), nn.Linear(d, d // 2), nn.LeakyReLU(0.2),
+                                       nn.Linear(d // 2, d // 4), nn.Linear(d // 4, 2))
+        if H == 64:
+            self.fc1 = make(160)
+            self._pack()
+        else:
+            D = hidden_dim
+            true = [make(D)]
+            st = torch.get_rng_state()
+            self.fc1 = make(160)
+            torch.set_rng_state(st)
+            self._pack()
+            cin = torch.cat([_ar(H), _ar(H, 64), _ar(H // 2, 128)])      # cat[h, s, z] inside the kernels' 64 | 64 | 32 columns
+            self._adopt(true, [self._idx(_ar(D), cin, 160), _ar(D), self._idx(_ar(D // 2), _ar(D), 160), _ar(D // 2),
+                               self._idx(_ar(D // 4), _ar(D // 2), 80), _ar(D // 4), self._idx(_ar(2), _ar(D // 4), 40), _ar(2)])
         self._move(device)
 
     def forward(self, h, s, z, _encoder=None):
         """cat[h,s,z] -> velocity (B,2) (train.py:330-335): one decode step of the rollout kernel."""
         L.require_gpu(h)
+        H = self.hidden_size
+        if H < 64:          # zero-padded inputs (exact)
+            pad = nn.functional.pad
+            h, s, z = pad(h, (0, 64 - H)), pad(s, (0, 64 - H)), pad(z, (0, 32 - H // 2))
         B = h.shape[0]
         dev = h.device
         zero_obs = torch.zeros(B, 2, 2, device=dev)
@@ -448,20 +602,34 @@ class Discriminator(_Packed):
 
     def __init__(self, n_next, hidden_dim, n_latent_code, device=None):
         super().__init__()
-        if hidden_dim != 64 or n_latent_code != 2:
-            raise L.SocialWaysHipError("Discriminator kernels are built for hidden_dim=64, n_latent_code=2")
+        if n_latent_code != 2:
+            raise L.SocialWaysHipError("Discriminator kernels are built for n_latent_code=2")
+        _check_hidden(hidden_dim, "Discriminator")
         self.lstm_dim = hidden_dim
         self.n_next = n_next
-        self.obsv_encoder_lstm = nn.LSTM(4, hidden_dim, batch_first=True)
-        self.obsv_encoder_fc = nn.Sequential(nn.Linear(hidden_dim, hidden_dim // 2), nn.LeakyReLU(0.2),
-                                             nn.Linear(hidden_dim // 2, hidden_dim // 2))
-        self.pred_encoder = nn.Sequential(nn.Linear(n_next * 4, hidden_dim // 2), nn.LeakyReLU(0.2),
-                                          nn.Linear(hidden_dim // 2, hidden_dim // 2))
-        self.classifier = nn.Sequential(nn.Linear(hidden_dim, hidden_dim // 2), nn.LeakyReLU(0.2),
-                                        nn.Linear(hidden_dim // 2, 1))
-        self.latent_decoder = nn.Sequential(nn.Linear(hidden_dim, hidden_dim // 2), nn.LeakyReLU(0.2),
-                                            nn.Linear(self.lstm_dim // 2, n_latent_code))
+        H = hidden_dim
+
+        def make(d):
+            return [nn.LSTM(4, d, batch_first=True),
+                    nn.Sequential(nn.Linear(d, d // 2), nn.LeakyReLU(0.2), nn.Linear(d // 2, d // 2)),
+                    nn.Sequential(nn.Linear(n_next * 4, d // 2), nn.LeakyReLU(0.2), nn.Linear(d // 2, d // 2)),
+                    nn.Sequential(nn.Linear(d, d // 2), nn.LeakyReLU(0.2), nn.Linear(d // 2, 1)),
+                    nn.Sequential(nn.Linear(d, d // 2), nn.LeakyReLU(0.2), nn.Linear(d // 2, n_latent_code))]
+        true = make(H) if H < 64 else None
+        st = torch.get_rng_state()
+        (self.obsv_encoder_lstm, self.obsv_encoder_fc, self.pred_encoder, self.classifier, self.latent_decoder) = make(64)
+        if H < 64:
+            torch.set_rng_state(st)
         self._pack()
+        if H < 64:
+            Hh, K4, g = H // 2, 4 * n_next, _gate_rows(H)
+            both = torch.cat([_ar(Hh), _ar(Hh, 32)])      # cat[obsv_code, pred_code] inside the kernels' 32 | 32 columns
+            I = self._idx
+            self._adopt(true, [I(g, _ar(4), 4), I(g, _ar(H), 64), g, g,
+                               I(_ar(Hh), _ar(H), 64), _ar(Hh), I(_ar(Hh), _ar(Hh), 32), _ar(Hh),
+                               I(_ar(Hh), _ar(K4), K4), _ar(Hh), I(_ar(Hh), _ar(Hh), 32), _ar(Hh),
+                               I(_ar(Hh), both, 64), _ar(Hh), I(_ar(1), _ar(Hh), 32), _ar(1),
+                               I(_ar(Hh), both, 64), _ar(Hh), I(_ar(2), _ar(Hh), 32), _ar(2)])
         self._move(device)
 
     def _tp(self):
@@ -524,6 +692,7 @@ class Generator(nn.Module):
         self.attention = AttentionPooling(hidden_size, hidden_size)
         self.decoder = DecoderFC(hidden_size + hidden_size + hidden_size // 2)
         self.use_social = use_social            # train.py:83 hard-codes False; the flag is explicit here
+        self.hidden_size = hidden_size
         self.noise_len = hidden_size // 2
         if device is not None and torch.device(device).type != "cpu":
             self.to(device)                     # built on the CPU generator first, like train.py:370-375
@@ -562,7 +731,8 @@ class Generator(nn.Module):
         base = self._flat_all.data_ptr()
         for m in (self.attention, self.feature_embedder, self.encoder, self.decoder):
             moff = (m._flat.data_ptr() - base) // 4
-            out += [(moff + off, k, tuple(p.shape)) for (off, k), p in zip(m._slices, m.parameters())]
+            for i, ((off, k), p) in enumerate(zip(m._slices, m.parameters())):
+                out.append((moff + off, k, tuple(p.shape)) + (m._true[i] if m._true is not None else ()))
         return out
 
     def _apply(self, fn, *a, **k):
@@ -572,8 +742,10 @@ class Generator(nn.Module):
         return out
 
     def forward(self, obsv_p, noise, n_next, sub_batches=[]):
-        """predict(obsv_p (B,To,2), noise (B,32), n_next, sub_batches) -> pred_hat_4d (B,n_next,4)."""
+        """predict(obsv_p (B,To,2), noise (B, hidden_size / 2), n_next, sub_batches) -> pred_hat_4d (B,n_next,4)."""
         L.require_gpu(obsv_p)
+        if noise.shape[-1] < 32:     # smaller hidden size: zero-padded to the kernels' 32 noise columns (their weights are zero)
+            noise = nn.functional.pad(noise, (0, 32 - noise.shape[-1]))
         scenes = _scene_index(sub_batches, obsv_p.shape[0], obsv_p.device)
         params = list(self.predictor_params())
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):

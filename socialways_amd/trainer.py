@@ -92,10 +92,19 @@ class PackedAdam:
         g["params"] = list(range(len(self.slices)))
         state = {}
         if self.t > 0:
-            for i, (off, n, shape) in enumerate(self.slices):
-                state[i] = {"step": torch.tensor(float(self.t)), "exp_avg": self.m[off:off + n].view(shape).clone(),
-                            "exp_avg_sq": self.v[off:off + n].view(shape).clone()}
+            for i, sl in enumerate(self.slices):
+                off, n, shape = sl[:3]
+                pick = lambda buf: self._true(buf[off:off + n], sl).clone()
+                state[i] = {"step": torch.tensor(float(self.t)), "exp_avg": pick(self.m), "exp_avg_sq": pick(self.v)}
         return {"state": state, "param_groups": [g]}
+
+    @staticmethod
+    def _true(flat_slice, sl):
+        """A parameter's slice of a packed buffer in the reference's shape: (offset, numel, kernel shape) alone, or
+        followed by (true shape, index of the true entries) for zero-padded hidden sizes (model._Packed._true)."""
+        if len(sl) == 3:
+            return flat_slice.view(sl[2])
+        return flat_slice[sl[4].to(flat_slice.device)].view(sl[3])
 
     def load_state_dict(self, sd):
         grp = sd["param_groups"][0]
@@ -106,21 +115,30 @@ class PackedAdam:
         self.m.zero_()
         self.v.zero_()
         self.t = 0
-        for i, (off, n, shape) in enumerate(self.slices):
+        for i, sl in enumerate(self.slices):
+            off, n = sl[0], sl[1]
             # torch Adam keeps state only for parameters that ever received a gradient: the unmodified reference
             # runs with use_social=False (train.py:83), so its checkpoints hold no entries for the attention /
             # feature-embedder parameters (optimizer indices 0..7).  Their moments stay zero here.
             e = state.get(i, state.get(str(i)))
             if e is None:
                 continue
-            self.m[off:off + n] = e["exp_avg"].to(self.flat.device).reshape(-1)
-            self.v[off:off + n] = e["exp_avg_sq"].to(self.flat.device).reshape(-1)
+            for buf, key in ((self.m, "exp_avg"), (self.v, "exp_avg_sq")):
+                val = e[key].to(self.flat.device).reshape(-1)
+                if len(sl) == 3:
+                    buf[off:off + n] = val
+                else:                              # zero-padded hidden size: the true entries into their padded places
+                    buf[off:off + n].index_copy_(0, sl[4].to(self.flat.device), val)
             self.t = max(self.t, int(float(e["step"])))       # one shared counter: every present entry was stepped together
         self.step_t.fill_(float(self.t))
 
 
 class SocialWaysTrainer:
     STEPS_PER_LAUNCH = 4    # train_epoch: consecutive packed batches of one scene layout per graph launch (step_many)
+    Z_COLS = 32             # noise columns of the kernels (hidden size 64: train.py:81); smaller models are zero-padded
+
+    def _pad_z(self, z):
+        return z if z.shape[-1] == self.Z_COLS else torch.nn.functional.pad(z, (0, self.Z_COLS - z.shape[-1]))
 
     def __init__(self, n_next, hidden_size=64, lr_g=1e-4, lr_d=1e-3, n_unrolling_steps=1, use_social=True,
                  use_info_loss=True, loss_info_w=0.5, n_latent_codes=2, device="cuda", process_group=None,
@@ -169,8 +187,8 @@ class SocialWaysTrainer:
         self.D = Discriminator(n_next, hidden_size, n_latent_codes, device=self.device)
         if packed:
             self.D_optimizer = PackedAdam(self.D._flat, self.D._gflat,
-                                          [(off, k, tuple(p.shape)) for (off, k), p in
-                                           zip(self.D._slices, self.D.parameters())], lr_d)
+                                          [(off, k, tuple(p.shape)) + (self.D._true[i] if self.D._true is not None else ())
+                                           for i, ((off, k), p) in enumerate(zip(self.D._slices, self.D.parameters()))], lr_d)
         else:
             self.D_optimizer = opt.Adam(self.D.parameters(), lr=lr_d, betas=(0.9, 0.999))
         self.pg = process_group
@@ -340,7 +358,7 @@ class SocialWaysTrainer:
             vn = variety_noise if variety_noise is not None else torch.rand((self.variety_k - 1) * B, self.noise_len)
             if vn.shape != ((self.variety_k - 1) * B, self.noise_len):
                 raise ValueError("variety_noise must be ((variety_k - 1) * B, %d)" % self.noise_len)
-            self._vnoise = vn.to(dev, non_blocking=True).contiguous()
+            self._vnoise = self._pad_z(vn.to(dev, non_blocking=True)).contiguous()
         part = None
         if self.use_graph and self.use_variety_loss != "fixed":    # the folded K-sample step runs eagerly
             # one graph set per packed-batch layout; datasets with ragged scenes produce many layouts, so the
@@ -352,7 +370,7 @@ class SocialWaysTrainer:
         if part is None:
             part = torch.zeros(self.n_unrolling_steps + 3, (B + 7) // 8, 3, device=dev)     # one triple per (8- or 16-agent) tile
             scenes = ops.SceneIndex.get(sub_batches, B, dev)
-            noise = noise.to(dev, non_blocking=True).contiguous()
+            noise = self._pad_z(noise.to(dev, non_blocking=True)).contiguous()
             # label-noise scalars of train.py:471-472 live in device memory: [zeros_val, ones_val]
             targets = torch.tensor([float(zeros_val), float(ones_val)], dtype=torch.float32).to(dev, non_blocking=True)
             self._step_impl(obsv.contiguous(), pred.contiguous(), None, scenes, targets, noise, float(ss), Bg, part)
@@ -391,10 +409,10 @@ class SocialWaysTrainer:
             st = self._graphs[key] = dict(
                 n=0, graph=None, flip=0, scenes=scenes, obsv=torch.empty(B, To, 2, device=dev),
                 pred=torch.empty(B, Tp, 2, device=dev), pred4=torch.empty(B, Tp, 4, device=dev),
-                targets=torch.empty(4, device=dev), noise=torch.empty(B, self.noise_len, device=dev),
+                targets=torch.empty(4, device=dev), noise=torch.zeros(B, self.Z_COLS, device=dev),
                 steps=torch.zeros(self.n_unrolling_steps + 2, device=dev),   # Adam step indices of the U+1 D updates, the G update
                 outs=[torch.zeros(self.n_unrolling_steps + 3, (B + 7) // 8, 3, device=dev) for _ in range(K)],
-                slots=[[torch.zeros(HDR + B * self.noise_len, dtype=torch.float32).pin_memory() for _ in range(K)]
+                slots=[[torch.zeros(HDR + B * self.Z_COLS, dtype=torch.float32).pin_memory() for _ in range(K)]
                        for _ in range(2)],
                 done=[torch.cuda.Event(), torch.cuda.Event()], keep=[None, None])
         # Inputs of a step travel through a pinned host slot that the step's first graph node (sw_stage_step)
@@ -415,7 +433,8 @@ class SocialWaysTrainer:
                 hn[6], hn[7] = float(self.D_optimizer.t), float(self.predictor_optimizer.t)
                 self.D_optimizer.t += self.n_unrolling_steps + 1
                 self.predictor_optimizer.t += 1
-            np.copyto(hn[HDR:].reshape(B, self.noise_len), (noise.cpu() if noise.is_cuda else noise).numpy())   # plain memcpy
+            # (a hidden size below 64 draws fewer z columns: the kernels' remaining columns stay zero, like their weights)
+            np.copyto(hn[HDR:].reshape(B, self.Z_COLS)[:, :self.noise_len], (noise.cpu() if noise.is_cuda else noise).numpy())
         st["keep"][k] = keep
 
         def stage(kk, j):

@@ -380,3 +380,68 @@ def test_graphs_survive_workspace_growth():
             assert tr._graphs and not tr.ws.retired
     assert all(torch.equal(a, b) for a, b in zip(res[0][0], res[1][0]))
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize("H", [32, 16, 48])
+def test_smaller_hidden_sizes_run_zero_padded_and_match_the_oracle(H, tmp_path):
+    """`--hidden-size` below the default 64 (train.py:42-44, 76-81): the network runs on the same kernels with its
+    weights zero-padded to 64 hidden units - exactly, a padded unit never leaves 0.  Same initial weights as the
+    reference would draw (construction order and RNG stream), the checkpoint in the reference's shapes, two whole GAN
+    steps against the oracle built with that hidden size (9 MSE terms, rollout, ADE/FDE, the gradients of the second
+    step in the reference's shapes), the padding still exactly zero afterwards, and a resume from the saved file."""
+    import socialways_amd as sw
+    torch.manual_seed(7)
+    tr = sw.SocialWaysTrainer(12, hidden_size=H, use_social=True, device="cuda:0")
+    torch.manual_seed(7)
+    orc = O.SocialWaysOracle(12, hidden_size=H, use_social=True)
+    ck = tr.checkpoint()
+    for name, mod in (("encoder_dict", orc.encoder), ("decoder_dict", orc.decoder), ("feature_embedder_dict", orc.feature_embedder),
+                      ("attentioner_dict", orc.attention), ("D_dict", orc.D)):
+        for k, v in mod.state_dict().items():      # identical initialisation, reference shapes
+            assert tuple(ck[name][k].shape) == tuple(v.shape) and torch.equal(ck[name][k].cpu(), v), (name, k)
+    t = sw.synth_tracks(8, [5, 1, 9, 16, 3, 2, 2, 2], 8, 12, seed=5)
+    data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
+    B, sb = 36, data.the_batches[:6]
+    gen = torch.Generator().manual_seed(2)
+    for it in range(2):
+        noise = torch.rand(B, H // 2, generator=gen)
+        rec = {}
+        out = tr.step(data.obsv[:B], data.pred[:B], sb, 0.03, 0.94, noise, data.ss)
+        got = tr.losses_from(out, [B], 12, data.ss)[0]
+        want, ade, fde = orc.train_step(data.obsv[:B].cpu(), data.pred[:B].cpu(), sb, 0.03, 0.94, noise, data.ss, record=rec)
+        assert_close(got, np.asarray(want), 1e-4 if it else 5e-5, 3e-6, "9 MSE terms, step %d" % it)
+        o = out.double().cpu().numpy()
+        assert abs(o[-1, 0] - ade) / ade < 2e-5 and abs(o[-1, 1] - fde) / fde < 2e-5
+        assert_close(tr.last_pred_hat.cpu(), rec["pred_hat_4d"], 1e-4, 1e-5, "rollout, step %d" % it)
+        if it == 0:      # same-weight gradients of the first step, in the reference's shapes
+            for name in ("attention", "feature_embedder", "encoder", "decoder"):
+                mod = getattr(tr.G, name)
+                for i, (k, p) in enumerate(mod.named_parameters()):
+                    w = rec["g_grads"][name + "." + k]
+                    g = mod.true_view(i, p.grad)
+                    assert_close(g.cpu(), w, 2e-4, 2e-4 * max(float(w.abs().max()), 1e-12), "dG %s.%s" % (name, k))
+    for mod in (tr.G.encoder, tr.G.decoder, tr.G.feature_embedder, tr.G.attention, tr.D):
+        assert float((mod._flat * (1 - mod.pad_mask())).abs().max()) == 0.0, "zero padding stayed exactly zero: %s" % type(mod).__name__
+    # checkpoint in the reference's shapes (incl. both Adam dicts), resume in a fresh trainer: same next step
+    path = tmp_path / "h.pt"
+    tr.save(str(path), epoch=3)
+    ck = torch.load(str(path))
+    for k, v in orc.decoder.state_dict().items():
+        assert tuple(ck["decoder_dict"][k].shape) == tuple(v.shape)
+    assert tuple(ck["pred_optimizer"]["state"][0]["exp_avg"].shape) == (H, H)          # attention W, reference shape
+    assert tuple(ck["pred_optimizer"]["state"][6]["exp_avg_sq"].shape) == (H, 64)      # feature_embedder fc.4.weight
+    assert tuple(ck["D_optimizer"]["state"][1]["exp_avg"].shape) == (4 * H, H)         # D's LSTM weight_hh
+    tr2 = sw.SocialWaysTrainer(12, hidden_size=H, use_social=True, device="cuda:0")
+    assert tr2.load_checkpoint(str(path)) == 4
+    noise = torch.rand(B, H // 2, generator=gen)
+    a = tr.step(data.obsv[:B], data.pred[:B], sb, 0.05, 0.9, noise, data.ss)
+    b = tr2.step(data.obsv[:B], data.pred[:B], sb, 0.05, 0.9, noise, data.ss)
+    assert torch.equal(a, b) and torch.equal(tr.G._flat_all, tr2.G._flat_all) and torch.equal(tr.D._flat, tr2.D._flat)
+
+
+def test_hidden_sizes_above_64_are_refused():
+    import socialways_amd as sw
+    with pytest.raises(sw.SocialWaysHipError):
+        sw.SocialWaysTrainer(12, hidden_size=128, device="cuda:0")
+    with pytest.raises(sw.SocialWaysHipError):
+        sw.EncoderLstm(20, 1)

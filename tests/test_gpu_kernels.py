@@ -360,3 +360,36 @@ def test_standalone_encoder_and_decoder_are_differentiable():
     for name, a, b in zip(("h", "s", "z"), outs[0][1:], outs[1][1:]):
         _grad_close(a, b, "decoder d/d" + name)
     _check_param_grads(dec, odec, "decoder")
+
+
+def test_standalone_modules_at_a_smaller_hidden_size():
+    """The module API at `--hidden-size 32` (zero-padded onto the 64-unit kernels): true-shaped inputs / outputs / state
+    dicts, forward and autograd of the four sub-modules against the oracle modules built with that size."""
+    import socialways_amd as sw
+    dev = torch.device("cuda:0")
+    H, B, T = 32, 21, 5
+    torch.manual_seed(2)
+    sb = np.array([[0, 6], [6, 7], [7, 21]])
+    fe, att = sw.EmbedSocialFeatures(3, H, device=dev), sw.AttentionPooling(H, H, device=dev)
+    enc, dec = sw.EncoderLstm(H, 1, device=dev), sw.DecoderFC(H + H + H // 2, device=dev)
+    ofe, oatt = _pair(fe, O.EmbedSocialFeatures(3, H)), _pair(att, O.AttentionPooling(H, H))
+    oenc, odec = _pair(enc, O.EncoderLstm(H, 1)), _pair(dec, O.DecoderFC(H + H + H // 2))
+    feats, h, x = torch.rand(B, B, 3), torch.randn(B, H) * 0.5, torch.randn(B, T, 4) * 0.5
+    z, wS, wy, wv = torch.rand(B, H // 2), torch.randn(B, H), torch.randn(B, T, H), torch.randn(B, 2)
+    res = []
+    for fe_, att_, enc_, dec_, d in ((fe, att, enc, dec, dev), (ofe, oatt, oenc, odec, torch.device("cpu"))):
+        xs, hs = x.to(d).requires_grad_(), h.to(d).requires_grad_()
+        enc_.init_lstm(torch.zeros(1, B, H, device=d), torch.zeros(1, B, H, device=d))
+        y = enc_(xs)
+        assert tuple(y.shape) == (B, T, H) and tuple(enc_.lstm_h[0].shape) == (1, B, H)
+        S = att_(fe_(feats.to(d), sb), hs, sb)
+        v = dec_(enc_.lstm_h[0].view(B, H), S, z.to(d))
+        ((y * wy.to(d)).sum() + (S * wS.to(d)).sum() + (v * wv.to(d)).sum()).backward()
+        res.append((y, S, v, xs.grad, hs.grad))
+    for name, a, b in zip(("y", "S", "v"), res[0][:3], res[1][:3]):
+        assert_close(a.detach().cpu(), b.detach(), 2e-5, 2e-6, name)
+    _grad_close(res[0][3], res[1][3], "d/dx")
+    _grad_close(res[0][4], res[1][4], "d/dh")
+    for m, o, nm in ((fe, ofe, "feature_embedder"), (att, oatt, "attention"), (enc, oenc, "encoder"), (dec, odec, "decoder")):
+        for i, ((k, p), (_, q)) in enumerate(zip(m.named_parameters(), o.named_parameters())):
+            _grad_close(m.true_view(i, p.grad), q.grad, "%s d/d%s" % (nm, k))

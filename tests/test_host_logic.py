@@ -130,3 +130,49 @@ def test_scene_index_small_and_large_scenes():
         SceneIndex(np.array([[0, 3], [4, 6]]), 6, "cpu")                     # must tile [0, B)
     one = SceneIndex([], 9, "cpu")                                           # predict() default: one scene
     assert one.S == 1 and one.amax == 9 and one.NB == 0
+
+
+@pytest.mark.parametrize("H", [16, 32, 48])
+def test_smaller_hidden_sizes_are_zero_padded_with_the_reference_initialisation(H):
+    """`--hidden-size` below 64 (train.py:42-44): modules keep kernel-shaped (padded) parameters; the initial weights are
+    the ones the reference draws (same construction order, same RNG stream), state_dict() / load_state_dict() speak the
+    reference's shapes, the padding is exactly zero, and sizes the kernels cannot hold are refused."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import sw_oracle as O
+    import socialways_amd as sw
+    torch.manual_seed(1)
+    G, D = sw.Generator(H, 1, use_social=True), sw.Discriminator(12, H, 2)
+    after = torch.get_rng_state()
+    torch.manual_seed(1)
+    ref = [O.EncoderLstm(H, 1), O.EmbedSocialFeatures(3, H), O.AttentionPooling(H, H), O.DecoderFC(H + H + H // 2),
+           O.Discriminator(12, H, 2)]
+    assert torch.equal(after, torch.get_rng_state()), "the generator is left where the reference's construction leaves it"
+    for m, o in zip((G.encoder, G.feature_embedder, G.attention, G.decoder, D), ref):
+        sd = m.state_dict()
+        for k, v in o.state_dict().items():
+            assert tuple(sd[k].shape) == tuple(v.shape) and torch.equal(sd[k], v), (type(m).__name__, k)
+        for p in o.parameters():
+            p.data.mul_(1.5)
+        m.load_state_dict(o.state_dict())
+        assert all(torch.equal(m.state_dict()[k], v) for k, v in o.state_dict().items())
+        assert float((m._flat * (1 - m.pad_mask())).abs().max()) == 0.0
+        assert int(m.pad_mask().sum()) == sum(p.numel() for p in o.parameters())
+    # optimizer state in the reference's shapes
+    G.unify()
+    slices = G.packed_slices()
+    opt = PackedAdam(G._flat_all, G._gflat_all, slices, 1e-4)
+    G._gflat_all.normal_()
+    opt.step()
+    sd = opt.state_dict()
+    order = [p for m in (ref[2], ref[1], ref[0], ref[3]) for p in m.parameters()]      # attention, embedder, encoder, decoder
+    assert [tuple(sd["state"][i]["exp_avg"].shape) for i in range(len(order))] == [tuple(p.shape) for p in order]
+    opt2 = PackedAdam(torch.zeros_like(G._flat_all), torch.zeros_like(G._gflat_all), slices, 1e-4)
+    opt2.load_state_dict(sd)
+    mask = torch.cat([torch.nn.functional.pad(m.pad_mask(), (0, (-m.pad_mask().numel()) % 4))
+                      for m in (G.attention, G.feature_embedder, G.encoder, G.decoder)])
+    assert torch.equal(opt2.m, opt.m * mask) and torch.equal(opt2.v, opt.v * mask)
+    for bad in (128, 20, 0):
+        with pytest.raises(sw.SocialWaysHipError):
+            sw.EncoderLstm(bad, 1)
