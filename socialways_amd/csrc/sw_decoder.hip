@@ -198,10 +198,17 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
   // recovered from dv^T [a2 | 1], sw_misc.hip).  W43 and the composed LSTM input matrix come from the image buffer of
   // this step when one is registered (swimg: straight into operand registers), else they are derived here through LDS
   // with the very same arithmetic.
-  f32x4 w43[5], b43i = {0.f, 0.f, 0.f, 0.f};   // A operand: rows 0, 1 live, the other 14 rows of the tile zero; bias in C layout
+  // fc4 . fc3 is 2 x 80: on the matrix cores it is 20 MFMAs per wave with 2 live rows of 16; on the VALU the lane that
+  // holds a2[agent][16 j + 4 lg + r] (its B operand of a matrix product) multiplies it with the two weights of that
+  // column - 40 FMAs - and the four lane groups of an agent meet in two shuffles: ~400 cycles per decode step less
+  f32x4 w43[2][5];      // [output c][j] = W43[c][16 j + 4 lg .. + 3]
+  float b43i[2] = {0.f, 0.f};
   if (gimg) {
 #pragma unroll
-    for (int j = 0; j < 5; ++j) w43[j] = ld4(gimg + swimg::W43 + (ln & 1) * 80 + 16 * j + 4 * lg);
+    for (int j = 0; j < 5; ++j) {
+      w43[0][j] = ld4(gimg + swimg::W43 + 16 * j + 4 * lg);
+      w43[1][j] = ld4(gimg + swimg::W43 + 80 + 16 * j + 4 * lg);
+    }
     b43i[0] = gimg[swimg::W43 + 160];
     b43i[1] = gimg[swimg::W43 + 161];
   } else {
@@ -243,14 +250,13 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
   if (!gimg) {
     lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
 #pragma unroll
-    for (int j = 0; j < 5; ++j) w43[j] = ld4(w43_lds + (ln & 1) * 80 + 16 * j + 4 * lg);
+    for (int j = 0; j < 5; ++j) {
+      w43[0][j] = ld4(w43_lds + 16 * j + 4 * lg);
+      w43[1][j] = ld4(w43_lds + 80 + 16 * j + 4 * lg);
+    }
     b43i[0] = w43_lds[160];
     b43i[1] = w43_lds[161];
   }
-#pragma unroll
-  for (int j = 0; j < 5; ++j)
-    if (ln >= 2) w43[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (lg != 0) b43i[0] = b43i[1] = 0.f;
   // u = W1[:, 64:160] [S; z] + b1 is constant over the steps (train.py:411,421): it is the initial accumulator of
   // this wave's layer-1 tiles (K-half 0 carries it for the split tiles)
   {
@@ -360,17 +366,25 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
         for (int r = 0; r < 4; ++r) b2v[4][r] = sw_lrelu(s[r]);
       }
       if (gsave && live && wave == 1) st4(gsave + gs.a2 + ((size_t)i * B + b) * 80 + 64 + 4 * lg, b2v[4]);
-      f32x4 acc = b43i, acc1 = {0.f, 0.f, 0.f, 0.f};
+      float vx0 = 0.f, vx1 = 0.f, vy0 = 0.f, vy1 = 0.f;      // this lane's 20 columns, two chains per output
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
-        acc = SW_MFMA(w43[j][0], b2v[j][0], acc);
-        acc1 = SW_MFMA(w43[j][1], b2v[j][1], acc1);
-        acc = SW_MFMA(w43[j][2], b2v[j][2], acc);
-        acc1 = SW_MFMA(w43[j][3], b2v[j][3], acc1);
+        vx0 = fmaf(w43[0][j][0], b2v[j][0], vx0);
+        vx1 = fmaf(w43[0][j][1], b2v[j][1], vx1);
+        vx0 = fmaf(w43[0][j][2], b2v[j][2], vx0);
+        vx1 = fmaf(w43[0][j][3], b2v[j][3], vx1);
+        vy0 = fmaf(w43[1][j][0], b2v[j][0], vy0);
+        vy1 = fmaf(w43[1][j][1], b2v[j][1], vy1);
+        vy0 = fmaf(w43[1][j][2], b2v[j][2], vy0);
+        vy1 = fmaf(w43[1][j][3], b2v[j][3], vy1);
       }
-      acc = acc + acc1;
-      // rows 0,1 (= v_x, v_y of agent ln) sit in the lg == 0 lanes; every lane fetches its agent's pair
-      float vx = __shfl(acc[0], ln), vy = __shfl(acc[1], ln);
+      float vx = vx0 + vx1, vy = vy0 + vy1;
+      vx += __shfl_xor(vx, 16);      // the four lane groups (k quarters) of agent ln: every lane ends with the sum
+      vy += __shfl_xor(vy, 16);
+      vx += __shfl_xor(vx, 32);
+      vy += __shfl_xor(vy, 32);
+      vx += b43i[0];
+      vy += b43i[1];
       px += vx;
       py += vy;
       SW_STAMP(11);
@@ -492,7 +506,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
 #endif
   LstmWT WT;
   f32x4 wxT[4], w2t[2][5], w2p[3], w1t[10];
-  float w43t[2][2];
+  f32x4 w43c[2][2];     // (fc4 . fc3) columns of this wave's two dz2 tiles in C layout: [tile][c][r] = W43[c][m0 + 4 lg + r]
   if (gimg) {
     auto op = [&](int base, int KJ, int tile, int j) { return ld4(gimg + base + (((size_t)tile * KJ + j) * 64 + lane) * 4); };
 #pragma unroll
@@ -513,8 +527,8 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
       for (int r = 0; r < 4; ++r) wxT[j][r] = gimg[swimg::WX + (64 * wave + 16 * j + 4 * lg + r) * 4 + (ln & 3)];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      w43t[q][0] = gimg[swimg::W43 + m2q[q] + ln];
-      w43t[q][1] = gimg[swimg::W43 + 80 + m2q[q] + ln];
+      w43c[q][0] = ld4(gimg + swimg::W43 + m2q[q] + 4 * lg);
+      w43c[q][1] = ld4(gimg + swimg::W43 + 80 + m2q[q] + 4 * lg);
     }
   } else {
     // no image buffer registered (stand-alone module calls): strided loads from the weights themselves, the composed
@@ -562,8 +576,8 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
       for (int r = 0; r < 4; ++r) wxT[j][r] = wx_lds[(64 * wave + 16 * j + 4 * lg + r) * 4 + (ln & 3)];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      w43t[q][0] = w43_lds[m2q[q] + ln];
-      w43t[q][1] = w43_lds[80 + m2q[q] + ln];
+      w43c[q][0] = ld4(w43_lds + m2q[q] + 4 * lg);
+      w43c[q][1] = ld4(w43_lds + 80 + m2q[q] + 4 * lg);
     }
   }
 #pragma unroll
@@ -571,9 +585,6 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (ln >= 4) wxT[j][r] = 0.f;
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-    if (lg != 0) w43t[q][0] = w43t[q][1] = 0.f;
   sw_barrier();   // the prologue aliases of dgbuf are dead
   SW_STAMP(5);
   SW_STAMP(6);
@@ -658,13 +669,13 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
       f32x4 o = {dvx, dvy, 0.f, 0.f};
       st4(gdelta + gd.dv + ((size_t)i * B + b) * 4, o);
     }
-    // dz2 = (W43^T dv) * lrelu'(a2)   (80): fc3 and fc4 are one linear map, so d(a2) comes straight from dv
-    // (2 MFMAs per tile, k = 4 lg + r with only k = 0, 1 live, both operands straight from registers)
+    // dz2 = (W43^T dv) * lrelu'(a2)   (80): fc3 and fc4 are one linear map, so d(a2) comes straight from dv - a rank-2
+    // product: two FMAs per element on the VALU (every lane knows its agent's dv)
 #pragma unroll
     for (int q2 = 0; q2 < 2; ++q2) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      acc = SW_MFMA(w43t[q2][0], lg == 0 ? dvx : 0.f, acc);
-      acc = SW_MFMA(w43t[q2][1], lg == 0 ? dvy : 0.f, acc);
+      f32x4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = fmaf(w43c[q2][0][r], dvx, w43c[q2][1][r] * dvy);
       const f32x4 a2 = R.a2[q2];
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(a2[r], acc[r]);
