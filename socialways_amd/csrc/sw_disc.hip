@@ -194,6 +194,22 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_fwd_kernel(
   // its transposed weight images and delta buffers follow the forward carve in LDS, the activations never leave LDS
   const HeadLdsB LB = head_lds_b(Tp, L.total);
   SW_STAMP_INIT;
+  // The prediction rows of this workgroup's branches (inputs of the pred_encoder heads) are requested NOW: staged
+  // where the heads start they cost one global round trip per branch behind the observation LSTM.  Unconditional loads
+  // from clamped addresses (4 per thread and branch cover the [16][4 Tp + pad] tile up to Tp = 12; longer horizons
+  // load in place).
+  const bool x_pre = 16 * L.ldp <= 4 * SW_THREADS;
+  float xpre[2][4];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const float* pk = (k_lo + kk == 0 || nb == 1) ? pred_a : pred_b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = min((int)threadIdx.x + SW_THREADS * e, 16 * L.ldp - 1);
+      const int a = i / L.ldp, cc = i - a * L.ldp;
+      xpre[kk][e] = pk[(size_t)min(a0 + a, B - 1) * K4 + min(cc, K4 - 1)];
+    }
+  }
   if (fuse) stage_zero(smem + LB.of0T, LB.dc1 - LB.of0T);   // transposed images (zero padded) + dlab, dcod
   const bool obs_pre = save_lstm == 2;   // LSTM rows already in dsave (sw_dec_rollout_fwd_aux ran the observation LSTM)
   LstmW W;
@@ -304,12 +320,26 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_fwd_kernel(
     float* label = k == 0 ? label_a : label_b;
     float* code = k == 0 ? code_a : code_b;
     sw_barrier();
-    for (int i = threadIdx.x; i < 16 * L.ldp; i += blockDim.x) {
-      int a = i / L.ldp, cc = i - a * L.ldp;
-      int bb = min(a0 + a, B - 1);
-      float v = cc < K4 ? pred[(size_t)bb * K4 + cc] : 0.f;
-      smem[L.x + i] = v;
-      if (dsave && cc < K4 && a0 + a < B) dsave[ds.px + ((size_t)k * B + bb) * K4 + cc] = v;
+    if (x_pre) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = threadIdx.x + SW_THREADS * e;
+        if (i < 16 * L.ldp) {
+          const int a = i / L.ldp, cc = i - a * L.ldp;
+          const int bb = min(a0 + a, B - 1);
+          const float v = cc < K4 ? (k == k_lo ? xpre[0][e] : xpre[1][e]) : 0.f;
+          smem[L.x + i] = v;
+          if (dsave && cc < K4 && a0 + a < B) dsave[ds.px + ((size_t)k * B + bb) * K4 + cc] = v;
+        }
+      }
+    } else {
+      for (int i = threadIdx.x; i < 16 * L.ldp; i += blockDim.x) {
+        int a = i / L.ldp, cc = i - a * L.ldp;
+        int bb = min(a0 + a, B - 1);
+        float v = cc < K4 ? pred[(size_t)bb * K4 + cc] : 0.f;
+        smem[L.x + i] = v;
+        if (dsave && cc < K4 && a0 + a < B) dsave[ds.px + ((size_t)k * B + bb) * K4 + cc] = v;
+      }
     }
     sw_barrier();
     // q1 = lrelu(pe0 x + b)   (waves 0,1)
