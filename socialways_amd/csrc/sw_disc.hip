@@ -210,6 +210,9 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_fwd_kernel(
       xpre[kk][e] = pk[(size_t)min(a0 + a, B - 1) * K4 + min(cc, K4 - 1)];
     }
   }
+  // (generator phase) the label target and the agent's latent code for the loss gradients formed behind the heads
+  const float* ztop = fuse ? gl.z + (size_t)b * SW_Z : d_w;
+  const float ftg = (fuse ? gl.targets + gl.t0 : d_w)[0], fz0 = ztop[0], fz1 = ztop[1];
   if (fuse) stage_zero(smem + LB.of0T, LB.dc1 - LB.of0T);   // transposed images (zero padded) + dlab, dcod
   const bool obs_pre = save_lstm == 2;   // LSTM rows already in dsave (sw_dec_rollout_fwd_aux ran the observation LSTM)
   LstmW W;
@@ -389,11 +392,11 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_fwd_kernel(
         float sl = 0.f;
         if (lg == 0) {
           if (cls) {
-            const float e = acc[0] - gl.targets[gl.t0];
+            const float e = acc[0] - ftg;
             smem[LB.dlab + ln * LD16] = 2.0f * e * gl.g_label;
             sl = live ? e * e : 0.f;
           } else {
-            const float c0 = acc[0] - gl.z[(size_t)b * SW_Z], c1 = acc[1] - gl.z[(size_t)b * SW_Z + 1];
+            const float c0 = acc[0] - fz0, c1 = acc[1] - fz1;
             smem[LB.dcod + ln * LD16] = 2.0f * c0 * gl.g_code;
             smem[LB.dcod + ln * LD16 + 1] = 2.0f * c1 * gl.g_code;
             sl = live ? c0 * c0 + c1 * c1 : 0.f;
@@ -490,6 +493,36 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
     pq1[k] = ld4(dsave + ds.q1 + kb * 32 + m0h + 4 * lg);
   }
   po1 = ld4(dsave + ds.o1 + (size_t)b * 32 + m0h + 4 * lg);
+  // ... and the inputs of the loss gradients (forward outputs label / code_hat, z, the label targets): requested here,
+  // not where the head backward starts (a global round trip of its own behind the staging barrier).  Element e of the
+  // [16][LD16] delta tiles this thread fills, plus the per-agent values of the reported sums; unconditional loads.
+  float hl[2][2], hc[2][2], hz[2], htg[2], rl[2], rc[2], rz[2];
+  {
+    const float* zsrc = gl.on ? gl.z : dsave;            // no GAN mode: any readable address, the value is unused
+    const float* tsrc = gl.on ? gl.targets : dsave;
+    htg[0] = tsrc[gl.on ? gl.t0 : 0];
+    htg[1] = tsrc[gl.on ? gl.t1 : 0];
+    const float* dl1 = nb > 1 ? dlabel_b : dlabel_a;
+    const float* dc1p = nb > 1 ? dcode_b : dcode_a;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int i = min((int)threadIdx.x + SW_THREADS * e, 16 * LD16 - 1);
+      const int a = i / LD16, c1 = min(i - a * LD16, 1);
+      const int bb = min(a0 + a, B - 1);
+      hl[e][0] = dlabel_a[bb];
+      hl[e][1] = dl1[bb];
+      hc[e][0] = dcode_a[(size_t)bb * 2 + c1];
+      hc[e][1] = dc1p[(size_t)bb * 2 + c1];
+      hz[e] = zsrc[(size_t)bb * SW_Z + c1];
+    }
+    const int bb = min(a0 + ln, B - 1);
+    rl[0] = dlabel_a[bb];
+    rl[1] = dl1[bb];
+    rc[0] = dcode_a[(size_t)bb * 2];
+    rc[1] = dcode_a[(size_t)bb * 2 + 1];
+    rz[0] = zsrc[(size_t)bb * SW_Z];
+    rz[1] = zsrc[(size_t)bb * SW_Z + 1];
+  }
   // transposed weight images: all global loads are issued before the zero fill and its barrier
   f32x4 t_of0[2], t_of1[1], t_pe0[2], t_pe1[1], t_cl0[2], t_la0[2], t_cl1[1], t_la1[1];
   const bool pe0_small = 8 * K4 <= 2 * SW_THREADS;
@@ -515,37 +548,39 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
   for (int i = threadIdx.x; i < 16 * LD32; i += blockDim.x) smem[L.docode + i] = 0.f;
 
   for (int k = 0; k < nb; ++k) {
-    const float* dlabel = k == 0 ? dlabel_a : dlabel_b;
-    const float* dcode = k == 0 ? dcode_a : dcode_b;
     float* dpred = k == 0 ? dpred_a : dpred_b;
     sw_barrier();
     if (k == 0) SW_STAMP(8);
-    for (int i = threadIdx.x; i < 16 * LD16; i += blockDim.x) {
-      int a = i / LD16, cc = i - a * LD16;
-      int bb = min(a0 + a, B - 1);
-      float vl, vc;
-      if (gl.on) {  // LSGAN / InfoGAN loss gradients formed here from the forward outputs (train.py:484-494, 512-523)
-        const float tgt = gl.targets[k == 0 ? gl.t0 : gl.t1];
-        vl = cc == 0 ? 2.0f * (dlabel[bb] - tgt) * gl.g_label : 0.f;
-        vc = (k == 0 && cc < 2) ? 2.0f * (dcode[(size_t)bb * 2 + cc] - gl.z[(size_t)bb * SW_Z + cc]) * gl.g_code : 0.f;
-      } else {
-        vl = cc == 0 ? dlabel[bb] : 0.f;
-        vc = cc < 2 ? dcode[(size_t)bb * 2 + cc] : 0.f;
-      }
-      smem[L.dlab + i] = vl;
-      smem[L.dcod + i] = vc;
-      if (want_w && a0 + a < B && cc < 4) {
-        ddelta[dd.dlab + ((size_t)k * B + bb) * 4 + cc] = vl;
-        ddelta[dd.dcod + ((size_t)k * B + bb) * 4 + cc] = vc;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int i = threadIdx.x + SW_THREADS * e;
+      if (i < 16 * LD16) {
+        const int a = i / LD16, cc = i - a * LD16;
+        const int bb = min(a0 + a, B - 1);
+        const float xl = k == 0 ? hl[e][0] : hl[e][1], xc = k == 0 ? hc[e][0] : hc[e][1];
+        float vl, vc;
+        if (gl.on) {  // LSGAN / InfoGAN loss gradients formed here from the forward outputs (train.py:484-494, 512-523)
+          const float tgt = k == 0 ? htg[0] : htg[1];
+          vl = cc == 0 ? 2.0f * (xl - tgt) * gl.g_label : 0.f;
+          vc = (k == 0 && cc < 2) ? 2.0f * (xc - hz[e]) * gl.g_code : 0.f;
+        } else {
+          vl = cc == 0 ? xl : 0.f;
+          vc = cc < 2 ? xc : 0.f;
+        }
+        smem[L.dlab + i] = vl;
+        smem[L.dcod + i] = vc;
+        if (want_w && a0 + a < B && cc < 4) {
+          ddelta[dd.dlab + ((size_t)k * B + bb) * 4 + cc] = vl;
+          ddelta[dd.dcod + ((size_t)k * B + bb) * 4 + cc] = vc;
+        }
       }
     }
     if (gl.on && gl.loss_part && wave == 3 && k < 2) {  // the reported MSE sums of this tile (train.py:484-488, 512-516)
       const bool lv = lane < 16 && a0 + lane < B;
-      const int bb = min(a0 + (lane & 15), B - 1);
-      const float e = dlabel[bb] - gl.targets[k == 0 ? gl.t0 : gl.t1];
+      const float e = (k == 0 ? rl[0] : rl[1]) - (k == 0 ? htg[0] : htg[1]);
       float sl = lv ? e * e : 0.f, sc = 0.f;
       if (k == 0 && lv) {
-        const float c0 = dcode[(size_t)bb * 2] - gl.z[(size_t)bb * SW_Z], c1 = dcode[(size_t)bb * 2 + 1] - gl.z[(size_t)bb * SW_Z + 1];
+        const float c0 = rc[0] - rz[0], c1 = rc[1] - rz[1];
         sc = c0 * c0 + c1 * c1;
       }
 #pragma unroll
