@@ -197,10 +197,13 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_bwd_kernel(
   const int b = min(a0 + ln, B - 1);
   LstmWT W;
   lstm_load_wT(W, whh, u0, ln, lg);
-  f32x4 dh = {0.f, 0.f, 0.f, 0.f}, dc = {0.f, 0.f, 0.f, 0.f};
-  if (dhT) dh = ld4(dhT + (size_t)b * 64 + u0 + 4 * lg);
-  if (dcT) dc = ld4(dcT + (size_t)b * 64 + u0 + 4 * lg);
+  // optional inputs are read unconditionally from a selected address (a load under a branch costs the exact vmcnt
+  // bookkeeping of everything behind it) and zeroed afterwards
   const float* act_b = act + ((size_t)t0 * B + b) * 384 + u0 + 4 * lg;
+  f32x4 dh = ld4(dhT ? dhT + (size_t)b * 64 + u0 + 4 * lg : act_b);
+  f32x4 dc = ld4(dcT ? dcT + (size_t)b * 64 + u0 + 4 * lg : act_b);
+  if (!dhT) dh = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (!dcT) dc = f32x4{0.f, 0.f, 0.f, 0.f};
   const size_t tstep = (size_t)B * 384;
   using T_ = std::true_type;
   using F_ = std::false_type;
@@ -213,9 +216,8 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_bwd_kernel(
     if constexpr (decltype(has_prev)::value) {
       cp_ = ld4(row - tstep + 256);
     } else {   // the sequence start: c_{-1} = c0 or zero (or the row in front of t0)
-      cp_ = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t0 > 0) cp_ = ld4(row - tstep + 256);
-      else if (c0) cp_ = ld4(c0 + (size_t)b * 64 + u0 + 4 * lg);
+      cp_ = ld4(t0 > 0 ? row - tstep + 256 : c0 ? c0 + (size_t)b * 64 + u0 + 4 * lg : row + 256);
+      if (t0 <= 0 && !c0) cp_ = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   f32x4 gate[4], ct, cprev;
