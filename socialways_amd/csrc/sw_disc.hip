@@ -145,12 +145,16 @@ __host__ __device__ inline HeadLdsB head_lds_b(int Tp, int base) {
   L.dc1 = o; o += 16 * LD32;
   L.dl1 = o; o += 16 * LD32;
   L.dboth = o; o += 16 * LD64;
-  L.docode = o; o += 16 * LD32;
   L.dq1 = o; o += 16 * LD32;
-  L.do1 = o; o += 16 * LD32;
+  L.docode = o; o += 16 * LD32;     // docode, do1 last: they are read after the heads (observation path), everything
+  L.do1 = o; o += 16 * LD32;        // from pe0T up to here is dead by then and carries the BPTT's dgates tiles (below)
   L.total = o;
   return L;
 }
+// disc_bwd's double-buffered dgates tiles [2][16][SW_GLD] live where the prediction heads' transposed weight images and
+// delta tiles were (all dead once the heads are done, one barrier earlier): 33 KB less LDS, and with <= 256 VGPRs two
+// workgroups fit a CU - what dense crowds (8+ tiles per CU) need to hide one tile's latencies behind another's work
+static_assert(7040 + 36 * 16 + 320 + 320 + 576 + 576 + 1088 + 576 >= 2 * 16 * SW_GLD, "dgates tiles fit the dead region");
 }  // namespace
 
 // GAN mode of the backward kernel: dlabel_* / dcode_* then carry the forward OUTPUTS (label, code) and
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_fwd_kernel(
 // ---------------------------------------------------------------------------------------------
 #define SW_SPLIT_MAX_WGS 256   // CUs of an MI355X: splitting only pays while the launch leaves some of them idle
 
-__global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
+__global__ __launch_bounds__(SW_THREADS, 2) void disc_bwd_kernel(
     const float* __restrict__ d_w, const float* __restrict__ dsave, const float* __restrict__ dlabel_a,
     const float* __restrict__ dlabel_b, const float* __restrict__ dcode_a, const float* __restrict__ dcode_b, int nb,
     int B, int To, int Tp, int want_w, float* __restrict__ ddelta, float* __restrict__ dpred_a,
@@ -468,8 +472,8 @@ __global__ __launch_bounds__(SW_THREADS) void disc_bwd_kernel(
     return;
   }
   const bool riding = ride.nriders > 0;
-  float* dgbuf = smem;  // [2][16][260]
-  const HeadLdsB L = head_lds_b(Tp, 2 * 16 * SW_GLD);
+  const HeadLdsB L = head_lds_b(Tp, 0);
+  float* dgbuf = smem + L.pe0T;  // [2][16][260], aliasing the prediction heads' images / deltas (dead when the BPTT starts)
   const swp::Disc O = swp::disc(Tp);
   const DSave ds = dsave_layout(B, To, Tp, nb);
   const DDelta dd = ddelta_layout(B, To, Tp, nb);
@@ -800,7 +804,7 @@ static int disc_bwd_impl(const float* d_w, const float* dsave, const float* cons
   if (d_d_w && (!ddelta || !wgrad_ws)) return SW_EARG;
   if (Tp > 64) return SW_ESHAPE;
   if (B == 0) return SW_OK;
-  int lds = head_lds_b(Tp, 2 * 16 * SW_GLD).total * 4;
+  int lds = head_lds_b(Tp, 0).total * 4;
   if (lds > 163840) return SW_ESHAPE;
   static int attr = 0;
   if (attr < lds) {
