@@ -27,6 +27,7 @@ def main(argv=None):
     ap.add_argument("--epochs", type=int, default=10)
     ap.add_argument("--batch-size", type=int, default=64)            # train.py --batch-size
     ap.add_argument("--unrolling-steps", type=int, default=1)        # train.py --unrolling-steps
+    ap.add_argument("--hidden-size", type=int, default=64)           # train.py --hidden-size (8, 16, .. 64)
     ap.add_argument("--social", type=int, default=1)
     ap.add_argument("--n-samples", type=int, default=768)
     ap.add_argument("--test-every", type=int, default=5)             # train.py:665
@@ -39,7 +40,8 @@ def main(argv=None):
     np.random.seed(args.seed)
     toy = sw.toy_tracks(args.n_samples, n_conditions=6, n_modes=3)
     data = sw.SceneDataset(toy["obsvs"], toy["preds"], toy["batches"], toy["times"], device="cuda:0")
-    tr = sw.SocialWaysTrainer(data.n_next, use_social=bool(args.social), n_unrolling_steps=args.unrolling_steps,
+    tr = sw.SocialWaysTrainer(data.n_next, hidden_size=args.hidden_size, use_social=bool(args.social),
+                              n_unrolling_steps=args.unrolling_steps,
                               device="cuda:0")
     real = np.concatenate((toy["obsvs"], toy["preds"]), axis=1).reshape((-1, 6, 4, 2))[:args.k]
     pred_root = os.path.join(args.out, "preds")
