@@ -352,7 +352,23 @@ int sw_gen_images(const float* enc_w, const float* dec_w, const float* emb_w /*o
 int sw_stage_step_img(const float* slot, int B, int To, int Tp, float* obsv_dst, float* pred_dst, float* pred4_dst,
                       float* targets_dst, float* z_dst, float* steps_dst, int n_d_updates, const float* enc_w,
                       const float* dec_w, const float* emb_w /*or NULL*/, const float* att_w /*or NULL*/, float* img,
-                      void* stream);
+                      /* d_img != NULL: the launch also scatters and registers the discriminator's images (sw_disc_images) */
+                      const float* d_w /*or NULL*/, float* d_img /*or NULL*/, const int* d_tab /*or NULL*/, void* stream);
+
+/* ---- derived weight images of the DISCRIMINATOR (Discriminator.forward, train.py:294-309, as the kernels consume it):
+ *      MFMA A-operand images of lstm.weight_hh and its transpose, and the eight head matrices transposed and zero-padded
+ *      exactly as the backward kernels keep them in LDS (their prologue becomes one contiguous copy).  D's weights change
+ *      three times per training step (two Adam updates, D.load(backup)), so the images are maintained element-wise through
+ *      a table: sw_disc_image_table(Tp, tab) fills HOST memory with 2 ints per packed float (sw_param_count(SW_GRP_DISC, Tp)
+ *      pairs): its image offsets, -1 = none.  sw_disc_images(d_w, img, tab_device, Tp, stream) scatters the whole packed
+ *      buffer into img (sw_disc_image_floats(Tp) floats, ZERO-FILLED by the caller once - padding is never written) and
+ *      REGISTERS (img, tab) for d_w: until the registration is dropped - sw_disc_images(NULL, NULL, NULL, 0, NULL) -
+ *      sw_disc_fwd / sw_disc_dpred / sw_disc_bwd* called with these weights and this Tp read the images, and
+ *      sw_disc_bwd_gan_adam / sw_adam_packed keep them current while they update the weights.  Whoever changes the
+ *      weights by other means re-scatters or drops the registration.  Same values bit for bit either way.           */
+int sw_disc_image_floats(int Tp);
+int sw_disc_image_table(int Tp, int* tab_host);
+int sw_disc_images(const float* d_w, float* img, const int* tab, int Tp, void* stream);
 
 /* ---- ADE/FDE partial sums of train.py:546-551:
  *      out[3] = { sum_{b,t} err / Tp, sum_b err[:, -1], sum_{b,t} err^2 },  err = |(p_hat - p) / ss|   */

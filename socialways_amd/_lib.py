@@ -74,7 +74,10 @@ PROTOTYPES = {
     "sw_stage_step": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sw_gen_image_floats": (_i, []),
     "sw_gen_images": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
-    "sw_stage_step_img": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sw_stage_step_img": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sw_disc_image_floats": (_i, [_i]),
+    "sw_disc_image_table": (_i, [_i, _vp]),
+    "sw_disc_images": (_i, [_vp, _vp, _vp, _i, _vp]),
     "sw_ade_fde": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
 }
 

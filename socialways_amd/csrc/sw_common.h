@@ -337,6 +337,42 @@ const float* sw_gen_images_for(const float* enc_w, const float* dec_w);
 // ... whose social part (swimg::OP_E*, OP_ATT_T) was derived from these embedder / attention weights, or null
 const float* sw_soc_images_for(const float* emb_w, const float* att_w);
 
+// ---------------------------------------------------------------------------------------------
+// Derived images of the DISCRIMINATOR's weights (sw_disc_images, sw_disc.hip).  D's weights change three times per
+// training step (two Adam updates, the Linear-only restore of train.py:541-542), so unlike the generator's images they
+// are not re-derived by a launch: a per-parameter TABLE maps every float of the packed D buffer to its (<= 2) places in
+// the image buffer; the staging launch of a step scatters the whole buffer once, and the thread that applies D's Adam
+// update to an element (wgrad_reduce, sw_adam_packed) also stores the new value to its image places.
+//   OP_WHH   A-operand image of weight_hh [256][64] (forward: 16 row tiles, KJ 4)         - as swimg::OP_WHH
+//   OP_WHHT  A-operand image of weight_hh^T [64][256] (BPTT: 4 row tiles, KJ 16)          - as swimg::OP_WHHT
+//   HEADT    the eight TRANSPOSED, zero-padded head matrices exactly as disc_bwd / the fused generator-phase pass keep
+//            them in LDS (HeadLdsB, sw_disc.hip: of0T | of1T | pe0T | pe1T | cl0T | la0T | cl1T | la1T), so that their
+//            prologues are one contiguous float4 copy instead of eight row gathers + scalar LDS scatters with 8-way
+//            bank conflicts.  Padding floats are zero from the allocation on and never written.
+// ---------------------------------------------------------------------------------------------
+namespace swdimg {
+constexpr int OP_WHH = 0;
+constexpr int OP_WHHT = 16384;
+constexpr int HEADT = 32768;
+}  // namespace swdimg
+struct DiscImages {
+  const float* img = nullptr;   // null: not registered (row-per-lane / gather prologues)
+  const int* tab = nullptr;     // [n][2] image offsets per packed float (-1: none)
+};
+// the images registered for these packed D weights at this horizon (sw_disc_images / sw_stage_step_img), or {null, null}
+DiscImages sw_disc_images_for(const float* d_w, int Tp);
+void sw_disc_images_register(const float* d_w, const float* img, const int* tab, int Tp);   // all null / 0: drop
+// scatter of the packed D weights into their image places, work split over nblk workgroups of 256 threads
+__device__ __forceinline__ void disc_images_scatter(const float* __restrict__ d_w, float* __restrict__ img,
+                                                    const int* __restrict__ tab, int n, int blk, int nblk) {
+  for (int i = blk * 256 + (int)threadIdx.x; i < n; i += nblk * 256) {
+    const int2 t = reinterpret_cast<const int2*>(tab)[i];
+    const float w = d_w[i];
+    if (t.x >= 0) img[t.x] = w;
+    if (t.y >= 0) img[t.y] = w;
+  }
+}
+
 // tiling choice of the serial kernels (sw_misc.hip: sw_set_tile_mode / SW_TILE_MODE)
 bool sw_narrow_tiles(int B);
 

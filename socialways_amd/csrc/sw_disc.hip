@@ -172,13 +172,11 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_fwd_kernel(
     const float* __restrict__ obsv, int To, int x_mode, const float* __restrict__ pred_a,
     const float* __restrict__ pred_b, int nb, const float* __restrict__ d_w, int B, int Tp, float* __restrict__ label_a, float* __restrict__ label_b,
     float* __restrict__ code_a, float* __restrict__ code_b, float* __restrict__ dsave, int save_lstm, int split,
-    float* __restrict__ w_snap, int fuse, DiscLoss gl, float* __restrict__ dpred_out) {
+    float* __restrict__ w_snap, int fuse, DiscLoss gl, float* __restrict__ dpred_out, const float* __restrict__ dimg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // LSTM part
   float* hbuf = smem;                        // [2][16][68]
-  float* wx_lds = smem + 2 * 16 * SW_HLD;    // [256][4]
-  float* bx_lds = wx_lds + 1024;             // [256]
-  const HeadLds L = head_lds(Tp, 2 * 16 * SW_HLD + 1280);
+  const HeadLds L = head_lds(Tp, 2 * 16 * SW_HLD + 1280);   // (the 1280 floats in between: Wx | bx of disc_obs_lstm_tile)
   const swp::Disc O = swp::disc(Tp);
   const DSave ds = dsave_layout(B, To, Tp, nb);
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
@@ -217,10 +215,28 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_fwd_kernel(
   // (generator phase) the label target and the agent's latent code for the loss gradients formed behind the heads
   const float* ztop = fuse ? gl.z + (size_t)b * SW_Z : d_w;
   const float ftg = (fuse ? gl.targets + gl.t0 : d_w)[0], fz0 = ztop[0], fz1 = ztop[1];
-  if (fuse) stage_zero(smem + LB.of0T, LB.dc1 - LB.of0T);   // transposed images (zero padded) + dlab, dcod
+  if (fuse) {
+    if (dimg) stage_zero(smem + LB.dlab, LB.dc1 - LB.dlab);   // dlab, dcod (the image block below carries its own zero padding)
+    else stage_zero(smem + LB.of0T, LB.dc1 - LB.of0T);        // transposed images (zero padded) + dlab, dcod
+  }
   const bool obs_pre = save_lstm == 2;   // LSTM rows already in dsave (sw_dec_rollout_fwd_aux ran the observation LSTM)
   LstmW W;
-  if (!obs_pre) lstm_load_whh(W, d_w + O.whh, u0, ln, lg);   // global loads in flight during the LDS staging
+  if (!obs_pre) {   // global loads in flight during the LDS staging
+    if (dimg) {     // operand-layout image: a wave's load = 1 KB of consecutive memory
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) W.whh[g][j] = ld4(dimg + swdimg::OP_WHH + ((((size_t)4 * g + wave) * 4 + j) * 64 + lane) * 4);
+    } else {
+      lstm_load_whh(W, d_w + O.whh, u0, ln, lg);
+    }
+    // input matrix W_ih [256][4] and b_ih + b_hh straight into their registers (no LDS staging, nothing behind a barrier)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      W.wx[g] = d_w[O.wih + (g * 64 + u0 + ln) * 4 + lg];
+      W.bias[g] = ld4(d_w + O.bih + g * 64 + u0 + 4 * lg) + ld4(d_w + O.bhh + g * 64 + u0 + 4 * lg);
+    }
+  }
   if (w_snap)   // deepcopy(D) of train.py:499: the weights this pass runs with, a few floats per thread
     for (int i = blockIdx.x * SW_THREADS + threadIdx.x; i < O.n; i += gridDim.x * SW_THREADS) w_snap[i] = d_w[i];
   // ---- stage head weights / biases: ALL global loads first, then the LDS stores (one L2 round trip for the eight
@@ -256,17 +272,33 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_fwd_kernel(
     const float v = d_w[boff + min(k, lim - 1)];
     smem[L.bias + i] = k < lim ? v : 0.f;
   }
+  if (fuse && dimg) {
+    // transposed head images of the fused backward (swdimg::HEADT): the block pe0T .. la1T is one contiguous float4
+    // copy, zero padding included - requested behind every other load of the prologue, so nothing waits for it alone
+    constexpr int HB = 12;
+    const int n4 = (LB.dlab - LB.pe0T) >> 2;
+    const float* src = dimg + swdimg::HEADT + (LB.pe0T - LB.of0T);
+    f32x4 hbv[HB];
+#pragma unroll
+    for (int e = 0; e < HB; ++e) hbv[e] = ld4(src + 4 * (size_t)min((int)threadIdx.x + SW_THREADS * e, n4 - 1));
+#pragma unroll
+    for (int e = 0; e < HB; ++e) {
+      const int f = threadIdx.x + SW_THREADS * e;
+      if (f < n4) st4(smem + LB.pe0T + 4 * f, hbv[e]);
+    }
+    for (int f = threadIdx.x + SW_THREADS * HB; f < n4; f += SW_THREADS) st4(smem + LB.pe0T + 4 * f, ld4(src + 4 * (size_t)f));
+  }
   f32x4 c = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};  // h0 = c0 = 0 (train.py:296-297)
   if (!obs_pre) {
-    lstm_prep_rows(nullptr, nullptr, d_w + O.wih, d_w + O.bih, d_w + O.bhh, false, wx_lds, bx_lds);
     st4(&hbuf[ln * SW_HLD + u0 + 4 * lg], h);
   } else {   // h_T of the tile from the saved rows
     st4(&hbuf[(To & 1) * 16 * SW_HLD + ln * SW_HLD + u0 + 4 * lg],
         ld4(dsave + ds.act + ((size_t)(To - 1) * B + b) * 384 + 320 + u0 + 4 * lg));
   }
   sw_barrier();
-  if (!obs_pre) lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
-  if (fuse) {
+  if (fuse && dimg) {
+    // (copied from the image block in front of the barrier above)
+  } else if (fuse) {
     f32x4 t_pe0[2], t_pe1[1], t_cl0[2], t_la0[2], t_cl1[1], t_la1[1];
     const bool pe0_small = 8 * K4 <= 2 * SW_THREADS;
     if (pe0_small) stage_wT_load<2>(t_pe0, d_w + O.pe0w, K4, 32, K4);
@@ -463,7 +495,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_bwd_kernel(
     const float* __restrict__ d_w, const float* __restrict__ dsave, const float* __restrict__ dlabel_a,
     const float* __restrict__ dlabel_b, const float* __restrict__ dcode_a, const float* __restrict__ dcode_b, int nb,
     int B, int To, int Tp, int want_w, float* __restrict__ ddelta, float* __restrict__ dpred_a,
-    float* __restrict__ dpred_b, DiscLoss gl, WgBatch wbatch, WgRide ride) {
+    float* __restrict__ dpred_b, DiscLoss gl, WgBatch wbatch, WgRide ride, const float* __restrict__ dimg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // Workgroups beyond the agent tiles are RIDERS (sw_wgrad_dev.h): they run the weight-gradient jobs of this very
   // pass while the tiles compute - rows of the heads (event 0), then of BPTT step t (event To - t) as they are published
@@ -527,6 +559,21 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_bwd_kernel(
     rz[0] = zsrc[(size_t)bb * SW_Z];
     rz[1] = zsrc[(size_t)bb * SW_Z + 1];
   }
+  if (dimg) {
+    // registered images (swdimg::HEADT): the eight transposed, zero-padded head matrices are ONE contiguous block in
+    // the LDS layout of this kernel - a float4 copy, no zero fill, no scalar scatter
+    constexpr int HB = 12;
+    const int n4 = L.dlab >> 2;
+    f32x4 hbv[HB];
+#pragma unroll
+    for (int e = 0; e < HB; ++e) hbv[e] = ld4(dimg + swdimg::HEADT + 4 * (size_t)min((int)threadIdx.x + SW_THREADS * e, n4 - 1));
+#pragma unroll
+    for (int e = 0; e < HB; ++e) {
+      const int f = threadIdx.x + SW_THREADS * e;
+      if (f < n4) st4(smem + 4 * f, hbv[e]);
+    }
+    for (int f = threadIdx.x + SW_THREADS * HB; f < n4; f += SW_THREADS) st4(smem + 4 * f, ld4(dimg + swdimg::HEADT + 4 * (size_t)f));
+  } else {
   // transposed weight images: all global loads are issued before the zero fill and its barrier
   f32x4 t_of0[2], t_of1[1], t_pe0[2], t_pe1[1], t_cl0[2], t_la0[2], t_cl1[1], t_la1[1];
   const bool pe0_small = 8 * K4 <= 2 * SW_THREADS;
@@ -549,6 +596,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_bwd_kernel(
   stage_wT_store<2>(t_la0, smem + L.la0T, LD32, 32, 64);
   stage_wT_store<1>(t_cl1, smem + L.cl1T, LD16, 1, 32);
   stage_wT_store<1>(t_la1, smem + L.la1T, LD16, 2, 32);
+  }
   for (int i = threadIdx.x; i < 16 * LD32; i += blockDim.x) smem[L.docode + i] = 0.f;
 
   for (int k = 0; k < nb; ++k) {
@@ -669,7 +717,12 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_bwd_kernel(
   f32x4 dh = {0.f, 0.f, 0.f, 0.f}, dc = {0.f, 0.f, 0.f, 0.f};
   dh = tile_mm_rt(smem + L.of0T + (u0 + ln) * LD32 + 4 * lg, smem + L.do1 + ln * LD32 + 4 * lg, 2, dh);
   LstmWT WT;
-  lstm_load_wT(WT, d_w + O.whh, u0, ln, lg);
+  if (dimg) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) WT.whhT[j] = ld4(dimg + swdimg::OP_WHHT + (((size_t)wave * 16 + j) * 64 + lane) * 4);
+  } else {
+    lstm_load_wT(WT, d_w + O.whh, u0, ln, lg);
+  }
   // Saved rows are fetched one step ahead.  Every memory operation of the loop body is UNCONDITIONAL (the two
   // boundary steps are peeled; padding lanes of the last tile store to a trash row): with conditional loads or
   // stores the compiler cannot count what is in flight and waits for everything (s_waitcnt vmcnt(0)) right after
@@ -768,7 +821,8 @@ extern "C" int sw_disc_fwd(const float* obsv, int To, int x_mode, const float* c
   const int split = (nb == 2 && 2 * tiles <= SW_SPLIT_MAX_WGS) ? 1 : 0;   // idle CUs: one workgroup per (tile, branch)
   hipLaunchKernelGGL(disc_fwd_kernel, dim3(split ? 2 * tiles : tiles), dim3(SW_THREADS), lds, (hipStream_t)stream,
                      obsv, To, x_mode, pred4[0], nb > 1 ? pred4[1] : nullptr, nb, d_w, B, Tp, label[0],
-                     nb > 1 ? label[1] : nullptr, code[0], nb > 1 ? code[1] : nullptr, dsave, save_lstm, split, w_snapshot, 0, DiscLoss{}, nullptr);
+                     nb > 1 ? label[1] : nullptr, code[0], nb > 1 ? code[1] : nullptr, dsave, save_lstm, split, w_snapshot, 0, DiscLoss{}, nullptr,
+                     sw_disc_images_for(d_w, Tp).img);
   SW_CHECK_LAUNCH("disc_fwd_kernel");
   return SW_OK;
 }
@@ -790,7 +844,7 @@ extern "C" int sw_disc_dpred(const float* obsv, int To, int x_mode, const float*
   const int tiles = (B + SW_TILE - 1) / SW_TILE;
   hipLaunchKernelGGL(disc_fwd_kernel, dim3(tiles), dim3(SW_THREADS), lds, (hipStream_t)stream, obsv, To, x_mode, pred4,
                      (const float*)nullptr, 1, d_w, B, Tp, label, (float*)nullptr, code, (float*)nullptr, (float*)nullptr, 0, 0,
-                     (float*)nullptr, 1, gl, dpred4);
+                     (float*)nullptr, 1, gl, dpred4, sw_disc_images_for(d_w, Tp).img);
   SW_CHECK_LAUNCH("disc_fwd_kernel");
   return SW_OK;
 }
@@ -859,7 +913,8 @@ static int disc_bwd_impl(const float* d_w, const float* dsave, const float* cons
   }
   hipLaunchKernelGGL(disc_bwd_kernel, dim3(tiles + ride.nriders), dim3(SW_THREADS), lds, st, d_w, dsave,
                      dlabel[0], nb > 1 ? dlabel[1] : nullptr, dcode[0], nb > 1 ? dcode[1] : nullptr, nb, B, To, Tp,
-                     d_d_w ? 1 : 0, ddelta, dpred4 ? dpred4[0] : nullptr, (dpred4 && nb > 1) ? dpred4[1] : nullptr, gl, wb, ride);
+                     d_d_w ? 1 : 0, ddelta, dpred4 ? dpred4[0] : nullptr, (dpred4 && nb > 1) ? dpred4[1] : nullptr, gl, wb, ride,
+                     sw_disc_images_for(d_w, Tp).img);
   SW_CHECK_LAUNCH("disc_bwd_kernel");
   if (!d_d_w) return SW_OK;
   if (ride.nriders > 0) return wg_reduce_launch_adam(wb, wgrad_ws, adam, st);
@@ -889,6 +944,9 @@ extern "C" int sw_disc_bwd_gan_adam(const float* d_w, const float* dsave, const 
   if (adam_w) {
     ad.w = adam_w; ad.m = adam_m; ad.v = adam_v; ad.g0 = d_d_w; ad.step = adam_step;
     ad.lr = lr; ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps;
+    const DiscImages di = sw_disc_images_for(adam_w, Tp);   // registered images follow the update element by element
+    ad.img = const_cast<float*>(di.img);
+    ad.tab = di.tab;
   }
   return disc_bwd_impl(d_w, dsave, label, code, nb, B, To, Tp, ddelta, d_d_w, dpred4, wgrad_ws, stream, gl, ad);
 }
@@ -898,4 +956,65 @@ extern "C" int sw_disc_bwd_gan(const float* d_w, const float* dsave, const float
                                float* d_d_w, float* const* dpred4, float* wgrad_ws, float* loss_part, void* stream) {
   return sw_disc_bwd_gan_adam(d_w, dsave, label, code, targets, t0, t1, z, g_label, g_code, nb, B, To, Tp, ddelta, d_d_w,
                               dpred4, wgrad_ws, loss_part, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, stream);
+}
+
+// ---- derived images of the discriminator's weights (swdimg, sw_common.h) --------------------------------------------
+extern "C" int sw_disc_image_floats(int Tp) {
+  if (Tp < 1 || Tp > 64) return SW_EARG;
+  return swdimg::HEADT + head_lds_b(Tp, 0).dlab;
+}
+// tab[2 i], tab[2 i + 1] = image offsets of packed float i (or -1); host memory, sw_param_count(SW_GRP_DISC, Tp) pairs
+extern "C" int sw_disc_image_table(int Tp, int* tab) {
+  if (Tp < 1 || Tp > 64 || !tab) return SW_EARG;
+  const swp::Disc O = swp::disc(Tp);
+  const HeadLdsB L = head_lds_b(Tp, 0);
+  for (int i = 0; i < 2 * O.n; ++i) tab[i] = -1;
+  for (int R = 0; R < 256; ++R)
+    for (int C = 0; C < 64; ++C) {
+      const int i = O.whh + R * 64 + C;
+      tab[2 * i] = swdimg::OP_WHH + ((((R >> 4) * 4 + (C >> 4)) * 64 + ((C & 15) >> 2) * 16 + (R & 15)) * 4) + (C & 3);
+      tab[2 * i + 1] = swdimg::OP_WHHT + ((((C >> 4) * 16 + (R >> 4)) * 64 + ((R & 15) >> 2) * 16 + (C & 15)) * 4) + (R & 3);
+    }
+  auto head = [&](int w_off, int M, int K, int img_off, int ld) {   // XT[c][r] = X[r][c]
+    for (int r = 0; r < M; ++r)
+      for (int c = 0; c < K; ++c) tab[2 * (w_off + r * K + c)] = swdimg::HEADT + img_off + c * ld + r;
+  };
+  head(O.of0w, 32, 64, L.of0T, LD32);
+  head(O.of1w, 32, 32, L.of1T, LD32);
+  head(O.pe0w, 32, 4 * Tp, L.pe0T, LD32);
+  head(O.pe1w, 32, 32, L.pe1T, LD32);
+  head(O.cl0w, 32, 64, L.cl0T, LD32);
+  head(O.la0w, 32, 64, L.la0T, LD32);
+  head(O.cl1w, 1, 32, L.cl1T, LD16);
+  head(O.la1w, 2, 32, L.la1T, LD16);
+  return SW_OK;
+}
+static const float* g_dimg_w = nullptr;
+static DiscImages g_dimg;
+static int g_dimg_tp = 0;
+DiscImages sw_disc_images_for(const float* d_w, int Tp) {
+  return (g_dimg.img && d_w == g_dimg_w && Tp == g_dimg_tp) ? g_dimg : DiscImages();
+}
+void sw_disc_images_register(const float* d_w, const float* img, const int* tab, int Tp) {
+  g_dimg_w = d_w; g_dimg.img = img; g_dimg.tab = tab; g_dimg_tp = Tp;
+}
+__global__ __launch_bounds__(256) void disc_images_kernel(const float* __restrict__ d_w, float* __restrict__ img,
+                                                           const int* __restrict__ tab, int n) {
+  disc_images_scatter(d_w, img, tab, n, blockIdx.x, gridDim.x);
+}
+// Scatter the packed weights d_w into img (sw_disc_image_floats(Tp) floats, ZERO-FILLED by the caller once: padding is
+// never written) through the device copy `tab` of sw_disc_image_table(Tp), and register the images for d_w: until the
+// registration is dropped - sw_disc_images(NULL, NULL, NULL, 0, NULL) - sw_disc_fwd / sw_disc_dpred / sw_disc_bwd* called with
+// these weights read the images, and sw_disc_bwd_gan_adam keeps them current while it updates the weights.  Whoever
+// changes the weights by other means re-scatters or drops the registration.
+extern "C" int sw_disc_images(const float* d_w, float* img, const int* tab, int Tp, void* stream) {
+  if (!img) {
+    sw_disc_images_register(nullptr, nullptr, nullptr, 0);
+    return SW_OK;
+  }
+  if (!d_w || !tab || Tp < 1 || Tp > 64) return SW_EARG;
+  hipLaunchKernelGGL(disc_images_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, d_w, img, tab, swp::disc(Tp).n);
+  SW_CHECK_LAUNCH("disc_images_kernel");
+  sw_disc_images_register(d_w, img, tab, Tp);
+  return SW_OK;
 }

@@ -189,14 +189,19 @@ template <bool DY>
 __global__ __launch_bounds__(SW_THREADS) void enc_lstm_bwd_kernel(
     const float* __restrict__ whh, const float* __restrict__ act, const float* __restrict__ c0,
     const float* __restrict__ dhT, const float* __restrict__ dcT, const float* __restrict__ dy, int B, int T,
-    int t0, float* __restrict__ dgates, float* __restrict__ dh0, float* __restrict__ dc0) {
+    int t0, float* __restrict__ dgates, float* __restrict__ dh0, float* __restrict__ dc0, const float* __restrict__ gimg) {
   __shared__ __attribute__((aligned(16))) float dgbuf[2][SW_TILE * SW_GLD];
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
   const int u0 = wave * 16;
   const int a0 = blockIdx.x * SW_TILE;
   const int b = min(a0 + ln, B - 1);
   LstmWT W;
-  lstm_load_wT(W, whh, u0, ln, lg);
+  if (gimg) {   // operand-layout image of W_hh^T of this step (swimg::OP_WHHT): 16 contiguous 1 KB loads per wave
+#pragma unroll
+    for (int j = 0; j < 16; ++j) W.whhT[j] = ld4(gimg + swimg::OP_WHHT + (((size_t)wave * 16 + j) * 64 + lane) * 4);
+  } else {
+    lstm_load_wT(W, whh, u0, ln, lg);
+  }
   // optional inputs are read unconditionally from a selected address (a load under a branch costs the exact vmcnt
   // bookkeeping of everything behind it) and zeroed afterwards
   const float* act_b = act + ((size_t)t0 * B + b) * 384 + u0 + 4 * lg;
@@ -352,12 +357,13 @@ extern "C" int sw_enc_lstm_bwd(const float* enc_w, const float* act, const float
                                float* dh0, float* dc0, void* stream) {
   if (!enc_w || !act || !dgates || B < 0 || T < 1 || t0 < 0) return SW_EARG;
   if (B == 0) return SW_OK;
+  const float* gimg = sw_gen_images_for(enc_w, nullptr);
   if (dy)
     hipLaunchKernelGGL(enc_lstm_bwd_kernel<true>, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS), 0,
-                       (hipStream_t)stream, enc_w + swp::ENC_WHH, act, c0, dhT, dcT, dy, B, T, t0, dgates, dh0, dc0);
+                       (hipStream_t)stream, enc_w + swp::ENC_WHH, act, c0, dhT, dcT, dy, B, T, t0, dgates, dh0, dc0, gimg);
   else
     hipLaunchKernelGGL(enc_lstm_bwd_kernel<false>, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS), 0,
-                       (hipStream_t)stream, enc_w + swp::ENC_WHH, act, c0, dhT, dcT, dy, B, T, t0, dgates, dh0, dc0);
+                       (hipStream_t)stream, enc_w + swp::ENC_WHH, act, c0, dhT, dcT, dy, B, T, t0, dgates, dh0, dc0, gimg);
   SW_CHECK_LAUNCH("enc_lstm_bwd_kernel");
   return SW_OK;
 }

@@ -733,16 +733,23 @@ __global__ __launch_bounds__(256) void stage_step_kernel(const float* __restrict
                                                           int n_d_updates, const float* __restrict__ enc_w,
                                                           const float* __restrict__ dec_w, const float* __restrict__ emb_w,
                                                           const float* __restrict__ att_w, float* __restrict__ img,
-                                                          int img_blocks) {
-  // the last img_blocks workgroups derive the generator's weight images of this step (sw_gen_images)
+                                                          int img_blocks, const float* __restrict__ d_w,
+                                                          float* __restrict__ d_img, const int* __restrict__ d_tab, int d_n,
+                                                          int dimg_blocks) {
+  // the last img_blocks workgroups derive the generator's weight images of this step (sw_gen_images), the dimg_blocks
+  // in front of them scatter the discriminator's weights into theirs (sw_disc_images)
   if ((int)blockIdx.x >= (int)gridDim.x - img_blocks) {
     gen_images_block(enc_w, dec_w, emb_w, att_w, img, (int)blockIdx.x - ((int)gridDim.x - img_blocks));
+    return;
+  }
+  if ((int)blockIdx.x >= (int)gridDim.x - img_blocks - dimg_blocks) {
+    disc_images_scatter(d_w, d_img, d_tab, d_n, (int)blockIdx.x - ((int)gridDim.x - img_blocks - dimg_blocks), dimg_blocks);
     return;
   }
   const unsigned long long* ptrs = reinterpret_cast<const unsigned long long*>(slot);
   const float* obsv = reinterpret_cast<const float*>(ptrs[0]);
   const float* pred = reinterpret_cast<const float*>(ptrs[1]);
-  const int gid = blockIdx.x * 256 + threadIdx.x, gsz = ((int)gridDim.x - img_blocks) * 256;
+  const int gid = blockIdx.x * 256 + threadIdx.x, gsz = ((int)gridDim.x - img_blocks - dimg_blocks) * 256;
   if (z_dst)
     for (int i = gid; i < B * SW_Z / 4; i += gsz) st4(z_dst + 4 * (size_t)i, ld4(slot + 8 + 4 * (size_t)i));
   if (gid < 2) targets_dst[gid] = slot[4 + gid];
@@ -758,27 +765,31 @@ __global__ __launch_bounds__(256) void stage_step_kernel(const float* __restrict
     st4(pred4_dst + 4 * (size_t)k, f32x4{p.x, p.y, p.x - q.x, p.y - q.y});
   }
 }
+#define SW_DIMG_BLOCKS 16
 extern "C" int sw_stage_step_img(const float* slot, int B, int To, int Tp, float* obsv_dst, float* pred_dst,
                                  float* pred4_dst, float* targets_dst, float* z_dst, float* steps_dst, int n_d_updates,
                                  const float* enc_w, const float* dec_w, const float* emb_w, const float* att_w, float* img,
-                                 void* stream) {
+                                 const float* d_w, float* d_img, const int* d_tab, void* stream) {
   if (!slot || !obsv_dst || !pred_dst || !pred4_dst || !targets_dst || B < 1 || To < 2 || Tp < 1 ||
       n_d_updates < 0 || n_d_updates > 254)
     return SW_EARG;
   if (img && (!enc_w || !dec_w || ((emb_w != nullptr) != (att_w != nullptr)))) return SW_EARG;
+  if (d_img && (!d_w || !d_tab || Tp > 64)) return SW_EARG;
   int n = z_dst ? B * SW_Z / 4 : B * (To > Tp ? To : Tp);
   int blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  const int ib = img ? SW_IMG_BLOCKS : 0;
-  hipLaunchKernelGGL(stage_step_kernel, dim3(blocks + ib), dim3(256), 0, (hipStream_t)stream, slot, B, To, Tp, obsv_dst,
-                     pred_dst, pred4_dst, targets_dst, z_dst, steps_dst, n_d_updates, enc_w, dec_w, emb_w, att_w, img, ib);
+  const int ib = img ? SW_IMG_BLOCKS : 0, db = d_img ? SW_DIMG_BLOCKS : 0;
+  hipLaunchKernelGGL(stage_step_kernel, dim3(blocks + ib + db), dim3(256), 0, (hipStream_t)stream, slot, B, To, Tp, obsv_dst,
+                     pred_dst, pred4_dst, targets_dst, z_dst, steps_dst, n_d_updates, enc_w, dec_w, emb_w, att_w, img, ib,
+                     d_w, d_img, d_tab, d_img ? swp::disc(Tp).n : 0, db);
   SW_CHECK_LAUNCH("stage_step_kernel");
   if (img) gen_images_register(enc_w, dec_w, emb_w, att_w, img);
+  if (d_img) sw_disc_images_register(d_w, d_img, d_tab, Tp);
   return SW_OK;
 }
 extern "C" int sw_stage_step(const float* slot, int B, int To, int Tp, float* obsv_dst, float* pred_dst,
                              float* pred4_dst, float* targets_dst, float* z_dst, float* steps_dst, int n_d_updates,
                              void* stream) {
   return sw_stage_step_img(slot, B, To, Tp, obsv_dst, pred_dst, pred4_dst, targets_dst, z_dst, steps_dst, n_d_updates, nullptr,
-                           nullptr, nullptr, nullptr, nullptr, stream);
+                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }

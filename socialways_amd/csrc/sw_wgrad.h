@@ -49,6 +49,8 @@ struct WgAdam {
   size_t n = ~(size_t)0;       // floats in the packed buffers: gradient outputs outside [g0, g0 + n) are scratch, not parameters
   const float* bc = nullptr;   // {bias_correction1, sqrt(bias_correction2)} of this update if some earlier kernel of the
                                // sequence has computed them (wg_launch_adam: the GEMM launch), else every wave does
+  float* img = nullptr;        // derived weight images kept current by the update (swdimg, sw_common.h): the new value of
+  const int* tab = nullptr;    // element i also goes to img[tab[2i]], img[tab[2i+1]] (entries < 0: none)
 };
 // bias corrections of the update whose 1-based index sits in *step (torch: 1 - beta^step in double, then float)
 __device__ __forceinline__ void wg_adam_bc_compute(const float* step, double beta1, double beta2, float& bc1, float& bc2s) {
@@ -71,10 +73,12 @@ __device__ __forceinline__ void wg_adam_bc(const WgAdam& A, float& bc1, float& b
 struct WgAdamPre {
   size_t i;
   float m, v, w;
+  int2 t;      // image places of the element (WgAdam::tab), fetched with the state
 };
 __device__ __forceinline__ WgAdamPre wg_adam_pre(const WgAdam& A, const float* gptr) {
   WgAdamPre s;
   s.i = (size_t)(gptr - A.g0);
+  s.t = int2{-1, -1};
   if (s.i >= A.n) {          // scratch output, not a parameter
     s.i = ~(size_t)0;
     s.m = s.v = s.w = 0.f;
@@ -83,6 +87,7 @@ __device__ __forceinline__ WgAdamPre wg_adam_pre(const WgAdam& A, const float* g
   s.m = A.m[s.i];
   s.v = A.v[s.i];
   s.w = A.w[s.i];
+  if (A.img) s.t = reinterpret_cast<const int2*>(A.tab)[s.i];
   return s;
 }
 __device__ __forceinline__ void wg_adam_fin(const WgAdam& A, const WgAdamPre& s, float bc1, float bc2s, float grad) {
@@ -96,7 +101,12 @@ __device__ __forceinline__ void wg_adam_fin(const WgAdam& A, const WgAdamPre& s,
   const float denom = (float)((sqrtf(v) / bc2s) + A.eps);
   A.m[s.i] = m;
   A.v[s.i] = v;
-  A.w[s.i] = s.w - step_size * m / denom;
+  const float wn = s.w - step_size * m / denom;
+  A.w[s.i] = wn;
+  if (A.img) {
+    if (s.t.x >= 0) A.img[s.t.x] = wn;
+    if (s.t.y >= 0) A.img[s.t.y] = wn;
+  }
 }
 __device__ __forceinline__ void wg_adam1(const WgAdam& A, float bc1, float bc2s, const float* gptr, float grad) {
   wg_adam_fin(A, wg_adam_pre(A, gptr), bc1, bc2s, grad);

@@ -202,6 +202,17 @@ class SocialWaysTrainer:
         # computed once per step by the staging launch instead of by every workgroup of four launches (sw_gen_images)
         self._gimg = (torch.empty(L.load().sw_gen_image_floats(), device=self.device)
                       if self.device.type == "cuda" and os.environ.get("SW_GEN_IMAGES", "1") == "1" else None)
+        # ... and of the discriminator's (A-operand images of weight_hh / its transpose, the transposed head matrices in the
+        # backward kernels' LDS layout): scattered by the staging launch, kept current by the kernels that apply D's Adam
+        # update (sw_disc_images; include/socialways_hip.h)
+        self._dimg = self._dtab = None
+        if self.device.type == "cuda" and os.environ.get("SW_DISC_IMAGES", "1") == "1":
+            lib = L.load()
+            tab = np.empty((self.D._flat.numel(), 2), dtype=np.int32)
+            if lib.sw_disc_image_table(n_next, tab.ctypes.data) != 0:
+                raise L.SocialWaysHipError("sw_disc_image_table(%d)" % n_next)
+            self._dtab = torch.from_numpy(tab).to(self.device)
+            self._dimg = torch.zeros(lib.sw_disc_image_floats(n_next), device=self.device)    # padding stays zero for good
         self._lin_mask = None
         self._lin_maskf = None
         self._noise_src = None
@@ -442,7 +453,8 @@ class SocialWaysTrainer:
             L.call("sw_stage_step_img", slot.data_ptr(), B, To, Tp, L.ptr(st["obsv"]), L.ptr(st["pred"]),
                    L.ptr(st["pred4"]), L.ptr(st["targets"]), None, L.ptr(st["steps"]), self.n_unrolling_steps + 1,
                    L.ptr(self.G.encoder._flat), L.ptr(self.G.decoder._flat), L.ptr(self.G.feature_embedder._flat),
-                   L.ptr(self.G.attention._flat), L.ptr(self._gimg), L.stream())
+                   L.ptr(self.G.attention._flat), L.ptr(self._gimg),
+                   L.ptr(self.D._flat) if self._dimg is not None else None, L.ptr(self._dimg), L.ptr(self._dtab), L.stream())
             self._noise_src = slot.data_ptr() + 4 * HDR        # z: pulled by idle workgroups of the encoder launch
 
         def args(j):
@@ -525,14 +537,23 @@ class SocialWaysTrainer:
         # this runtime - more than any of the small kernels that could be overlapped (measured).
         if pre is not None:
             pre()
-        elif self._gimg is not None:     # eager step without a staging launch: derive the weight images here
-            L.call("sw_gen_images", L.ptr(G.encoder._flat), L.ptr(G.decoder._flat), L.ptr(G.feature_embedder._flat),
-                   L.ptr(G.attention._flat), L.ptr(self._gimg), L.stream())
+        else:                            # eager step without a staging launch: derive the weight images here
+            if self._gimg is not None:
+                L.call("sw_gen_images", L.ptr(G.encoder._flat), L.ptr(G.decoder._flat), L.ptr(G.feature_embedder._flat),
+                       L.ptr(G.attention._flat), L.ptr(self._gimg), L.stream())
+            self._disc_images()
         try:
             yield from self._step_body(obsv, pred, pred4, scenes, targets, noise, ss, Bg, out, steps)
         finally:
             if self._gimg is not None:   # the generator's Adam step follows / has run: the images are stale
                 L.call("sw_gen_images", None, None, None, None, None, None)
+            if self._dimg is not None:   # D.load(backup) has run (train.py:541-542) / the weights are the caller's again
+                L.call("sw_disc_images", None, None, None, 0, None)
+
+    def _disc_images(self):
+        """(Re-)scatter the packed D weights into their images and register them (sw_disc_images)."""
+        if self._dimg is not None:
+            L.call("sw_disc_images", L.ptr(self.D._flat), L.ptr(self._dimg), L.ptr(self._dtab), self.n_next, L.stream())
 
     def _step_body(self, obsv, pred, pred4, scenes, targets, noise, ss, Bg, out, steps):
         G, D = self.G, self.D
@@ -589,6 +610,7 @@ class SocialWaysTrainer:
             yield d_gflat
             if not fuse:
                 self.D_optimizer.step() if steps is None else self.D_optimizer.step(steps[u])
+                self._disc_images()        # an update the image table did not see: scatter again
         # ---- generator update (train.py:503-539) ----------------------------------------------------
         # D forward on the prediction + backward of its heads down to d(g_loss)/d(pred_hat), one launch, nothing saved
         dpred = ops.disc_dpred(D._flat, obsv, pred_hat, targets, 1, noise, g_label, g_code, loss_part=out[U + 1])

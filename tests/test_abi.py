@@ -126,3 +126,53 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "sw_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+
+
+@pytest.mark.parametrize("tp", [2, 12, 20])
+def test_disc_image_table_describes_the_documented_layouts(tp):
+    """sw_disc_image_table (host function, no GPU): every packed Discriminator float maps to its places in the image
+    buffer - the MFMA A-operand images of lstm.weight_hh / its transpose and the transposed, zero-padded head
+    matrices; rebuilt here independently with numpy from the layout comments of csrc/sw_common.h / sw_disc.hip."""
+    from socialways_amd import _lib as L
+    lib = L.load()
+    n = lib.sw_param_count(L.GRP_DISC, tp)
+    nimg = lib.sw_disc_image_floats(tp)
+    tab = np.empty((n, 2), dtype=np.int32)
+    assert lib.sw_disc_image_table(tp, tab.ctypes.data) == 0
+    w = np.arange(1, n + 1, dtype=np.float64)            # distinct non-zero values
+    img = np.zeros(nimg)
+    used = tab[tab >= 0]
+    assert used.max() < nimg and len(np.unique(used)) == len(used), "image places are distinct and inside the buffer"
+    for c in range(2):
+        m = tab[:, c] >= 0
+        img[tab[m, c]] = w[m]
+    off = [lib.sw_param_offset(L.GRP_DISC, i, tp) for i in range(20)]
+    whh = w[off[1]:off[1] + 256 * 64].reshape(256, 64)
+    lane = np.arange(64)
+    ln, lg = lane & 15, lane >> 4
+    # A-operand image of M [rows][K]: float4 of (row tile t, k-step j, lane l) = M[16 t + ln][16 j + 4 lg .. + 3]
+    op = img[:16384].reshape(16, 4, 64, 4)
+    opT = img[16384:32768].reshape(4, 16, 64, 4)
+    for t in range(16):
+        for j in range(4):
+            for e in range(4):
+                assert np.array_equal(op[t, j, :, e], whh[16 * t + ln, 16 * j + 4 * lg + e])
+    whhT = whh.T                                           # [64][256]
+    for t in range(4):
+        for j in range(16):
+            for e in range(4):
+                assert np.array_equal(opT[t, j, :, e], whhT[16 * t + ln, 16 * j + 4 * lg + e])
+    # heads: XT [K (padded)][ld] row-major, in the order of0 of1 pe0 pe1 cl0 la0 (ld 36) cl1 la1 (ld 20)
+    kp = (4 * tp + 15) // 16 * 16
+    pos = 32768
+    for idx, (M, K, rows, ld) in zip((4, 6, 8, 10, 12, 16, 14, 18),
+                                     ((32, 64, 64, 36), (32, 32, 32, 36), (32, 4 * tp, kp, 36), (32, 32, 32, 36),
+                                      (32, 64, 64, 36), (32, 64, 64, 36), (1, 32, 32, 20), (2, 32, 32, 20))):
+        X = w[off[idx]:off[idx] + M * K].reshape(M, K)
+        blk = img[pos:pos + rows * ld].reshape(rows, ld)
+        want = np.zeros((rows, ld))
+        want[:K, :M] = X.T
+        assert np.array_equal(blk, want), idx
+        pos += rows * ld
+    assert pos == nimg
+    assert (tab[off[0]:off[1]] < 0).all() and (tab[off[2]:off[4]] < 0).all(), "W_ih and the biases have no image"

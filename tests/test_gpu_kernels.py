@@ -393,3 +393,58 @@ def test_standalone_modules_at_a_smaller_hidden_size():
     for m, o, nm in ((fe, ofe, "feature_embedder"), (att, oatt, "attention"), (enc, oenc, "encoder"), (dec, odec, "decoder")):
         for i, ((k, p), (_, q)) in enumerate(zip(m.named_parameters(), o.named_parameters())):
             _grad_close(m.true_view(i, p.grad), q.grad, "%s d/d%s" % (nm, k))
+
+
+def test_disc_weight_images_are_bit_identical_and_follow_adam():
+    """Discriminator passes with registered weight images (sw_disc_images: operand-layout W_hh / W_hh^T, transposed head
+    matrices as one LDS-layout block) produce bit-identical outputs, gradients and d/dpred; the Adam update fused into
+    the gradient reduction keeps the images equal to a fresh scatter of the updated weights."""
+    from socialways_amd import _lib as L
+    from socialways_amd import ops
+    g = golden("syn_ragged_on")
+    G, D, dev = _models(g, 12, True)
+    data, obsv, pred, sb, noise = _step_inputs(g)
+    obsv, z = obsv.to(dev), noise.to(dev)
+    import socialways_amd as sw
+    o4, p4 = sw.get_traj_4d(obsv, pred.to(dev))
+    fake = torch.from_numpy(g["pred_hat_4d"]).to(dev)
+    B = obsv.shape[0]
+    lib = L.load()
+    n = D._flat.numel()
+    tab_h = np.empty((n, 2), dtype=np.int32)
+    assert lib.sw_disc_image_table(12, tab_h.ctypes.data) == 0
+    tab = torch.from_numpy(tab_h).to(dev)
+    img = torch.zeros(lib.sw_disc_image_floats(12), device=dev)
+    targets = torch.tensor([0.03, 0.97], device=dev)
+    w0 = D._flat.clone()
+
+    def run(with_images):
+        D._flat.copy_(w0)
+        ws = ops.Workspaces(dev)
+        if with_images:
+            L.call("sw_disc_images", L.ptr(D._flat), L.ptr(img), L.ptr(tab), 12, L.stream())
+        try:
+            labels, codes, ctx = ops.disc_forward(D._flat, obsv, [fake, p4], save=True, ws=ws)
+            dflat = torch.zeros_like(D._flat)
+            m, v = torch.zeros_like(D._flat), torch.zeros_like(D._flat)
+            step = torch.ones((), device=dev)
+            part = torch.zeros((B + 7) // 8, 3, device=dev)
+            ops.disc_backward_gan(D._flat, ctx, labels, codes, targets, (0, 1), z, 1.0 / B, 0.25 / B, dflat, (), ws=ws,
+                                  loss_part=part, adam=(m, v, step, 1e-3, 0.9, 0.999, 1e-8))
+            dpred = ops.disc_dpred(D._flat, obsv, fake, targets, 1, z, 1.0 / B, 0.25 / B)     # with the UPDATED weights
+            torch.cuda.synchronize()
+            return [t.clone() for t in labels + codes] + [dflat, D._flat.clone(), dpred, part]
+        finally:
+            L.call("sw_disc_images", None, None, None, 0, None)
+
+    plain = run(False)
+    imaged = run(True)
+    for a, b in zip(plain, imaged):
+        assert torch.equal(a, b)
+    after = img.clone()                       # images as the fused Adam left them
+    fresh = torch.zeros_like(img)
+    L.call("sw_disc_images", L.ptr(D._flat), L.ptr(fresh), L.ptr(tab), 12, L.stream())
+    L.call("sw_disc_images", None, None, None, 0, None)
+    torch.cuda.synchronize()
+    assert torch.equal(after, fresh)
+    assert not torch.equal(w0, D._flat)
