@@ -20,11 +20,14 @@ N > 1: one process per GPU, gradients all-reduced with RCCL three times per step
 Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
   config.repeats          min / median / max ms_per_step over R further blocks of K steps (spread of this box),
   config.other_workloads  short legs of the other BASELINE shapes (c2 = --batch-size 256, c4 = dense crowd),
-  roofline                the dominant kernel timed with HIP events (fp32 MFMA peak; HBM view alongside),
+  roofline                the kernel that takes the most time per step, timed live with HIP events around every launch
+                          of an eager pass (sw_kernel_timing; fp32 MFMA peak), `roofline.kernels` = the top-6 table,
+                          `roofline.step_traffic` = HBM bytes per step from the committed PMC pass of these kernel sources,
   cpu_baseline            the CPU oracle on this host: block-diagonal port (all threads, 1 thread) and the
                           reference's own dense + per-agent-loop formulation at a reduced batch.
 """
 import argparse
+import ctypes
 import glob
 import hashlib
 import json
@@ -60,6 +63,30 @@ def alg_flops(B, P, To, Tp):
                 sw_dec_rollout_fwd=2.0 * B * (Tp * 41680 + (Tp - 1) * 33024),
                 sw_enc_lstm_fwd=2.0 * B * To * 33024,
                 sw_gen_wgrad=2.0 * B * ((To + Tp - 1) * 33024 + Tp * 41680))
+
+
+def kernel_alg_flops(B, P, To, Tp):
+    """Algorithmic FLOPs PER STEP of each kernel of the step (all of its launches together), MAC = 2 FLOP, from the
+    per-agent / per-pair MAC counts of SURVEY.md §8a (data-gradient passes = forward MACs, weight gradients = forward
+    MACs).  U + 1 = 2 discriminator updates + the generator-phase D pass."""
+    lstm, dec = 33024, 41680                              # EncoderLstm step (embed + LSTM), DecoderFC
+    d_lstm, d_obs, d_br = 17408, 2048 + 1024, 4 * Tp * 32 + 1024 + 4096 + 32 + 64     # D: LSTM step, obs fc, one branch
+    gen_rows = (To + Tp - 1) * lstm + Tp * dec
+    soc = B * 4096 + P * 6368
+    return {
+        "enc_lstm_fwd_kernel": 2.0 * B * To * lstm,
+        "enc_lstm_bwd_kernel": 2.0 * B * To * lstm,
+        "dec_rollout_fwd_kernel": 2.0 * B * (Tp * dec + (Tp - 1) * lstm) + 2.0 * B * To * d_lstm,   # + D's first obs LSTM (rides here)
+        "dec_rollout_bwd_kernel": 2.0 * B * (Tp * dec + (Tp - 1) * lstm),
+        "social_pool_fwd_kernel": 2.0 * soc,
+        "social_pool_bwd_rows_kernel": 2.0 * 2 * soc,     # recomputes the pair MLP + its data gradients
+        "social_pool_bwd_kernel": 2.0 * 3 * soc,          # ... + the pair-MLP weight gradients in registers
+        # 3 launches: pass 1 heads only (LSTM rode in the decode launch), pass 2 whole, generator phase (1 branch fwd + bwd)
+        "disc_fwd_kernel": 2.0 * B * ((d_obs + 2 * d_br) + (To * d_lstm + d_obs + 2 * d_br) + (To * d_lstm + d_obs + 2 * d_br)),
+        "disc_bwd_kernel": 2.0 * 2 * B * (To * d_lstm + d_obs + 2 * d_br),
+        # 3 launches: two D passes + the generator's (incl. the social block's rows when they are deferred)
+        "wgrad_partial_kernel": 2.0 * (2 * B * (To * d_lstm + d_obs + 2 * d_br) + B * gen_rows + soc),
+    }
 
 
 def alg_bytes(B, To, Tp):
@@ -132,7 +159,7 @@ def cpu_baseline(tracks, S, A, To, Tp, budget_s=10.0):
 class Leg:
     """One workload on this rank: trainer, resident synthetic batches and the stepping closures."""
 
-    def __init__(self, name, dev, pg, world, rank, scaling, global_scenes, KG):
+    def __init__(self, name, dev, pg, world, rank, scaling, global_scenes, KG, **trainer_kw):
         import socialways_amd as sw
         self.name, self.world, self.KG = name, world, KG
         S, A, To, Tp = WORKLOADS[name]
@@ -140,7 +167,7 @@ class Leg:
         self.strong = scaling == "strong"
         torch.manual_seed(0)                      # identical replicas on every rank
         np.random.seed(0)
-        self.tr = sw.SocialWaysTrainer(Tp, use_social=True, device=dev, process_group=pg)
+        self.tr = sw.SocialWaysTrainer(Tp, use_social=True, device=dev, process_group=pg, **trainer_kw)
         if scaling == "strong":
             # the same global dataset on every rank; this rank's rows = its scene-aligned shard of every packed batch
             Sg = global_scenes
@@ -160,15 +187,19 @@ class Leg:
         self.P = Sl * A * A if A > 1 else 0
         self.sb = np.stack([np.arange(Sl) * A, (np.arange(Sl) + 1) * A], axis=1).astype(np.int64)
         self.last = None
+        # z is drawn into a ring of preallocated host buffers (same generator calls, same values as torch.rand(B, Z)):
+        # a fresh 256 KB tensor per step went through the allocator 2400 times a second
+        self._zring = [torch.empty(self.Bg if self.strong else self.B, self.tr.noise_len) for _ in range(2 * max(KG, 1) + 2)]
+        self._zi = 0
 
     def draw(self, i):
         a = (i % N_BATCHES) * self.stride + self.row0
         zv = np.random.uniform(0, 0.1)                         # train.py:471-473, same host RNG use
         ov = np.random.uniform(0.9, 1.0)
-        if self.strong:                                        # z is drawn for the whole packed batch and sliced
-            noise = torch.rand(self.Bg, self.tr.noise_len)[self.row0:self.row0 + self.B]
-        else:
-            noise = torch.rand(self.B, self.tr.noise_len)      # host generator, copied to HBM inside the step
+        buf = self._zring[self._zi % len(self._zring)]
+        self._zi += 1
+        torch.rand(buf.shape, out=buf)                         # train.py:473, host generator; copied to HBM inside the step
+        noise = buf[self.row0:self.row0 + self.B] if self.strong else buf   # strong: drawn for the whole packed batch and sliced
         return self.data.obsv[a:a + self.B], self.data.pred[a:a + self.B], zv, ov, noise
 
     def one_step(self, i):
@@ -220,7 +251,7 @@ def main():
     ap.add_argument("--global-scenes", type=int, default=2048, help="--scaling strong: scenes of the ONE global packed batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true")
-    ap.add_argument("--dominant", default="sw_dec_rollout_bwd", help="C-ABI call timed with HIP events")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -262,24 +293,59 @@ def main():
             return float(t.item())
         return x
 
+    import gc
     leg = Leg(args.workload, dev, pg, world, rank, args.scaling, args.global_scenes, KG)
     tr, To, Tp, A = leg.tr, leg.To, leg.Tp, leg.A
     leg.prime()
     leg.run_steps(0, args.warmup)
+    # host-side noise sources of a 20-step window: the collector (a gen-2 pass over torch's module graph is ~10 ms) is off
+    # inside timed regions; the noise ring (Leg) keeps the allocator out of the loop
+    gc.collect()
+    gc.disable()
     dt = max_over_ranks(leg.timed(fence, args.warmup, args.steps))          # THE timed region: exactly K steps
     reps = [max_over_ranks(leg.timed(fence, args.warmup + (r + 1) * args.steps, args.steps)) for r in range(REPEATS)]
-    # Roofline leg: the timed region replays hipGraphs, where no per-kernel event can be placed, so the
-    # dominant kernel is timed right here with HIP events around its C-ABI call (on the launch stream)
-    # over a few EAGER steps of the same workload; profiles/ holds the rocprofv3 trace of the graph run.
+    # a sustained leg (>= ~2 s of back-to-back steps): long enough for an external GPU-busy sampler to see the device
+    sustained = None
+    if not args.no_sustained:
+        n_sus = max(args.steps, int(2.2 / max(dt / args.steps, 1e-5)) // KG * KG)
+        d_sus = max_over_ranks(leg.timed(fence, 0, n_sus))
+        sustained = {"steps": n_sus, "seconds": d_sus, "steps_s": n_sus * (world if args.scaling == "weak" else 1) / d_sus,
+                     "ms_per_step": 1e3 * d_sus / n_sus}
+    gc.enable()
+    # Roofline leg: the timed region replays hipGraphs, where no per-kernel event can be placed, so EVERY kernel launch
+    # of a few EAGER steps of the same workload is bracketed by HIP events on its launch stream (sw_kernel_timing); a
+    # spin kernel queued in front lets the host run ahead, so the launches reach the GPU back to back and the event
+    # intervals hold no host gaps.  profiles/ holds the rocprofv3 trace of the graph-replayed run for comparison.
     n_ev = max(4, min(args.steps, 20))
     tr.use_graph = False
     for i in range(2):
         leg.one_step(i)
-    L.TIMING = {"names": {args.dominant, args.dominant + "_aux"}, "events": []}   # the step calls the _aux entry of the same kernel
+    # inputs of the timed eager steps are placed on the device beforehand: a host-to-device copy inside the pass would
+    # make the host wait for the stream and the launches behind it would reach an idle GPU one by one
+    from socialways_amd import ops as sw_ops
+    scenes = sw_ops.SceneIndex.get(leg.sb, leg.B, dev)
+    ins = []
     for i in range(n_ev):
-        leg.one_step(i)
+        o, p_, zv, ov, nz = leg.draw(i)
+        ins.append((o.contiguous(), p_.contiguous(), torch.tensor([zv, ov], dtype=torch.float32).to(dev),
+                    tr._pad_z(nz.to(dev)).contiguous()))
+    part = torch.zeros(tr.n_unrolling_steps + 3, (leg.B + 15) // 16, 3, device=dev)
+    tr._row0, tr._vnoise = 0, None
     fence()
-    timing, L.TIMING = L.TIMING, None
+    lib = L.load()
+    lib.sw_kernel_timing(1)
+    lib.sw_debug_spin(float(os.environ.get("SW_BENCH_SPIN_US", 2500.0 * n_ev)), L.stream())
+    for o, p_, tg, nz in ins:
+        leg.last = tr._step_impl(o, p_, None, scenes, tg, nz, float(leg.data.ss), float(leg.Bg), part)
+    fence()
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.sw_kernel_timing_read(buf, len(buf))
+    lib.sw_kernel_timing(0)
+    ktimes = {}
+    for line in buf.value.decode().splitlines():
+        name, calls, total_us = line.split()
+        if name != "spin_kernel":
+            ktimes[name] = (int(calls), float(total_us))
     assert torch.isfinite(leg.last).all(), "non-finite losses"
     replicas_identical = None
     if world > 1:      # data-parallel replicas must hold bit-identical weights after the same all-reduced updates
@@ -292,26 +358,68 @@ def main():
     if pg is not None:
         tr.release_graphs()                     # recorded collectives go before their communicator
 
+    def short_leg(lg, n, w):
+        lg.prime()
+        lg.run_steps(0, w)
+        gc.collect()
+        gc.disable()
+        d = lg.timed(fence, w, n)
+        gc.enable()
+        assert torch.isfinite(lg.last).all(), "non-finite losses (%s)" % lg.name
+        return d
+
     other = None
-    if world == 1 and not args.no_other_workloads:
+    if world == 1 and pg is None and not args.no_other_workloads:
         other = {}
         del tr
+        leg.tr = None
         for name in sorted(WORKLOADS):
             if name == args.workload:
                 continue
-            leg.tr = None
             torch.cuda.empty_cache()
             lg = Leg(name, dev, None, 1, 0, "weak", 0, KG)
             n, w = OTHER_STEPS[name]
-            lg.prime()
-            lg.run_steps(0, w)
-            d = lg.timed(fence, w, n)
+            d = short_leg(lg, n, w)
             fl_o = alg_flops(lg.B, lg.P, lg.To, lg.Tp)
             S_o, A_o = WORKLOADS[name][:2]
             other[name] = {"workload": "%d scenes x %d agents x %d+%d" % (S_o, A_o, lg.To, lg.Tp), "steps": n, "warmup": w,
                            "steps_s": n / d, "ms_per_step": 1e3 * d / n, "step_alg_gflop": fl_o["step"] / 1e9,
                            "step_frac_of_fp32_peak": fl_o["step"] / (d / n) / (PEAK_FP32_TFLOPS * 1e12)}
-            assert torch.isfinite(lg.last).all(), "non-finite losses (%s)" % name
+            del lg
+        # The data-parallel step structure at N = 1 - the only scaling evidence a 1-GPU box can give: the same workload on a
+        # 1-rank RCCL group (SW_FORCE_DIST: all three all-reduces are issued, the Adam updates run behind them as kernels
+        # of their own instead of inside the gradient reductions).  `delta_us_per_step` = what the DP structure costs
+        # per step before any wire time; weak-scaling efficiency at N ranks <= t_plain / (t_dp1 + 3 x all-reduce latency).
+        if args.workload == "m1":
+            torch.cuda.empty_cache()
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29537")
+            os.environ["SW_FORCE_DIST"] = "1"
+            try:
+                torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                lg = Leg("m1", dev, torch.distributed.group.WORLD, 1, 0, "weak", 0, KG)
+                n, w = OTHER_STEPS["m1"]
+                d = short_leg(lg, n, w)
+                other["dp1_rccl"] = {"workload": "m1 on a 1-rank RCCL process group (3 all-reduces per step issued, Adam behind them)",
+                                     "steps": n, "steps_s": n / d, "ms_per_step": 1e3 * d / n,
+                                     "delta_us_per_step": 1e3 * (1e3 * d / n - 1e3 * dt / args.steps),
+                                     "collectives": "in-graph" if lg.tr._graph_collectives else "between graph segments",
+                                     "implied_weak_scaling_ceiling": (dt / args.steps) / (d / n)}
+                lg.tr.release_graphs()
+                del lg
+                torch.distributed.destroy_process_group()
+            except Exception as e:      # noqa: BLE001 - a box without a working RCCL must not lose the bench line
+                other["dp1_rccl"] = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")}
+            finally:
+                os.environ.pop("SW_FORCE_DIST", None)
+            # the best-of-K variety term (K = 20 rollouts folded into one batch of 20 x 2048 agents) as a
+            # throughput stress of the generator path; eager steps (the folded step is not graph-captured)
+            torch.cuda.empty_cache()
+            lg = Leg("m1", dev, None, 1, 0, "weak", 0, 1, use_variety_loss="fixed", variety_k=20, use_l2_loss=True)
+            n, w = 40, 6
+            d = short_leg(lg, n, w)
+            other["m1_variety_k20"] = {"workload": "m1 + best-of-20 variety loss (use_variety_loss='fixed'): generator batch 40 960 agents",
+                                       "steps": n, "steps_s": n / d, "ms_per_step": 1e3 * d / n}
             del lg
 
     if rank == 0:
@@ -319,18 +427,30 @@ def main():
         B, P = leg.B, leg.P
         fl = alg_flops(B, P, To, Tp)
         per_step = dt / args.steps
-        kern_ms = [e0.elapsed_time(e1) for _, e0, e1 in timing["events"]]
-        kern_s = float(np.mean(kern_ms)) * 1e-3 if kern_ms else float("nan")
-        achieved = fl.get(args.dominant, float("nan")) / kern_s / 1e12
-        # HBM traffic of the dominant kernel: from the committed PMC pass (separate --pmc runs, tools/collect_profiles.sh) -
-        # valid only for the kernel sources it was taken with (same sha) and this workload; otherwise null
-        traffic, traffic_src = None, None
+        # per-kernel table of the eager roofline pass: launches / step, mean launch time, algorithmic GFLOP / step, fraction
+        kfl = kernel_alg_flops(B, P, To, Tp)
+        rows = []
+        for name, (calls, total_us) in ktimes.items():
+            us_step = total_us / n_ev
+            gf = kfl.get(name)
+            rows.append({"name": name, "launches_per_step": calls / n_ev, "avg_us": total_us / calls, "us_per_step": us_step,
+                         "alg_gflop_per_step": (gf / 1e9) if gf else None,
+                         "frac": (gf / (us_step * 1e-6) / (PEAK_FP32_TFLOPS * 1e12)) if gf else None})
+        rows.sort(key=lambda r: -r["us_per_step"])
+        top = rows[0]
+        kern_s = top["avg_us"] * 1e-6
+        achieved = (top["alg_gflop_per_step"] or float("nan")) * 1e9 / (top["us_per_step"] * 1e-6) / 1e12
+        # HBM traffic: from the committed PMC pass (separate --pmc runs, tools/collect_profiles.sh) - valid only for the
+        # kernel sources it was taken with (same sha) and this workload; otherwise null
+        traffic, step_traffic, traffic_src = None, None, None
         sha = kernel_src_sha16()
         for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % args.workload)), reverse=True):
             rec = json.load(open(pmc))
             meta = rec.get("_meta", {})
             if meta.get("kernel_src_sha16") == sha and args.scaling == "weak":
-                traffic = rec.get(args.dominant, {}).get("hbm_bytes_per_launch")
+                by_kernel = {v.get("kernel", "").replace("void ", "").split("<")[0]: v for k, v in rec.items() if not k.startswith("_")}
+                traffic = by_kernel.get(top["name"], {}).get("hbm_bytes_per_launch")
+                step_traffic = rec.get("_step", {}).get("hbm_bytes_per_step")
                 traffic_src = {"file": os.path.relpath(pmc, ROOT), "commit": meta.get("commit"), "kernel_src_sha16": sha}
                 break
         if traffic_src is None:
@@ -360,18 +480,28 @@ def main():
                        "step_frac_of_hbm_peak": alg_bytes(B, To, Tp) / per_step / PEAK_HBM_BPS,
                        "repeats": {"n": len(rep_ms), "steps_each": args.steps, "ms_per_step_min": rep_ms[0],
                                    "ms_per_step_median": rep_ms[len(rep_ms) // 2], "ms_per_step_max": rep_ms[-1]},
+                       "sustained": sustained,
                        "other_workloads": other},
-            "roofline": {"bound": "mfma", "kernel": args.dominant.replace("sw_", "") + "_kernel", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": top["name"], "achieved": achieved,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
-                         "avg_launch_ms": kern_s * 1e3, "launches": len(kern_ms), "traffic": traffic,
+                         "avg_launch_ms": kern_s * 1e3, "launches": int(round(top["launches_per_step"] * n_ev)),
+                         "launches_per_step": top["launches_per_step"],
+                         "how": "HIP events around every kernel launch of %d eager steps (sw_kernel_timing), host running ahead "
+                                "of the GPU behind a spin kernel; algorithmic FLOPs of all of the kernel's launches in a step "
+                                "/ their summed time" % n_ev,
+                         "kernels": rows[:6],
+                         "eager_step_kernel_us": sum(r["us_per_step"] for r in rows),
+                         "traffic": traffic, "step_traffic": step_traffic,
+                         "step_traffic_vs_algorithmic": (step_traffic / alg_bytes(B, To, Tp)) if step_traffic else None,
                          "traffic_source": traffic_src,
                          # north_star also asks for the HBM view: measured bytes / launch time vs 8 TB/s
                          "hbm_GBps": (traffic / kern_s / 1e9) if traffic else None,
-                         "hbm_frac": (traffic / kern_s / PEAK_HBM_BPS) if traffic else None},
+                         "hbm_frac": (traffic / kern_s / PEAK_HBM_BPS) if traffic else None,
+                         "step_hbm_GBps": (step_traffic / per_step / 1e9) if step_traffic else None,
+                         "step_hbm_frac": (step_traffic / per_step / PEAK_HBM_BPS) if step_traffic else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(leg.tracks, S if args.workload != "c4" else 16, A, To, Tp)
-        import ctypes
         ctypes.CDLL(None).fflush(None)          # RCCL's version banner sits in the C stdio buffer: keep the JSON line last
         print(json.dumps(res), flush=True)
     if pg is not None:

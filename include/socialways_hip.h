@@ -51,24 +51,6 @@ enum {
 };
 
 int sw_version(void);
-/* Tiling of the time-unrolled kernels: 0 = chosen by batch size (default; currently always the 16-agent workgroups
- * on v_mfma_f32_16x16x4_f32 - see DESIGN.md for the measurements), 1 = 16-agent tiles always, 2 = 8-agent workgroups
- * on v_mfma_f32_4x4x1_16B_f32 where a kernel has them (encoder forward, decode forward; 256 workgroups at the metric
- * shape).  Results of the two tilings differ in summation order only.  Environment SW_TILE_MODE sets the start value. */
-int sw_set_tile_mode(int mode);
-int sw_get_tile_mode(void);
-/* Co-scheduled weight gradients ("riders"): while a backward kernel runs its 16-agent tiles on at most half of the CUs
- * (B <= 2048), the spare workgroups of the same launch run the deferred weight-gradient GEMM jobs as soon as the rows
- * they need are published.  The hand-off between workgroups goes through UNCACHED device memory: with riding on, the
- * caller must keep the delta workspaces (SW_WS_GDELTA, SW_WS_DDELTA) in memory obtained from sw_uc_alloc.
- * sw_set_cosched(0 / 1); environment SW_COSCHED sets the start value (default 0).                                     */
-int sw_set_cosched(int on);
-int sw_get_cosched(void);
-void* sw_uc_alloc(size_t bytes);     /* hipExtMallocWithFlags(hipDeviceMallocUncached); NULL on failure */
-void sw_uc_free(void* p);
-/* 1 if a batch of B agents currently runs on 8-agent tiles.  Callers size per-tile partial buffers (ADE/FDE and loss
- * sums: one triple per tile) for ceil(B/8) tiles and do not hand auxiliary work to launches that fill the chip.   */
-int sw_serial_narrow(int B);
 const char* sw_last_error(void);
 
 /* Packed-weight layout: number of floats of group `grp` and the float offset of its `idx`-th
@@ -369,6 +351,23 @@ int sw_stage_step_img(const float* slot, int B, int To, int Tp, float* obsv_dst,
 int sw_disc_image_floats(int Tp);
 int sw_disc_image_table(int Tp, int* tab_host);
 int sw_disc_images(const float* d_w, float* img, const int* tab, int Tp, void* stream);
+
+/* ---- Adam on a packed buffer (train.py:379-385: lr, betas, eps; no weight decay), torch's fused Adam restated operation
+ *      by operation (the arithmetic of sw_disc_bwd_gan_adam / sw_gen_wgrad_adam as a kernel of its own): the optimizer
+ *      step of data-parallel ranks, whose gradients pass through an all-reduce first.  step = device scalar, 1-based
+ *      index of the update.  disc_Tp > 0: w is the packed Discriminator and its registered images (sw_disc_images)
+ *      follow the update; 0 otherwise.                                                                          */
+int sw_adam_packed(float* w, const float* g, float* m, float* v, long long n, const float* step, double lr, double beta1,
+                   double beta2, double eps, int disc_Tp, void* stream);
+
+/* ---- measurement aids.  sw_kernel_timing(1): every kernel launch of the library is bracketed by two HIP events on its
+ *      own stream (never inside a graph capture) until sw_kernel_timing(0); sw_kernel_timing_read(buf, cap) waits for
+ *      the device and writes one line "kernel calls total_us" per kernel, returning the bytes needed.  sw_debug_spin
+ *      queues a kernel that occupies the stream for ~us microseconds (queued in front of a timed sequence it lets the
+ *      host run ahead, so the event intervals hold no launch gaps).                                                */
+int sw_kernel_timing(int on);
+int sw_kernel_timing_read(char* buf, int cap);
+int sw_debug_spin(double us, void* stream);
 
 /* ---- ADE/FDE partial sums of train.py:546-551:
  *      out[3] = { sum_{b,t} err / Tp, sum_b err[:, -1], sum_{b,t} err^2 },  err = |(p_hat - p) / ss|   */

@@ -22,13 +22,6 @@ _vp, _i, _f, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longl
 PROTOTYPES = {
     "sw_version": (_i, []),
     "sw_last_error": (ctypes.c_char_p, []),
-    "sw_set_tile_mode": (_i, [_i]),
-    "sw_get_tile_mode": (_i, []),
-    "sw_serial_narrow": (_i, [_i]),
-    "sw_set_cosched": (_i, [_i]),
-    "sw_get_cosched": (_i, []),
-    "sw_uc_alloc": (_vp, [ctypes.c_size_t]),
-    "sw_uc_free": (None, [_vp]),
     "sw_param_count": (_i, [_i, _i]),
     "sw_param_offset": (_i, [_i, _i, _i]),
     "sw_param_tensors": (_i, [_i]),
@@ -79,6 +72,11 @@ PROTOTYPES = {
     "sw_disc_image_table": (_i, [_i, _vp]),
     "sw_disc_images": (_i, [_vp, _vp, _vp, _i, _vp]),
     "sw_ade_fde": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
+    "sw_adam_packed": (_i, [_vp, _vp, _vp, _vp, _ll, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                            ctypes.c_double, _i, _vp]),
+    "sw_kernel_timing": (_i, [_i]),
+    "sw_kernel_timing_read": (_i, [ctypes.c_char_p, _i]),
+    "sw_debug_spin": (_i, [ctypes.c_double, _vp]),
 }
 
 _lib = None

@@ -373,8 +373,18 @@ __device__ __forceinline__ void disc_images_scatter(const float* __restrict__ d_
   }
 }
 
-// tiling choice of the serial kernels (sw_misc.hip: sw_set_tile_mode / SW_TILE_MODE)
-bool sw_narrow_tiles(int B);
+// Every kernel launch of the library goes through SW_LAUNCH: with sw_kernel_timing(1) on (bench.py's roofline leg,
+// tools/) each launch is bracketed by two HIP events on ITS stream and sw_kernel_timing_read() reports calls / total
+// time per kernel; off (always inside graph capture) it is hipLaunchKernelGGL and nothing else.
+void sw_ktime_begin(const char* name, hipStream_t st);
+void sw_ktime_end(hipStream_t st);
+extern bool g_sw_ktime_on;
+#define SW_LAUNCH(kernel, grid, block, lds, stream, ...)                           \
+  do {                                                                              \
+    if (g_sw_ktime_on) sw_ktime_begin(#kernel, (stream));                           \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);              \
+    if (g_sw_ktime_on) sw_ktime_end((stream));                                      \
+  } while (0)
 
 // host-side error plumbing ---------------------------------------------------------------------
 void sw_set_error(const char* what, hipError_t e);

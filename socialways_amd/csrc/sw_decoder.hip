@@ -798,11 +798,6 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
   }
 }
 
-int sw_dec_rollout_fwd8_launch(const float* obsv, int To, const float* z, const float* S_pool, const float* hT,
-                               const float* cT, const float* enc_w, const float* dec_w, int B, int Tp, float* pred4,
-                               float* h_end, float* c_end, float* gsave, const float* gt, float inv_ss, float* ade_part,
-                               hipStream_t stream);
-
 static int set_lds(const void* fn, int bytes) {
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) {
@@ -821,11 +816,6 @@ extern "C" int sw_dec_rollout_fwd_aux(const float* obsv, int To, const float* z,
   if (ade_part && !gt) return SW_EARG;
   if ((d_w != nullptr) != (dsave != nullptr)) return SW_EARG;
   if (B == 0) return SW_OK;
-  // 8-agent tiles (sw_decoder8.hip) fill the chip themselves: no idle workgroups for the discriminator's observation
-  // LSTM, so a caller that hands it over (d_w) gets the 16-agent kernel
-  if (!d_w && sw_narrow_tiles(B))
-    return sw_dec_rollout_fwd8_launch(obsv, To, z, S_pool, hT, cT, enc_w, dec_w, B, Tp, pred4, h_end, c_end, gsave, gt, inv_ss,
-                                      ade_part, (hipStream_t)stream);
   static bool attr = false;
   if (!attr) {
     if (int rc = set_lds((const void*)dec_rollout_fwd_kernel, FwdLds::total * 4)) return rc;
@@ -835,7 +825,7 @@ extern "C" int sw_dec_rollout_fwd_aux(const float* obsv, int To, const float* z,
   // rows of the D observation LSTM inside the save buffer of sw_disc_fwd (independent of its branch count)
   float* act = dsave;
   float* x4s = dsave ? dsave + (size_t)To * B * 384 : nullptr;
-  hipLaunchKernelGGL(dec_rollout_fwd_kernel, dim3(d_w ? 2 * tiles : tiles), dim3(SW_THREADS), FwdLds::total * 4,
+  SW_LAUNCH(dec_rollout_fwd_kernel, dim3(d_w ? 2 * tiles : tiles), dim3(SW_THREADS), FwdLds::total * 4,
                      (hipStream_t)stream, obsv, To, z, S_pool, hT, cT, enc_w, dec_w, B, Tp, pred4, h_end, c_end, gsave, gt,
                      inv_ss, ade_part, d_w, act, x4s, sw_gen_images_for(enc_w, dec_w));
   SW_CHECK_LAUNCH("dec_rollout_fwd_kernel");
@@ -866,7 +856,7 @@ extern "C" int sw_dec_rollout_bwd_aux(const float* dpred4, const float* enc_w, c
   const int tiles = (B + SW_TILE - 1) / SW_TILE;
   int extra = aux_n > 0 ? (int)((aux_n + SW_THREADS - 1) / SW_THREADS) : 0;
   if (extra > 64) extra = 64;
-  hipLaunchKernelGGL(dec_rollout_bwd_kernel, dim3(tiles + extra), dim3(SW_THREADS), BwdLds::total * 4, (hipStream_t)stream,
+  SW_LAUNCH(dec_rollout_bwd_kernel, dim3(tiles + extra), dim3(SW_THREADS), BwdLds::total * 4, (hipStream_t)stream,
                      dpred4, enc_w, dec_w, gsave, B, To, Tp, gdelta, dhT, dcT, dS_pool, aux_src, aux_dst, aux_mask, aux_n,
                      sw_gen_images_for(enc_w, dec_w));
   SW_CHECK_LAUNCH("dec_rollout_bwd_kernel");

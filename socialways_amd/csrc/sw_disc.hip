@@ -495,15 +495,8 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_bwd_kernel(
     const float* __restrict__ d_w, const float* __restrict__ dsave, const float* __restrict__ dlabel_a,
     const float* __restrict__ dlabel_b, const float* __restrict__ dcode_a, const float* __restrict__ dcode_b, int nb,
     int B, int To, int Tp, int want_w, float* __restrict__ ddelta, float* __restrict__ dpred_a,
-    float* __restrict__ dpred_b, DiscLoss gl, WgBatch wbatch, WgRide ride, const float* __restrict__ dimg) {
+    float* __restrict__ dpred_b, DiscLoss gl, const float* __restrict__ dimg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // Workgroups beyond the agent tiles are RIDERS (sw_wgrad_dev.h): they run the weight-gradient jobs of this very
-  // pass while the tiles compute - rows of the heads (event 0), then of BPTT step t (event To - t) as they are published
-  if ((int)blockIdx.x >= (B + SW_TILE - 1) / SW_TILE) {
-    wg_ride(wbatch, ride, (int)blockIdx.x - (B + SW_TILE - 1) / SW_TILE, smem);
-    return;
-  }
-  const bool riding = ride.nriders > 0;
   const HeadLdsB L = head_lds_b(Tp, 0);
   float* dgbuf = smem + L.pe0T;  // [2][16][260], aliasing the prediction heads' images / deltas (dead when the BPTT starts)
   const swp::Disc O = swp::disc(Tp);
@@ -711,9 +704,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_bwd_kernel(
     st4(smem + L.do1 + ln * LD32 + m0 + 4 * lg, acc);
     if (live) st4(ddelta + dd.do1 + (size_t)b * 32 + m0 + 4 * lg, acc);
   }
-  if (riding) wg_drain();                        // every row of the heads is in memory ...
   sw_barrier();
-  if (riding) wg_signal(ride.cnt + 0);           // ... for all four waves: event 0
   f32x4 dh = {0.f, 0.f, 0.f, 0.f}, dc = {0.f, 0.f, 0.f, 0.f};
   dh = tile_mm_rt(smem + L.of0T + (u0 + ln) * LD32 + 4 * lg, smem + L.do1 + ln * LD32 + 4 * lg, 2, dh);
   LstmWT WT;
@@ -760,8 +751,6 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_bwd_kernel(
     dgg -= dgg_step;
     SW_STAMP(12);
     sw_barrier();
-    // behind this barrier every wave has drained the rows of the PREVIOUS step (wg_drain at its end): event To - (t+1)
-    if (riding && t + 1 < To) wg_signal(ride.cnt + (To - (t + 1)));
     SW_STAMP(13);
     if constexpr (decltype(nx)::value) dh = lstm_dh_prev(WT, &dgbuf[(t & 1) * 16 * SW_GLD + ln * SW_GLD + 4 * lg]);
     if constexpr (decltype(pf)::value) {
@@ -770,16 +759,11 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_bwd_kernel(
       ct = nct;
       cprev = ncp;
     }
-    if (riding) wg_drain();                        // the dgates rows of step t (stored in front of the barrier above)
     SW_STAMP(14);
   };
   for (int t = To - 1; t >= 2; --t) step(t, T_{}, T_{}, T_{});
   if (To > 1) step(1, T_{}, F_{}, T_{});
   step(0, F_{}, F_{}, F_{});
-  if (riding) {                                    // the rows of step 0: event To
-    sw_barrier();
-    wg_signal(ride.cnt + To);
-  }
   SW_STAMP(11);
 }
 
@@ -819,7 +803,7 @@ extern "C" int sw_disc_fwd(const float* obsv, int To, int x_mode, const float* c
   if (int rc = disc_fwd_lds(lds)) return rc;
   const int tiles = (B + SW_TILE - 1) / SW_TILE;
   const int split = (nb == 2 && 2 * tiles <= SW_SPLIT_MAX_WGS) ? 1 : 0;   // idle CUs: one workgroup per (tile, branch)
-  hipLaunchKernelGGL(disc_fwd_kernel, dim3(split ? 2 * tiles : tiles), dim3(SW_THREADS), lds, (hipStream_t)stream,
+  SW_LAUNCH(disc_fwd_kernel, dim3(split ? 2 * tiles : tiles), dim3(SW_THREADS), lds, (hipStream_t)stream,
                      obsv, To, x_mode, pred4[0], nb > 1 ? pred4[1] : nullptr, nb, d_w, B, Tp, label[0],
                      nb > 1 ? label[1] : nullptr, code[0], nb > 1 ? code[1] : nullptr, dsave, save_lstm, split, w_snapshot, 0, DiscLoss{}, nullptr,
                      sw_disc_images_for(d_w, Tp).img);
@@ -842,7 +826,7 @@ extern "C" int sw_disc_dpred(const float* obsv, int To, int x_mode, const float*
   if (int rc = disc_fwd_lds(lds)) return rc;
   DiscLoss gl{targets, z, t_idx, t_idx, g_label, g_code, 1, loss_part};
   const int tiles = (B + SW_TILE - 1) / SW_TILE;
-  hipLaunchKernelGGL(disc_fwd_kernel, dim3(tiles), dim3(SW_THREADS), lds, (hipStream_t)stream, obsv, To, x_mode, pred4,
+  SW_LAUNCH(disc_fwd_kernel, dim3(tiles), dim3(SW_THREADS), lds, (hipStream_t)stream, obsv, To, x_mode, pred4,
                      (const float*)nullptr, 1, d_w, B, Tp, label, (float*)nullptr, code, (float*)nullptr, (float*)nullptr, 0, 0,
                      (float*)nullptr, 1, gl, dpred4, sw_disc_images_for(d_w, Tp).img);
   SW_CHECK_LAUNCH("disc_fwd_kernel");
@@ -868,7 +852,6 @@ static int disc_bwd_impl(const float* d_w, const float* dsave, const float* cons
   hipStream_t st = (hipStream_t)stream;
   const int tiles = (B + SW_TILE - 1) / SW_TILE;
   WgBatch wb;
-  WgRide ride;
   if (d_d_w) {
     const swp::Disc O = swp::disc(Tp);
     const DSave ds = dsave_layout(B, To, Tp, nb);
@@ -889,35 +872,13 @@ static int disc_bwd_impl(const float* d_w, const float* dsave, const float* cons
     rc_add |= wg_add(wb, ddelta + dd.dl1, 32, dsave + ds.both, 64, R, 32, 64, d_d_w + O.la0w, 64, d_d_w + O.la0b, nullptr, 0);
     rc_add |= wg_add(wb, ddelta + dd.dcod, 4, dsave + ds.l1, 32, R, 2, 32, d_d_w + O.la1w, 32, d_d_w + O.la1b, nullptr, 0);
     if (rc_add) return SW_ESHAPE;
-    // Riders: with at most half of the CUs busy on tiles, the other workgroups of the launch run these jobs while the
-    // BPTT proceeds (the caller keeps ddelta in uncached memory: sw_set_cosched)
-    const int nriders = (wg_cosched() && tiles <= 128 && To + 1 < SW_RIDE_SLOTS) ? 256 - tiles : 0;
-    if (nriders > 0) {
-      if (wg_finalize_for(wb, 2 * nriders) > SW_WG_WS_FLOATS) return SW_ESHAPE;
-      struct Need : WgNeed {
-        const float* dg; int B, To;
-        int operator()(const WgProblem& P, int rbeg, int rend) const override {
-          if (P.delta != dg) return 0;                    // heads: event 0
-          return To - rbeg / B;                           // BPTT runs t = To-1 .. 0: the job's EARLIEST step completes last
-        }
-      } need;
-      need.dg = ddelta + dd.dgates; need.B = B; need.To = To;
-      const unsigned long long key = ((unsigned long long)B << 24) ^ ((unsigned long long)To << 16) ^ ((unsigned long long)Tp << 8) ^ (unsigned long long)nb;
-      if (int rc = wg_ride_setup(wb, ride, 0, key, nriders, (unsigned)tiles, To + 1, wgrad_ws, need)) return rc;
-      lds = lds > SW_WG_RED_FLOATS * 4 ? lds : SW_WG_RED_FLOATS * 4;
-      if (attr < lds) {
-        if (int rc = set_lds((const void*)disc_bwd_kernel, lds)) return rc;
-        attr = lds;
-      }
-    }
   }
-  hipLaunchKernelGGL(disc_bwd_kernel, dim3(tiles + ride.nriders), dim3(SW_THREADS), lds, st, d_w, dsave,
+  SW_LAUNCH(disc_bwd_kernel, dim3(tiles), dim3(SW_THREADS), lds, st, d_w, dsave,
                      dlabel[0], nb > 1 ? dlabel[1] : nullptr, dcode[0], nb > 1 ? dcode[1] : nullptr, nb, B, To, Tp,
-                     d_d_w ? 1 : 0, ddelta, dpred4 ? dpred4[0] : nullptr, (dpred4 && nb > 1) ? dpred4[1] : nullptr, gl, wb, ride,
+                     d_d_w ? 1 : 0, ddelta, dpred4 ? dpred4[0] : nullptr, (dpred4 && nb > 1) ? dpred4[1] : nullptr, gl,
                      sw_disc_images_for(d_w, Tp).img);
   SW_CHECK_LAUNCH("disc_bwd_kernel");
   if (!d_d_w) return SW_OK;
-  if (ride.nriders > 0) return wg_reduce_launch_adam(wb, wgrad_ws, adam, st);
   WgAdam ad = adam;
   return wg_launch_adam(wb, wgrad_ws, ad, st);
 }
@@ -1013,7 +974,7 @@ extern "C" int sw_disc_images(const float* d_w, float* img, const int* tab, int 
     return SW_OK;
   }
   if (!d_w || !tab || Tp < 1 || Tp > 64) return SW_EARG;
-  hipLaunchKernelGGL(disc_images_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, d_w, img, tab, swp::disc(Tp).n);
+  SW_LAUNCH(disc_images_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, d_w, img, tab, swp::disc(Tp).n);
   SW_CHECK_LAUNCH("disc_images_kernel");
   sw_disc_images_register(d_w, img, tab, Tp);
   return SW_OK;

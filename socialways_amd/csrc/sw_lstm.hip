@@ -3,7 +3,6 @@
 // registers, h exchanged through a double-buffered 4 KB LDS tile: one barrier per time step.
 #include "../../include/socialways_hip.h"
 #include "sw_lstm_dev.h"
-#include "sw_n8.h"
 #include <type_traits>
 
 // XMODE 0: x = positions [B][T][2] (4-d state formed on the fly); 1: x = [B][T][4].  ACT / Y / X4S: which per-step
@@ -88,95 +87,6 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
   }
   st4(hT + (size_t)b * 64 + u0 + 4 * lg, h);
   st4(cT + (size_t)b * 64 + u0 + 4 * lg, c);
-}
-
-// The same on 8-agent tiles (sw_n8.h): twice the workgroups, half the matrix work per workgroup.  Template parameters
-// and the no-conditional-memory-operation rules as above; padding agents of the last tile are replicas of agent B-1.
-template <int XMODE, bool ACT, bool Y, bool X4S>
-__global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd8_kernel(
-    const float* __restrict__ x, const float* __restrict__ enc_w, const float* __restrict__ h0,
-    const float* __restrict__ c0, int B, int T, float* __restrict__ hT, float* __restrict__ cT,
-    float* __restrict__ y, float* __restrict__ act, float* __restrict__ x4s, int t0, const float* __restrict__ aux_src,
-    float* __restrict__ aux_dst, long long aux_n) {
-  const int tiles = (B + SW8_TILE - 1) / SW8_TILE;
-  if ((int)blockIdx.x >= tiles) {
-    const long long n4 = aux_n >> 2, stride = (long long)(gridDim.x - tiles) * SW_THREADS;
-    for (long long i = (long long)(blockIdx.x - tiles) * SW_THREADS + threadIdx.x; i < n4; i += stride)
-      st4(aux_dst + 4 * i, ld4(aux_src + 4 * i));
-    return;
-  }
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* w_lds = smem;                                      // [256][SW8_WLD]  prologue only: W_ih, then W_hh
-  float* wx_lds = smem + 256 * SW8_WLD;                     // [256][4]
-  float* bx_lds = wx_lds + 1024;                            // [256]
-  float (*hbuf)[SW8_TILE * SW8_LD64] = reinterpret_cast<float (*)[SW8_TILE * SW8_LD64]>(bx_lds + 256);   // [2][8][80]
-  const Lstm8Lane L;
-  const int a0 = blockIdx.x * SW8_TILE + 4 * L.ag;
-  const int bA = min(a0 + L.ai, B - 1);                     // agent whose input / h this lane feeds as the A operand
-  int bD[4];                                                // agents of the result registers
-#pragma unroll
-  for (int r = 0; r < 4; ++r) bD[r] = min(a0 + r, B - 1);
-  Lstm8W W;
-  {   // both 64 KB weight matrices: coalesced loads issued together, parked in LDS one after the other (the kernel
-      // stays below half of the CU's LDS and 256 registers: the z-copy workgroups co-reside with the tiles)
-    f32x4 va[16], vb[16];
-    sw8_stage256_load(vb, enc_w + swp::ENC_WIH);
-    sw8_stage256_load(va, enc_w + swp::ENC_WHH);
-    sw8_stage256_store(vb, w_lds);
-    sw_barrier();
-    lstm8_prep_rows_lds(enc_w + swp::ENC_EMB_W, enc_w + swp::ENC_EMB_B, w_lds, enc_w + swp::ENC_BIH, enc_w + swp::ENC_BHH,
-                        wx_lds, bx_lds);
-    sw_barrier();
-    sw8_stage256_store(va, w_lds);
-  }
-  sw_barrier();
-  lstm8_load_whh(W, w_lds, L, SW8_WLD);
-  f32x4 c = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    if (h0) h[r] = h0[(size_t)bD[r] * 64 + L.u];
-    if (c0) c[r] = c0[(size_t)bD[r] * 64 + L.u];
-  }
-  lstm8_put_h(hbuf[0], L, h);
-  sw_barrier();
-  lstm8_load_wx(W, wx_lds, bx_lds, L);
-
-  const int comp = L.blk & 3;
-  float xa, xq = 0.f;
-  auto load_x = [&](int t) {
-    if constexpr (XMODE == 0) obs_x4_load(x, bA, t, T, comp, xa, xq);
-    else xa = x[((size_t)bA * T + t) * 4 + comp];
-  };
-  load_x(0);
-  asm volatile("" : "+v"(xa), "+v"(xq));   // waited for HERE: the loop header must see no pending load on any path in
-  const int o_gate0 = (L.up ? 64 : 0) + L.u, o_gate1 = (L.up ? 192 : 128) + L.u, o_state = (L.up ? 320 : 256) + L.u;
-  const float* hrow = &hbuf[0][(4 * L.ag + L.ai) * SW8_LD64 + 4 * L.blk];
-  for (int t = 0; t < T; ++t) {
-    const float xb = XMODE == 0 ? xa - (comp >= 2 ? xq : 0.f) : xa;
-    load_x(min(t + 1, T - 1));
-    f32x4 g0, g1;
-    lstm8_cell(W, L, xb, hrow + (t & 1) * SW8_TILE * SW8_LD64, g0, g1, c, h);
-    lstm8_put_h(hbuf[(t + 1) & 1], L, h);
-    if constexpr (ACT) {
-      float* trow = act + (size_t)(t0 + t) * B * 384;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float* row = trow + (size_t)bD[r] * 384;
-        row[o_gate0] = g0[r];
-        row[o_gate1] = g1[r];
-        row[o_state] = L.up ? h[r] : c[r];
-      }
-    }
-    if constexpr (Y) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) y[((size_t)bD[r] * T + t) * 64 + L.u] = h[r];
-    }
-    if constexpr (X4S) x4s[((size_t)(t0 + t) * B + bA) * 4 + comp] = xb;   // every lane holds one (agent, component)
-    sw_barrier();
-    asm volatile("" : "+v"(xa), "+v"(xq));   // the prefetched input is not touched before this point
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) (L.up ? cT : hT)[(size_t)bD[r] * 64 + L.u] = L.up ? c[r] : h[r];
 }
 
 // BPTT.  Per step: elementwise gate gradients (lane-local) -> dgates row to HBM (for the
@@ -290,7 +200,7 @@ extern "C" int sw_traj_4d(const float* obsv, const float* pred, int B, int To, i
   if (!obsv || !obsv4 || B < 0 || To < 2 || (pred && (!pred4 || Tp < 1))) return SW_EARG;
   if (B == 0) return SW_OK;
   int n = B * To + (pred ? B * Tp : 0);
-  hipLaunchKernelGGL(traj4d_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, obsv, pred, B,
+  SW_LAUNCH(traj4d_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, obsv, pred, B,
                      To, Tp, obsv4, pred4);
   SW_CHECK_LAUNCH("traj4d_kernel");
   return SW_OK;
@@ -304,26 +214,13 @@ extern "C" int sw_enc_lstm_fwd_aux(const float* x, int x_mode, const float* enc_
   if (aux_n < 0 || (aux_n & 3) || (aux_n > 0 && (!aux_src || !aux_dst))) return SW_EARG;
   if (x_mode == 0 && T < 2) return SW_ESHAPE;  // the observation velocity rule needs 2 points
   if (B == 0) return SW_OK;
-  const bool narrow = sw_narrow_tiles(B);
   const float* gimg = sw_gen_images_for(enc_w, nullptr);
-  const int tiles = narrow ? (B + SW8_TILE - 1) / SW8_TILE : (B + SW_TILE - 1) / SW_TILE;
+  const int tiles = (B + SW_TILE - 1) / SW_TILE;
   int extra = aux_n > 0 ? (int)((aux_n / 4 + SW_THREADS - 1) / SW_THREADS) : 0;
   if (extra > 64) extra = 64;
-  constexpr int lds8 = (256 * SW8_WLD + 1280 + 2 * SW8_TILE * SW8_LD64) * 4;   // 79 872 B: two workgroups per CU
 #define SW_ENC_FWD(XM, A, Y_, X4)                                                                                   \
-  if (narrow) {                                                                                                     \
-    static bool attr = false;                                                                                       \
-    if (!attr) {                                                                                                    \
-      hipError_t e = hipFuncSetAttribute((const void*)enc_lstm_fwd8_kernel<XM, A, Y_, X4>,                          \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds8);                         \
-      if (e != hipSuccess) { sw_set_error("hipFuncSetAttribute(enc_lstm_fwd8)", e); return SW_EHIP; }               \
-      attr = true;                                                                                                  \
-    }                                                                                                               \
-    hipLaunchKernelGGL((enc_lstm_fwd8_kernel<XM, A, Y_, X4>), dim3(tiles + extra), dim3(SW_THREADS), lds8, (hipStream_t)stream, \
-                       x, enc_w, h0, c0, B, T, hT, cT, y, act, x4s, t0, aux_src, aux_dst, aux_n);                   \
-  } else                                                                                                            \
-    hipLaunchKernelGGL((enc_lstm_fwd_kernel<XM, A, Y_, X4>), dim3(tiles + extra), dim3(SW_THREADS), 0, (hipStream_t)stream, \
-                       x, enc_w, h0, c0, B, T, hT, cT, y, act, x4s, t0, aux_src, aux_dst, aux_n, gimg)
+  SW_LAUNCH((enc_lstm_fwd_kernel<XM, A, Y_, X4>), dim3(tiles + extra), dim3(SW_THREADS), 0, (hipStream_t)stream,    \
+            x, enc_w, h0, c0, B, T, hT, cT, y, act, x4s, t0, aux_src, aux_dst, aux_n, gimg)
   switch ((x_mode ? 8 : 0) | (act ? 4 : 0) | (y ? 2 : 0) | (x4s ? 1 : 0)) {
     case 0: SW_ENC_FWD(0, false, false, false); break;
     case 1: SW_ENC_FWD(0, false, false, true); break;
@@ -359,10 +256,10 @@ extern "C" int sw_enc_lstm_bwd(const float* enc_w, const float* act, const float
   if (B == 0) return SW_OK;
   const float* gimg = sw_gen_images_for(enc_w, nullptr);
   if (dy)
-    hipLaunchKernelGGL(enc_lstm_bwd_kernel<true>, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS), 0,
+    SW_LAUNCH(enc_lstm_bwd_kernel<true>, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS), 0,
                        (hipStream_t)stream, enc_w + swp::ENC_WHH, act, c0, dhT, dcT, dy, B, T, t0, dgates, dh0, dc0, gimg);
   else
-    hipLaunchKernelGGL(enc_lstm_bwd_kernel<false>, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS), 0,
+    SW_LAUNCH(enc_lstm_bwd_kernel<false>, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS), 0,
                        (hipStream_t)stream, enc_w + swp::ENC_WHH, act, c0, dhT, dcT, dy, B, T, t0, dgates, dh0, dc0, gimg);
   SW_CHECK_LAUNCH("enc_lstm_bwd_kernel");
   return SW_OK;

@@ -13,35 +13,108 @@ void sw_set_error(const char* what, hipError_t e) {
   snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
 }
 extern "C" const char* sw_last_error(void) { return g_err; }
-extern "C" int sw_version(void) { return 2; }
 
-// Tiling of the serial (time-unrolled) kernels: 0 = by batch size, 1 = always 16-agent tiles (v_mfma_f32_16x16x4),
-// 2 = 8-agent tiles (v_mfma_f32_4x4x1_16B) where a kernel has them (encoder forward, decode forward).  Measured on
-// MI355X: the 8-agent kernels halve the matrix work per workgroup but are instruction-issue bound (an
-// 8-cycle MFMA hides no VALU / memory instruction, and one weight row per lane means dword instead of dwordx4 loads
-// and stores), and on full-chip launches they lose the idle CUs other work rides in - they do not win at any
-// BASELINE shape yet, so mode 0 picks them for no batch size (SW_NARROW_MAX_B, default 0).  SW_TILE_MODE sets the
-// start-up value; tests force both tilings.
-bool sw_narrow_tiles(int B);
-static int g_tile_mode = -1;
-extern "C" int sw_set_tile_mode(int mode) {
-  if (mode < 0 || mode > 2) return SW_EARG;
-  g_tile_mode = mode;
+// ---- per-kernel timing with HIP events on the launch stream (SW_LAUNCH, sw_common.h) ----------------------------------
+#include <string>
+#include <vector>
+#include <map>
+bool g_sw_ktime_on = false;
+namespace {
+struct KtRec { const char* name; hipEvent_t e0, e1; bool ended; };
+std::vector<KtRec> g_kt;
+}
+void sw_ktime_begin(const char* name, hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+  KtRec r{name, nullptr, nullptr, false};
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) { (void)hipGetLastError(); return; }
+  (void)hipEventRecord(r.e0, st);
+  g_kt.push_back(r);
+}
+void sw_ktime_end(hipStream_t st) {
+  if (g_kt.empty() || g_kt.back().ended) return;
+  (void)hipEventRecord(g_kt.back().e1, st);
+  g_kt.back().ended = true;
+}
+extern "C" int sw_kernel_timing(int on) {
+  for (auto& r : g_kt) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  g_kt.clear();
+  g_sw_ktime_on = on != 0;
   return SW_OK;
 }
-extern "C" int sw_get_tile_mode(void) {
-  if (g_tile_mode < 0) {
-    const char* e = getenv("SW_TILE_MODE");
-    g_tile_mode = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0;
+// "kernel calls total_us\n" per kernel name (template arguments stripped) into buf; returns the bytes needed (<= cap: complete)
+extern "C" int sw_kernel_timing_read(char* buf, int cap) {
+  if (hipDeviceSynchronize() != hipSuccess) return SW_EHIP;
+  std::map<std::string, std::pair<long, double>> agg;
+  for (auto& r : g_kt) {
+    if (!r.ended) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+    std::string n(r.name);
+    size_t a = n.find_first_not_of("( ");
+    n = n.substr(a == std::string::npos ? 0 : a);
+    n = n.substr(0, n.find_first_of("<)"));
+    auto& e = agg[n];
+    e.first += 1;
+    e.second += 1e3 * ms;
   }
-  return g_tile_mode;
+  std::string out;
+  char line[256];
+  for (auto& kv : agg) {
+    snprintf(line, sizeof(line), "%s %ld %.3f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+    out += line;
+  }
+  if (buf && cap > 0) {
+    const size_t k = out.size() < (size_t)cap - 1 ? out.size() : (size_t)cap - 1;
+    memcpy(buf, out.data(), k);
+    buf[k] = 0;
+  }
+  return (int)out.size() + 1;
 }
-extern "C" int sw_serial_narrow(int B) { return sw_narrow_tiles(B) ? 1 : 0; }
-bool sw_narrow_tiles(int B) {
-  const int m = sw_get_tile_mode();
-  static const int max_b = getenv("SW_NARROW_MAX_B") ? atoi(getenv("SW_NARROW_MAX_B")) : 0;
-  return m == 2 || (m == 0 && B <= max_b);
+// a kernel that keeps the stream busy for ~`us` microseconds: queued in front of a timed sequence, it lets the host run
+// ahead so that the sequence's launches reach the GPU back to back (event timings then hold no host gaps)
+__global__ void spin_kernel(long long cycles) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
 }
+extern "C" int sw_debug_spin(double us, void* stream) {
+  if (us < 0 || us > 2e6) return SW_EARG;
+  SW_LAUNCH(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)(us * 100.0));   // wall_clock64: 100 MHz
+  SW_CHECK_LAUNCH("spin_kernel");
+  return SW_OK;
+}
+
+// ---- Adam over a packed buffer (train.py:379-385; torch's fused Adam restated operation by operation: sw_wgrad.h) for the
+//      paths where no gradient-finishing kernel can carry the update: data-parallel ranks all-reduce the packed gradient
+//      buffer between the backward pass and the optimizer step.  Keeps registered discriminator images current. --------
+__global__ __launch_bounds__(256) void adam_packed_kernel(WgAdam ad, long long n) {
+  __shared__ float bc[2];
+  if (threadIdx.x == 0) wg_adam_bc_compute(ad.step, ad.beta1, ad.beta2, bc[0], bc[1]);
+  __syncthreads();
+  const float bc1 = bc[0], bc2s = bc[1];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float g = ad.g0[i];
+    wg_adam_fin(ad, wg_adam_pre(ad, ad.g0 + i), bc1, bc2s, g);
+  }
+}
+extern "C" int sw_adam_packed(float* w, const float* g, float* m, float* v, long long n, const float* step, double lr,
+                              double beta1, double beta2, double eps, int disc_Tp, void* stream) {
+  if (!w || !g || !m || !v || !step || n < 1) return SW_EARG;
+  WgAdam ad;
+  ad.w = w; ad.m = m; ad.v = v; ad.g0 = g; ad.step = step; ad.n = (size_t)n;
+  ad.lr = lr; ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps;
+  if (disc_Tp > 0) {
+    const DiscImages di = sw_disc_images_for(w, disc_Tp);
+    ad.img = const_cast<float*>(di.img);
+    ad.tab = di.tab;
+  }
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 512) blocks = 512;
+  SW_LAUNCH(adam_packed_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ad, n);
+  SW_CHECK_LAUNCH("adam_packed_kernel");
+  return SW_OK;
+}
+extern "C" int sw_version(void) { return 3; }
 
 size_t sw_dsave_floats(int B, int To, int Tp, int nb);
 size_t sw_ddelta_floats(int B, int To, int Tp, int nb);
@@ -264,7 +337,7 @@ static int gen_wgrad_impl(const float* enc_w, const float* dec_w, const float* g
   if (rc_add) return SW_ESHAPE;
   if (int rc = ad.w ? wg_launch_adam(wb, wgrad_ws, ad, st) : wg_launch(wb, wgrad_ws, st)) return rc;
   if (part != 1) {
-    hipLaunchKernelGGL(enc_compose_bwd_kernel, dim3(128 + SW_DEC_COMPOSE_BLOCKS), dim3(256), 0, st, enc_w, dWx, dbx, d_enc_w,
+    SW_LAUNCH(enc_compose_bwd_kernel, dim3(128 + SW_DEC_COMPOSE_BLOCKS), dim3(256), 0, st, enc_w, dWx, dbx, d_enc_w,
                        dec_w, dM, d_dec_w, ad, snap);
     SW_CHECK_LAUNCH("enc_compose_bwd_kernel");
   }
@@ -322,7 +395,7 @@ extern "C" int sw_enc_lstm_wgrad(const float* enc_w, const float* act, const flo
     if (wg_add(w0, dgates, 256, h0, 64, B, 256, 64, d_enc_w + ENC_WHH, 64, nullptr, nullptr, 1)) return SW_ESHAPE;
     if (int rc = wg_launch(w0, wgrad_ws, st)) return rc;
   }
-  hipLaunchKernelGGL(compose_bwd_part_kernel, dim3(128), dim3(256), 0, st, enc_w, dWx, dbx, d_enc_w, nullptr, nullptr, nullptr, 0);
+  SW_LAUNCH(compose_bwd_part_kernel, dim3(128), dim3(256), 0, st, enc_w, dWx, dbx, d_enc_w, nullptr, nullptr, nullptr, 0);
   SW_CHECK_LAUNCH("compose_bwd_part_kernel");
   return SW_OK;
 }
@@ -348,7 +421,7 @@ extern "C" int sw_dec_fc_wgrad(const float* dec_w, const float* gsave, const flo
   if (!s) {     // no pooled social vector: that block of fc1.0.weight has no gradient
     if (hipMemset2DAsync(d_dec_w + DEC_W1 + 64, 160 * sizeof(float), 0, 64 * sizeof(float), 160, st) != hipSuccess) return SW_EHIP;
   }
-  hipLaunchKernelGGL(compose_bwd_part_kernel, dim3(SW_DEC_COMPOSE_BLOCKS), dim3(256), 0, st, nullptr, nullptr, nullptr, nullptr,
+  SW_LAUNCH(compose_bwd_part_kernel, dim3(SW_DEC_COMPOSE_BLOCKS), dim3(256), 0, st, nullptr, nullptr, nullptr, nullptr,
                      dec_w, dM, d_dec_w, 128);
   SW_CHECK_LAUNCH("compose_bwd_part_kernel");
   return SW_OK;
@@ -437,11 +510,11 @@ extern "C" int sw_gan_loss(const float* label_a, const float* targets, int ia, c
                            void* stream) {
   if (!label_a || !targets || !code_a || !z || !out_sums || B < 1 || ia < 0 || ib < 0) return SW_EARG;
   const int G = red_blocks((long long)B * 4, scratch);
-  hipLaunchKernelGGL(gan_loss_kernel, dim3(G), dim3(1024), 0, (hipStream_t)stream, label_a, targets, ia, code_a, z,
+  SW_LAUNCH(gan_loss_kernel, dim3(G), dim3(1024), 0, (hipStream_t)stream, label_a, targets, ia, code_a, z,
                      label_b, ib, B, g_label, g_code, G > 1 ? scratch : out_sums, dlabel_a, dcode_a, dlabel_b, dcode_b);
   SW_CHECK_LAUNCH("gan_loss_kernel");
   if (G > 1) {
-    hipLaunchKernelGGL(sum3_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, G, 1.0f, out_sums);
+    SW_LAUNCH(sum3_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, G, 1.0f, out_sums);
     SW_CHECK_LAUNCH("sum3_kernel");
   }
   return SW_OK;
@@ -487,11 +560,11 @@ extern "C" int sw_ade_fde(const float* pred4, const float* gt, int B, int Tp, fl
                           void* stream) {
   if (!pred4 || !gt || !out || B < 1 || Tp < 1) return SW_EARG;
   const int G = red_blocks((long long)B * Tp, scratch);
-  hipLaunchKernelGGL(ade_fde_kernel, dim3(G), dim3(1024), 0, (hipStream_t)stream, pred4, gt, B, Tp, inv_ss,
+  SW_LAUNCH(ade_fde_kernel, dim3(G), dim3(1024), 0, (hipStream_t)stream, pred4, gt, B, Tp, inv_ss,
                      G > 1 ? scratch : out, G == 1 ? 1 : 0);
   SW_CHECK_LAUNCH("ade_fde_kernel");
   if (G > 1) {
-    hipLaunchKernelGGL(sum3_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, G, 1.0f / (float)Tp, out);
+    SW_LAUNCH(sum3_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, G, 1.0f / (float)Tp, out);
     SW_CHECK_LAUNCH("sum3_kernel");
   }
   return SW_OK;
@@ -519,7 +592,7 @@ extern "C" int sw_l2_grad(const float* pred4, const float* gt, int B, int Tp, in
   long long n = (long long)(row1 - row0) * Tp;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(l2_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred4, gt, Tp, row0, row1, scale,
+  SW_LAUNCH(l2_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred4, gt, Tp, row0, row1, scale,
                      dpred4);
   SW_CHECK_LAUNCH("l2_grad_kernel");
   return SW_OK;
@@ -575,7 +648,7 @@ extern "C" int sw_variety_grad(const float* predK, const float* gt, int K, int B
                                int* kmin, float* l2min, void* stream) {
   if (!predK || !gt || !dpredK || B < 1 || Tp < 1 || K < 1) return SW_EARG;
   if (K > 64) return SW_ESHAPE;
-  hipLaunchKernelGGL(variety_grad_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, predK, gt, K, B, Tp, scale,
+  SW_LAUNCH(variety_grad_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, predK, gt, K, B, Tp, scale,
                      dpredK, kmin, l2min);
   SW_CHECK_LAUNCH("variety_grad_kernel");
   return SW_OK;
@@ -605,7 +678,7 @@ extern "C" int sw_traj_dist(const float* a, const float* b, int Na, int Nb, int 
   long long n = (long long)nPed * Na * Nb;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(traj_dist_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, Na, Nb, nPed, T, t0, D);
+  SW_LAUNCH(traj_dist_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, Na, Nb, nPed, T, t0, D);
   SW_CHECK_LAUNCH("traj_dist_kernel");
   return SW_OK;
 }
@@ -712,7 +785,7 @@ extern "C" int sw_gen_images(const float* enc_w, const float* dec_w, const float
     return SW_OK;
   }
   if (!enc_w || !dec_w || ((emb_w != nullptr) != (att_w != nullptr))) return SW_EARG;
-  hipLaunchKernelGGL(gen_images_kernel, dim3(SW_IMG_BLOCKS), dim3(256), 0, (hipStream_t)stream, enc_w, dec_w, emb_w, att_w, img);
+  SW_LAUNCH(gen_images_kernel, dim3(SW_IMG_BLOCKS), dim3(256), 0, (hipStream_t)stream, enc_w, dec_w, emb_w, att_w, img);
   SW_CHECK_LAUNCH("gen_images_kernel");
   gen_images_register(enc_w, dec_w, emb_w, att_w, img);
   return SW_OK;
@@ -779,7 +852,7 @@ extern "C" int sw_stage_step_img(const float* slot, int B, int To, int Tp, float
   int blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   const int ib = img ? SW_IMG_BLOCKS : 0, db = d_img ? SW_DIMG_BLOCKS : 0;
-  hipLaunchKernelGGL(stage_step_kernel, dim3(blocks + ib + db), dim3(256), 0, (hipStream_t)stream, slot, B, To, Tp, obsv_dst,
+  SW_LAUNCH(stage_step_kernel, dim3(blocks + ib + db), dim3(256), 0, (hipStream_t)stream, slot, B, To, Tp, obsv_dst,
                      pred_dst, pred4_dst, targets_dst, z_dst, steps_dst, n_d_updates, enc_w, dec_w, emb_w, att_w, img, ib,
                      d_w, d_img, d_tab, d_img ? swp::disc(Tp).n : 0, db);
   SW_CHECK_LAUNCH("stage_step_kernel");

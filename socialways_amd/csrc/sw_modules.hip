@@ -36,7 +36,7 @@ extern "C" int sw_rows_gemm(const float* x, int ldx, const float* w, int w_rs, i
   if (!x || !w || !y || R < 0 || K < 1 || N < 1 || ldx < K || ldy < N) return SW_EARG;
   if (R == 0) return SW_OK;
   const long long n = R * N;
-  hipLaunchKernelGGL(rows_gemm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, w, w_rs,
+  SW_LAUNCH(rows_gemm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, w, w_rs,
                      w_cs, bias, R, K, N, y, ldy, accumulate);
   SW_CHECK_LAUNCH("rows_gemm_kernel");
   return SW_OK;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void attention_dense_col_bwd_kernel(const floa
 extern "C" int sw_attention_dense_fwd(const float* f, const float* h, const float* wh, const int* scene_off, int S, int B,
                                       float* attn, float* S_out, void* stream) {
   if (!f || !h || !wh || !scene_off || !attn || !S_out || S < 1 || B < 1) return SW_EARG;
-  hipLaunchKernelGGL(attention_dense_row_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, f, h, wh, scene_off, S, B, attn,
+  SW_LAUNCH(attention_dense_row_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, f, h, wh, scene_off, S, B, attn,
                      S_out);
   SW_CHECK_LAUNCH("attention_dense_row_fwd_kernel");
   return SW_OK;
@@ -214,10 +214,10 @@ extern "C" int sw_attention_dense_bwd(const float* f, const float* h, const floa
                                       const int* scene_off, int S, int B, float* dsig, float* df, float* dwh, float* dh,
                                       void* stream) {
   if (!f || !h || !wh || !attn || !dS || !scene_off || !dsig || !dwh || !dh || S < 1 || B < 1) return SW_EARG;
-  hipLaunchKernelGGL(attention_dense_row_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, h, wh, attn, dS, scene_off, S,
+  SW_LAUNCH(attention_dense_row_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, h, wh, attn, dS, scene_off, S,
                      B, dsig, df);
   SW_CHECK_LAUNCH("attention_dense_row_bwd_kernel");
-  hipLaunchKernelGGL(attention_dense_col_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, f, attn, dsig, dS, scene_off, S,
+  SW_LAUNCH(attention_dense_col_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, f, attn, dsig, dS, scene_off, S,
                      B, dwh, dh);
   SW_CHECK_LAUNCH("attention_dense_col_bwd_kernel");
   return SW_OK;

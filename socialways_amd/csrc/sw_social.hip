@@ -1390,7 +1390,7 @@ extern "C" int sw_embed_features_bwd(const float* feat, long long R, const float
     if (int rc = set_lds((const void*)embed_features_bwd_kernel, soc_lds(16).fwd_total * 4)) return rc;
     attr = true;
   }
-  hipLaunchKernelGGL(embed_features_bwd_kernel, dim3((unsigned)((R + 63) / 64)), dim3(SW_THREADS), soc_lds(16).fwd_total * 4,
+  SW_LAUNCH(embed_features_bwd_kernel, dim3((unsigned)((R + 63) / 64)), dim3(SW_THREADS), soc_lds(16).fwd_total * 4,
                      (hipStream_t)stream, feat, R, emb_w, dout, rows, dfeat);
   SW_CHECK_LAUNCH("embed_features_bwd_kernel");
   return SW_OK;
@@ -1405,7 +1405,7 @@ extern "C" int sw_attention_pool_dense(const float* f, const float* h, const int
     if (int rc = set_lds((const void*)attention_pool_dense_kernel, soc_lds(SW_AMAX).fwd_total * 4)) return rc;
     attr = true;
   }
-  hipLaunchKernelGGL(attention_pool_dense_kernel, dim3(S), dim3(SW_THREADS), soc_lds(SW_AMAX).fwd_total * 4,
+  SW_LAUNCH(attention_pool_dense_kernel, dim3(S), dim3(SW_THREADS), soc_lds(SW_AMAX).fwd_total * 4,
                      (hipStream_t)stream, f, h, scene_off, B, att_w, S_out, SW_AMAX);
   SW_CHECK_LAUNCH("attention_pool_dense_kernel");
   return SW_OK;
@@ -1419,7 +1419,7 @@ extern "C" int sw_embed_features(const float* feat, long long R, const float* em
     if (int rc = set_lds((const void*)embed_features_kernel, soc_lds(16).fwd_total * 4)) return rc;
     attr = true;
   }
-  hipLaunchKernelGGL(embed_features_kernel, dim3((unsigned)((R + 63) / 64)), dim3(SW_THREADS), soc_lds(16).fwd_total * 4,
+  SW_LAUNCH(embed_features_kernel, dim3((unsigned)((R + 63) / 64)), dim3(SW_THREADS), soc_lds(16).fwd_total * 4,
                      (hipStream_t)stream, feat, R, emb_w, out);
   SW_CHECK_LAUNCH("embed_features_kernel");
   return SW_OK;
@@ -1429,7 +1429,7 @@ extern "C" int sw_social_features(const float* x4_last, int B, float* feat, void
   if (!x4_last || !feat || B < 0) return SW_EARG;
   if (B == 0) return SW_OK;
   size_t n = (size_t)B * B;
-  hipLaunchKernelGGL(social_features_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  SW_LAUNCH(social_features_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      x4_last, B, feat);
   SW_CHECK_LAUNCH("social_features_kernel");
   return SW_OK;
@@ -1452,15 +1452,15 @@ extern "C" int sw_social_pool_fwd_aux(const float* obsv, int To, const float* h,
   const int a16 = Amax < 16 ? 16 : ((Amax + 15) & ~15);
   int extra = aux_n > 0 ? (int)((aux_n / 4 + SW_THREADS - 1) / SW_THREADS) : 0;
   if (extra > 64) extra = 64;
-  hipLaunchKernelGGL(social_pool_fwd_kernel, dim3(S + extra), dim3(SW_THREADS), soc_lds(a16).fwd_total * 4, (hipStream_t)stream,
+  SW_LAUNCH(social_pool_fwd_kernel, dim3(S + extra), dim3(SW_THREADS), soc_lds(a16).fwd_total * 4, (hipStream_t)stream,
                      obsv, To, h, scene_off, emb_w, att_w, S_out, attn, a16, S, aux_src, aux_dst, aux_n,
                      sw_soc_images_for(emb_w, att_w));
   SW_CHECK_LAUNCH("social_pool_fwd_kernel");
   if (NB > 0) {   // scenes above SW_AMAX agents
-    hipLaunchKernelGGL(social_wh_kernel, dim3(NB), dim3(SW_THREADS), 0, (hipStream_t)stream, h, scene_off, big_blocks, att_w,
+    SW_LAUNCH(social_wh_kernel, dim3(NB), dim3(SW_THREADS), 0, (hipStream_t)stream, h, scene_off, big_blocks, att_w,
                        wh_ws);
     SW_CHECK_LAUNCH("social_wh_kernel");
-    hipLaunchKernelGGL(social_big_fwd_kernel, dim3(NB), dim3(SW_THREADS), soc_lds(16).fwd_total * 4, (hipStream_t)stream,
+    SW_LAUNCH(social_big_fwd_kernel, dim3(NB), dim3(SW_THREADS), soc_lds(16).fwd_total * 4, (hipStream_t)stream,
                        obsv, To, h, wh_ws, scene_off, big_blocks, emb_w, S_out, ml);
     SW_CHECK_LAUNCH("social_big_fwd_kernel");
   }
@@ -1508,7 +1508,7 @@ extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, con
       attr2 = true;
     }
     PairRows pr = pair_rows(pair_ws + (size_t)B * 64, P);
-    hipLaunchKernelGGL(social_pool_bwd_rows_kernel, dim3(S), dim3(SW_THREADS), soc_lds(a16).bwd_total * 4, st, obsv, To, h,
+    SW_LAUNCH(social_pool_bwd_rows_kernel, dim3(S), dim3(SW_THREADS), soc_lds(a16).bwd_total * 4, st, obsv, To, h,
                        scene_off, pair_off, emb_w, att_w, attn, dS, dh, dwh_rows, pr, a16, sw_soc_images_for(emb_w, att_w));
     SW_CHECK_LAUNCH("social_pool_bwd_rows_kernel");
     WgBatch wr_local;
@@ -1540,14 +1540,14 @@ extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, con
   if (rc_add) return SW_ESHAPE;
   SocPart part{wgrad_ws + wb.p[i3].ws_off, wgrad_ws + wb.p[i2].ws_off, wgrad_ws + wb.p[i1].ws_off};
   if (NB > 0) {   // scenes above SW_AMAX agents: fills dh / dwh_rows of their agents
-    hipLaunchKernelGGL(social_big_bwd_kernel, dim3(NB), dim3(SW_THREADS), lds_big, st, obsv, To, h, wh_ws, scene_off,
+    SW_LAUNCH(social_big_bwd_kernel, dim3(NB), dim3(SW_THREADS), lds_big, st, obsv, To, h, wh_ws, scene_off,
                        big_blocks, emb_w, S_pool, ml, dS, big_part_ws, part, G);
     SW_CHECK_LAUNCH("social_big_bwd_kernel");
-    hipLaunchKernelGGL(social_big_finish_kernel, dim3(NB), dim3(SW_THREADS), 0, st, scene_off, big_blocks, att_w,
+    SW_LAUNCH(social_big_finish_kernel, dim3(NB), dim3(SW_THREADS), 0, st, scene_off, big_blocks, att_w,
                        big_part_ws, dh, dwh_rows);
     SW_CHECK_LAUNCH("social_big_finish_kernel");
   }
-  hipLaunchKernelGGL(social_pool_bwd_kernel, dim3(G), dim3(SW_THREADS), lds, st, obsv, To, h, scene_off, S, emb_w,
+  SW_LAUNCH(social_pool_bwd_kernel, dim3(G), dim3(SW_THREADS), lds, st, obsv, To, h, scene_off, S, emb_w,
                      att_w, attn, dS, dh, dwh_rows, part, a16);
   SW_CHECK_LAUNCH("social_pool_bwd_kernel");
   if (defer) return SW_OK;

@@ -112,31 +112,10 @@ __device__ __forceinline__ void wg_adam1(const WgAdam& A, float bc1, float bc2s,
   wg_adam_fin(A, wg_adam_pre(A, gptr), bc1, bc2s, grad);
 }
 int wg_reduce_launch_adam(WgBatch& b, float* ws, const WgAdam& ad, hipStream_t stream);
+int wg_reduce_launch(WgBatch& b, float* ws, hipStream_t stream);
 // GEMM + reduction; `ad` comes back with `bc` set when the GEMM launch computed the bias corrections (kernels that
 // follow in the same stream - the composition back-propagation - may use them)
 int wg_launch_adam(WgBatch& b, float* ws, WgAdam& ad, hipStream_t stream);
-
-// ---- riders: weight-gradient jobs run by the spare workgroups of a serial launch (sw_wgrad_dev.h) ----------------
-#define SW_RIDE_SLOTS 48      // event counters per host kernel; the last one counts riders that have left
-struct WgRide {
-  const int* order = nullptr;   // pinned host memory: job | (event + 1) << 20 in the order the events complete
-  unsigned* cnt = nullptr;      // uncached device memory [SW_RIDE_SLOTS]
-  float* ws = nullptr;          // partial workspace
-  int njobs = 0, nriders = 0, nevents = 0;
-  unsigned target = 0;          // producer waves per event
-};
-// Is riding enabled (sw_set_cosched / SW_COSCHED; the caller then keeps its delta rows in memory from sw_uc_alloc)?
-bool wg_cosched();
-// Jobs of the finalized batch `b` sorted by the event their rows need; need(problem, first row, end row of a
-// workgroup-job) = index of that event in COMPLETION order, or -1 (rows complete before the launch).
-// kind: 0 disc_bwd, 1 dec_rollout_bwd, 2 enc_lstm_bwd (own counters each); key: identifies the layout (cache of lists).
-struct WgNeed {
-  virtual int operator()(const WgProblem& P, int rbeg, int rend) const = 0;
-};
-int wg_ride_setup(const WgBatch& b, WgRide& ride, int kind, unsigned long long key, int nriders, unsigned target,
-                  int nevents, float* ws, const WgNeed& need, int job_lo = 0, int job_hi = -1);
-int wg_reduce_launch(WgBatch& b, float* ws, hipStream_t stream);
-size_t wg_finalize_for(WgBatch& b, int max_wgs);
 
 int wg_add(WgBatch& b, const float* delta, int ldd, const float* act, int lda, int R, int N, int K, float* dW,
            int ldw, float* db, float* db2, int accumulate);

@@ -205,14 +205,6 @@ double wg_total_work(const WgBatch& b) {
   return w;
 }
 
-static double g_force_maxwg = 0.0;
-size_t wg_finalize_for(WgBatch& b, int max_wgs) {
-  g_force_maxwg = max_wgs;
-  const size_t r = wg_finalize(b);
-  g_force_maxwg = 0.0;
-  return r;
-}
-
 size_t wg_finalize(WgBatch& b) {
   // ~1024 workgroups = 4096 wave-jobs per launch (4 per SIMD), equal cost each
   const double total = wg_total_work(b) + 1.0;
@@ -225,7 +217,7 @@ size_t wg_finalize(WgBatch& b) {
   // full pipeline (swept: 512 -> 63 us, 448 -> 72, 576 -> 78, 1024 -> 69 for the generator pass at m1) - unless the
   // batch is so large that a second round still leaves each wave several grains of work (dense crowds: better balance)
   static const double maxwg_env = getenv("SW_WG_MAXWG") ? atof(getenv("SW_WG_MAXWG")) : 0.0;
-  const double maxwg = g_force_maxwg > 0.0 ? g_force_maxwg : maxwg_env > 0.0 ? maxwg_env : (target >= 4096.0 ? 1024.0 : 512.0);
+  const double maxwg = maxwg_env > 0.0 ? maxwg_env : (target >= 4096.0 ? 1024.0 : 512.0);
   if (target > maxwg) target = maxwg;
   size_t ws = 0;
   int job = 0, out = 0;
@@ -278,7 +270,7 @@ int wg_launch(WgBatch& b, float* ws, hipStream_t stream) {
 
 int wg_reduce_launch_adam(WgBatch& b, float* ws, const WgAdam& ad, hipStream_t stream) {
   if (b.total_out == 0) return SW_OK;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((b.total_out * SW_WG_RSUB + 255) / 256), dim3(256), 0, stream, b, ws, ad);
+  SW_LAUNCH(wgrad_reduce_kernel, dim3((b.total_out * SW_WG_RSUB + 255) / 256), dim3(256), 0, stream, b, ws, ad);
   SW_CHECK_LAUNCH("wgrad_reduce_kernel");
   return SW_OK;
 }
@@ -291,7 +283,7 @@ int wg_launch_adam(WgBatch& b, float* ws, WgAdam& ad, hipStream_t stream) {
   ad.bc = nullptr;
   if (b.total_jobs > 0) {
     float* bc = ad.w ? wg_bc_slot() : nullptr;
-    hipLaunchKernelGGL(wgrad_partial_kernel, dim3(b.total_jobs + (bc ? 1 : 0)), dim3(SW_THREADS), 0, stream, b, ws, ad.step,
+    SW_LAUNCH(wgrad_partial_kernel, dim3(b.total_jobs + (bc ? 1 : 0)), dim3(SW_THREADS), 0, stream, b, ws, ad.step,
                        ad.beta1, ad.beta2, bc);
     SW_CHECK_LAUNCH("wgrad_partial_kernel");
     ad.bc = bc;
@@ -299,92 +291,10 @@ int wg_launch_adam(WgBatch& b, float* ws, WgAdam& ad, hipStream_t stream) {
   return wg_reduce_launch_adam(b, ws, ad, stream);
 }
 
-// ---- riders (host side) ------------------------------------------------------------------------------------------
-#include <algorithm>
-#include <map>
-#include <vector>
-static int g_cosched = -1;
-extern "C" int sw_set_cosched(int on) {
-  g_cosched = on ? 1 : 0;
-  return SW_OK;
-}
-extern "C" int sw_get_cosched(void) {
-  if (g_cosched < 0) {
-    const char* e = getenv("SW_COSCHED");
-    g_cosched = (e && e[0] == '1') ? 1 : 0;
-  }
-  return g_cosched;
-}
-bool wg_cosched() { return sw_get_cosched() != 0; }
-extern "C" void* sw_uc_alloc(size_t bytes) {
-  void* p = nullptr;
-  if (hipExtMallocWithFlags(&p, bytes ? bytes : 4, hipDeviceMallocUncached) != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
-  return p;
-}
-extern "C" void sw_uc_free(void* p) {
-  if (p) (void)hipFree(p);
-}
-int wg_ride_setup(const WgBatch& b, WgRide& ride, int kind, unsigned long long key, int nriders, unsigned target,
-                  int nevents, float* ws, const WgNeed& need, int job_lo, int job_hi) {
-  static unsigned* counters = nullptr;
-  static std::map<unsigned long long, int*> lists;
-  ride = WgRide();
-  if (nriders <= 0 || b.total_jobs <= 0 || nevents >= SW_RIDE_SLOTS || kind < 0 || kind > 2) return SW_OK;
-  if (!counters) {
-    counters = (unsigned*)sw_uc_alloc(3 * SW_RIDE_SLOTS * sizeof(unsigned));
-    if (!counters || hipMemset(counters, 0, 3 * SW_RIDE_SLOTS * sizeof(unsigned)) != hipSuccess) {
-      sw_set_error("rider counters (hipExtMallocWithFlags uncached)", hipGetLastError());
-      return SW_EHIP;
-    }
-  }
-  if (job_hi < 0) job_hi = b.total_jobs;
-  std::vector<std::pair<int, int>> jobs;   // (event, job)
-  for (int pi = 0; pi < b.np; ++pi) {
-    const WgProblem& P = b.p[pi];
-    if (P.pre) continue;
-    const int NB = (P.N + 63) / 64, nsub = P.nsplit * 4;
-    const int rows_per = (((P.R + nsub - 1) / nsub) + 3) & ~3;
-    for (int sg = 0; sg < P.nsplit; ++sg) {
-      const int rbeg = std::min(P.R, sg * 4 * rows_per), rend = std::min(P.R, (sg * 4 + 4) * rows_per);
-      const int ev = need(P, rbeg, rend);
-      for (int nb = 0; nb < NB; ++nb) {
-        const int job = P.job0 + sg * NB + nb;
-        if (job >= job_lo && job < job_hi) jobs.emplace_back(ev, job);
-      }
-    }
-  }
-  std::stable_sort(jobs.begin(), jobs.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first < y.first; });
-  key = key * 4 + (unsigned long long)kind;
-  int*& list = lists[key];
-  const size_t cap = 4096;
-  if (jobs.size() > cap) return SW_ESHAPE;
-  if (!list) {
-    if (hipHostMalloc((void**)&list, cap * sizeof(int), hipHostMallocDefault) != hipSuccess) {
-      sw_set_error("rider job list (hipHostMalloc)", hipGetLastError());
-      return SW_EHIP;
-    }
-  }
-  static const int dbg = getenv("SW_RIDE_DEBUG") ? atoi(getenv("SW_RIDE_DEBUG")) : 0;   // timing experiments only (wrong results)
-  if (dbg == 1) jobs.clear();                                   // producers publish, riders idle
-  if (dbg == 2) for (auto& j : jobs) j.first = -1;              // riders never wait
-  for (size_t i = 0; i < jobs.size(); ++i) list[i] = jobs[i].second | ((jobs[i].first + 1) << 20);
-  ride.order = list;
-  ride.cnt = counters + kind * SW_RIDE_SLOTS;
-  ride.ws = ws;
-  ride.njobs = (int)jobs.size();
-  ride.nriders = nriders;
-  ride.nevents = nevents;
-  ride.target = target;
-  return SW_OK;
-}
-
 int wg_launch_finalized(WgBatch& b, float* ws, hipStream_t stream) {
   if (b.total_out == 0) return SW_OK;
   if (b.total_jobs > 0) {
-    hipLaunchKernelGGL(wgrad_partial_kernel, dim3(b.total_jobs), dim3(SW_THREADS), 0, stream, b, ws, (const float*)nullptr,
+    SW_LAUNCH(wgrad_partial_kernel, dim3(b.total_jobs), dim3(SW_THREADS), 0, stream, b, ws, (const float*)nullptr,
                        0.0, 0.0, (float*)nullptr);
     SW_CHECK_LAUNCH("wgrad_partial_kernel");
   }

@@ -1,5 +1,5 @@
-// sw_wgrad_dev.h - device code of the grouped split-K weight-gradient GEMM (see sw_wgrad.hip): the per-job body, shared by
-// wgrad_partial_kernel and by the serial kernels whose spare workgroups RIDE along (run jobs while the kernel computes).
+// sw_wgrad_dev.h - device code of the grouped split-K weight-gradient GEMM (see sw_wgrad.hip): the per-job body of
+// wgrad_partial_kernel.
 #pragma once
 #include <type_traits>
 #include "sw_common.h"
@@ -12,9 +12,6 @@
 #endif
 #ifndef SW_WG_DEPTH_TAIL
 #define SW_WG_DEPTH_TAIL SW_WG_DEPTH
-#endif
-#ifndef SW_RIDE_DSCALE
-#define SW_RIDE_DSCALE 2
 #endif
 
 #define SW_WG_RLD 69   // LDS row stride of a wave's 64 x (<= 69) block: 64 act columns + tail segment + ones
@@ -83,8 +80,7 @@ __device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const fl
 #pragma unroll
     for (int c = 0; c < (XC > 0 ? XC : 1); ++c) xacc[i][c] = 0.f;
   }
-  // 4-row groups in flight (swept on the GPU for the stand-alone launch at 8 waves per CU); riders have one workgroup
-  // per CU and the whole register file: DSCALE times deeper
+  // 4-row groups in flight (swept on the GPU at 8 waves per CU)
   constexpr int DEPTH = (K2 > 0 ? SW_WG_DEPTH_TAIL : SW_WG_DEPTH) * DSCALE;
   float a[DEPTH][NA], b[DEPTH][KT];
   f32x4 xq[DEPTH];
@@ -231,54 +227,6 @@ __device__ __forceinline__ void wg_job(const WgBatch& batch, float* __restrict__
     if (cc >= cols) {
       cc -= cols;
       ++rr;
-    }
-  }
-}
-
-// ---- riders ------------------------------------------------------------------------------------------------------
-// Spare workgroups of a serial (BPTT) launch run weight-gradient jobs WHILE the launch computes: the tile workgroups
-// publish "rows of event e are in memory" (their delta rows live in UNCACHED device memory: plain stores,
-// s_waitcnt vmcnt(0), one relaxed device-scope increment per wave - tools/mb/uc_handoff.hip: no stale read in 2.5 M
-// checked values, 8 cycles of waiting per step), a rider waits for the event its next job needs.  Riders never block
-// tile workgroups, the launch holds at most one workgroup per CU in total, tile workgroups come first in the grid.
-// Publishing an event costs ONE atomic per workgroup (512 waves incrementing one counter serialise at ~12 ns each, and
-// the next publish of a wave waits for its previous atomic: measured +42 us on a 27 us kernel): every wave drains its
-// own stores (wg_drain) in front of a workgroup barrier the kernel has anyway, one lane signals behind it (wg_signal).
-__device__ __forceinline__ void wg_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void wg_signal(unsigned* cnt_e) {
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt_e, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void wg_ride(const WgBatch& batch, const WgRide& ride, int rider, float* red) {
-  __shared__ int s_packed;
-  for (int k = rider; k < ride.njobs; k += ride.nriders) {
-    if (threadIdx.x == 0) {
-      const int packed = ride.order[k];                // job | (event + 1) << 20, event + 1 == 0: ready at launch
-      const int ev = (packed >> 20) - 1;
-      if (ev >= 0) {
-        int spins = 0;
-        while (__hip_atomic_load(ride.cnt + ev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ride.target) {
-          __builtin_amdgcn_s_sleep(8);
-          if (++spins > (1 << 24)) break;              // ~seconds: a lost producer must not hang the device
-        }
-      }
-      s_packed = packed & 0xfffff;
-    }
-    __syncthreads();
-    const int job = s_packed;
-    wg_job<SW_RIDE_DSCALE>(batch, ride.ws, job, red);
-    __syncthreads();
-  }
-  // the last rider to leave re-arms the counters for the next launch (every event it could reset is complete: it
-  // has run its jobs, and every other rider has left)
-  if (threadIdx.x == 0) {
-    const unsigned old = __hip_atomic_fetch_add(ride.cnt + SW_RIDE_SLOTS - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old == (unsigned)ride.nriders - 1) {
-      for (int e = 0; e < ride.nevents; ++e) {         // (an event no job waited for may still be filling up)
-        int spins = 0;
-        while (__hip_atomic_load(ride.cnt + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ride.target && ++spins < (1 << 24))
-          __builtin_amdgcn_s_sleep(8);
-      }
-      for (int i = 0; i < SW_RIDE_SLOTS; ++i) __hip_atomic_store(ride.cnt + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }

@@ -228,7 +228,7 @@ class _AttFn(torch.autograd.Function):
         S = torch.empty(B, 64, device=dev)
         L.call("sw_attention_dense_fwd", L.ptr(f), L.ptr(h), L.ptr(wh), L.ptr(sc.scene_off), sc.S, B, L.ptr(attn), L.ptr(S),
                L.stream())
-        ctx.att, ctx.sc, ctx.need_f = att, sc, f.requires_grad
+        ctx.att, ctx.sc, ctx.need_f = att, sc, ctx.needs_input_grad[1]
         ctx.save_for_backward(f, h, wh, attn)
         return S
 
@@ -260,7 +260,7 @@ class _EmbFn(torch.autograd.Function):
         R = x.numel() // 3
         out = torch.empty(*x.shape[:-1], 64, device=x.device)
         L.call("sw_embed_features", L.ptr(x), R, L.ptr(emb.packed()), L.ptr(out), L.stream())
-        ctx.emb, ctx.need_x = emb, x.requires_grad
+        ctx.emb, ctx.need_x = emb, ctx.needs_input_grad[1]
         ctx.save_for_backward(x)
         return out
 
@@ -300,7 +300,7 @@ class _EncFn(torch.autograd.Function):
         act, x4s = torch.empty(T, B, 384, device=dev), torch.empty(T, B, 4, device=dev)
         L.call("sw_enc_lstm_fwd", L.ptr(x), 1, L.ptr(enc.packed()), L.ptr(h0), L.ptr(c0), B, T, L.ptr(hT), L.ptr(cT), L.ptr(y),
                L.ptr(act), L.ptr(x4s), 0, L.stream())
-        ctx.enc, ctx.need_x, ctx.need_state = enc, x.requires_grad, (h0.requires_grad or c0.requires_grad)
+        ctx.enc, ctx.need_x, ctx.need_state = enc, ctx.needs_input_grad[1], (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
         ctx.save_for_backward(act, x4s, h0, c0)
         return y, hT, cT
 
@@ -349,7 +349,7 @@ class _DecFn(torch.autograd.Function):
         L.call("sw_dec_rollout_fwd", L.ptr(zero_obs), _DecFn.TO, L.ptr(z), L.ptr(s), L.ptr(h), L.ptr(c), L.ptr(enc_w),
                L.ptr(dec.packed()), B, 1, L.ptr(pred4), None, None, L.ptr(gsave), None, 0.0, None, L.stream())
         ctx.dec, ctx.enc_w = dec, enc_w
-        ctx.need = (h.requires_grad, s.requires_grad, z.requires_grad)
+        ctx.need = tuple(ctx.needs_input_grad[1:4])
         ctx.save_for_backward(h, s, z, gsave)
         return pred4[:, 0, 2:4].contiguous()
 

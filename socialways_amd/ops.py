@@ -61,30 +61,6 @@ class SceneIndex:
         return hit
 
 
-def _want_uc():
-    import os
-    return bool(L.load().sw_get_cosched()) or os.environ.get("SW_FORCE_UC", "") == "1"
-
-
-class _UncachedBuffer:
-    """n floats of UNCACHED device memory (sw_uc_alloc: hipExtMallocWithFlags(hipDeviceMallocUncached)) exposed to
-    torch through __cuda_array_interface__: where workgroups of one launch hand rows to each other (riders)."""
-
-    def __init__(self, nfloats):
-        lib = L.load()
-        self._free = lib.sw_uc_free
-        self.ptr = lib.sw_uc_alloc(4 * int(nfloats))
-        if not self.ptr:
-            raise L.SocialWaysHipError("sw_uc_alloc(%d bytes) failed" % (4 * int(nfloats)))
-        self.__cuda_array_interface__ = {"shape": (int(nfloats),), "typestr": "<f4", "data": (int(self.ptr), False),
-                                         "version": 2, "strides": None}
-
-    def __del__(self):
-        if getattr(self, "ptr", None):
-            self._free(self.ptr)
-            self.ptr = None
-
-
 class Workspaces:
     """Grow-only fp32 scratch buffers keyed by name (saves, deltas, split-K partials) and the host-side handle
     that lets the weight-gradient problems of one backward pass share a launch."""
@@ -99,7 +75,6 @@ class Workspaces:
         # (SocialWaysTrainer) drops its graphs and then calls `release_retired()` at its next safe point.
         self.retired = []
         self.version = 0
-        self._uc = {}
 
     @property
     def wgrad_batch(self):
@@ -113,21 +88,15 @@ class Workspaces:
             self._free(self._wgb)
             self._wgb = None
 
-    def get(self, name, nfloats, uncached=False):
-        """`uncached`: the buffer must live in uncached device memory (delta rows while riders are on, see
-        include/socialways_hip.h: sw_set_cosched); a cached buffer of that name is replaced."""
+    def get(self, name, nfloats):
         t = self.buf.get(name)
-        if t is None or t.numel() < nfloats or (uncached and name not in self._uc):
+        if t is None or t.numel() < nfloats:
             if t is not None:
-                self.retired.append((t, self._uc.pop(name, None)))
+                self.retired.append(t)
                 self.version += 1
-            n = max(int(nfloats), 1)
-            if uncached:
-                owner = _UncachedBuffer(n)
-                t = torch.as_tensor(owner, device=self.device)
-                self._uc[name] = owner          # keeps the allocation alive as long as the tensor is in use here
-            else:
-                t = torch.empty(n, dtype=torch.float32, device=self.device)
+            # geometric growth: ragged datasets with slowly increasing batch sizes would otherwise retire a buffer per step
+            n = max(int(nfloats), 1) if t is None else max(int(nfloats), int(1.25 * t.numel()))
+            t = torch.empty(n, dtype=torch.float32, device=self.device)
             self.buf[name] = t
         return t
 
@@ -176,12 +145,9 @@ def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_soc
         gsave = ws.get(tag + ".gsave", nfl) if ws is not None else torch.empty(nfl, device=dev)
     # act rows live at offset 0 of gsave, x4s right behind (sw_common.h:gsave_layout)
     x4s_off = (To + n_next - 1) * B * 384
-    # z (256 KB over PCIe: ~16 us, request-bound) is first read by the decode launch.  The 16-agent encoder launch
-    # leaves half of the CUs idle for ~22 us: its spare workgroups pull z for free.  On 8-agent tiles the encoder
-    # launch fills the chip and is shorter than the pull, so the (light) social launch behind it takes the copy.
-    in_soc = bool(use_social) and bool(L.load().sw_serial_narrow(B))
-    z_in_enc = None if in_soc else noise_src
-    z_in_soc = noise_src if in_soc else None
+    # z (256 KB over PCIe: ~16 us, request-bound) is first read by the decode launch.  The encoder launch leaves half of
+    # the CUs idle for ~20 us at the metric shape: its spare workgroups pull z for free.
+    z_in_enc, z_in_soc = noise_src, None
     L.call("sw_enc_lstm_fwd_aux", L.ptr(obsv), 0, L.ptr(enc_w), None, None, B, To, L.ptr(hT), L.ptr(cT), None,
            L.ptr(gsave), (gsave.data_ptr() + 4 * x4s_off) if save else None, 0,
            z_in_enc, L.ptr(noise) if z_in_enc else None, noise.numel() if z_in_enc else 0, st)
@@ -266,7 +232,7 @@ D_OBS_MAX_TILES = 128      # the decode launch has idle CUs for the D observatio
 def d_obs_buffer(ws, B, To, Tp, nb=2, tag="d"):
     """The save buffer disc_forward(tag, nb branches) will use, or None when the decode launch has no idle CUs to
     precompute the observation LSTM in (gen_forward(d_obs=...) / disc_forward(save_lstm=2))."""
-    if (B + 15) // 16 > D_OBS_MAX_TILES or L.load().sw_serial_narrow(B):    # 8-agent tiles fill the chip themselves
+    if (B + 15) // 16 > D_OBS_MAX_TILES:
         return None
     return ws.get(tag + ".dsave", L.workspace_floats(L.WS_DSAVE, B, To, Tp, nb))
 
@@ -313,7 +279,7 @@ def disc_backward(d_w, ctx, dlabels, dcodes, d_d_w=None, want_dpred=(), ws=None,
     dpreds = [torch.empty(B, Tp, 4, device=dev) if w else None for w in want]
     ddelta = wgrad = None
     if d_d_w is not None:
-        ddelta = ws.get(tag + ".ddelta", L.workspace_floats(L.WS_DDELTA, B, To, Tp, nb), uncached=_want_uc())
+        ddelta = ws.get(tag + ".ddelta", L.workspace_floats(L.WS_DDELTA, B, To, Tp, nb))
         wgrad = ws.get("wgrad", L.workspace_floats(L.WS_WGRAD, B, To, Tp))
     lp, _k1 = L.ptr_array(dlabels)
     cp, _k2 = L.ptr_array(dcodes)
@@ -348,7 +314,7 @@ def disc_backward_gan(d_w, ctx, labels, codes, targets, t_idx, z, g_label, g_cod
     dpreds = [torch.empty(B, Tp, 4, device=dev) if w else None for w in want]
     ddelta = wgrad = None
     if d_d_w is not None:
-        ddelta = ws.get(tag + ".ddelta", L.workspace_floats(L.WS_DDELTA, B, To, Tp, nb), uncached=_want_uc())
+        ddelta = ws.get(tag + ".ddelta", L.workspace_floats(L.WS_DDELTA, B, To, Tp, nb))
         wgrad = ws.get("wgrad", L.workspace_floats(L.WS_WGRAD, B, To, Tp))
     lp, _k1 = L.ptr_array(labels)
     cp, _k2 = L.ptr_array(codes)

@@ -43,9 +43,16 @@ class PackedAdam:
     # most MAX_CHUNKS of them, beyond which the update is split into a second kernel launch (~5 us per graph node)
     MIN_CHUNK, MAX_CHUNKS = 2048, 30      # swept 8..36 / 512..4096 on one box: flat within noise
 
-    def __init__(self, flat, gflat, slices, lr, betas=(0.9, 0.999), eps=1e-8, capturable=False):
+    def __init__(self, flat, gflat, slices, lr, betas=(0.9, 0.999), eps=1e-8, capturable=False, disc_tp=0):
         self.slices = slices
         self.flat = flat
+        self.gflat = gflat
+        # On the GPU the update is the library's own kernel (sw_adam_packed: torch's fused Adam restated operation by
+        # operation, the arithmetic the gradient-finishing kernels apply in a single process) - one launch, and the
+        # Discriminator's weight images (disc_tp = its horizon) follow the update.  torch's kernel remains for CPU
+        # buffers and for a checkpoint that carries weight decay (the reference never sets it, train.py:379-385).
+        self.native = flat.is_cuda
+        self.disc_tp = int(disc_tp)
         n = flat.numel()
         c = self.CHUNK = max(self.MIN_CHUNK, (-(-n // self.MAX_CHUNKS) + 255) // 256 * 256)
         self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
@@ -65,9 +72,25 @@ class PackedAdam:
             self.step_t.fill_(float(self.t))      # eager only: a captured update always gets its index from the caller
             step_tensor = self.step_t
         g = self.group
+        if self.native and not g["weight_decay"]:
+            L.call("sw_adam_packed", L.ptr(self.flat), L.ptr(self.gflat), L.ptr(self.m), L.ptr(self.v), self.flat.numel(),
+                   L.ptr(step_tensor), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                   self.disc_tp, L.stream())
+            return
         torch._fused_adam_(self.ps, self.gs, self.ms, self.vs, [], [step_tensor] * len(self.ps), amsgrad=False,
                            lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], weight_decay=g["weight_decay"],
                            eps=g["eps"], maximize=False, grad_scale=None, found_inf=None)
+
+    @property
+    def keeps_images(self):
+        """Does step() keep registered Discriminator images current (sw_adam_packed does, torch's kernel cannot)?"""
+        return bool(self.native and not self.group["weight_decay"] and self.disc_tp > 0)
+
+    @property
+    def fusable(self):
+        """May a gradient-finishing kernel apply this update itself (sw_disc_bwd_gan_adam / sw_gen_wgrad_adam)?  Their
+        arithmetic is Adam without weight decay."""
+        return not self.group["weight_decay"]
 
     def fused_args(self, step_tensor=None):
         """(m, v, step scalar, lr, beta1, beta2, eps) for a kernel that applies this update itself
@@ -188,7 +211,8 @@ class SocialWaysTrainer:
         if packed:
             self.D_optimizer = PackedAdam(self.D._flat, self.D._gflat,
                                           [(off, k, tuple(p.shape)) + (self.D._true[i] if self.D._true is not None else ())
-                                           for i, ((off, k), p) in enumerate(zip(self.D._slices, self.D.parameters()))], lr_d)
+                                           for i, ((off, k), p) in enumerate(zip(self.D._slices, self.D.parameters()))], lr_d,
+                                          disc_tp=n_next)
         else:
             self.D_optimizer = opt.Adam(self.D.parameters(), lr=lr_d, betas=(0.9, 0.999))
         self.pg = process_group
@@ -336,7 +360,8 @@ class SocialWaysTrainer:
         og, od = self.predictor_optimizer.param_groups[0], self.D_optimizer.param_groups[0]
         return (scenes.key, To, float(ss), float(Bg), self._row0, K, self.n_unrolling_steps, self.use_info_loss,
                 self.loss_info_w, self.use_l2_loss, self.use_variety_loss, self.loss_l2_w, self.variety_k,
-                og["lr"], tuple(og["betas"]), og["eps"], od["lr"], tuple(od["betas"]), od["eps"])
+                og["lr"], tuple(og["betas"]), og["eps"], og.get("weight_decay", 0), od["lr"], tuple(od["betas"]), od["eps"],
+                od.get("weight_decay", 0))
 
     def _graphs_current(self):
         """A workspace outgrown since the last capture means captured graphs hold retired addresses: they stay valid
@@ -379,7 +404,7 @@ class SocialWaysTrainer:
             if self._graph_key(scenes, obsv.shape[1], ss, Bg, 1) in self._graphs or len(self._graphs) < self.max_graphs:
                 part = self._step_graph([(obsv, pred, zeros_val, ones_val, noise)], sub_batches, float(ss), Bg)[0]
         if part is None:
-            part = torch.zeros(self.n_unrolling_steps + 3, (B + 7) // 8, 3, device=dev)     # one triple per (8- or 16-agent) tile
+            part = torch.zeros(self.n_unrolling_steps + 3, (B + 15) // 16, 3, device=dev)     # one triple per 16-agent tile
             scenes = ops.SceneIndex.get(sub_batches, B, dev)
             noise = self._pad_z(noise.to(dev, non_blocking=True)).contiguous()
             # label-noise scalars of train.py:471-472 live in device memory: [zeros_val, ones_val]
@@ -422,7 +447,7 @@ class SocialWaysTrainer:
                 pred=torch.empty(B, Tp, 2, device=dev), pred4=torch.empty(B, Tp, 4, device=dev),
                 targets=torch.empty(4, device=dev), noise=torch.zeros(B, self.Z_COLS, device=dev),
                 steps=torch.zeros(self.n_unrolling_steps + 2, device=dev),   # Adam step indices of the U+1 D updates, the G update
-                outs=[torch.zeros(self.n_unrolling_steps + 3, (B + 7) // 8, 3, device=dev) for _ in range(K)],
+                outs=[torch.zeros(self.n_unrolling_steps + 3, (B + 15) // 16, 3, device=dev) for _ in range(K)],
                 slots=[[torch.zeros(HDR + B * self.Z_COLS, dtype=torch.float32).pin_memory() for _ in range(K)]
                        for _ in range(2)],
                 done=[torch.cuda.Event(), torch.cuda.Event()], keep=[None, None])
@@ -603,14 +628,16 @@ class SocialWaysTrainer:
             # the loss gradients AND the reported loss sums (per-tile partials) are formed inside the backward kernel;
             # in a single process (no all-reduce between gradient and update) D's Adam step rides in the kernel that
             # finishes the gradients
-            fuse = self._fuse_d_adam and isinstance(self.D_optimizer, PackedAdam) and not (self.world > 1 or self._force_dist)
+            fuse = (self._fuse_d_adam and isinstance(self.D_optimizer, PackedAdam) and self.D_optimizer.fusable
+                    and not (self.world > 1 or self._force_dist))
             ops.disc_backward_gan(D._flat, dctx, labels, codes, targets, (0, 1), noise, g_label, g_code, d_gflat, (), ws=ws,
                                   loss_part=out[u],
                                   adam=self.D_optimizer.fused_args(None if steps is None else steps[u]) if fuse else None)
             yield d_gflat
             if not fuse:
                 self.D_optimizer.step() if steps is None else self.D_optimizer.step(steps[u])
-                self._disc_images()        # an update the image table did not see: scatter again
+                if not getattr(self.D_optimizer, "keeps_images", False):
+                    self._disc_images()        # an update the image table did not see (torch's Adam): scatter again
         # ---- generator update (train.py:503-539) ----------------------------------------------------
         # D forward on the prediction + backward of its heads down to d(g_loss)/d(pred_hat), one launch, nothing saved
         dpred = ops.disc_dpred(D._flat, obsv, pred_hat, targets, 1, noise, g_label, g_code, loss_part=out[U + 1])
@@ -639,7 +666,7 @@ class SocialWaysTrainer:
         # image buffer).  Without social problems in the launch the attention / embedder weights would miss their
         # (zero-gradient) update: torch's kernel then.
         fuse = (self._fuse_g_adam and self._gimg is not None and isinstance(self.predictor_optimizer, PackedAdam)
-                and not (self.world > 1 or self._force_dist)
+                and self.predictor_optimizer.fusable and not (self.world > 1 or self._force_dist)
                 and (not G.use_social or gctx.scenes.P > 0 or gctx.scenes.NB > 0))
         adam = None
         if fuse:

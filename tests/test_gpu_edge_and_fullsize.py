@@ -24,7 +24,7 @@ def pair(n_next, use_social=True, seed=0, **kw):
 
 @pytest.mark.parametrize("sizes,To,Tp", [([1, 5, 16, 2, 13], 3, 5), ([7], 2, 1), ([1, 1, 1], 8, 12), ([64, 3], 8, 12),
                                          ([2] * 9 + [3], 5, 7), ([4, 6, 9], 4, 20)])
-def test_step_matches_oracle_on_odd_shapes(sizes, To, Tp, tile_mode):
+def test_step_matches_oracle_on_odd_shapes(sizes, To, Tp):
     """B not a multiple of the 16-agent tile, single-agent scenes only, a 64-agent scene, To/Tp that are
     not multiples of anything, Tp = 1, a long horizon (Tp = 20: the wide pred_encoder staging path): losses, rollout and ADE/FDE sums of one full step vs the oracle."""
     import socialways_amd as sw
@@ -312,14 +312,7 @@ def test_c4_full_size_forward_locality_and_sub_batch_equivalence():
         pert = tr.G(obsv2, z.cuda(), 12, sb)
         assert not torch.equal(full[:A], pert[:A]) and torch.equal(full[A:], pert[A:])
         lo, hi = int(sb[100, 0]), int(sb[131, 1])
-        # (32 scenes alone are 2048 agents: by default they would run on 8-agent tiles, the full batch on 16-agent
-        # tiles - same results up to summation order; bitwise equality holds within one tiling)
-        from socialways_amd import _lib as L
-        L.load().sw_set_tile_mode(1)
-        try:
-            part = tr.G(obsv[lo:hi], z[lo:hi].cuda(), 12, sb[100:132] - lo)
-        finally:
-            L.load().sw_set_tile_mode(0)
+        part = tr.G(obsv[lo:hi], z[lo:hi].cuda(), 12, sb[100:132] - lo)
         assert torch.equal(part, full[lo:hi])
     # same-weight gradients at full size: generator (random cotangent on the rollout) and discriminator (random
     # cotangents on label / code).  A gradient entry here is a sum over up to 2.1 M pair rows of terms of both signs, so

@@ -33,7 +33,7 @@ def check_weights(tr, g, rtol, atol, frac_ok=1.0):
 
 
 @pytest.mark.parametrize("case", ["syn_s16a8_off", "syn_s16a8_on", "syn_ragged_on", "syn_big_on"])
-def test_one_step(case, tile_mode):
+def test_one_step(case):
     import socialways_amd as sw
     g = golden(case)
     ds = dataset_from(g)

@@ -504,7 +504,7 @@ int sw_dec_rollout_fwd8_launch(const float* obsv, int To, const float* z, const 
   }
   const int tiles = (B + SW8_TILE - 1) / SW8_TILE;
 #define SW_DEC8(SV, AD)                                                                                              \
-  hipLaunchKernelGGL((dec_rollout_fwd8_kernel<SV, AD>), dim3(tiles), dim3(SW_THREADS), F8::total * 4, stream, obsv, To, z, \
+  SW_LAUNCH((dec_rollout_fwd8_kernel<SV, AD>), dim3(tiles), dim3(SW_THREADS), F8::total * 4, stream, obsv, To, z, \
                      S_pool, hT, cT, enc_w, dec_w, B, Tp, pred4, h_end, c_end, gsave, gt, inv_ss, ade_part)
   if (gsave) {
     if (ade_part) SW_DEC8(true, true);
