@@ -1,36 +1,54 @@
-"""profiles/r01_pmc_<workload>.json from the FETCH_SIZE / WRITE_SIZE rocprofv3 passes (separate --pmc runs).
-HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB and, on gfx950,
-FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md §HBM) - validated here on
-dec_rollout_bwd, whose reads (saved LSTM rows + a1/a2) are 58 MB by construction vs 2 x 27.4 MB counted."""
-import json, sqlite3, sys
+"""profiles/rNN_pmc_<workload>.json from the FETCH_SIZE / WRITE_SIZE rocprofv3 passes (separate --pmc runs) + the kernel trace.
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB and, on gfx950, FETCH_SIZE reports
+half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) - validated in round 1 on dec_rollout_bwd, whose
+reads (saved LSTM rows + a1/a2) are 58 MB by construction vs 2 x 27.4 MB counted.
+`_step` = per-step totals: sum over kernels of (mean bytes per launch) x (launches per step; counted against the one
+dec_rollout_fwd launch every step has).
+    python tools/pmc_traffic.py fetch.db write.db out.json"""
+import glob
+import hashlib
+import json
+import os
+import sqlite3
+import subprocess
+import sys
 from collections import defaultdict
+
 
 def mean_counter(db, name):
     con = sqlite3.connect(db)
     per, cnt = defaultdict(float), defaultdict(set)
     for k, c, v, d in con.execute("select kernel_name, counter_name, value, dispatch_id from counters_collection"):
         if c == name:
-            key = k.split("(")[0]
+            key = k.split("(")[0].replace("void ", "").split("<")[0]
             per[key] += v
             cnt[key].add(d)
-    return {k: per[k] / len(cnt[k]) for k in per}
+    return {k: per[k] / len(cnt[k]) for k in per}, {k: len(cnt[k]) for k in per}
 
-fetch = mean_counter(sys.argv[1], "FETCH_SIZE")
-write = mean_counter(sys.argv[2], "WRITE_SIZE")
+
+fetch, nf = mean_counter(sys.argv[1], "FETCH_SIZE")
+write, nw = mean_counter(sys.argv[2], "WRITE_SIZE")
 abi = {"dec_rollout_bwd_kernel": "sw_dec_rollout_bwd", "dec_rollout_fwd_kernel": "sw_dec_rollout_fwd",
        "enc_lstm_fwd_kernel": "sw_enc_lstm_fwd", "enc_lstm_bwd_kernel": "sw_enc_lstm_bwd",
        "disc_fwd_kernel": "sw_disc_fwd", "disc_bwd_kernel": "sw_disc_bwd", "wgrad_partial_kernel": "wgrad_partial",
-       "social_pool_fwd_kernel": "sw_social_pool_fwd", "social_pool_bwd_kernel": "sw_social_pool_bwd"}
-out = {}
+       "wgrad_reduce_kernel": "wgrad_reduce", "social_pool_fwd_kernel": "sw_social_pool_fwd",
+       "social_pool_bwd_kernel": "sw_social_pool_bwd", "social_pool_bwd_rows_kernel": "sw_social_pool_bwd_rows",
+       "stage_step_kernel": "sw_stage_step", "enc_compose_bwd_kernel": "enc_compose_bwd"}
+steps = max(nf.get("dec_rollout_fwd_kernel", 1), 1)
+out, step_bytes, step_k = {}, 0.0, {}
 for k in sorted(set(fetch) | set(write)):
-    name = abi.get(k.replace("void ", ""), None)
+    name = abi.get(k)
     if name is None:
         continue
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+    per_launch = (2 * f + w) * 1024
+    lps = nf.get(k, nw.get(k, 0)) / steps
     out[name] = {"kernel": k, "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
-                 "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
+                 "hbm_bytes_per_launch": int(per_launch), "launches_per_step": round(lps, 3)}
+    step_bytes += per_launch * lps
+    step_k[k] = int(per_launch * lps)
+out["_step"] = {"hbm_bytes_per_step": int(step_bytes), "by_kernel": step_k, "steps_counted": steps}
 # identity of the kernel sources this pass was taken with: bench.py reports `roofline.traffic` only while they match
-import glob, hashlib, os, subprocess
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 h = hashlib.sha256()
 for f in sorted(glob.glob(os.path.join(root, "socialways_amd", "csrc", "*.h*"))):
@@ -42,4 +60,4 @@ except Exception:
 out["_meta"] = {"kernel_src_sha16": h.hexdigest()[:16], "commit": commit,
                 "units": "FETCH_SIZE / WRITE_SIZE in KiB; hbm_bytes_per_launch = (2 FETCH + WRITE) * 1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md)"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps(out, indent=1))
+print(json.dumps(out["_step"], indent=1))
