@@ -70,6 +70,13 @@ __device__ __forceinline__ f32x4 fwd_l2_part(const f32x4 (&w2p)[3], const f32x4 
 }
 }  // namespace
 
+// SAVE (gsave given) and ADE (displacement-error sums wanted) are template parameters, the last decode step is peeled and
+// nothing in the step is stored under a lane- or wave-dependent branch (padding lanes of the last tile are replicas of
+// agent B-1 and store the same values to the same rows; values every wave holds are stored by every wave): with a
+// conditional memory operation in the loop the compiler cannot count what is in flight and waited for EVERYTHING
+// (s_waitcnt vmcnt(0)) at the head of the third layer of every step - the round trip of the ~40 KB of rows the step had
+// just stored (found in the ISA in round 3; the backward kernels had been cleaned of this in round 1).
+template <bool SAVE, bool ADE>
 __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
     const float* __restrict__ obsv, int To, const float* __restrict__ z, const float* __restrict__ S_pool,
     const float* __restrict__ hT, const float* __restrict__ cT, const float* __restrict__ enc_w,
@@ -279,11 +286,18 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
 
   // displacement-error sums of this tile (train.py:546-551), lanes lg == 0 of wave 0
   float e_sum = 0.f, e_last = 0.f, e_sq = 0.f;
-  const bool ade_lane = ade_part && wave == 0 && lg == 0;
+  const bool ade_lane = ADE && wave == 0 && lg == 0 && live;
   int cur = 0;
-  for (int i = 0; i < Tp; ++i) {
+  // everything the prologue requested is waited for HERE, in front of the loop (see the note above the kernel)
+#pragma unroll
+  for (int j = 0; j < 5; ++j) asm volatile("" : "+v"(w43[0][j]), "+v"(w43[1][j]));
+  asm volatile("" : "+v"(b43i[0]), "+v"(b43i[1]), "+v"(px), "+v"(py), "+v"(c), "+v"(h));
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  auto step = [&](int i, auto last_) {
+    constexpr bool LAST = decltype(last_)::value;
     float2 gti = {0.f, 0.f};
-    if (ade_lane) gti = *reinterpret_cast<const float2*>(gt + ((size_t)b * Tp + i) * 2);   // in flight under the layers
+    if constexpr (ADE) gti = *reinterpret_cast<const float2*>(gt + ((size_t)b * Tp + i) * 2);   // in flight under the layers
     const float* hrow = &hbuf[cur * 16 * LD64 + ln * LD64 + 4 * lg];
     // ---- layer 1: z1 = W1h h + u ; a1 = lrelu(z1) --------------------------------------------------
     {
@@ -309,10 +323,10 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
       st4(&a1buf[ln * LD128 + m1a + 4 * lg], acc_a);
       st4(&a1buf[ln * LD128 + m1b + 4 * lg], acc_b);
       st4(&p1[hf * 16 * LD32 + ln * LD32 + 16 * t1p + 4 * lg], acc_p);
-      if (gsave && live) {
+      if constexpr (SAVE) {
         float* row = gsave + gs.a1 + ((size_t)i * B + b) * 160 + 4 * lg;
-        st4(row + m1a, acc_a);
-        st4(row + m1b, acc_b);
+        st4g(row + m1a, acc_a);
+        st4g(row + m1b, acc_b);
       }
     }
     sw_barrier();
@@ -328,8 +342,8 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) b1[j][r] = sw_lrelu(s[r]);
       }
-      if (gsave && live && wave >= 2)    // ... whose rows of the save buffer waves 2 and 3 write
-        st4(gsave + gs.a1 + ((size_t)i * B + b) * 160 + 128 + 16 * (wave - 2) + 4 * lg, wave == 2 ? b1[8] : b1[9]);
+      if constexpr (SAVE)    // ... whose rows of the save buffer every wave writes (even waves tile 8, odd waves tile 9)
+        st4g(gsave + gs.a1 + ((size_t)i * B + b) * 160 + 128 + 16 * (wave & 1) + 4 * lg, (wave & 1) ? b1[9] : b1[8]);
       f32x4 acc = b2f, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 10; ++j) {
@@ -348,13 +362,13 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
       for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu(acc[r]);
       st4(&a2buf[ln * LD64 + m2 + 4 * lg], acc);
       st4(&q2[wave * 16 * LD16 + ln * LD16 + 4 * lg], accq);
-      if (gsave && live) st4(gsave + gs.a2 + ((size_t)i * B + b) * 80 + m2 + 4 * lg, acc);
+      if constexpr (SAVE) st4g(gsave + gs.a2 + ((size_t)i * B + b) * 80 + m2 + 4 * lg, acc);
     }
     sw_barrier();
     SW_STAMP(10);
     // ---- layers 3+4 composed (v = W43 a2 + b43 ; p += v) and the re-fed encoder step (train.py:422-430) ----
-    // Every wave computes the 2-row map itself (20 MFMAs) and keeps its own copy of the running position, so
-    // the LSTM step needs no barrier / LDS hop for its input.
+    // Every wave computes the 2-row map itself and keeps its own copy of the running position, so the LSTM step needs
+    // no barrier / LDS hop for its input.
     {
       f32x4 b2v[5];
 #pragma unroll
@@ -365,7 +379,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) b2v[4][r] = sw_lrelu(s[r]);
       }
-      if (gsave && live && wave == 1) st4(gsave + gs.a2 + ((size_t)i * B + b) * 80 + 64 + 4 * lg, b2v[4]);
+      if constexpr (SAVE) st4g(gsave + gs.a2 + ((size_t)i * B + b) * 80 + 64 + 4 * lg, b2v[4]);   // every wave holds it
       float vx0 = 0.f, vx1 = 0.f, vy0 = 0.f, vy1 = 0.f;      // this lane's 20 columns, two chains per output
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
@@ -388,42 +402,52 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
       px += vx;
       py += vy;
       SW_STAMP(11);
-      if (ade_lane && live) {
-        float dx = (px - gti.x) * inv_ss, dy = (py - gti.y) * inv_ss;
-        float q = dx * dx + dy * dy;
-        float e = sqrtf(q);
-        e_sum += e;
-        e_sq += q;
-        if (i == Tp - 1) e_last = e;
+      if constexpr (ADE) {
+        const float dx = (px - gti.x) * inv_ss, dy = (py - gti.y) * inv_ss;
+        const float q = dx * dx + dy * dy;
+        const float e = sqrtf(q);
+        if (ade_lane) {      // arithmetic only: no memory operation under this branch
+          e_sum += e;
+          e_sq += q;
+          if (LAST) e_last = e;
+        }
       }
-      if (wave == 0 && lg == 0 && live) {
-        f32x4 x4 = {px, py, vx, vy};
+      {   // every lane of agent ln holds the same (p, v): all of them store it (no lane-dependent store)
+        const f32x4 x4 = {px, py, vx, vy};
         st4(pred4 + ((size_t)b * Tp + i) * 4, x4);
-        if (gsave && i < Tp - 1) st4(gsave + gs.x4s + ((size_t)(To + i) * B + b) * 4, x4);
+        if constexpr (SAVE && !LAST) st4(gsave + gs.x4s + ((size_t)(To + i) * B + b) * 4, x4);
       }
-      if (i < Tp - 1 || h_end) {  // the step after the last decode is dead compute (train.py:430)
-        float xb = lg == 0 ? px : (lg == 1 ? py : (lg == 2 ? vx : vy));
+      auto lstm_step = [&](auto save_) {
+        const float xb = lg == 0 ? px : (lg == 1 ? py : (lg == 2 ? vx : vy));
         f32x4 gate[4];
         lstm_cell(W, xb, hrow, gate, c, h);
         st4(&hbuf[(cur ^ 1) * 16 * LD64 + ln * LD64 + u0 + 4 * lg], h);
-        if (gsave && live && i < Tp - 1) {
+        if constexpr (decltype(save_)::value) {
           float* row = gsave + gs.act + ((size_t)(To + i) * B + b) * 384 + u0 + 4 * lg;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) st4(row + g * 64, gate[g]);
-          st4(row + 256, c);
-          st4(row + 320, h);
+          for (int g = 0; g < 4; ++g) st4g(row + g * 64, gate[g]);
+          st4g(row + 256, c);
+          st4g(row + 320, h);
         }
         cur ^= 1;
+      };
+      if constexpr (!LAST) {
+        if constexpr (SAVE) lstm_step(T_{});
+        else lstm_step(F_{});
+      } else {
+        if (h_end) lstm_step(F_{});     // the step after the last decode is dead compute (train.py:430) unless the state is wanted
       }
       sw_barrier();
       SW_STAMP(12);
     }
-  }
+  };
+  for (int i = 0; i < Tp - 1; ++i) step(i, F_{});
+  step(Tp - 1, T_{});
   if (h_end && live) {
     st4(h_end + (size_t)b * 64 + u0 + 4 * lg, h);
     if (c_end) st4(c_end + (size_t)b * 64 + u0 + 4 * lg, c);
   }
-  if (ade_part && wave == 0) {   // fixed shuffle tree over the tile's 16 agents -> one partial triple per workgroup
+  if (ADE && wave == 0) {   // fixed shuffle tree over the tile's 16 agents -> one partial triple per workgroup
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) {
       e_sum += __shfl_xor(e_sum, o);
@@ -643,7 +667,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         st4(&dgbuf[ln * SW_GLD + g * 64 + u0 + 4 * lg], dgate[g]);
-        st4(dgg + g * 64, dgate[g]);
+        st4g(dgg + g * 64, dgate[g]);
       }
       sw_barrier();
       SW_STAMP(0);
@@ -680,7 +704,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(a2[r], acc[r]);
       st4(&dz2buf[ln * LD80 + m2q[q2] + 4 * lg], acc);
-      st4(gdelta + gd.dz2 + ((size_t)i * B + b) * 80 + m2q[q2] + 4 * lg, acc);
+      st4g(gdelta + gd.dz2 + ((size_t)i * B + b) * 80 + m2q[q2] + 4 * lg, acc);
     }
     sw_barrier();
     SW_STAMP(3);
@@ -717,8 +741,8 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
       st4(&dz1buf[ln * LD128 + 32 * wave + 16 + 4 * lg], acc_b);
       st4(&pz1[(2 * t1p + hf) * 16 * LD16 + ln * LD16 + 4 * lg], acc_p);
       float* row = gdelta + gd.dz1 + ((size_t)i * B + b) * 160 + 32 * wave + 4 * lg;
-      st4(row, acc_a);
-      st4(row + 16, acc_b);
+      st4g(row, acc_a);
+      st4g(row + 16, acc_b);
       du_a += acc_a;
       du_b += acc_b;
     }
@@ -736,7 +760,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = sw_lrelu_grad(R.a1s[q][r], v[r]);
         b1[8 + q] = v;
-        st4(gdelta + gd.dz1 + ((size_t)i * B + b) * 160 + 128 + 16 * q + 4 * lg, v);
+        st4g(gdelta + gd.dz1 + ((size_t)i * B + b) * 160 + 128 + 16 * q + 4 * lg, v);
         du_s[q] += v;
       }
       f32x4 acc = decltype(lstm)::value ? dh : f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -816,18 +840,30 @@ extern "C" int sw_dec_rollout_fwd_aux(const float* obsv, int To, const float* z,
   if (ade_part && !gt) return SW_EARG;
   if ((d_w != nullptr) != (dsave != nullptr)) return SW_EARG;
   if (B == 0) return SW_OK;
-  static bool attr = false;
-  if (!attr) {
-    if (int rc = set_lds((const void*)dec_rollout_fwd_kernel, FwdLds::total * 4)) return rc;
-    attr = true;
-  }
   const int tiles = (B + SW_TILE - 1) / SW_TILE;
   // rows of the D observation LSTM inside the save buffer of sw_disc_fwd (independent of its branch count)
   float* act = dsave;
   float* x4s = dsave ? dsave + (size_t)To * B * 384 : nullptr;
-  SW_LAUNCH(dec_rollout_fwd_kernel, dim3(d_w ? 2 * tiles : tiles), dim3(SW_THREADS), FwdLds::total * 4,
-                     (hipStream_t)stream, obsv, To, z, S_pool, hT, cT, enc_w, dec_w, B, Tp, pred4, h_end, c_end, gsave, gt,
-                     inv_ss, ade_part, d_w, act, x4s, sw_gen_images_for(enc_w, dec_w));
+  const float* gimg = sw_gen_images_for(enc_w, dec_w);
+#define SW_DEC_FWD(SV, AD)                                                                                           \
+  do {                                                                                                               \
+    static bool attr = false;                                                                                        \
+    if (!attr) {                                                                                                     \
+      if (int rc = set_lds((const void*)dec_rollout_fwd_kernel<SV, AD>, FwdLds::total * 4)) return rc;               \
+      attr = true;                                                                                                   \
+    }                                                                                                                \
+    SW_LAUNCH((dec_rollout_fwd_kernel<SV, AD>), dim3(d_w ? 2 * tiles : tiles), dim3(SW_THREADS), FwdLds::total * 4,  \
+              (hipStream_t)stream, obsv, To, z, S_pool, hT, cT, enc_w, dec_w, B, Tp, pred4, h_end, c_end, gsave, gt,  \
+              inv_ss, ade_part, d_w, act, x4s, gimg);                                                                \
+  } while (0)
+  if (gsave) {
+    if (ade_part) SW_DEC_FWD(true, true);
+    else SW_DEC_FWD(true, false);
+  } else {
+    if (ade_part) SW_DEC_FWD(false, true);
+    else SW_DEC_FWD(false, false);
+  }
+#undef SW_DEC_FWD
   SW_CHECK_LAUNCH("dec_rollout_fwd_kernel");
   return SW_OK;
 }

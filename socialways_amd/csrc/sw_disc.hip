@@ -746,7 +746,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_bwd_kernel(
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       st4(dgl + g * 64, dgate[g]);
-      st4(dgg + g * 64, dgate[g]);
+      st4g(dgg + g * 64, dgate[g]);
     }
     dgg -= dgg_step;
     SW_STAMP(12);
@@ -761,6 +761,12 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_bwd_kernel(
     }
     SW_STAMP(14);
   };
+  // every load issued so far (the saved rows of the first step, W_hh^T) is waited for HERE: behind the heads' conditional
+  // stores the compiler cannot count what is pending on the way into the loop, and a loop header with an unknown state
+  // gets s_waitcnt vmcnt(0) - which every BPTT step then pays as the round trip of the dgates rows it has just stored
+  asm volatile("" : "+v"(gate[0]), "+v"(gate[1]), "+v"(gate[2]), "+v"(gate[3]), "+v"(ct), "+v"(cprev));
+#pragma unroll
+  for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(WT.whhT[j]));
   for (int t = To - 1; t >= 2; --t) step(t, T_{}, T_{}, T_{});
   if (To > 1) step(1, T_{}, F_{}, T_{});
   step(0, F_{}, F_{}, F_{});

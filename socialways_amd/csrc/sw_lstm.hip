@@ -69,9 +69,9 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
     st4(&hbuf[(t + 1) & 1][ln * SW_HLD + u0 + 4 * lg], h);
     if constexpr (ACT) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) st4(arow + g * 64, gate[g]);
-      st4(arow + 256, c);
-      st4(arow + 320, h);
+      for (int g = 0; g < 4; ++g) st4g(arow + g * 64, gate[g]);
+      st4g(arow + 256, c);
+      st4g(arow + 320, h);
       arow += (size_t)B * 384;
     }
     if constexpr (Y) {
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_bwd_kernel(
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       st4(dgl + g * 64, dgate[g]);
-      st4(dgg + g * 64, dgate[g]);
+      st4g(dgg + g * 64, dgate[g]);
     }
     dgg -= (size_t)B * 256;
     sw_barrier();

@@ -228,7 +228,7 @@ def test_step_many_equals_consecutive_steps():
 
 
 # ---- BASELINE configs 2 and 4 at full size --------------------------------------------------------------------------
-def _step_vs_oracle(S, A, seed, grads_rtol):
+def _step_vs_oracle(S, A, seed, grads_rtol, frac_ok=0.97):
     """One whole GAN step (2 D updates + 1 G update) of the HIP path vs the block-diagonal oracle on the same weights,
     noise and label scalars: the 9 MSE terms, the ADE/FDE sums, the gradients the last D update and the G update saw
     (relative to each tensor's largest entry: fp32 sums over up to 2.1 M pairs on both sides) and the weights after
@@ -252,18 +252,41 @@ def _step_vs_oracle(S, A, seed, grads_rtol):
         for k, p in getattr(tr.G, name).named_parameters():
             w = rec["g_grads"][name + "." + k]
             assert_close(p.grad.cpu(), w, grads_rtol, grads_rtol * max(float(w.abs().max()), 1e-12), "dG %s.%s" % (name, k))
-    # the LAST D update's gradients are taken at weights that already went through one Adam step, whose first update
-    # moves every weight by ~lr * sign(g): where a noise-level gradient has the other sign the two sides' weights differ
-    # by 2e-3, so these gradients agree less tightly than same-weight gradients do (those: the c4 forward/backward test
-    # below and tests/test_gpu_kernels.py)
-    for k, p in tr.D.named_parameters():
-        w = rec["d_grads"][-1][k]
-        assert_close(p.grad.cpu(), w, 4 * grads_rtol, 4 * grads_rtol * max(float(w.abs().max()), 1e-12), "dD %s" % k)
+    # The LAST D update's gradients are taken at weights that already went through one Adam step, whose first update moves
+    # every weight by ~lr * sign(g): where a noise-level gradient has the other sign the two sides' weights differ by
+    # 2e-3.  So they are compared at IDENTICAL weights: the HIP step keeps deepcopy(D) after the first update
+    # (train.py:498-499: the workspace "d_backup" - exactly the weights its second pass ran with); the oracle's D is
+    # given those weights and differentiates the same d_loss (train.py:482-495) on its own rollout.
+    nD = tr.D._flat.numel()
+    Dh = sw.Discriminator(12, 64, 2, device="cuda:0")
+    Dh._flat.copy_(tr.ws.buf["d_backup"][:nD])
+    Do = O.Discriminator(12, 64, 2)
+    Do.load_state_dict({k: v.cpu() for k, v in Dh.state_dict().items()})
+    mse = torch.nn.MSELoss()
+    o4, p4 = O.get_traj_4d(data.obsv[:B].cpu(), data.pred[:B].cpu())
+    fake, code = Do(o4, tr.last_pred_hat.cpu())
+    real, _ = Do(o4, p4)
+    (mse(fake, torch.zeros(B, 1) + 0.02) + mse(real, torch.ones(B, 1) * 0.96) + 0.5 * mse(code.squeeze(), noise[:, :2])).backward()
+    for (k, p), (_, q) in zip(tr.D.named_parameters(), Do.named_parameters()):
+        w = q.grad
+        assert_close(p.grad.cpu(), w, grads_rtol, grads_rtol * max(float(w.abs().max()), 1e-12), "dD (update 2, same weights) %s" % k)
+    # Weights after the step.  Adam's first updates move a weight by lr * sign(g) whatever |g| is, so an element whose
+    # gradient is at rounding level may land 2 lr (4 lr after D's two updates) away from the oracle's; everything else
+    # must agree to a small fraction of one update.  Hard bound per module: 2.2 updates' worth; and all but a small
+    # fraction of every tensor within 5 % of lr.
+    fracs = []
+    lr_of = {"encoder": 1e-4, "decoder": 1e-4, "feature_embedder": 1e-4, "attention": 1e-4, "D": 1e-3}
     for name, mod in (("encoder", tr.G.encoder), ("decoder", tr.G.decoder), ("feature_embedder", tr.G.feature_embedder),
                       ("attention", tr.G.attention), ("D", tr.D)):
         ref = getattr(orc, name).state_dict()
+        lr, n_upd = lr_of[name], (2 if name == "D" else 1)
         for k, v in mod.state_dict().items():
-            assert ((v.cpu() - ref[k]).abs() > 2e-3 * 1.01).float().mean().item() == 0.0, (name, k)
+            d = (v.cpu() - ref[k]).abs()
+            assert float(d.max()) <= 2.2 * lr * n_upd, (name, k, float(d.max()))
+            close = float((d <= 0.05 * lr + 1e-6 * ref[k].abs()).float().mean())
+            fracs.append((close, name, k))
+            assert close >= frac_ok, "%s.%s: only %.4f of the elements within 5 %% of lr" % (name, k, close)
+    print("weights within 5 %% of lr: worst tensors %s" % sorted(fracs)[:4])
     return tr, data, sb, B
 
 
