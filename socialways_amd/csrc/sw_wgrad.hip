@@ -219,36 +219,49 @@ size_t wg_finalize(WgBatch& b) {
   static const double maxwg_env = getenv("SW_WG_MAXWG") ? atof(getenv("SW_WG_MAXWG")) : 0.0;
   const double maxwg = maxwg_env > 0.0 ? maxwg_env : (target >= 4096.0 ? 1024.0 : 512.0);
   if (target > maxwg) target = maxwg;
-  size_t ws = 0;
-  int job = 0, out = 0;
-  for (int i = 0; i < b.np; ++i) {
-    WgProblem& P = b.p[i];
-    const int NB = (P.N + 63) / 64;
-    int ns;
-    if (P.pre) {
-      ns = P.pre;
-    } else {
-      ns = (int)(target * wg_cost(P) / total / NB + 0.5);   // workgroups (4 row slices each) per output block
-      int cap = (P.R + 127) / 128;  // at least 32 rows per wave
-      if (ns > cap) ns = cap;
-      if (ns > SW_WG_MAXSPLIT) ns = SW_WG_MAXSPLIT;
-      if (ns < 1) ns = 1;
+  // A batch whose natural size lies between one workgroup per CU and one resident round (a discriminator pass at the
+  // metric shape: ~300) runs best with AT MOST one workgroup on every CU: beyond 256 some CUs get two and the launch
+  // lasts as long as those (swept in round 3: 224 / 240 / 256 / 264 / 288 workgroups -> 0.4056 / 0.4057 / 0.4025 /
+  // 0.4095 / 0.4090 ms per training step).  SW_WG_SMALL overrides the count.
+  static const double small_env = getenv("SW_WG_SMALL") ? atof(getenv("SW_WG_SMALL")) : 256.0;
+  const bool one_per_cu = target > 256.0 && target < 448.0 && small_env > 0.0;
+  if (one_per_cu) target = small_env;
+  auto assign = [&](double tgt) {
+    size_t ws = 0;
+    int job = 0, out = 0;
+    for (int i = 0; i < b.np; ++i) {
+      WgProblem& P = b.p[i];
+      const int NB = (P.N + 63) / 64;
+      int ns;
+      if (P.pre) {
+        ns = P.pre;
+      } else {
+        ns = (int)(tgt * wg_cost(P) / total / NB + 0.5);   // workgroups (4 row slices each) per output block
+        int cap = (P.R + 127) / 128;  // at least 32 rows per wave
+        if (ns > cap) ns = cap;
+        if (ns > SW_WG_MAXSPLIT) ns = SW_WG_MAXSPLIT;
+        if (ns < 1) ns = 1;
+      }
+      P.nsplit = ns;
+      P.job0 = job;
+      b.job0s[i] = job;
+      b.out0s[i] = out;
+      if (!P.pre) job += ns * NB;
+      P.out0 = out;
+      const int Kc = P.K + P.K2 + P.ones;
+      out += P.N * Kc;
+      if (!P.pre) {
+        P.ws_off = ws;
+        ws += (size_t)ns * P.N * Kc;
+      }
     }
-    P.nsplit = ns;
-    P.job0 = job;
-    b.job0s[i] = job;
-    b.out0s[i] = out;
-    if (!P.pre) job += ns * NB;
-    P.out0 = out;
-    const int Kc = P.K + P.K2 + P.ones;
-    out += P.N * Kc;
-    if (!P.pre) {
-      P.ws_off = ws;
-      ws += (size_t)ns * P.N * Kc;
-    }
-  }
-  b.total_jobs = job;
-  b.total_out = out;
+    b.total_jobs = job;
+    b.total_out = out;
+    return ws;
+  };
+  size_t ws = assign(target);
+  if (one_per_cu)      // the per-problem rounding may overshoot the count: step down until it fits
+    for (double tgt = target - 4.0; b.total_jobs > (int)small_env && tgt > 64.0; tgt -= 4.0) ws = assign(tgt);
   return ws + b.top_reserved;
 }
 
