@@ -352,6 +352,36 @@ int sw_disc_image_floats(int Tp);
 int sw_disc_image_table(int Tp, int* tab_host);
 int sw_disc_images(const float* d_w, float* img, const int* tab, int Tp, void* stream);
 
+/* ---- GENERIC-WIDTH path: the per-layer pieces from which socialways_amd/generic.py runs the same model for any
+ *      `--hidden-size` (train.py:42-44, 76-81: encoder / social-feature / discriminator widths H, noise H/2) and any
+ *      latent-code count (train.py:65).  The fused kernels above hold a 64-unit layer per workgroup in registers and are
+ *      the path of every BASELINE config; H > 64 or n_latent_code != 2 run layer by layer through these entry points
+ *      plus sw_rows_gemm / sw_linear_wgrad - same mathematics, launch-bound.  All buffers row-major fp32.        */
+/* nn.LSTM cell, element-wise part: pre [B][4H] = gate pre-activations (i | f | g | o blocks); gates receives the
+ * activated gates, c / h [B][H] the new state; c_prev NULL = zeros.  Backward: dpre [B][4H], dc_prev [B][H] from
+ * dh / dc (either may be NULL = zeros).                                                                       */
+int sw_lstm_point_fwd(const float* pre, const float* c_prev, int B, int H, float* gates, float* c, float* h, void* stream);
+int sw_lstm_point_bwd(const float* gates, const float* c, const float* c_prev, const float* dh, const float* dc, int B,
+                      int H, float* dpre, float* dc_prev, void* stream);
+/* kind 0: ReLU, 1: LeakyReLU(0.2) (train.py:181-188, 280-292, 324-328); the backward takes the activated values */
+int sw_act_fwd(const float* x, long long n, int kind, float* y, void* stream);
+int sw_act_bwd(const float* y, const float* dy, long long n, int kind, float* dx, void* stream);
+/* sum over an [R][C] block of (a - b)^2 (b NULL: the scalar target[target_idx], read on the device) into out_sum[0]
+ * (or NULL), and da = gscale (a - b) (or NULL): the pieces of nn.MSELoss and its gradient (train.py:484-494, 512-523) */
+int sw_sqdiff(const float* a, int lda, const float* b, int ldb, const float* target, int target_idx, long long R, int C,
+              float gscale, float* out_sum, float* da, int ldda, void* stream);
+/* SocialFeatures (train.py:208-241) on the ordered in-scene pairs only: feat [P][4] = (dist, bearing, dca, 0) at row
+ * pair_off[s] + i_local n + j_local (pair_off as for sw_social_pool_bwd); x4_last [B][4] = last observed (p, v)   */
+int sw_pair_features(const float* x4_last, const int* scene_off, const long long* pair_off, int S, float* feat, void* stream);
+/* AttentionPooling (train.py:153-175) on pair rows f [P][F] with wh = W h + b [B][F], h [B][H]: attn [P] receives the
+ * softmax weights, S_out [B][H] the pooled states.  Backward: dsig [P] scratch, df [P][F] (or NULL), dwh [B][F] =
+ * dL/d(wh), dh [B][H] = sum_i a_ij dS_i (the caller adds the W^T dwh term and forms dW, db).                    */
+int sw_attn_pairs_fwd(const float* f, const float* wh, const float* h, const int* scene_off, const long long* pair_off, int S,
+                      int B, int F, int H, float* attn, float* S_out, void* stream);
+int sw_attn_pairs_bwd(const float* f, const float* wh, const float* h, const float* attn, const float* dS, const int* scene_off,
+                      const long long* pair_off, int S, int B, int F, int H, float* dsig, float* df, float* dwh, float* dh,
+                      void* stream);
+
 /* ---- Adam on a packed buffer (train.py:379-385: lr, betas, eps; no weight decay), torch's fused Adam restated operation
  *      by operation (the arithmetic of sw_disc_bwd_gan_adam / sw_gen_wgrad_adam as a kernel of its own): the optimizer
  *      step of data-parallel ranks, whose gradients pass through an all-reduce first.  step = device scalar, 1-based

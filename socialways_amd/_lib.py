@@ -72,6 +72,14 @@ PROTOTYPES = {
     "sw_disc_image_table": (_i, [_i, _vp]),
     "sw_disc_images": (_i, [_vp, _vp, _vp, _i, _vp]),
     "sw_ade_fde": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
+    "sw_lstm_point_fwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "sw_lstm_point_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "sw_act_fwd": (_i, [_vp, _ll, _i, _vp, _vp]),
+    "sw_act_bwd": (_i, [_vp, _vp, _ll, _i, _vp, _vp]),
+    "sw_sqdiff": (_i, [_vp, _i, _vp, _i, _vp, _i, _ll, _i, _f, _vp, _vp, _i, _vp]),
+    "sw_pair_features": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "sw_attn_pairs_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "sw_attn_pairs_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sw_adam_packed": (_i, [_vp, _vp, _vp, _vp, _ll, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                             ctypes.c_double, _i, _vp]),
     "sw_kernel_timing": (_i, [_i]),
@@ -111,6 +119,11 @@ def ptr(t):
         return None
     assert t.is_contiguous(), "socialways_amd kernels need contiguous tensors"
     return t.data_ptr()
+
+
+def ptr_strided(t):
+    """Device pointer of a tensor whose strides the callee is told about (None -> NULL)."""
+    return None if t is None else t.data_ptr()
 
 
 def stream():

@@ -1209,6 +1209,31 @@ __global__ void social_features_kernel(const float* __restrict__ x4, int B, floa
 }
 
 
+// SocialFeatures on the ordered IN-SCENE pairs only (the block-diagonal of train.py:229-241), as rows for the generic-width
+// path (sw_generic.hip): feat [P][4] = (dist, bearing, dca, 0) at row pair_off[s] + i_local n + j_local; single-agent
+// scenes own no rows.  x4_last [B][4] = (p, v) of the last observed step.
+__global__ __launch_bounds__(256) void pair_features_kernel(const float* __restrict__ x4, const int* __restrict__ scene_off,
+                                                            const long long* __restrict__ pair_off, int S,
+                                                            float* __restrict__ feat) {
+  const int s = blockIdx.x;
+  const int s0 = scene_off[s], n = scene_off[s + 1] - s0;
+  if (n <= 1) return;
+  const long long p0 = pair_off[s];
+  for (int e = threadIdx.x; e < n * n; e += 256) {
+    const int i = e / n, j = e - i * n;
+    float f0, f1, f2;
+    pair_feat(ld4(x4 + (size_t)(s0 + i) * 4), ld4(x4 + (size_t)(s0 + j) * 4), f0, f1, f2);
+    st4(feat + (size_t)(p0 + e) * 4, f32x4{f0, f1, f2, 0.f});
+  }
+}
+extern "C" int sw_pair_features(const float* x4_last, const int* scene_off, const long long* pair_off, int S, float* feat,
+                                void* stream) {
+  if (!x4_last || !scene_off || !pair_off || !feat || S < 1) return SW_EARG;
+  SW_LAUNCH(pair_features_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, x4_last, scene_off, pair_off, S, feat);
+  SW_CHECK_LAUNCH("pair_features_kernel");
+  return SW_OK;
+}
+
 static int set_lds(const void* fn, int bytes) {
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) {

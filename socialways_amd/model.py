@@ -45,7 +45,8 @@ def _check_hidden(H, what):
     an LSTM unit with zero pre-activations keeps c = h = 0), feeds nothing forward, and receives zero gradients."""
     if H > 64 or H < 8 or H % 8:
         raise L.SocialWaysHipError("%s: hidden size %d - the kernels hold 64 hidden units per layer in registers; sizes "
-                                   "8, 16, .. 64 are supported (smaller ones zero-padded), larger ones are not" % (what, H))
+                                   "8, 16, .. 64 run on them (smaller ones zero-padded); larger widths train on the "
+                                   "generic-width path (socialways_amd.generic / SocialWaysTrainer(hidden_size=...))" % (what, H))
 
 
 class _Packed(nn.Module):

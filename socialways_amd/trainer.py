@@ -160,6 +160,14 @@ class SocialWaysTrainer:
     STEPS_PER_LAUNCH = 4    # train_epoch: consecutive packed batches of one scene layout per graph launch (step_many)
     Z_COLS = 32             # noise columns of the kernels (hidden size 64: train.py:81); smaller models are zero-padded
 
+    def __new__(cls, n_next=None, hidden_size=64, *args, **kw):
+        """Widths above the fused kernels' 64 units and latent-code counts other than 2 (train.py:42-44, 65) train on
+        the generic-width path (generic.py: the same model layer by layer, same public surface)."""
+        if cls is SocialWaysTrainer and (int(hidden_size) > 64 or int(kw.get("n_latent_codes", 2)) != 2):
+            from .generic import GenericTrainer
+            return object.__new__(GenericTrainer)
+        return object.__new__(cls)
+
     def _pad_z(self, z):
         return z if z.shape[-1] == self.Z_COLS else torch.nn.functional.pad(z, (0, self.Z_COLS - z.shape[-1]))
 

@@ -228,7 +228,7 @@ def test_step_many_equals_consecutive_steps():
 
 
 # ---- BASELINE configs 2 and 4 at full size --------------------------------------------------------------------------
-def _step_vs_oracle(S, A, seed, grads_rtol, frac_ok=0.97):
+def _step_vs_oracle(S, A, seed, grads_rtol, frac_ok=0.999):
     """One whole GAN step (2 D updates + 1 G update) of the HIP path vs the block-diagonal oracle on the same weights,
     noise and label scalars: the 9 MSE terms, the ADE/FDE sums, the gradients the last D update and the G update saw
     (relative to each tensor's largest entry: fp32 sums over up to 2.1 M pairs on both sides) and the weights after
@@ -274,7 +274,6 @@ def _step_vs_oracle(S, A, seed, grads_rtol, frac_ok=0.97):
     # gradient is at rounding level may land 2 lr (4 lr after D's two updates) away from the oracle's; everything else
     # must agree to a small fraction of one update.  Hard bound per module: 2.2 updates' worth; and all but a small
     # fraction of every tensor within 5 % of lr.
-    fracs = []
     lr_of = {"encoder": 1e-4, "decoder": 1e-4, "feature_embedder": 1e-4, "attention": 1e-4, "D": 1e-3}
     for name, mod in (("encoder", tr.G.encoder), ("decoder", tr.G.decoder), ("feature_embedder", tr.G.feature_embedder),
                       ("attention", tr.G.attention), ("D", tr.D)):
@@ -284,9 +283,7 @@ def _step_vs_oracle(S, A, seed, grads_rtol, frac_ok=0.97):
             d = (v.cpu() - ref[k]).abs()
             assert float(d.max()) <= 2.2 * lr * n_upd, (name, k, float(d.max()))
             close = float((d <= 0.05 * lr + 1e-6 * ref[k].abs()).float().mean())
-            fracs.append((close, name, k))
             assert close >= frac_ok, "%s.%s: only %.4f of the elements within 5 %% of lr" % (name, k, close)
-    print("weights within 5 %% of lr: worst tensors %s" % sorted(fracs)[:4])
     return tr, data, sb, B
 
 
@@ -455,9 +452,68 @@ def test_smaller_hidden_sizes_run_zero_padded_and_match_the_oracle(H, tmp_path):
     assert torch.equal(a, b) and torch.equal(tr.G._flat_all, tr2.G._flat_all) and torch.equal(tr.D._flat, tr2.D._flat)
 
 
-def test_hidden_sizes_above_64_are_refused():
+@pytest.mark.parametrize("H,nl", [(128, 2), (96, 2), (64, 3)])
+def test_wider_networks_train_on_the_generic_path_and_match_the_oracle(H, nl, tmp_path):
+    """`--hidden-size` above the fused kernels' 64 units (train.py:42-44, 76-81) and latent-code counts other than 2
+    (train.py:65): SocialWaysTrainer hands these to the generic-width path (socialways_amd/generic.py - the same model
+    layer by layer through the C ABI).  Same initial weights as the reference draws, two whole GAN steps against the
+    oracle built with that width (9 MSE terms, rollout, ADE/FDE, the generator's gradients of the first step, the
+    weights after both steps), a checkpoint in the reference's format and a resume from the file."""
     import socialways_amd as sw
-    with pytest.raises(sw.SocialWaysHipError):
-        sw.SocialWaysTrainer(12, hidden_size=128, device="cuda:0")
+    from socialways_amd.generic import GenericTrainer
+    torch.manual_seed(7)
+    tr = sw.SocialWaysTrainer(12, hidden_size=H, use_social=True, n_latent_codes=nl, device="cuda:0")
+    assert isinstance(tr, GenericTrainer)
+    torch.manual_seed(7)
+    orc = O.SocialWaysOracle(12, hidden_size=H, use_social=True, n_latent_codes=nl)
+    ck = tr.checkpoint()
+    for name, mod in (("encoder_dict", orc.encoder), ("decoder_dict", orc.decoder), ("feature_embedder_dict", orc.feature_embedder),
+                      ("attentioner_dict", orc.attention), ("D_dict", orc.D)):
+        for k, v in mod.state_dict().items():      # identical initialisation, reference shapes and keys
+            assert tuple(ck[name][k].shape) == tuple(v.shape) and torch.equal(ck[name][k].cpu(), v), (name, k)
+    t = sw.synth_tracks(8, [5, 1, 9, 16, 3, 2, 2, 2], 8, 12, seed=5)
+    data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
+    B, sb = 36, data.the_batches[:6]
+    gen = torch.Generator().manual_seed(2)
+    for it in range(2):
+        noise = torch.rand(B, H // 2, generator=gen)
+        rec = {}
+        out = tr.step(data.obsv[:B], data.pred[:B], sb, 0.03, 0.94, noise, data.ss)
+        got = tr.losses_from(out, [B], 12, data.ss)[0]
+        want, ade, fde = orc.train_step(data.obsv[:B].cpu(), data.pred[:B].cpu(), sb, 0.03, 0.94, noise, data.ss, record=rec)
+        assert_close(got, np.asarray(want), 1e-4 if it else 5e-5, 3e-6, "9 MSE terms, step %d" % it)
+        o = out.double().cpu().numpy()
+        assert abs(o[-1, 0] - ade) / ade < 2e-5 and abs(o[-1, 1] - fde) / fde < 2e-5
+        assert_close(tr.last_pred_hat.cpu(), rec["pred_hat_4d"], 1e-4, 1e-5, "rollout, step %d" % it)
+        if it == 0:      # same-weight gradients of the first step
+            for name in ("attention", "feature_embedder", "encoder", "decoder"):
+                for k, p in getattr(tr.G, name).named_parameters():
+                    w = rec["g_grads"][name + "." + k]
+                    assert_close(p.grad.cpu(), w, 2e-4, 2e-4 * max(float(w.abs().max()), 1e-12), "dG %s.%s" % (name, k))
+    for name, mod in (("encoder", tr.G.encoder), ("decoder", tr.G.decoder), ("D", tr.D)):
+        ref = getattr(orc, name).state_dict()
+        for k, v in mod.state_dict().items():      # two Adam steps: within a fraction of lr except noise-level gradients
+            lr = 1e-3 if name == "D" else 1e-4
+            d = (v.cpu() - ref[k]).abs()
+            assert float(d.max()) <= 4.4 * lr and float((d <= 0.1 * lr).float().mean()) > 0.95, (name, k, float(d.max()))
+    path = tmp_path / "wide.pt"
+    tr.save(str(path), epoch=3)
+    tr2 = sw.SocialWaysTrainer(12, hidden_size=H, use_social=True, n_latent_codes=nl, device="cuda:0")
+    assert tr2.load_checkpoint(str(path)) == 4
+    noise = torch.rand(B, H // 2, generator=gen)
+    a = tr.step(data.obsv[:B], data.pred[:B], sb, 0.05, 0.9, noise, data.ss)
+    b = tr2.step(data.obsv[:B], data.pred[:B], sb, 0.05, 0.9, noise, data.ss)
+    assert torch.equal(a, b)
+    for p, q in zip(tr.G.parameters(), tr2.G.parameters()):
+        assert torch.equal(p, q)
+    # evaluation on the generic path: test() of train.py:563-616
+    res = tr.test(data, n_gen_samples=3)
+    assert all(np.isfinite(res))
+
+
+def test_unsupported_module_widths_say_where_to_go():
+    import socialways_amd as sw
+    with pytest.raises(sw.SocialWaysHipError, match="generic"):
+        sw.EncoderLstm(128, 1)
     with pytest.raises(sw.SocialWaysHipError):
         sw.EncoderLstm(20, 1)
