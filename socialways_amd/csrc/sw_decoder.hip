@@ -663,13 +663,10 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
       const int t = To + i;
       f32x4 dgate[4];
       lstm_cell_bwd(R.gate, R.ct, R.cprev, dh, dc, dgate);
-      float* dgg = gdelta + gd.dgates + ((size_t)t * B + b) * 256 + u0 + 4 * lg;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        st4(&dgbuf[ln * SW_GLD + g * 64 + u0 + 4 * lg], dgate[g]);
-        st4g(dgg + g * 64, dgate[g]);
-      }
+      for (int g = 0; g < 4; ++g) st4(&dgbuf[ln * SW_GLD + g * 64 + u0 + 4 * lg], dgate[g]);
       sw_barrier();
+      lstm_store_dgates_tile(dgbuf, gdelta + gd.dgates + ((size_t)t * B + a0) * 256, nullptr, a0, B, wave, lane);
       SW_STAMP(0);
       dh = lstm_dh_prev(WT, &dgbuf[ln * SW_GLD + 4 * lg]);
       // dx4 = Wx^T dgates: each wave reduces its own quarter of K, partials through LDS

@@ -733,9 +733,6 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_bwd_kernel(
   f32x4 gate[4], ct, cprev;
   if (To > 1) load_row(To - 1, gate, ct, cprev, T_{});
   else load_row(0, gate, ct, cprev, F_{});
-  float* dgg = live ? ddelta + dd.dgates + ((size_t)(To - 1) * B + b) * 256 + u0 + 4 * lg
-                    : ddelta + dd.trash + ln * 256 + u0 + 4 * lg;
-  const ptrdiff_t dgg_step = live ? (ptrdiff_t)B * 256 : 0;
   SW_STAMP(10);
   // one BPTT step; pf: rows of step t-1 are prefetched (pp: they have a predecessor row), nx: dh_{t-1} is needed
   auto step = [&](int t, auto pf, auto pp, auto nx) {
@@ -744,13 +741,11 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_bwd_kernel(
     lstm_cell_bwd(gate, ct, cprev, dh, dc, dgate);
     float* dgl = &dgbuf[(t & 1) * 16 * SW_GLD + ln * SW_GLD + u0 + 4 * lg];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      st4(dgl + g * 64, dgate[g]);
-      st4g(dgg + g * 64, dgate[g]);
-    }
-    dgg -= dgg_step;
+    for (int g = 0; g < 4; ++g) st4(dgl + g * 64, dgate[g]);
     SW_STAMP(12);
     sw_barrier();
+    lstm_store_dgates_tile(&dgbuf[(t & 1) * 16 * SW_GLD], ddelta + dd.dgates + ((size_t)t * B + a0) * 256, ddelta + dd.trash,
+                           a0, B, wave, lane);
     SW_STAMP(13);
     if constexpr (decltype(nx)::value) dh = lstm_dh_prev(WT, &dgbuf[(t & 1) * 16 * SW_GLD + ln * SW_GLD + 4 * lg]);
     if constexpr (decltype(pf)::value) {

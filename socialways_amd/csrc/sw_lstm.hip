@@ -138,7 +138,6 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_bwd_kernel(
   f32x4 gate[4], ct, cprev;
   if (T > 1) load_row(T - 1, gate, ct, cprev, T_{});
   else load_row(0, gate, ct, cprev, F_{});
-  float* dgg = dgates + ((size_t)(t0 + T - 1) * B + b) * 256 + u0 + 4 * lg;
   const float* dyp = DY ? dy + ((size_t)b * T + T - 1) * 64 + u0 + 4 * lg : nullptr;
   auto step = [&](int t, auto pf, auto pp) {   // pf: prefetch the rows of step t-1 (pp: which have a predecessor row)
     f32x4 ngate[4], nct, ncp, dgate[4];
@@ -150,12 +149,9 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_bwd_kernel(
     lstm_cell_bwd(gate, ct, cprev, dh, dc, dgate);
     float* dgl = &dgbuf[t & 1][ln * SW_GLD + u0 + 4 * lg];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      st4(dgl + g * 64, dgate[g]);
-      st4g(dgg + g * 64, dgate[g]);
-    }
-    dgg -= (size_t)B * 256;
+    for (int g = 0; g < 4; ++g) st4(dgl + g * 64, dgate[g]);
     sw_barrier();
+    lstm_store_dgates_tile(dgbuf[t & 1], dgates + ((size_t)(t0 + t) * B + a0) * 256, nullptr, a0, B, wave, lane);
     dh = lstm_dh_prev(W, &dgbuf[t & 1][ln * SW_GLD + 4 * lg]);
     if constexpr (decltype(pf)::value) {
       // the prefetched rows are not touched before the matrix products above have been issued

@@ -155,6 +155,27 @@ __device__ __forceinline__ void lstm_cell_bwd(const f32x4 gate[4], f32x4 ct, f32
   }
 }
 
+// The dgates rows of a BPTT step go to memory FROM THE LDS TILE the step builds anyway ([16 agents][SW_GLD]), behind the
+// step's barrier and one agent per store instruction: a wave writes 4 agents' rows, lane l the l-th float4 of the 256-float
+// row - 1 KB of consecutive memory per instruction (8 full cache lines).  Stored from the MFMA result registers a lane
+// holds 4 units of one agent, i.e. an instruction scatters sixteen 64-byte pieces over sixteen rows - half-line writes,
+// which the store path charges for: at the dense-crowd shape the dgates stores were a third of disc_bwd (round 3,
+// SW_EXP_NOSTORE).  Rows beyond agent B-1 (padding of the last tile) go to `trash` (16 x 256 floats).
+__device__ __forceinline__ void lstm_store_dgates_tile(const float* dgtile, float* __restrict__ rows /*row of agent a0*/,
+                                                       float* __restrict__ trash, int a0, int B, int wave, int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int a = 4 * wave + q;
+    const f32x4 v = ld4(dgtile + a * SW_GLD + 4 * lane);
+    // trash == nullptr: the padding rows of the tile are exact replicas of agent B-1 (every load of the kernel is clamped
+    // to it) and are stored over its row - the same values to the same place
+    float* dst = (a0 + a < B) ? rows + (size_t)a * 256 + 4 * lane
+                 : trash      ? trash + a * 256 + 4 * lane
+                              : rows + (size_t)(B - 1 - a0) * 256 + 4 * lane;
+    st4g(dst, v);
+  }
+}
+
 // W_hh^T in registers for dh_{t-1} = W_hh^T dgates: whhT[j][r] = Whh[16j + 4lg + r][u0 + ln].
 struct LstmWT {
   f32x4 whhT[16];
