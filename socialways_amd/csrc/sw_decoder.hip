@@ -47,8 +47,10 @@ struct FwdLds {
   static constexpr int LD128 = sw_ld(128);  // 132
   static constexpr int LD32 = sw_ld(32);    // 36
   static constexpr int LD16 = sw_ld(16);    // 20
-  static constexpr int hbuf = 0;                        // [2][16][68]
-  static constexpr int a1buf = hbuf + 2 * 16 * LD64;    // [16][132]  a1[:, :128]            (prologue: [S|z] tile [16][100])
+  static constexpr int hbuf = 0;                        // [2][16][SW_ALD]: the saved LSTM row of a step (i f g o | c | h), assembled
+                                                        //   here and stored row-wise behind the barrier; its h columns (320..) are
+                                                        //   the B operand of the next step's products (lstm_put_act_tile)
+  static constexpr int a1buf = hbuf + 2 * 16 * SW_ALD;  // [16][132]  a1[:, :128]            (prologue: [S|z] tile [16][100])
   static constexpr int p1 = a1buf + 16 * LD128;         // [2][16][36] K-halves of z1[:, 128:160] (u in half 0)
   static constexpr int a2buf = p1 + 2 * 16 * LD32;      // [16][68]   a2[:, :64]             (prologue: wx | bx | W43, 1456 floats)
   static constexpr int q2 = a2buf + 16 * LD64;          // [4][16][20] K-quarters of z2[:, 64:80] (no bias)
@@ -57,6 +59,7 @@ struct FwdLds {
 static_assert(16 * FwdLds::LD128 >= 16 * LD96, "prologue alias [S|z]");
 static_assert(16 * LD64 + 4 * 16 * FwdLds::LD16 >= 1280 + 176, "prologue alias wx | bx | W43");
 static_assert(FwdLds::total >= 2 * 16 * SW_HLD + 1280, "LDS of the observation-LSTM workgroups");
+static_assert(FwdLds::total * 4 <= 160 * 1024, "LDS of a CU");
 
 // the k-steps J0 .. J0+NJ-1 of layer 2's tile 4 (rows 64..79): acc += W2[64 + ln][16 j + 4 lg + r] a1[ln][16 j + 4 lg + r]
 template <int J0, int NJ>
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
     const int i = threadIdx.x + q * SW_THREADS, a = i / 96, cc = i - a * 96;
     szbuf[a * LD96 + cc] = cc < 64 ? (S_pool ? szs[q] : 0.f) : szz[q];
   }
-  st4(&hbuf[ln * LD64 + u0 + 4 * lg], h);
+  st4(&hbuf[ln * SW_ALD + 320 + u0 + 4 * lg], h);
   sw_barrier();
   SW_STAMP(14);
   if (!gimg) {
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
     constexpr bool LAST = decltype(last_)::value;
     float2 gti = {0.f, 0.f};
     if constexpr (ADE) gti = *reinterpret_cast<const float2*>(gt + ((size_t)b * Tp + i) * 2);   // in flight under the layers
-    const float* hrow = &hbuf[cur * 16 * LD64 + ln * LD64 + 4 * lg];
+    const float* hrow = &hbuf[cur * 16 * SW_ALD + ln * SW_ALD + 320 + 4 * lg];
     // ---- layer 1: z1 = W1h h + u ; a1 = lrelu(z1) --------------------------------------------------
     {
       f32x4 bh[4], bp[2];
@@ -421,14 +424,8 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
         const float xb = lg == 0 ? px : (lg == 1 ? py : (lg == 2 ? vx : vy));
         f32x4 gate[4];
         lstm_cell(W, xb, hrow, gate, c, h);
-        st4(&hbuf[(cur ^ 1) * 16 * LD64 + ln * LD64 + u0 + 4 * lg], h);
-        if constexpr (decltype(save_)::value) {
-          float* row = gsave + gs.act + ((size_t)(To + i) * B + b) * 384 + u0 + 4 * lg;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) st4g(row + g * 64, gate[g]);
-          st4g(row + 256, c);
-          st4g(row + 320, h);
-        }
+        if constexpr (decltype(save_)::value) lstm_put_act_tile(&hbuf[(cur ^ 1) * 16 * SW_ALD], gate, c, h, ln, lg, u0);
+        else st4(&hbuf[(cur ^ 1) * 16 * SW_ALD + ln * SW_ALD + 320 + u0 + 4 * lg], h);
         cur ^= 1;
       };
       if constexpr (!LAST) {
@@ -438,6 +435,8 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
         if (h_end) lstm_step(F_{});     // the step after the last decode is dead compute (train.py:430) unless the state is wanted
       }
       sw_barrier();
+      if constexpr (SAVE && !LAST)      // the saved row of LSTM step To + i, from the tile just completed
+        lstm_store_act_tile(&hbuf[cur * 16 * SW_ALD], gsave + gs.act + (size_t)(To + i) * B * 384, a0, B, wave, lane);
       SW_STAMP(12);
     }
   };

@@ -26,7 +26,10 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
       st4(aux_dst + 4 * i, ld4(aux_src + 4 * i));
     return;
   }
-  __shared__ __attribute__((aligned(16))) float hbuf[2][SW_TILE * SW_HLD];
+  // h exchange between the waves: with ACT the whole saved row of a step is assembled in LDS (lstm_put_act_tile) and its
+  // h columns are the next step's B operand; without, a plain [16][68] h tile
+  constexpr int HS = ACT ? SW_ALD : SW_HLD, HO = ACT ? 320 : 0;
+  __shared__ __attribute__((aligned(16))) float hbuf[2][SW_TILE * HS];
   __shared__ __attribute__((aligned(16))) float wx_lds[256 * 4];
   __shared__ __attribute__((aligned(16))) float bx_lds[256];
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
   f32x4 c = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};
   if (h0) h = ld4(h0 + (size_t)b * 64 + u0 + 4 * lg);
   if (c0) c = ld4(c0 + (size_t)b * 64 + u0 + 4 * lg);
-  st4(&hbuf[0][ln * SW_HLD + u0 + 4 * lg], h);
+  st4(&hbuf[0][ln * HS + HO + u0 + 4 * lg], h);
   sw_barrier();
   if (!gimg) lstm_load_wx(W, wx_lds, bx_lds, u0, ln, lg);
 
@@ -58,22 +61,15 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
   };
   load_x(0);
   asm volatile("" : "+v"(xa), "+v"(xq));   // waited for HERE: the loop header must see no pending load on any path in
-  float* arow = ACT ? act + ((size_t)t0 * B + b) * 384 + u0 + 4 * lg : nullptr;
   float* yrow = Y ? y + (size_t)b * T * 64 + u0 + 4 * lg : nullptr;
   float* xrow = X4S ? x4s + ((size_t)t0 * B + b) * 4 + lg : nullptr;
   for (int t = 0; t < T; ++t) {
     const float xb = XMODE == 0 ? xa - (lg >= 2 ? xq : 0.f) : xa;
     load_x(min(t + 1, T - 1));
     f32x4 gate[4];
-    lstm_cell(W, xb, &hbuf[t & 1][ln * SW_HLD + 4 * lg], gate, c, h);
-    st4(&hbuf[(t + 1) & 1][ln * SW_HLD + u0 + 4 * lg], h);
-    if constexpr (ACT) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) st4g(arow + g * 64, gate[g]);
-      st4g(arow + 256, c);
-      st4g(arow + 320, h);
-      arow += (size_t)B * 384;
-    }
+    lstm_cell(W, xb, &hbuf[t & 1][ln * HS + HO + 4 * lg], gate, c, h);
+    if constexpr (ACT) lstm_put_act_tile(hbuf[(t + 1) & 1], gate, c, h, ln, lg, u0);
+    else st4(&hbuf[(t + 1) & 1][ln * HS + u0 + 4 * lg], h);
     if constexpr (Y) {
       st4(yrow, h);
       yrow += 64;
@@ -83,6 +79,7 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
       xrow += (size_t)B * 4;
     }
     sw_barrier();
+    if constexpr (ACT) lstm_store_act_tile(hbuf[(t + 1) & 1], act + (size_t)(t0 + t) * B * 384, a0, B, wave, lane);
     asm volatile("" : "+v"(xa), "+v"(xq));   // the prefetched input is not touched before this point
   }
   st4(hT + (size_t)b * 64 + u0 + 4 * lg, h);

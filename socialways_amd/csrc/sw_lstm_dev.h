@@ -176,6 +176,28 @@ __device__ __forceinline__ void lstm_store_dgates_tile(const float* dgtile, floa
   }
 }
 
+// Forward counterpart: the saved row of an LSTM step (gates i f g o | c | h = 384 floats per agent) is assembled in an LDS
+// tile [16 agents][SW_ALD] - whose h columns double as the B operand of the next step's products - and written out behind
+// the step's barrier, a wave storing 4 agents' rows as six 1 KB instructions of consecutive memory.
+#define SW_ALD 388   // LDS row stride of a 384-wide saved row
+__device__ __forceinline__ void lstm_put_act_tile(float* tile, const f32x4 gate[4], f32x4 c, f32x4 h, int ln, int lg, int u0) {
+  float* row = tile + ln * SW_ALD + u0 + 4 * lg;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) st4(row + g * 64, gate[g]);
+  st4(row + 256, c);
+  st4(row + 320, h);
+}
+__device__ __forceinline__ void lstm_store_act_tile(const float* tile, float* __restrict__ rows_t /*row of agent 0 at this step*/,
+                                                    int a0, int B, int wave, int lane) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int f = k * 64 + lane, q = f / 96, c4 = f - q * 96;      // float4 c4 of agent 4 wave + q
+    const int a = 4 * wave + q;
+    const f32x4 v = ld4(tile + a * SW_ALD + 4 * c4);
+    st4g(rows_t + (size_t)min(a0 + a, B - 1) * 384 + 4 * c4, v);     // padding rows: replicas of agent B-1, same values
+  }
+}
+
 // W_hh^T in registers for dh_{t-1} = W_hh^T dgates: whhT[j][r] = Whh[16j + 4lg + r][u0 + ln].
 struct LstmWT {
   f32x4 whhT[16];
