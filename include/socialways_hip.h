@@ -261,6 +261,19 @@ int sw_disc_bwd_gan_adam(const float* d_w, const float* dsave, const float* cons
                          float* loss_part, float* adam_w, float* adam_m, float* adam_v, const float* adam_step,
                          double lr, double beta1, double beta2, double eps, void* stream);
 
+/* ---- one discriminator UPDATE pass in one launch (train.py:476-495): sw_disc_fwd(nb = 2: fake, real; x_mode 0;
+ *      save_lstm = obs_pre ? 2 : 1; w_snapshot) + sw_disc_bwd_gan[_adam](no d/dpred) fused per 16-agent tile - forward,
+ *      LSGAN / InfoGAN loss gradients, backward, the two branches' heads side by side on the two wave pairs - followed by
+ *      the weight-gradient GEMM (and the Adam update when adam_w = d_w).  Same buffers, same rows, same arguments as the
+ *      two calls.  For the shapes that leave CUs idle: sw_disc_update_supported() says whether this (d_w with registered
+ *      images - sw_disc_images -, B <= 2048, Tp <= 12) can run; SW_ESHAPE otherwise.                                 */
+int sw_disc_update_supported(const float* d_w, int B, int To, int Tp);
+int sw_disc_update(const float* obsv /*[B,To,2]*/, int To, const float* const* pred4 /*2 x [B,Tp,4]*/, const float* d_w, int B,
+                   int Tp, float* const* label, float* const* code, float* dsave, int obs_pre, float* w_snapshot /*or NULL*/,
+                   const float* targets, int t0, int t1, const float* z, float g_label, float g_code, float* ddelta,
+                   float* d_d_w, float* wgrad_ws, float* loss_part /*or NULL*/, float* adam_w /*or NULL*/, float* adam_m,
+                   float* adam_v, const float* adam_step, double lr, double beta1, double beta2, double eps, void* stream);
+
 /* ---- generator phase in one launch (train.py:510-523, 538): D forward on (obsv, pred_hat) fused with the backward of
  *      its prediction heads: dpred4 = d(g_loss)/d(pred_hat) with g_loss = mse(label, targets[t_idx]) +
  *      w mse(code, z[:, :2]) expressed through g_label = 1/B_global, g_code = w/(2 B_global).  No saves; label / code /

@@ -59,6 +59,9 @@ PROTOTYPES = {
     "sw_disc_bwd_gan": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sw_disc_bwd_gan_adam": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _f, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp]),
+    "sw_disc_update_supported": (_i, [_vp, _i, _i, _i]),
+    "sw_disc_update": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _f, _f, _vp, _vp, _vp, _vp,
+                            _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp]),
     "sw_disc_dpred": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "sw_gan_loss": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sw_l2_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),

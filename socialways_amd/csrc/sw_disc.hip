@@ -768,6 +768,384 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_bwd_kernel(
   SW_STAMP(11);
 }
 
+// ---------------------------------------------------------------------------------------------
+// One discriminator UPDATE pass in ONE launch (train.py:476-495): forward of D on the fake and the real branch, the LSGAN /
+// InfoGAN loss gradients (per-agent local: means over the batch, scale known up front) and the whole backward down to the
+// delta rows the weight-gradient GEMM contracts over.  One workgroup per 16-agent tile; used while the tiles leave CUs
+// idle (<= 128 tiles, the metric shape), where the two-launch form costs a launch, a second prologue and the round trip
+// of every head activation through the save buffer.  The two branches share the observation encoding; their heads run
+// SIDE BY SIDE on the two wave pairs (waves 0, 1: fake; 2, 3: real) - a head layer is 2 row tiles, so the pair that used
+// to idle now carries the other branch - forward and backward.  Rows for the weight gradients (saved activations, deltas)
+// are written exactly where sw_disc_fwd / sw_disc_bwd put them.  Needs the registered weight images (sw_disc_images).
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct UpdLds {
+  int hbuf, hw, bias, hwT, x, q1, both, c1, l1, o1, total;          // forward carve
+  int dlab, dcod, dc1, dl1, dboth, docode, do1, dend;                // deltas: alias the forward head weights (dead by then)
+  int ldp;
+  HeadLds F;      // offsets of the forward head weights (relative to 0: add hw - F.of0)
+  HeadLdsB T;     // offsets of the transposed block (relative to T.of0T: add hwT)
+};
+__host__ __device__ inline UpdLds upd_lds(int Tp) {
+  UpdLds U;
+  U.F = head_lds(Tp, 0);
+  U.T = head_lds_b(Tp, 0);
+  U.ldp = U.F.ldp;
+  int o = 0;
+  U.hbuf = o; o += 2 * 16 * SW_HLD;
+  U.hw = o; o += U.F.bias - U.F.of0;          // of0 | of1 | pe0 | pe1 | cl0 | la0 | cl1 | la1 (row-major, padded)
+  U.bias = o; o += 8 * 32;
+  U.hwT = o; o += U.T.dlab - U.T.of0T;        // the transposed block of the images (HeadLdsB layout)
+  U.x = o; o += 2 * 16 * U.ldp;
+  U.q1 = o; o += 2 * 16 * LD32;
+  U.both = o; o += 2 * 16 * LD64;
+  U.c1 = o; o += 2 * 16 * LD32;
+  U.l1 = o; o += 2 * 16 * LD32;
+  U.o1 = o; o += 16 * LD32;
+  U.total = o;
+  int d = U.hw;
+  U.dlab = d; d += 2 * 16 * LD16;
+  U.dcod = d; d += 2 * 16 * LD16;
+  U.dc1 = d; d += 2 * 16 * LD32;
+  U.dl1 = d; d += 2 * 16 * LD32;
+  U.dboth = d; d += 2 * 16 * LD64;
+  U.docode = d; d += 16 * LD32;
+  U.do1 = d; d += 16 * LD32;
+  U.dend = d;
+  return U;
+}
+}  // namespace
+
+__global__ __launch_bounds__(SW_THREADS) void disc_update_kernel(
+    const float* __restrict__ obsv, int To, const float* __restrict__ pred_a, const float* __restrict__ pred_b,
+    const float* __restrict__ d_w, int B, int Tp, float* __restrict__ label_a, float* __restrict__ label_b,
+    float* __restrict__ code_a, float* __restrict__ code_b, float* __restrict__ dsave, int obs_pre, float* __restrict__ w_snap,
+    DiscLoss gl, float* __restrict__ ddelta, const float* __restrict__ dimg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const UpdLds U = upd_lds(Tp);
+  const HeadLds& F = U.F;
+  const HeadLdsB& T = U.T;
+  const swp::Disc O = swp::disc(Tp);
+  const DSave ds = dsave_layout(B, To, Tp, 2);
+  const DDelta dd = ddelta_layout(B, To, Tp, 2);
+  float* hbuf = smem + U.hbuf;
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  const int u0 = wave * 16, br = wave >> 1, wp = wave & 1;       // br: the branch this wave's pair owns, wp: wave in pair
+  const int a0 = blockIdx.x * SW_TILE;
+  const int b = min(a0 + ln, B - 1);
+  const bool live = (a0 + ln) < B;
+  const int K4 = 4 * Tp, ldp = U.ldp;
+  auto hwp = [&](int off) { return smem + U.hw + (off - F.of0); };      // forward head matrix at HeadLds offset `off`
+  auto hwT = [&](int off) { return smem + U.hwT + (off - T.of0T); };    // transposed head matrix at HeadLdsB offset `off`
+
+  // ---- prologue: every global load first --------------------------------------------------------------------------
+  float xpre[2][4];       // prediction rows of both branches (unconditional loads from clamped addresses; Tp <= 12 here)
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const float* pk = kk == 0 ? pred_a : pred_b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = min((int)threadIdx.x + SW_THREADS * e, 16 * ldp - 1);
+      const int a = i / ldp, cc = i - a * ldp;
+      xpre[kk][e] = pk[(size_t)min(a0 + a, B - 1) * K4 + min(cc, K4 - 1)];
+    }
+  }
+  const float tg0 = gl.targets[gl.t0], tg1 = gl.targets[gl.t1];
+  const float z0 = gl.z[(size_t)b * SW_Z], z1 = gl.z[(size_t)b * SW_Z + 1];
+  LstmW W;
+  if (!obs_pre) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) W.whh[g][j] = ld4(dimg + swdimg::OP_WHH + ((((size_t)4 * g + wave) * 4 + j) * 64 + lane) * 4);
+      W.wx[g] = d_w[O.wih + (g * 64 + u0 + ln) * 4 + lg];
+      W.bias[g] = ld4(d_w + O.bih + g * 64 + u0 + 4 * lg) + ld4(d_w + O.bhh + g * 64 + u0 + 4 * lg);
+    }
+  }
+  if (w_snap)   // deepcopy(D) of train.py:499: the weights this pass runs with
+    for (int i = blockIdx.x * SW_THREADS + threadIdx.x; i < O.n; i += gridDim.x * SW_THREADS) w_snap[i] = d_w[i];
+  {
+    f32x4 s_of0[3], s_of1[2], s_pe0[2], s_pe1[2], s_cl0[3], s_la0[3], s_cl1[1], s_la1[1];
+    stage_w_load<3>(s_of0, LD64, 32, d_w + O.of0w, 64, 32, 64);
+    stage_w_load<2>(s_of1, LD32, 32, d_w + O.of1w, 32, 32, 32);
+    stage_w_load<2>(s_pe0, ldp, 32, d_w + O.pe0w, K4, 32, K4);
+    stage_w_load<2>(s_pe1, LD32, 32, d_w + O.pe1w, 32, 32, 32);
+    stage_w_load<3>(s_cl0, LD64, 32, d_w + O.cl0w, 64, 32, 64);
+    stage_w_load<3>(s_la0, LD64, 32, d_w + O.la0w, 64, 32, 64);
+    stage_w_load<1>(s_cl1, LD32, 16, d_w + O.cl1w, 32, 1, 32);
+    stage_w_load<1>(s_la1, LD32, 16, d_w + O.la1w, 32, 2, 32);
+    stage_w_store<3>(s_of0, hwp(F.of0), LD64, 32);
+    stage_w_store<2>(s_of1, hwp(F.of1), LD32, 32);
+    stage_w_store<2>(s_pe0, hwp(F.pe0), ldp, 32);
+    stage_w_store<2>(s_pe1, hwp(F.pe1), LD32, 32);
+    stage_w_store<3>(s_cl0, hwp(F.cl0), LD64, 32);
+    stage_w_store<3>(s_la0, hwp(F.la0), LD64, 32);
+    stage_w_store<1>(s_cl1, hwp(F.cl1), LD32, 16);
+    stage_w_store<1>(s_la1, hwp(F.la1), LD32, 16);
+  }
+  {
+    const int i = threadIdx.x;  // 256 = 8 x 32 bias slots
+    const int q = i >> 5, k = i & 31;
+    const int boff = q == 0 ? O.of0b : q == 1 ? O.of1b : q == 2 ? O.pe0b : q == 3 ? O.pe1b : q == 4 ? O.cl0b
+                     : q == 5 ? O.la0b : q == 6 ? O.cl1b : O.la1b;
+    const int lim = q < 6 ? 32 : (q == 6 ? 1 : 2);
+    const float v = d_w[boff + min(k, lim - 1)];
+    smem[U.bias + i] = k < lim ? v : 0.f;
+  }
+  {   // the transposed block of the images: one contiguous float4 copy (zero padding included)
+    constexpr int HB = 12;
+    const int n4 = (T.dlab - T.of0T) >> 2;
+    f32x4 hbv[HB];
+#pragma unroll
+    for (int e = 0; e < HB; ++e) hbv[e] = ld4(dimg + swdimg::HEADT + 4 * (size_t)min((int)threadIdx.x + SW_THREADS * e, n4 - 1));
+#pragma unroll
+    for (int e = 0; e < HB; ++e) {
+      const int f = threadIdx.x + SW_THREADS * e;
+      if (f < n4) st4(smem + U.hwT + 4 * f, hbv[e]);
+    }
+  }
+  // prediction rows into LDS (zero padded) and into the save buffer (rows of the pe0 weight gradient)
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = threadIdx.x + SW_THREADS * e;
+      if (i < 16 * ldp) {
+        const int a = i / ldp, cc = i - a * ldp;
+        const float v = cc < K4 ? xpre[kk][e] : 0.f;
+        smem[U.x + kk * 16 * ldp + i] = v;
+        if (cc < K4 && a0 + a < B) dsave[ds.px + ((size_t)kk * B + a0 + a) * K4 + cc] = v;
+      }
+    }
+  }
+  f32x4 c = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};
+  if (!obs_pre) {
+    st4(&hbuf[ln * SW_HLD + u0 + 4 * lg], h);
+  } else {   // h_T of the tile from the rows the decode launch left
+    st4(&hbuf[(To & 1) * 16 * SW_HLD + ln * SW_HLD + u0 + 4 * lg],
+        ld4(dsave + ds.act + ((size_t)(To - 1) * B + b) * 384 + 320 + u0 + 4 * lg));
+  }
+  sw_barrier();
+  if (!obs_pre) lstm_obs_loop<0, true>(W, hbuf, obsv, To, B, b, c, h, dsave + ds.act, dsave + ds.x4s);
+  const float* hlast = &hbuf[(To & 1) * 16 * SW_HLD];
+
+  // ---- observation fc (waves 0, 1): o1 = lrelu(of0 h + b), obsv_code = of1 o1 + b -> both[0 | 1][:, 0:32] --------------
+  f32x4 o1reg = {0.f, 0.f, 0.f, 0.f};
+  if (wave < 2) {
+    const int m0 = 16 * wave;
+    f32x4 acc = ld4(smem + U.bias + 0 * 32 + m0 + 4 * lg);
+    acc = tile_mm_rt(hwp(F.of0) + (m0 + ln) * LD64 + 4 * lg, hlast + ln * SW_HLD + 4 * lg, 4, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu(acc[r]);
+    o1reg = acc;
+    st4(smem + U.o1 + ln * LD32 + m0 + 4 * lg, acc);
+    if (live) st4(dsave + ds.o1 + (size_t)b * 32 + m0 + 4 * lg, acc);
+  }
+  sw_barrier();
+  if (wave < 2) {
+    const int m0 = 16 * wave;
+    f32x4 acc = ld4(smem + U.bias + 1 * 32 + m0 + 4 * lg);
+    acc = tile_mm_rt(hwp(F.of1) + (m0 + ln) * LD32 + 4 * lg, smem + U.o1 + ln * LD32 + 4 * lg, 2, acc);
+    st4(smem + U.both + ln * LD64 + m0 + 4 * lg, acc);
+    st4(smem + U.both + 16 * LD64 + ln * LD64 + m0 + 4 * lg, acc);
+  }
+  // ---- prediction heads, the two branches side by side: wave pair br, wave wp of the pair ------------------------------
+  float* xb_ = smem + U.x + br * 16 * ldp;
+  float* q1_ = smem + U.q1 + br * 16 * LD32;
+  float* both_ = smem + U.both + br * 16 * LD64;
+  float* c1_ = smem + U.c1 + br * 16 * LD32;
+  float* l1_ = smem + U.l1 + br * 16 * LD32;
+  const size_t kb = (size_t)br * B + b;
+  f32x4 q1reg, c1reg, l1reg;
+  {   // q1 = lrelu(pe0 x + b): row tile wp
+    const int m0 = 16 * wp;
+    f32x4 acc = ld4(smem + U.bias + 2 * 32 + m0 + 4 * lg);
+    acc = tile_mm_rt(hwp(F.pe0) + (m0 + ln) * ldp + 4 * lg, xb_ + ln * ldp + 4 * lg, (ldp - 4) / 16, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu(acc[r]);
+    q1reg = acc;
+    st4(q1_ + ln * LD32 + m0 + 4 * lg, acc);
+    if (live) st4(dsave + ds.q1 + kb * 32 + m0 + 4 * lg, acc);
+  }
+  sw_barrier();
+  {   // pred_code = pe1 q1 + b -> both[br][:, 32:64]
+    // (of0 / of1 are dead behind the barrier above: the dlab | dcod delta tiles that alias them are zeroed here - only
+    //  their columns 0 / 0..1 are written later)
+    stage_zero(smem + U.dlab, U.dc1 - U.dlab);
+    const int m0 = 16 * wp;
+    f32x4 acc = ld4(smem + U.bias + 3 * 32 + m0 + 4 * lg);
+    acc = tile_mm_rt(hwp(F.pe1) + (m0 + ln) * LD32 + 4 * lg, q1_ + ln * LD32 + 4 * lg, 2, acc);
+    st4(both_ + ln * LD64 + 32 + m0 + 4 * lg, acc);
+  }
+  sw_barrier();
+  {   // both codes saved (wave wp: columns 32 wp ..), then c1 = lrelu(cl0 both + b), l1 = lrelu(la0 both + b): row tile wp each
+    if (live) {
+      st4(dsave + ds.both + kb * 64 + 32 * wp + 4 * lg, ld4(both_ + ln * LD64 + 32 * wp + 4 * lg));
+      st4(dsave + ds.both + kb * 64 + 32 * wp + 16 + 4 * lg, ld4(both_ + ln * LD64 + 32 * wp + 16 + 4 * lg));
+    }
+    const int m0 = 16 * wp;
+    f32x4 ac = ld4(smem + U.bias + 4 * 32 + m0 + 4 * lg), al = ld4(smem + U.bias + 5 * 32 + m0 + 4 * lg);
+    ac = tile_mm_rt(hwp(F.cl0) + (m0 + ln) * LD64 + 4 * lg, both_ + ln * LD64 + 4 * lg, 4, ac);
+    al = tile_mm_rt(hwp(F.la0) + (m0 + ln) * LD64 + 4 * lg, both_ + ln * LD64 + 4 * lg, 4, al);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ac[r] = sw_lrelu(ac[r]);
+      al[r] = sw_lrelu(al[r]);
+    }
+    c1reg = ac;
+    l1reg = al;
+    st4(c1_ + ln * LD32 + m0 + 4 * lg, ac);
+    st4(l1_ + ln * LD32 + m0 + 4 * lg, al);
+    if (live) {
+      st4(dsave + ds.c1 + kb * 32 + m0 + 4 * lg, ac);
+      st4(dsave + ds.l1 + kb * 32 + m0 + 4 * lg, al);
+    }
+  }
+  sw_barrier();     // every reader of the forward head matrices up to la0 is done: the delta tiles overwrite them from here on
+  // ---- label = cl1 c1 + b (wave wp = 0), code_hat = la1 l1 + b (wp = 1); loss gradients (train.py:484-494) + reported sums
+  {
+    const bool cls = wp == 0;
+    f32x4 acc = ld4(smem + U.bias + (cls ? 6 : 7) * 32 + 4 * lg);
+    acc = tile_mm_rt(hwp(cls ? F.cl1 : F.la1) + ln * LD32 + 4 * lg, (cls ? c1_ : l1_) + ln * LD32 + 4 * lg, 2, acc);
+    float* label = br == 0 ? label_a : label_b;
+    float* code = br == 0 ? code_a : code_b;
+    float sl = 0.f;
+    if (lg == 0) {
+      if (cls) {
+        if (live) label[b] = acc[0];
+        const float e = acc[0] - (br == 0 ? tg0 : tg1);
+        const float g = 2.0f * e * gl.g_label;
+        smem[U.dlab + br * 16 * LD16 + ln * LD16] = g;
+        if (live) st4(ddelta + dd.dlab + kb * 4, f32x4{g, 0.f, 0.f, 0.f});
+        sl = live ? e * e : 0.f;
+      } else {
+        if (live) { code[(size_t)b * 2] = acc[0]; code[(size_t)b * 2 + 1] = acc[1]; }
+        const float e0 = acc[0] - z0, e1 = acc[1] - z1;
+        const float g0 = br == 0 ? 2.0f * e0 * gl.g_code : 0.f, g1 = br == 0 ? 2.0f * e1 * gl.g_code : 0.f;   // info term: fake branch only
+        smem[U.dcod + br * 16 * LD16 + ln * LD16] = g0;
+        smem[U.dcod + br * 16 * LD16 + ln * LD16 + 1] = g1;
+        if (live) st4(ddelta + dd.dcod + kb * 4, f32x4{g0, g1, 0.f, 0.f});
+        sl = live ? e0 * e0 + e1 * e1 : 0.f;
+      }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sl += __shfl_xor(sl, o);
+    if (gl.loss_part && lane == 0) {
+      if (cls) gl.loss_part[(size_t)blockIdx.x * 3 + (br == 0 ? 0 : 2)] = sl;
+      else if (br == 0) gl.loss_part[(size_t)blockIdx.x * 3 + 1] = sl;
+    }
+  }
+  sw_barrier();
+  // ---- backward of the heads, branches side by side ------------------------------------------------------------------
+  float* dlab_ = smem + U.dlab + br * 16 * LD16;
+  float* dcod_ = smem + U.dcod + br * 16 * LD16;
+  float* dc1_ = smem + U.dc1 + br * 16 * LD32;
+  float* dl1_ = smem + U.dl1 + br * 16 * LD32;
+  float* dboth_ = smem + U.dboth + br * 16 * LD64;
+  {   // dc1 = (cl1^T dlabel) * lrelu'(c1), dl1 = (la1^T dcode) * lrelu'(l1): row tile wp each
+    const int m0 = 16 * wp;
+    f32x4 ac = {0.f, 0.f, 0.f, 0.f}, al = ac;
+    ac = tile_mm_rt(hwT(T.cl1T) + (m0 + ln) * LD16 + 4 * lg, dlab_ + ln * LD16 + 4 * lg, 1, ac);
+    al = tile_mm_rt(hwT(T.la1T) + (m0 + ln) * LD16 + 4 * lg, dcod_ + ln * LD16 + 4 * lg, 1, al);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ac[r] = sw_lrelu_grad(c1reg[r], ac[r]);
+      al[r] = sw_lrelu_grad(l1reg[r], al[r]);
+    }
+    st4(dc1_ + ln * LD32 + m0 + 4 * lg, ac);
+    st4(dl1_ + ln * LD32 + m0 + 4 * lg, al);
+    if (live) {
+      st4(ddelta + dd.dc1 + kb * 32 + m0 + 4 * lg, ac);
+      st4(ddelta + dd.dl1 + kb * 32 + m0 + 4 * lg, al);
+    }
+  }
+  sw_barrier();
+  {   // dboth = cl0^T dc1 + la0^T dl1 (64 rows): row tiles 2 wp, 2 wp + 1
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int m0 = 16 * (2 * wp + q);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = tile_mm_rt(hwT(T.cl0T) + (m0 + ln) * LD32 + 4 * lg, dc1_ + ln * LD32 + 4 * lg, 2, acc);
+      acc = tile_mm_rt(hwT(T.la0T) + (m0 + ln) * LD32 + 4 * lg, dl1_ + ln * LD32 + 4 * lg, 2, acc);
+      st4(dboth_ + ln * LD64 + m0 + 4 * lg, acc);
+      if (wp == 1 && live) st4(ddelta + dd.dpcode + kb * 32 + (m0 - 32) + 4 * lg, acc);   // the prediction-code half
+    }
+  }
+  sw_barrier();
+  {   // dq1 = (pe1^T dpcode) * lrelu'(q1): row tile wp (only the weight gradient needs it: D updates want no d/dpred)
+    const int m0 = 16 * wp;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = tile_mm_rt(hwT(T.pe1T) + (m0 + ln) * LD32 + 4 * lg, dboth_ + ln * LD64 + 32 + 4 * lg, 2, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(q1reg[r], acc[r]);
+    if (live) st4(ddelta + dd.dq1 + kb * 32 + m0 + 4 * lg, acc);
+  }
+  if (wave < 2) {   // observation-code half summed over the branches (fixed order), then do1 = (of1^T docode) * lrelu'(o1)
+    const int m0 = 16 * wave;
+    const f32x4 v = ld4(smem + U.dboth + ln * LD64 + m0 + 4 * lg) + ld4(smem + U.dboth + 16 * LD64 + ln * LD64 + m0 + 4 * lg);
+    st4(smem + U.docode + ln * LD32 + m0 + 4 * lg, v);
+    if (live) st4(ddelta + dd.docode + (size_t)b * 32 + m0 + 4 * lg, v);
+  }
+  sw_barrier();
+  if (wave < 2) {
+    const int m0 = 16 * wave;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = tile_mm_rt(hwT(T.of1T) + (m0 + ln) * LD32 + 4 * lg, smem + U.docode + ln * LD32 + 4 * lg, 2, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = sw_lrelu_grad(o1reg[r], acc[r]);
+    st4(smem + U.do1 + ln * LD32 + m0 + 4 * lg, acc);
+    if (live) st4(ddelta + dd.do1 + (size_t)b * 32 + m0 + 4 * lg, acc);
+  }
+  sw_barrier();
+  // ---- observation LSTM backward (as disc_bwd_kernel): dh_T = of0^T do1, then BPTT over the saved rows ------------------
+  f32x4 dh = {0.f, 0.f, 0.f, 0.f}, dc = {0.f, 0.f, 0.f, 0.f};
+  dh = tile_mm_rt(hwT(T.of0T) + (u0 + ln) * LD32 + 4 * lg, smem + U.do1 + ln * LD32 + 4 * lg, 2, dh);
+  LstmWT WT;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) WT.whhT[j] = ld4(dimg + swdimg::OP_WHHT + (((size_t)wave * 16 + j) * 64 + lane) * 4);
+  float* dgbuf = smem + U.hwT + (T.pe0T - T.of0T);   // [2][16][SW_GLD] over the prediction heads' transposed images (dead now)
+  const float* act_b = dsave + ds.act + (size_t)b * 384 + u0 + 4 * lg;
+  const size_t tstep = (size_t)B * 384;
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  auto load_row = [&](int t, f32x4 g[4], f32x4& ct_, f32x4& cp_, auto has_prev) {
+    const float* row = act_b + (size_t)t * tstep;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g[q] = ld4(row + q * 64);
+    ct_ = ld4(row + 256);
+    if constexpr (decltype(has_prev)::value) cp_ = ld4(row - tstep + 256);
+    else cp_ = f32x4{0.f, 0.f, 0.f, 0.f};   // c_{-1} = 0
+  };
+  f32x4 gate[4], ct, cprev;
+  if (To > 1) load_row(To - 1, gate, ct, cprev, T_{});
+  else load_row(0, gate, ct, cprev, F_{});
+  sw_barrier();      // every wave has read of0T / do1: (the dgates tiles start behind of0T / of1T; kept for symmetry with disc_bwd)
+  asm volatile("" : "+v"(gate[0]), "+v"(gate[1]), "+v"(gate[2]), "+v"(gate[3]), "+v"(ct), "+v"(cprev));
+#pragma unroll
+  for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(WT.whhT[j]));
+  auto step = [&](int t, auto pf, auto pp, auto nx) {
+    f32x4 ngate[4], nct, ncp, dgate[4];
+    if constexpr (decltype(pf)::value) load_row(t - 1, ngate, nct, ncp, pp);
+    lstm_cell_bwd(gate, ct, cprev, dh, dc, dgate);
+    float* dgl = &dgbuf[(t & 1) * 16 * SW_GLD + ln * SW_GLD + u0 + 4 * lg];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) st4(dgl + g * 64, dgate[g]);
+    sw_barrier();
+    lstm_store_dgates_tile(&dgbuf[(t & 1) * 16 * SW_GLD], ddelta + dd.dgates + ((size_t)t * B + a0) * 256, ddelta + dd.trash,
+                           a0, B, wave, lane);
+    if constexpr (decltype(nx)::value) dh = lstm_dh_prev(WT, &dgbuf[(t & 1) * 16 * SW_GLD + ln * SW_GLD + 4 * lg]);
+    if constexpr (decltype(pf)::value) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gate[g] = ngate[g];
+      ct = nct;
+      cprev = ncp;
+    }
+  };
+  for (int t = To - 1; t >= 2; --t) step(t, T_{}, T_{}, T_{});
+  if (To > 1) step(1, T_{}, F_{}, T_{});
+  step(0, F_{}, F_{}, F_{});
+}
+
 static int set_lds(const void* fn, int bytes) {
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) {
@@ -834,6 +1212,29 @@ extern "C" int sw_disc_dpred(const float* obsv, int To, int x_mode, const float*
   return SW_OK;
 }
 
+// the weight-gradient problems of a discriminator pass over its saved / delta rows (dW = delta^T act per layer)
+static int disc_wgrad_problems(WgBatch& wb, const float* dsave, float* ddelta, int nb, int B, int To, int Tp, float* d_d_w) {
+  const swp::Disc O = swp::disc(Tp);
+  const DSave ds = dsave_layout(B, To, Tp, nb);
+  const DDelta dd = ddelta_layout(B, To, Tp, nb);
+  const int R = nb * B, K4 = 4 * Tp;
+  int rc_add = 0;
+  // LSTM: dW_hh over rows t >= 1 against h_{t-1}; dW_ih / biases over all rows against x4
+  rc_add |= wg_add_tail(wb, ddelta + dd.dgates, 256, dsave + ds.act + 320 - (ptrdiff_t)B * 384, 384, To * B, 256, 64,
+                        d_d_w + O.whh, 64, dsave + ds.x4s, 4, 4, d_d_w + O.wih, 4, B /*h_{t-1}: rows t >= 1*/,
+                        d_d_w + O.bih, d_d_w + O.bhh, 0);
+  rc_add |= wg_add(wb, ddelta + dd.do1, 32, dsave + ds.act + (size_t)(To - 1) * B * 384 + 320, 384, B, 32, 64, d_d_w + O.of0w,
+                   64, d_d_w + O.of0b, nullptr, 0);
+  rc_add |= wg_add(wb, ddelta + dd.docode, 32, dsave + ds.o1, 32, B, 32, 32, d_d_w + O.of1w, 32, d_d_w + O.of1b, nullptr, 0);
+  rc_add |= wg_add(wb, ddelta + dd.dq1, 32, dsave + ds.px, K4, R, 32, K4, d_d_w + O.pe0w, K4, d_d_w + O.pe0b, nullptr, 0);
+  rc_add |= wg_add(wb, ddelta + dd.dpcode, 32, dsave + ds.q1, 32, R, 32, 32, d_d_w + O.pe1w, 32, d_d_w + O.pe1b, nullptr, 0);
+  rc_add |= wg_add(wb, ddelta + dd.dc1, 32, dsave + ds.both, 64, R, 32, 64, d_d_w + O.cl0w, 64, d_d_w + O.cl0b, nullptr, 0);
+  rc_add |= wg_add(wb, ddelta + dd.dlab, 4, dsave + ds.c1, 32, R, 1, 32, d_d_w + O.cl1w, 32, d_d_w + O.cl1b, nullptr, 0);
+  rc_add |= wg_add(wb, ddelta + dd.dl1, 32, dsave + ds.both, 64, R, 32, 64, d_d_w + O.la0w, 64, d_d_w + O.la0b, nullptr, 0);
+  rc_add |= wg_add(wb, ddelta + dd.dcod, 4, dsave + ds.l1, 32, R, 2, 32, d_d_w + O.la1w, 32, d_d_w + O.la1b, nullptr, 0);
+  return rc_add ? SW_ESHAPE : SW_OK;
+}
+
 static int disc_bwd_impl(const float* d_w, const float* dsave, const float* const* dlabel, const float* const* dcode,
                          int nb, int B, int To, int Tp, float* ddelta, float* d_d_w, float* const* dpred4,
                          float* wgrad_ws, void* stream, DiscLoss gl, const WgAdam& adam = WgAdam()) {
@@ -853,27 +1254,8 @@ static int disc_bwd_impl(const float* d_w, const float* dsave, const float* cons
   hipStream_t st = (hipStream_t)stream;
   const int tiles = (B + SW_TILE - 1) / SW_TILE;
   WgBatch wb;
-  if (d_d_w) {
-    const swp::Disc O = swp::disc(Tp);
-    const DSave ds = dsave_layout(B, To, Tp, nb);
-    const DDelta dd = ddelta_layout(B, To, Tp, nb);
-    const int R = nb * B, K4 = 4 * Tp;
-    int rc_add = 0;
-    // LSTM: dW_hh over rows t >= 1 against h_{t-1}; dW_ih / biases over all rows against x4
-    rc_add |= wg_add_tail(wb, ddelta + dd.dgates, 256, dsave + ds.act + 320 - (ptrdiff_t)B * 384, 384, To * B, 256, 64,
-                          d_d_w + O.whh, 64, dsave + ds.x4s, 4, 4, d_d_w + O.wih, 4, B /*h_{t-1}: rows t >= 1*/,
-                          d_d_w + O.bih, d_d_w + O.bhh, 0);
-    rc_add |= wg_add(wb, ddelta + dd.do1, 32, dsave + ds.act + (size_t)(To - 1) * B * 384 + 320, 384, B, 32, 64, d_d_w + O.of0w,
-           64, d_d_w + O.of0b, nullptr, 0);
-    rc_add |= wg_add(wb, ddelta + dd.docode, 32, dsave + ds.o1, 32, B, 32, 32, d_d_w + O.of1w, 32, d_d_w + O.of1b, nullptr, 0);
-    rc_add |= wg_add(wb, ddelta + dd.dq1, 32, dsave + ds.px, K4, R, 32, K4, d_d_w + O.pe0w, K4, d_d_w + O.pe0b, nullptr, 0);
-    rc_add |= wg_add(wb, ddelta + dd.dpcode, 32, dsave + ds.q1, 32, R, 32, 32, d_d_w + O.pe1w, 32, d_d_w + O.pe1b, nullptr, 0);
-    rc_add |= wg_add(wb, ddelta + dd.dc1, 32, dsave + ds.both, 64, R, 32, 64, d_d_w + O.cl0w, 64, d_d_w + O.cl0b, nullptr, 0);
-    rc_add |= wg_add(wb, ddelta + dd.dlab, 4, dsave + ds.c1, 32, R, 1, 32, d_d_w + O.cl1w, 32, d_d_w + O.cl1b, nullptr, 0);
-    rc_add |= wg_add(wb, ddelta + dd.dl1, 32, dsave + ds.both, 64, R, 32, 64, d_d_w + O.la0w, 64, d_d_w + O.la0b, nullptr, 0);
-    rc_add |= wg_add(wb, ddelta + dd.dcod, 4, dsave + ds.l1, 32, R, 2, 32, d_d_w + O.la1w, 32, d_d_w + O.la1b, nullptr, 0);
-    if (rc_add) return SW_ESHAPE;
-  }
+  if (d_d_w)
+    if (int rc = disc_wgrad_problems(wb, dsave, ddelta, nb, B, To, Tp, d_d_w)) return rc;
   SW_LAUNCH(disc_bwd_kernel, dim3(tiles), dim3(SW_THREADS), lds, st, d_w, dsave,
                      dlabel[0], nb > 1 ? dlabel[1] : nullptr, dcode[0], nb > 1 ? dcode[1] : nullptr, nb, B, To, Tp,
                      d_d_w ? 1 : 0, ddelta, dpred4 ? dpred4[0] : nullptr, (dpred4 && nb > 1) ? dpred4[1] : nullptr, gl,
@@ -881,6 +1263,53 @@ static int disc_bwd_impl(const float* d_w, const float* dsave, const float* cons
   SW_CHECK_LAUNCH("disc_bwd_kernel");
   if (!d_d_w) return SW_OK;
   WgAdam ad = adam;
+  return wg_launch_adam(wb, wgrad_ws, ad, st);
+}
+
+// Can sw_disc_update run this pass (else: sw_disc_fwd + sw_disc_bwd_gan*)?  It is built for the shapes that leave CUs idle.
+extern "C" int sw_disc_update_supported(const float* d_w, int B, int To, int Tp) {
+  if (!d_w || B < 1 || To < 1 || Tp < 1 || Tp > 12) return 0;
+  if ((B + SW_TILE - 1) / SW_TILE > 128) return 0;
+  if (!sw_disc_images_for(d_w, Tp).img) return 0;
+  return upd_lds(Tp).total * 4 <= 163840 ? 1 : 0;
+}
+// One discriminator update pass (train.py:476-495) in ONE launch + its weight-gradient GEMM (+ the Adam update when
+// adam_w = d_w): what sw_disc_fwd(nb = 2, x_mode 0, save_lstm 1 | 2) followed by sw_disc_bwd_gan[_adam] computes, to the
+// same buffers.  obs_pre = 1: the observation-LSTM rows are already in dsave (sw_dec_rollout_fwd_aux).  Requires
+// sw_disc_update_supported() (SW_ESHAPE otherwise).
+extern "C" int sw_disc_update(const float* obsv, int To, const float* const* pred4, const float* d_w, int B, int Tp,
+                              float* const* label, float* const* code, float* dsave, int obs_pre, float* w_snapshot,
+                              const float* targets, int t0, int t1, const float* z, float g_label, float g_code, float* ddelta,
+                              float* d_d_w, float* wgrad_ws, float* loss_part, float* adam_w, float* adam_m, float* adam_v,
+                              const float* adam_step, double lr, double beta1, double beta2, double eps, void* stream) {
+  if (!obsv || !pred4 || !pred4[0] || !pred4[1] || !d_w || !label || !label[0] || !label[1] || !code || !code[0] || !code[1] ||
+      !dsave || !targets || !z || !ddelta || !d_d_w || !wgrad_ws || t0 < 0 || t1 < 0 || To < 2)
+    return SW_EARG;
+  if (adam_w && (!adam_m || !adam_v || !adam_step || adam_w != d_w)) return SW_EARG;
+  if (B == 0) return SW_OK;
+  if (!sw_disc_update_supported(d_w, B, To, Tp)) return SW_ESHAPE;
+  const int lds = upd_lds(Tp).total * 4;
+  static int attr = 0;
+  if (attr < lds) {
+    if (int rc = set_lds((const void*)disc_update_kernel, lds)) return rc;
+    attr = lds;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const DiscImages di = sw_disc_images_for(d_w, Tp);
+  DiscLoss gl{targets, z, t0, t1, g_label, g_code, 1, loss_part};
+  const int tiles = (B + SW_TILE - 1) / SW_TILE;
+  WgBatch wb;
+  if (int rc = disc_wgrad_problems(wb, dsave, ddelta, 2, B, To, Tp, d_d_w)) return rc;
+  SW_LAUNCH(disc_update_kernel, dim3(tiles), dim3(SW_THREADS), lds, st, obsv, To, pred4[0], pred4[1], d_w, B, Tp, label[0],
+            label[1], code[0], code[1], dsave, obs_pre ? 1 : 0, w_snapshot, gl, ddelta, di.img);
+  SW_CHECK_LAUNCH("disc_update_kernel");
+  WgAdam ad;
+  if (adam_w) {
+    ad.w = adam_w; ad.m = adam_m; ad.v = adam_v; ad.g0 = d_d_w; ad.step = adam_step;
+    ad.lr = lr; ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps;
+    ad.img = const_cast<float*>(di.img);
+    ad.tab = di.tab;
+  }
   return wg_launch_adam(wb, wgrad_ws, ad, st);
 }
 

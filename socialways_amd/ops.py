@@ -329,3 +329,36 @@ def disc_backward_gan(d_w, ctx, labels, codes, targets, t_idx, z, g_label, g_cod
     L.call("sw_disc_bwd_gan", L.ptr(d_w), L.ptr(ctx.dsave), lp, cp, L.ptr(targets), t0, t1, L.ptr(z), g_label, g_code, nb,
            B, To, Tp, L.ptr(ddelta), L.ptr(d_d_w), dp, L.ptr(wgrad), L.ptr(loss_part), L.stream())
     return dpreds
+
+
+def disc_update_supported(d_w, B, To, Tp):
+    """Can one discriminator update pass run as ONE launch (sw_disc_update: shapes that leave CUs idle, registered images)?"""
+    return bool(L.load().sw_disc_update_supported(L.ptr(d_w), int(B), int(To), int(Tp)))
+
+
+def disc_update(d_w, obsv, preds, targets, t_idx, z, g_label, g_code, d_d_w, ws, tag="d", obs_pre=False, w_snapshot=None,
+                loss_part=None, adam=None):
+    """disc_forward(obsv, [fake, real]) + disc_backward_gan(...) of one D update (train.py:476-495) as one launch
+    (sw_disc_update) + the weight-gradient GEMM (+ the Adam update).  Returns (labels, codes)."""
+    L.require_gpu(obsv)
+    obsv = obsv.contiguous()
+    preds = [p.contiguous() for p in preds]
+    B, To, Tp = obsv.shape[0], obsv.shape[1], preds[0].shape[1]
+    dev = obsv.device
+    labels = [torch.empty(B, 1, device=dev) for _ in preds]
+    codes = [torch.empty(B, 2, device=dev) for _ in preds]
+    dsave = ws.get(tag + ".dsave", L.workspace_floats(L.WS_DSAVE, B, To, Tp, 2))
+    ddelta = ws.get(tag + ".ddelta", L.workspace_floats(L.WS_DDELTA, B, To, Tp, 2))
+    wgrad = ws.get("wgrad", L.workspace_floats(L.WS_WGRAD, B, To, Tp))
+    pp, _k1 = L.ptr_array(preds)
+    lp, _k2 = L.ptr_array(labels)
+    cp, _k3 = L.ptr_array(codes)
+    m = v = step = None
+    lr = b1 = b2 = eps = 0.0
+    if adam is not None:
+        m, v, step, lr, b1, b2, eps = adam
+    L.call("sw_disc_update", L.ptr(obsv), To, pp, L.ptr(d_w), B, Tp, lp, cp, L.ptr(dsave), int(bool(obs_pre)), L.ptr(w_snapshot),
+           L.ptr(targets), int(t_idx[0]), int(t_idx[1]), L.ptr(z), g_label, g_code, L.ptr(ddelta), L.ptr(d_d_w), L.ptr(wgrad),
+           L.ptr(loss_part), L.ptr(d_w) if adam is not None else None, L.ptr(m), L.ptr(v), L.ptr(step), float(lr), float(b1),
+           float(b2), float(eps), L.stream())
+    return labels, codes

@@ -204,6 +204,7 @@ class SocialWaysTrainer:
         self._force_dist = os.environ.get("SW_FORCE_DIST", "") == "1"   # 1-rank group still runs the collectives (tests)
         self._fuse_d_adam = os.environ.get("SW_FUSE_D_ADAM", "1") == "1"  # D's Adam inside the gradient reduction (world 1)
         self._fuse_g_adam = os.environ.get("SW_FUSE_G_ADAM", "1") == "1"  # ... and the generator's (needs the weight images)
+        self._one_launch_d = os.environ.get("SW_DISC_UPDATE", "1") == "1"   # a D update pass as one launch where it pays (sw_disc_update)
         # Data parallel: are the RCCL all-reduces recorded INSIDE the step graph (one launch for K steps) or run
         # eagerly between graph segments (3 segment boundaries per step)?  SW_GRAPH_COLLECTIVES=1 / 0 decides;
         # unset = probe once (a small captured all-reduce replayed twice and checked on every rank) and use the
@@ -630,17 +631,23 @@ class SocialWaysTrainer:
         for u in range(self.n_unrolling_steps + 1):
             if u == 1:     # deepcopy(D) after the first update (train.py:498-499) = the weights of this forward pass
                 backup = ws.get("d_backup", D._flat.numel())
-            labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat, pred4], save=True, ws=ws,
-                                                   save_lstm=2 if (u == 0 and d_pre is not None) else 1,
-                                                   w_snapshot=backup if u == 1 else None)
             # the loss gradients AND the reported loss sums (per-tile partials) are formed inside the backward kernel;
             # in a single process (no all-reduce between gradient and update) D's Adam step rides in the kernel that
             # finishes the gradients
             fuse = (self._fuse_d_adam and isinstance(self.D_optimizer, PackedAdam) and self.D_optimizer.fusable
                     and not (self.world > 1 or self._force_dist))
-            ops.disc_backward_gan(D._flat, dctx, labels, codes, targets, (0, 1), noise, g_label, g_code, d_gflat, (), ws=ws,
-                                  loss_part=out[u],
-                                  adam=self.D_optimizer.fused_args(None if steps is None else steps[u]) if fuse else None)
+            adam = self.D_optimizer.fused_args(None if steps is None else steps[u]) if fuse else None
+            if self._one_launch_d and obsv.shape[2] == 2 and ops.disc_update_supported(D._flat, B, obsv.shape[1], Tp):
+                # shapes that leave CUs idle: forward + loss gradients + backward of the pass in ONE launch (sw_disc_update)
+                ops.disc_update(D._flat, obsv, [pred_hat, pred4], targets, (0, 1), noise, g_label, g_code, d_gflat, ws,
+                                obs_pre=(u == 0 and d_pre is not None), w_snapshot=backup if u == 1 else None,
+                                loss_part=out[u], adam=adam)
+            else:
+                labels, codes, dctx = ops.disc_forward(D._flat, obsv, [pred_hat, pred4], save=True, ws=ws,
+                                                       save_lstm=2 if (u == 0 and d_pre is not None) else 1,
+                                                       w_snapshot=backup if u == 1 else None)
+                ops.disc_backward_gan(D._flat, dctx, labels, codes, targets, (0, 1), noise, g_label, g_code, d_gflat, (), ws=ws,
+                                      loss_part=out[u], adam=adam)
             yield d_gflat
             if not fuse:
                 self.D_optimizer.step() if steps is None else self.D_optimizer.step(steps[u])

@@ -437,3 +437,60 @@ def test_adam_packed_kernel_equals_torch_fused_adam():
         tol = floor + 4e-6 * b.abs()
         assert bool((err <= tol).all()), "%s: max err %.3e" % (name, err.max().item())
     assert float((ws[0] == ws[1]).float().mean()) > 0.95, "bit-identical on almost every element"
+
+
+@pytest.mark.parametrize("B,obs_pre", [(136, False), (2048, False), (40, True)])
+def test_disc_update_in_one_launch_equals_forward_plus_backward(B, obs_pre):
+    """sw_disc_update (forward + loss gradients + backward of a discriminator update pass per 16-agent tile, the two
+    branches' heads side by side on the two wave pairs) against sw_disc_fwd + sw_disc_bwd_gan_adam: labels, codes, the
+    reported loss sums, every gradient, the weights and moments after the fused Adam update and the deepcopy snapshot -
+    bit for bit (same products in the same order)."""
+    import socialways_amd as sw
+    from socialways_amd import _lib as L
+    from socialways_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B)
+    D = sw.Discriminator(12, 64, 2, device=dev)
+    obsv = torch.randn(B, 8, 2, device=dev).cumsum(1) * 0.1
+    fake, real = torch.randn(B, 12, 4, device=dev) * 0.1, torch.randn(B, 12, 4, device=dev) * 0.1
+    z = torch.rand(B, 32, device=dev)
+    targets = torch.tensor([0.05, 0.95], device=dev)
+    lib = L.load()
+    n = D._flat.numel()
+    tab_h = np.empty((n, 2), dtype=np.int32)
+    assert lib.sw_disc_image_table(12, tab_h.ctypes.data) == 0
+    tab = torch.from_numpy(tab_h).to(dev)
+    img = torch.zeros(lib.sw_disc_image_floats(12), device=dev)
+    w0 = D._flat.clone()
+    res = []
+    for one_launch in (False, True):
+        D._flat.copy_(w0)
+        ws = ops.Workspaces(dev)
+        L.call("sw_disc_images", L.ptr(D._flat), L.ptr(img), L.ptr(tab), 12, L.stream())
+        try:
+            assert ops.disc_update_supported(D._flat, B, 8, 12)
+            if obs_pre:      # the observation LSTM rows as the decode launch leaves them (here: by a plain forward pass)
+                ops.disc_forward(D._flat, obsv, [fake, real], save=True, ws=ws, save_lstm=1)
+            g = torch.zeros_like(D._flat)
+            m, v = torch.zeros_like(D._flat), torch.zeros_like(D._flat)
+            step = torch.ones((), device=dev)
+            part = torch.zeros((B + 15) // 16, 3, device=dev)
+            snap = torch.zeros_like(D._flat)
+            adam = (m, v, step, 1e-3, 0.9, 0.999, 1e-8)
+            if one_launch:
+                labels, codes = ops.disc_update(D._flat, obsv, [fake, real], targets, (0, 1), z, 1.0 / B, 0.25 / B, g, ws,
+                                                obs_pre=obs_pre, w_snapshot=snap, loss_part=part, adam=adam)
+            else:
+                labels, codes, ctx = ops.disc_forward(D._flat, obsv, [fake, real], save=True, ws=ws, save_lstm=2 if obs_pre else 1,
+                                                      w_snapshot=snap)
+                ops.disc_backward_gan(D._flat, ctx, labels, codes, targets, (0, 1), z, 1.0 / B, 0.25 / B, g, (), ws=ws,
+                                      loss_part=part, adam=adam)
+            torch.cuda.synchronize()
+            res.append([t.clone() for t in labels + codes] + [part, g, D._flat.clone(), m, v, snap, img.clone()])
+        finally:
+            L.call("sw_disc_images", None, None, None, 0, None)
+    names = ["label_fake", "label_real", "code_fake", "code_real", "loss sums", "gradients", "weights", "exp_avg", "exp_avg_sq",
+             "snapshot", "images"]
+    for name, a, b in zip(names, res[0], res[1]):
+        assert torch.equal(a, b), "%s: max |diff| %.3e" % (name, float((a - b).abs().max()))
+    assert float(res[1][5].abs().max()) > 0 and not torch.equal(res[1][6], w0)
