@@ -439,19 +439,20 @@ def test_adam_packed_kernel_equals_torch_fused_adam():
     assert float((ws[0] == ws[1]).float().mean()) > 0.95, "bit-identical on almost every element"
 
 
-@pytest.mark.parametrize("B,obs_pre", [(136, False), (2048, False), (40, True)])
-def test_disc_update_in_one_launch_equals_forward_plus_backward(B, obs_pre):
+@pytest.mark.parametrize("B,obs_pre,To", [(136, False, 8), (2048, False, 8), (40, True, 8), (100, False, 5), (33, True, 3)])
+def test_disc_update_in_one_launch_equals_forward_plus_backward(B, obs_pre, To):
     """sw_disc_update (forward + loss gradients + backward of a discriminator update pass per 16-agent tile, the two
     branches' heads side by side on the two wave pairs) against sw_disc_fwd + sw_disc_bwd_gan_adam: labels, codes, the
     reported loss sums, every gradient, the weights and moments after the fused Adam update and the deepcopy snapshot -
-    bit for bit (same products in the same order)."""
+    bit for bit (same products in the same order).  To = 8 keeps the LSTM's gates in registers
+    between forward and BPTT, other horizons and precomputed observation rows go through the saved rows."""
     import socialways_amd as sw
     from socialways_amd import _lib as L
     from socialways_amd import ops
     dev = torch.device("cuda:0")
     torch.manual_seed(B)
     D = sw.Discriminator(12, 64, 2, device=dev)
-    obsv = torch.randn(B, 8, 2, device=dev).cumsum(1) * 0.1
+    obsv = torch.randn(B, To, 2, device=dev).cumsum(1) * 0.1
     fake, real = torch.randn(B, 12, 4, device=dev) * 0.1, torch.randn(B, 12, 4, device=dev) * 0.1
     z = torch.rand(B, 32, device=dev)
     targets = torch.tensor([0.05, 0.95], device=dev)
@@ -468,7 +469,7 @@ def test_disc_update_in_one_launch_equals_forward_plus_backward(B, obs_pre):
         ws = ops.Workspaces(dev)
         L.call("sw_disc_images", L.ptr(D._flat), L.ptr(img), L.ptr(tab), 12, L.stream())
         try:
-            assert ops.disc_update_supported(D._flat, B, 8, 12)
+            assert ops.disc_update_supported(D._flat, B, To, 12)
             if obs_pre:      # the observation LSTM rows as the decode launch leaves them (here: by a plain forward pass)
                 ops.disc_forward(D._flat, obsv, [fake, real], save=True, ws=ws, save_lstm=1)
             g = torch.zeros_like(D._flat)
