@@ -65,7 +65,7 @@ def alg_flops(B, P, To, Tp):
                 sw_gen_wgrad=2.0 * B * ((To + Tp - 1) * 33024 + Tp * 41680))
 
 
-def kernel_alg_flops(B, P, To, Tp):
+def kernel_alg_flops(B, P, To, Tp, one_launch_d=False):
     """Algorithmic FLOPs PER STEP of each kernel of the step (all of its launches together), MAC = 2 FLOP, from the
     per-agent / per-pair MAC counts of SURVEY.md §8a (data-gradient passes = forward MACs, weight gradients = forward
     MACs).  U + 1 = 2 discriminator updates + the generator-phase D pass."""
@@ -73,7 +73,15 @@ def kernel_alg_flops(B, P, To, Tp):
     d_lstm, d_obs, d_br = 17408, 2048 + 1024, 4 * Tp * 32 + 1024 + 4096 + 32 + 64     # D: LSTM step, obs fc, one branch
     gen_rows = (To + Tp - 1) * lstm + Tp * dec
     soc = B * 4096 + P * 6368
+    d_all = To * d_lstm + d_obs + 2 * d_br                 # a whole D pass on both branches (forward = data-gradient MACs)
+    if one_launch_d:      # sw_disc_update: pass 1 (its LSTM forward rode in the decode launch) + pass 2; disc_fwd = the G phase only
+        d_kernels = {"disc_update_kernel": 2.0 * B * ((d_obs + 2 * d_br) + d_all + 2 * d_all),
+                     "disc_fwd_kernel": 2.0 * B * (To * d_lstm + d_obs + 2 * d_br)}     # one branch forward + its heads backward
+    else:                 # 3 disc_fwd launches (pass 1 heads only, pass 2, G phase) + 2 disc_bwd launches
+        d_kernels = {"disc_fwd_kernel": 2.0 * B * ((d_obs + 2 * d_br) + d_all + d_all),
+                     "disc_bwd_kernel": 2.0 * 2 * B * d_all}
     return {
+        **d_kernels,
         "enc_lstm_fwd_kernel": 2.0 * B * To * lstm,
         "enc_lstm_bwd_kernel": 2.0 * B * To * lstm,
         "dec_rollout_fwd_kernel": 2.0 * B * (Tp * dec + (Tp - 1) * lstm) + 2.0 * B * To * d_lstm,   # + D's first obs LSTM (rides here)
@@ -81,9 +89,6 @@ def kernel_alg_flops(B, P, To, Tp):
         "social_pool_fwd_kernel": 2.0 * soc,
         "social_pool_bwd_rows_kernel": 2.0 * 2 * soc,     # recomputes the pair MLP + its data gradients
         "social_pool_bwd_kernel": 2.0 * 3 * soc,          # ... + the pair-MLP weight gradients in registers
-        # 3 launches: pass 1 heads only (LSTM rode in the decode launch), pass 2 whole, generator phase (1 branch fwd + bwd)
-        "disc_fwd_kernel": 2.0 * B * ((d_obs + 2 * d_br) + (To * d_lstm + d_obs + 2 * d_br) + (To * d_lstm + d_obs + 2 * d_br)),
-        "disc_bwd_kernel": 2.0 * 2 * B * (To * d_lstm + d_obs + 2 * d_br),
         # 3 launches: two D passes + the generator's (incl. the social block's rows when they are deferred)
         "wgrad_partial_kernel": 2.0 * (2 * B * (To * d_lstm + d_obs + 2 * d_br) + B * gen_rows + soc),
     }
@@ -337,14 +342,18 @@ def main():
     lib.sw_debug_spin(float(os.environ.get("SW_BENCH_SPIN_US", 2500.0 * n_ev)), L.stream())
     for o, p_, tg, nz in ins:
         leg.last = tr._step_impl(o, p_, None, scenes, tg, nz, float(leg.data.ss), float(leg.Bg), part)
+    for _ in range(32):
+        lib.sw_debug_spin(0.0, L.stream())       # calibration: the event interval of a kernel that does nothing
     fence()
     buf = ctypes.create_string_buffer(1 << 16)
     lib.sw_kernel_timing_read(buf, len(buf))
     lib.sw_kernel_timing(0)
-    ktimes = {}
+    ktimes, event_overhead_us = {}, None
     for line in buf.value.decode().splitlines():
         name, calls, total_us = line.split()
-        if name != "spin_kernel":
+        if name == "nop_kernel":
+            event_overhead_us = float(total_us) / int(calls)
+        elif name != "spin_kernel":
             ktimes[name] = (int(calls), float(total_us))
     assert torch.isfinite(leg.last).all(), "non-finite losses"
     replicas_identical = None
@@ -428,7 +437,7 @@ def main():
         fl = alg_flops(B, P, To, Tp)
         per_step = dt / args.steps
         # per-kernel table of the eager roofline pass: launches / step, mean launch time, algorithmic GFLOP / step, fraction
-        kfl = kernel_alg_flops(B, P, To, Tp)
+        kfl = kernel_alg_flops(B, P, To, Tp, one_launch_d="disc_update_kernel" in ktimes)
         rows = []
         for name, (calls, total_us) in ktimes.items():
             us_step = total_us / n_ev
@@ -490,6 +499,9 @@ def main():
                                 "of the GPU behind a spin kernel; algorithmic FLOPs of all of the kernel's launches in a step "
                                 "/ their summed time" % n_ev,
                          "kernels": rows[:6],
+                         # what an event pair adds to a launch (a kernel that does nothing, same queue): subtract from avg_us
+                         # for the kernel's own duration; `frac` is computed from the RAW times (conservative)
+                         "event_overhead_us": event_overhead_us,
                          "eager_step_kernel_us": sum(r["us_per_step"] for r in rows),
                          "traffic": traffic, "step_traffic": step_traffic,
                          "step_traffic_vs_algorithmic": (step_traffic / alg_bytes(B, To, Tp)) if step_traffic else None,
