@@ -30,16 +30,17 @@ fetch, nf = mean_counter(sys.argv[1], "FETCH_SIZE")
 write, nw = mean_counter(sys.argv[2], "WRITE_SIZE")
 abi = {"dec_rollout_bwd_kernel": "sw_dec_rollout_bwd", "dec_rollout_fwd_kernel": "sw_dec_rollout_fwd",
        "enc_lstm_fwd_kernel": "sw_enc_lstm_fwd", "enc_lstm_bwd_kernel": "sw_enc_lstm_bwd",
-       "disc_fwd_kernel": "sw_disc_fwd", "disc_bwd_kernel": "sw_disc_bwd", "wgrad_partial_kernel": "wgrad_partial",
-       "wgrad_reduce_kernel": "wgrad_reduce", "social_pool_fwd_kernel": "sw_social_pool_fwd",
-       "social_pool_bwd_kernel": "sw_social_pool_bwd", "social_pool_bwd_rows_kernel": "sw_social_pool_bwd_rows",
-       "stage_step_kernel": "sw_stage_step", "enc_compose_bwd_kernel": "enc_compose_bwd"}
+       "disc_fwd_kernel": "sw_disc_fwd", "disc_bwd_kernel": "sw_disc_bwd", "disc_update_kernel": "sw_disc_update",
+       "wgrad_partial_kernel": "wgrad_partial", "wgrad_reduce_kernel": "wgrad_reduce",
+       "social_pool_fwd_kernel": "sw_social_pool_fwd", "social_pool_bwd_kernel": "sw_social_pool_bwd",
+       "social_pool_bwd_rows_kernel": "sw_social_pool_bwd_rows", "stage_step_kernel": "sw_stage_step",
+       "enc_compose_bwd_kernel": "enc_compose_bwd"}
 steps = max(nf.get("dec_rollout_fwd_kernel", 1), 1)
 out, step_bytes, step_k = {}, 0.0, {}
 for k in sorted(set(fetch) | set(write)):
-    name = abi.get(k)
-    if name is None:
-        continue
+    if "at::" in k or "rocclr" in k or k in ("spin_kernel", "nop_kernel", "traj4d_kernel", "gen_images_kernel", "disc_images_kernel"):
+        continue            # torch's own kernels and helpers that are not part of a replayed step
+    name = abi.get(k, k)
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
     per_launch = (2 * f + w) * 1024
     lps = nf.get(k, nw.get(k, 0)) / steps
