@@ -301,12 +301,13 @@ def main():
     import gc
     leg = Leg(args.workload, dev, pg, world, rank, args.scaling, args.global_scenes, KG)
     tr, To, Tp, A = leg.tr, leg.To, leg.Tp, leg.A
-    leg.prime()
-    leg.run_steps(0, args.warmup)
     # host-side noise sources of a 20-step window: the collector (a gen-2 pass over torch's module graph is ~10 ms) is off
-    # inside timed regions; the noise ring (Leg) keeps the allocator out of the loop
+    # inside timed regions; the noise ring (Leg) keeps the allocator out of the loop.  The collection runs BEFORE the
+    # priming and warmup steps: tens of idle milliseconds right in front of the timed region cost its first launches ~0.4 ms
     gc.collect()
     gc.disable()
+    leg.prime()
+    leg.run_steps(0, args.warmup)
     dt = max_over_ranks(leg.timed(fence, args.warmup, args.steps))          # THE timed region: exactly K steps
     reps = [max_over_ranks(leg.timed(fence, args.warmup + (r + 1) * args.steps, args.steps)) for r in range(REPEATS)]
     # a sustained leg (>= ~2 s of back-to-back steps): long enough for an external GPU-busy sampler to see the device
