@@ -29,6 +29,12 @@
 // this wave's 64x64 block): loads are unconditional from clamped addresses and masked by a 0/1
 // factor, so the hot loop is NI+KT loads, a few multiplies and NI*KT MFMAs - no exec-mask branches,
 // no accumulator shuffling through control flow.
+#ifdef SW_WG_STAMP      // timing experiment (tools/build_variant.sh): start / end of every workgroup of the last launch
+__device__ unsigned long long g_wg_stamps[4 * 4096];
+extern "C" int sw_debug_wg_stamps(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -1;
+}
+#endif
 __global__ __launch_bounds__(SW_THREADS, 2) void wgrad_partial_kernel(WgBatch batch, float* __restrict__ ws,
                                                                       const float* __restrict__ adam_step, double beta1,
                                                                       double beta2, float* __restrict__ bc_out) {
@@ -43,7 +49,20 @@ __global__ __launch_bounds__(SW_THREADS, 2) void wgrad_partial_kernel(WgBatch ba
     }
     return;
   }
+#ifdef SW_WG_STAMP
+  const unsigned long long t0 = wall_clock64();
+#endif
   wg_job(batch, ws, blockIdx.x, red);
+#ifdef SW_WG_STAMP
+  if (threadIdx.x == 0 && blockIdx.x < 4096) {
+    int p = 0;
+    while (p + 1 < batch.np && (int)blockIdx.x >= batch.job0s[p + 1]) ++p;
+    g_wg_stamps[4 * blockIdx.x] = t0;
+    g_wg_stamps[4 * blockIdx.x + 1] = wall_clock64();
+    g_wg_stamps[4 * blockIdx.x + 2] = p;
+    g_wg_stamps[4 * blockIdx.x + 3] = batch.total_jobs;
+  }
+#endif
 }
 // scratch for those two floats: a ring of slots per device (launches of one stream are ordered; 64 slots cover
 // concurrent streams)
@@ -187,6 +206,9 @@ int wg_add_pre(WgBatch& b, int N, int K, float* dW, int ldw, float* db, int nsli
 
 // Cost of a problem in wave-cycles: per 4-row group a wave issues NI x KT MFMAs (32 cycles each) but
 // never less than the issue time of its ~8 operand loads; a problem has ceil(N/64) output blocks.
+#ifndef SW_WG_ROUND_UP
+#define SW_WG_ROUND_UP 0.75
+#endif
 static double wg_cost(const WgProblem& P) {
   double c = 0;
   for (int n0 = 0; n0 < P.N; n0 += 64) {
@@ -236,7 +258,11 @@ size_t wg_finalize(WgBatch& b) {
       if (P.pre) {
         ns = P.pre;
       } else {
-        ns = (int)(tgt * wg_cost(P) / total / NB + 0.5);   // workgroups (4 row slices each) per output block
+        // workgroups (4 row slices each) per output block.  All workgroups of a launch start together and the launch
+        // lasts as long as its longest job: a share of 1.3 rounded DOWN leaves jobs 30 % above the average (the decoder's
+        // fc1.0 z block at m1 ended the launch 5 us after everything else), rounded up they merely finish early
+        const double share = tgt * wg_cost(P) / total / NB;
+        ns = (int)(share + (share < 4.0 && maxwg <= 512.0 ? SW_WG_ROUND_UP : 0.5));   // (two rounds: the second evens out)
         int cap = (P.R + 127) / 128;  // at least 32 rows per wave
         if (ns > cap) ns = cap;
         if (ns > SW_WG_MAXSPLIT) ns = SW_WG_MAXSPLIT;
@@ -260,8 +286,9 @@ size_t wg_finalize(WgBatch& b) {
     return ws;
   };
   size_t ws = assign(target);
-  if (one_per_cu)      // the per-problem rounding may overshoot the count: step down until it fits
-    for (double tgt = target - 4.0; b.total_jobs > (int)small_env && tgt > 64.0; tgt -= 4.0) ws = assign(tgt);
+  // the per-problem rounding may overshoot the count: step down until it fits (one workgroup per CU / one resident round)
+  const int limit = one_per_cu ? (int)small_env : (target >= maxwg ? (int)maxwg : 1 << 30);
+  for (double tgt = target - 4.0; b.total_jobs > limit && tgt > 64.0; tgt -= 4.0) ws = assign(tgt);
   return ws + b.top_reserved;
 }
 
