@@ -54,13 +54,14 @@ __global__ __launch_bounds__(SW_THREADS, 2) void wgrad_partial_kernel(WgBatch ba
 #endif
   wg_job(batch, ws, blockIdx.x, red);
 #ifdef SW_WG_STAMP
-  if (threadIdx.x == 0 && blockIdx.x < 4096) {
+  if (threadIdx.x == 0 && blockIdx.x < 2048) {      // launches below 400 jobs (discriminator passes at m1): second half
     int p = 0;
     while (p + 1 < batch.np && (int)blockIdx.x >= batch.job0s[p + 1]) ++p;
-    g_wg_stamps[4 * blockIdx.x] = t0;
-    g_wg_stamps[4 * blockIdx.x + 1] = wall_clock64();
-    g_wg_stamps[4 * blockIdx.x + 2] = p;
-    g_wg_stamps[4 * blockIdx.x + 3] = batch.total_jobs;
+    unsigned long long* o = g_wg_stamps + (batch.total_jobs < 400 ? 4 * 2048 : 0) + 4 * blockIdx.x;
+    o[0] = t0;
+    o[1] = wall_clock64();
+    o[2] = p;
+    o[3] = batch.total_jobs;
   }
 #endif
 }
@@ -157,20 +158,33 @@ int wg_add(WgBatch& b, const float* delta, int ldd, const float* act, int lda, i
   // column blocks of <= 64 REAL act columns; the ones column (bias gradient) rides with the last block on the VALU
   // (it used to open a block of its own whenever K was a multiple of 64: every delta row read again for a row sum)
   if (K < 1) return SW_ESHAPE;
-  for (int c0 = 0; c0 < K; c0 += 64) {
-    if (b.np >= SW_WG_MAXP) return SW_ESHAPE;
-    const int c1 = c0 + 64 < K ? c0 + 64 : K;
-    const bool has_ones = db && c1 == K;
-    WgProblem& P = b.p[b.np++];
-    P.delta = delta; P.ldd = ldd; P.act = act + c0; P.lda = lda;
-    P.R = R; P.N = N; P.K = c1 - c0; P.ones = has_ones ? 1 : 0;
-    P.dW = dW + c0; P.ldw = ldw; P.db = has_ones ? db : nullptr; P.db2 = has_ones ? db2 : nullptr;
-    P.accumulate = accumulate;
-    P.pre = 0;
-    P.act2 = nullptr; P.dW2 = nullptr; P.lda2 = P.ldw2 = P.K2 = P.row0 = 0;
-    if (!wg_shape_ok(N, P.K)) return SW_ESHAPE;
-    P.nbn = (N + 15) / 16;
-    P.nbk = P.K > 0 ? wg_tiles(P.K, true) : 1;     // the ones column costs no matrix tile (VALU)
+  // A last output block narrower than 64 delta columns (fc2: 80 = 64 + 16) is a problem of its own: every output block
+  // of a problem gets the same number of row slices, and the narrow block's jobs - a quarter of the matrix work over the
+  // same rows - finished at two thirds of the launch (and, the blocks alternating with the workgroup index, all on the
+  // even XCDs).  With its own split it gets fewer, longer slices.
+#ifdef SW_WG_NOSPLIT     // timing experiment
+  const int Nfull = N;
+#else
+  const int Nfull = N > 64 && (N & 63) && (N & 63) <= 32 && b.np + 2 * ((K + 63) / 64) <= SW_WG_MAXP ? (N & ~63) : N;
+#endif
+  for (int n0 = 0; n0 < N; n0 = (n0 == 0 ? Nfull : N)) {
+    const int Nseg = n0 == 0 ? Nfull : N - Nfull;
+    for (int c0 = 0; c0 < K; c0 += 64) {
+      if (b.np >= SW_WG_MAXP) return SW_ESHAPE;
+      const int c1 = c0 + 64 < K ? c0 + 64 : K;
+      const bool has_ones = db && c1 == K;
+      WgProblem& P = b.p[b.np++];
+      P.delta = delta + n0; P.ldd = ldd; P.act = act + c0; P.lda = lda;
+      P.R = R; P.N = Nseg; P.K = c1 - c0; P.ones = has_ones ? 1 : 0;
+      P.dW = dW + (size_t)n0 * ldw + c0; P.ldw = ldw; P.db = has_ones ? db + n0 : nullptr;
+      P.db2 = has_ones && db2 ? db2 + n0 : nullptr;
+      P.accumulate = accumulate;
+      P.pre = 0;
+      P.act2 = nullptr; P.dW2 = nullptr; P.lda2 = P.ldw2 = P.K2 = P.row0 = 0;
+      if (!wg_shape_ok(Nseg, P.K)) return SW_ESHAPE;
+      P.nbn = (Nseg + 15) / 16;
+      P.nbk = P.K > 0 ? wg_tiles(P.K, true) : 1;     // the ones column costs no matrix tile (VALU)
+    }
   }
   return SW_OK;
 }
@@ -204,8 +218,15 @@ int wg_add_pre(WgBatch& b, int N, int K, float* dW, int ldw, float* db, int nsli
   return SW_OK;
 }
 
-// Cost of a problem in wave-cycles: per 4-row group a wave issues NI x KT MFMAs (32 cycles each) but
-// never less than the issue time of its ~8 operand loads; a problem has ceil(N/64) output blocks.
+// Cost of a problem in wave-cycles: per 4-row group a wave issues NI x KT MFMAs (32 cycles each), the tail / ones columns
+// on the VALU (4 cycles per instruction) and SW_WG_GROUP_C0 cycles of loads, masks and address arithmetic; a problem has
+// ceil(N/64) output blocks.  C0 and the VALU term are fitted on per-workgroup start / end stamps of the launches at the
+// metric shape (-DSW_WG_STAMP, tools/scratch/wg_stamps.py): the LSTM problem measures 848 cycles per group and wave = 512 +
+// 80 + 256.  With C0 = 0 the narrow problems (K = 32 blocks, the 2048-row S / z blocks of fc1.0) were undersplit and their
+// jobs ended the generator's launch 8 us after the average job.
+#ifndef SW_WG_GROUP_C0
+#define SW_WG_GROUP_C0 256.0
+#endif
 #ifndef SW_WG_ROUND_UP
 #define SW_WG_ROUND_UP 0.75
 #endif
@@ -214,8 +235,8 @@ static double wg_cost(const WgProblem& P) {
   for (int n0 = 0; n0 < P.N; n0 += 64) {
     int ni = (P.N - n0 + 15) / 16;
     if (ni > 4) ni = 4;
-    double per_group = ni * P.nbk * 32.0;
-    if (per_group < 192.0) per_group = 192.0;
+    double per_group = ni * P.nbk * 32.0 + ni * (P.K2 + P.ones) * 4.0 + SW_WG_GROUP_C0;   // MFMAs, tail / ones columns (VALU),   // + loads / masks / address arithmetic of a group (fitted on
+    if (per_group < 192.0) per_group = 192.0;                // per-job stamps of the generator pass, tools/scratch/wg_stamps.py)
     c += per_group;
   }
   return c * (P.R / 4.0 + 8.0);
@@ -232,7 +253,7 @@ size_t wg_finalize(WgBatch& b) {
   const double total = wg_total_work(b) + 1.0;
   // workgroups per launch: every wave should carry >= ~16K cycles of work (fixed per-workgroup costs -
   // pipeline fill, LDS reduction, partial store - are ~8 us), at most 1024 (two rounds of residency)
-  static const double grain = getenv("SW_WG_GRAIN") ? atof(getenv("SW_WG_GRAIN")) : 8192.0;   // tuning knob (cycles of work per wave)
+  static const double grain = getenv("SW_WG_GRAIN") ? atof(getenv("SW_WG_GRAIN")) : 8192.0 * (1.0 + SW_WG_GROUP_C0 / 512.0);   // tuning knob (cycles of work per wave)
   double target = total / grain / 4.0;
   if (target < 64.0) target = 64.0;
   // ... at most ONE round of residency (2 workgroups x 256 CUs) - a sharp optimum once every workgroup streams with a
