@@ -29,6 +29,8 @@
 // this wave's 64x64 block): loads are unconditional from clamped addresses and masked by a 0/1
 // factor, so the hot loop is NI+KT loads, a few multiplies and NI*KT MFMAs - no exec-mask branches,
 // no accumulator shuffling through control flow.
+// workgroups that carry jobs: the job count padded to whole rounds of 8 XCDs x chunks of 4 (see the kernel)
+__host__ __device__ inline int wg_grid_jobs(int total_jobs) { return (total_jobs + 31) & ~31; }
 #ifdef SW_WG_STAMP      // timing experiment (tools/build_variant.sh): start / end of every workgroup of the last launch
 __device__ unsigned long long g_wg_stamps[4 * 4096];
 extern "C" int sw_debug_wg_stamps(unsigned long long* host, int n) {
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void wgrad_partial_kernel(WgBatch ba
                                                                       double beta2, float* __restrict__ bc_out) {
   __shared__ __attribute__((aligned(16))) float red[SW_WG_RED_FLOATS];   // per-wave 64 x <=69 blocks, summed before the store
   // Adam's bias corrections for the reduction that follows (it applies the update): one extra workgroup, no job delayed
-  if ((int)blockIdx.x >= batch.total_jobs) {
+  if ((int)blockIdx.x >= wg_grid_jobs(batch.total_jobs)) {
     if (threadIdx.x == 0) {
       float bc1, bc2s;
       wg_adam_bc_compute(adam_step, beta1, beta2, bc1, bc2s);
@@ -49,14 +51,21 @@ __global__ __launch_bounds__(SW_THREADS, 2) void wgrad_partial_kernel(WgBatch ba
     }
     return;
   }
+  // Workgroup v runs on XCD v % 8 (round-robin dispatch).  Jobs are numbered so that the output blocks of one row slice
+  // are consecutive (and wg_finalize puts the problems with 4 blocks first, then 2, then 1): chunks of 4 consecutive jobs
+  // go to ONE XCD, the chunks round-robin over the XCDs - the 4 gate blocks of the LSTM problem fetch their h rows into
+  // one L2 instead of four, and every XCD gets the same mix of problems.
+  const int v = blockIdx.x, l = v >> 3;
+  const int job = ((((l >> 2) << 3) + (v & 7)) << 2) + (l & 3);
+  if (job >= batch.total_jobs) return;
 #ifdef SW_WG_STAMP
   const unsigned long long t0 = wall_clock64();
 #endif
-  wg_job(batch, ws, blockIdx.x, red);
+  wg_job(batch, ws, job, red);
 #ifdef SW_WG_STAMP
   if (threadIdx.x == 0 && blockIdx.x < 2048) {      // launches below 400 jobs (discriminator passes at m1): second half
     int p = 0;
-    while (p + 1 < batch.np && (int)blockIdx.x >= batch.job0s[p + 1]) ++p;
+    while (p + 1 < batch.np && job >= batch.job0s[p + 1]) ++p;
     unsigned long long* o = g_wg_stamps + (batch.total_jobs < 400 ? 4 * 2048 : 0) + 4 * blockIdx.x;
     o[0] = t0;
     o[1] = wall_clock64();
@@ -249,6 +258,17 @@ double wg_total_work(const WgBatch& b) {
 }
 
 size_t wg_finalize(WgBatch& b) {
+  // problems in the order 4 / 3 / 2 / 1 output blocks (stable), precomputed-partial problems last: the kernel's job chunks
+  // of 4 then hold whole row slices (every problem's job count is a multiple of its block count)
+  {
+    auto key = [](const WgProblem& P) { return P.pre ? 0 : (P.N + 63) / 64; };
+    for (int i = 1; i < b.np; ++i) {          // insertion sort, <= 24 entries
+      const WgProblem t = b.p[i];
+      int j = i;
+      for (; j > 0 && key(b.p[j - 1]) < key(t); --j) b.p[j] = b.p[j - 1];
+      b.p[j] = t;
+    }
+  }
   // ~1024 workgroups = 4096 wave-jobs per launch (4 per SIMD), equal cost each
   const double total = wg_total_work(b) + 1.0;
   // workgroups per launch: every wave should carry >= ~16K cycles of work (fixed per-workgroup costs -
@@ -344,7 +364,7 @@ int wg_launch_adam(WgBatch& b, float* ws, WgAdam& ad, hipStream_t stream) {
   ad.bc = nullptr;
   if (b.total_jobs > 0) {
     float* bc = ad.w ? wg_bc_slot() : nullptr;
-    SW_LAUNCH(wgrad_partial_kernel, dim3(b.total_jobs + (bc ? 1 : 0)), dim3(SW_THREADS), 0, stream, b, ws, ad.step,
+    SW_LAUNCH(wgrad_partial_kernel, dim3(wg_grid_jobs(b.total_jobs) + (bc ? 1 : 0)), dim3(SW_THREADS), 0, stream, b, ws, ad.step,
                        ad.beta1, ad.beta2, bc);
     SW_CHECK_LAUNCH("wgrad_partial_kernel");
     ad.bc = bc;
@@ -355,7 +375,7 @@ int wg_launch_adam(WgBatch& b, float* ws, WgAdam& ad, hipStream_t stream) {
 int wg_launch_finalized(WgBatch& b, float* ws, hipStream_t stream) {
   if (b.total_out == 0) return SW_OK;
   if (b.total_jobs > 0) {
-    SW_LAUNCH(wgrad_partial_kernel, dim3(b.total_jobs), dim3(SW_THREADS), 0, stream, b, ws, (const float*)nullptr,
+    SW_LAUNCH(wgrad_partial_kernel, dim3(wg_grid_jobs(b.total_jobs)), dim3(SW_THREADS), 0, stream, b, ws, (const float*)nullptr,
                        0.0, 0.0, (float*)nullptr);
     SW_CHECK_LAUNCH("wgrad_partial_kernel");
   }
