@@ -339,7 +339,8 @@ int sw_stage_step(const float* slot, int B, int To, int Tp, float* obsv_dst /*[B
  *      registration is dropped, sw_enc_lstm_fwd*, sw_dec_rollout_fwd*, sw_dec_rollout_bwd*, sw_social_pool_fwd/bwd
  *      called with these weight buffers load the images instead of deriving / gathering per workgroup (same values bit
  *      for bit).  The images are valid while the weights are unchanged: the caller drops the registration -
- *      sw_gen_images(NULL, NULL, NULL, NULL, NULL, NULL) - before it updates them.
+ *      sw_gen_images(NULL, NULL, NULL, NULL, NULL, NULL) - before it updates them.  Registrations (these and
+ *      sw_disc_images') are per HOST THREAD: register, launch and drop on the thread that steps the trainer.
  *      sw_stage_step_img = sw_stage_step whose launch derives and registers the images as well (no extra launch).   */
 int sw_gen_image_floats(void);
 int sw_gen_images(const float* enc_w, const float* dec_w, const float* emb_w /*or NULL*/, const float* att_w /*or NULL*/,

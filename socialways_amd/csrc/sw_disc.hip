@@ -1425,9 +1425,9 @@ extern "C" int sw_disc_image_table(int Tp, int* tab) {
   head(O.la1w, 2, 32, L.la1T, LD16);
   return SW_OK;
 }
-static const float* g_dimg_w = nullptr;
-static DiscImages g_dimg;
-static int g_dimg_tp = 0;
+static thread_local const float* g_dimg_w = nullptr;     // per host thread, like the generator's registration (sw_misc.hip)
+static thread_local DiscImages g_dimg;
+static thread_local int g_dimg_tp = 0;
 DiscImages sw_disc_images_for(const float* d_w, int Tp) {
   return (g_dimg.img && d_w == g_dimg_w && Tp == g_dimg_tp) ? g_dimg : DiscImages();
 }

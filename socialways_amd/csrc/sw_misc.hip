@@ -772,7 +772,10 @@ __global__ __launch_bounds__(256) void gen_images_kernel(const float* __restrict
                                                           float* __restrict__ img) {
   gen_images_block(enc_w, dec_w, emb_w, att_w, img, blockIdx.x);
 }
-static const float *g_img_enc = nullptr, *g_img_dec = nullptr, *g_img_emb = nullptr, *g_img_att = nullptr, *g_img = nullptr;
+// The registration is PER HOST THREAD (a step registers, launches and drops on one thread): trainers stepping on different
+// threads do not see or clear each other's images.
+static thread_local const float *g_img_enc = nullptr, *g_img_dec = nullptr, *g_img_emb = nullptr, *g_img_att = nullptr,
+                                *g_img = nullptr;
 const float* sw_soc_images_for(const float* emb_w, const float* att_w) {
   return (g_img && emb_w && emb_w == g_img_emb && att_w == g_img_att) ? g_img : nullptr;
 }

@@ -405,6 +405,8 @@ class SocialWaysTrainer:
                 raise ValueError("variety_noise must be ((variety_k - 1) * B, %d)" % self.noise_len)
             self._vnoise = self._pad_z(vn.to(dev, non_blocking=True)).contiguous()
         part = None
+        if not self._graphs and self.ws.retired:      # eager-only runs: nothing captured can reference an outgrown workspace
+            self.ws.release_retired()                 # (stream-ordered allocator: kernels already queued on it stay valid)
         if self.use_graph and self.use_variety_loss != "fixed":    # the folded K-sample step runs eagerly
             # one graph set per packed-batch layout; datasets with ragged scenes produce many layouts, so the
             # number of captured layouts is capped and the rest of the steps run eagerly
