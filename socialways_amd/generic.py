@@ -207,24 +207,55 @@ def _mlp(seq, x):
     return x
 
 
-def _lstm_step(lstm, x, h, c):
-    """One nn.LSTM(num_layers=1) step on x (B, in): the two gate products + the cell."""
-    pre = _Lin.apply(x, lstm.weight_ih_l0, lstm.bias_ih_l0) + _Lin.apply(h, lstm.weight_hh_l0, lstm.bias_hh_l0)
+def _lstm_step(lstm, x, h, c, layer=0):
+    """One step of layer `layer` of an nn.LSTM on x (B, in): the two gate products + the cell."""
+    w_ih, w_hh = getattr(lstm, "weight_ih_l%d" % layer), getattr(lstm, "weight_hh_l%d" % layer)
+    b_ih, b_hh = getattr(lstm, "bias_ih_l%d" % layer), getattr(lstm, "bias_hh_l%d" % layer)
+    pre = _Lin.apply(x, w_ih, b_ih) + _Lin.apply(h, w_hh, b_hh)
     return _LstmCell.apply(pre, c)
 
 
 # ---- the reference's modules as parameter containers (same construction order = same initial weights) ------------------
 class EncoderLstm(nn.Module):                               # train.py:245-269
-    def __init__(self, hidden_size, n_layers=1):
+    """Any width, any number of stacked layers (the class default is 2, train.py:246; the script builds 1, train.py:82)."""
+
+    def __init__(self, hidden_size, n_layers=2, device=None):
         super().__init__()
-        if n_layers != 1:
-            raise L.SocialWaysHipError("EncoderLstm: n_layers=1 (train.py:82)")
-        self.hidden_size = hidden_size
+        if n_layers < 1:
+            raise L.SocialWaysHipError("EncoderLstm: n_layers >= 1")
+        self.hidden_size, self.n_layers = hidden_size, n_layers
         self.embed = nn.Linear(4, hidden_size)
-        self.lstm = nn.LSTM(hidden_size, hidden_size, num_layers=1, batch_first=True)
+        self.lstm = nn.LSTM(hidden_size, hidden_size, num_layers=n_layers, batch_first=True)
+        self.lstm_h = []
+        if device is not None:
+            self.to(device)
+
+    def init_lstm(self, h, c):
+        self.lstm_h = (h, c)
 
     def step(self, x4, h, c):
+        """One step of a one-layer encoder on states (B, H) (the generator's rollout)."""
         return _lstm_step(self.lstm, _lin(self.embed, x4), h, c)
+
+    def forward(self, obsv):
+        """obsv (B,T,4) or (B,4): embed + the stacked LSTM from the stored state (n_layers, B, H); returns the top layer's
+        y (B,T,H) and keeps the new state in `self.lstm_h`, like train.py:262-269."""
+        L.require_gpu(obsv)
+        bs, H = obsv.shape[0], self.hidden_size
+        x = obsv.reshape(bs, -1, 4)
+        T = x.shape[1]
+        e = _lin(self.embed, x.reshape(bs * T, 4)).view(bs, T, H)
+        h = [self.lstm_h[0][k].reshape(bs, H) for k in range(self.n_layers)]
+        c = [self.lstm_h[1][k].reshape(bs, H) for k in range(self.n_layers)]
+        ys = []
+        for t in range(T):
+            inp = e[:, t]
+            for k in range(self.n_layers):
+                h[k], c[k] = _lstm_step(self.lstm, inp, h[k], c[k], k)
+                inp = h[k]
+            ys.append(inp)
+        self.lstm_h = (torch.stack(h, 0), torch.stack(c, 0))
+        return torch.stack(ys, 1)
 
 
 class EmbedSocialFeatures(nn.Module):                       # train.py:178-189

@@ -461,11 +461,18 @@ class EmbedSocialFeatures(_Packed):
 class EncoderLstm(_Packed):
     _GRP = L.GRP_ENC
 
-    def __init__(self, hidden_size, n_layers=2, device=None):
+    def __new__(cls, hidden_size=64, n_layers=2, device=None):
+        # The fused kernels are built for ONE layer of <= 64 units (what train.py:82 constructs).  The class signature's
+        # default of 2 stacked layers (train.py:246) and wider encoders are served by the generic-width module: same
+        # parameters / state_dict keys / initialisation, its steps run layer by layer through the C-ABI pieces.
+        if cls is EncoderLstm and (n_layers != 1 or hidden_size > 64):
+            from . import generic
+            return generic.EncoderLstm(hidden_size, n_layers, device)
+        return super().__new__(cls)
+
+    def __init__(self, hidden_size, n_layers=1, device=None):
         self.hidden_size = hidden_size
         super().__init__()
-        if n_layers != 1:
-            raise L.SocialWaysHipError("EncoderLstm kernels are built for n_layers=1 (train.py:82)")
         _check_hidden(hidden_size, "EncoderLstm")
         H = hidden_size
         if H == 64:

@@ -514,6 +514,42 @@ def test_wider_networks_train_on_the_generic_path_and_match_the_oracle(H, nl, tm
 def test_unsupported_module_widths_say_where_to_go():
     import socialways_amd as sw
     with pytest.raises(sw.SocialWaysHipError, match="generic"):
-        sw.EncoderLstm(128, 1)
+        sw.DecoderFC(128 + 128 + 64)
     with pytest.raises(sw.SocialWaysHipError):
         sw.EncoderLstm(20, 1)
+
+
+@pytest.mark.parametrize("H,nl", [(64, 2), (128, 1), (32, 3)])
+def test_encoder_with_stacked_layers_or_wide_units_matches_the_reference_module(H, nl):
+    """EncoderLstm(hidden_size) with the class signature's default of 2 stacked layers (train.py:246), and widths above 64:
+    served by the generic-width module - sequence call, single-step calls from the stored state and all gradients against
+    the oracle's nn.LSTM-based restatement with the same parameters."""
+    import socialways_amd as sw
+    from socialways_amd import generic
+    torch.manual_seed(11)
+    enc = sw.EncoderLstm(H) if nl == 2 else sw.EncoderLstm(H, nl)
+    assert isinstance(enc, generic.EncoderLstm) and enc.n_layers == nl
+    ref = O.EncoderLstm(H, nl)
+    ref.load_state_dict(enc.state_dict())                     # same keys, same shapes
+    enc = enc.to("cuda:0")
+    bs, T = 37, 6
+    x = torch.randn(bs, T, 4)
+    h0, c0 = 0.3 * torch.randn(nl, bs, H), 0.3 * torch.randn(nl, bs, H)
+    xg = x.cuda().requires_grad_(True)
+    enc.init_lstm(h0.cuda(), c0.cuda())
+    y = enc(xg)
+    y1 = enc(x[:, 0].cuda())                                  # one more step from the stored state, (B,4) input
+    xr = x.clone().requires_grad_(True)
+    ref.init_lstm(h0, c0)
+    yr = ref(xr)
+    yr1 = ref(x[:, 0])
+    assert_close(y.detach().cpu(), yr.detach(), 2e-5, 2e-6, "y")
+    assert_close(y1.detach().cpu(), yr1.detach(), 2e-5, 2e-6, "single step")
+    for k in range(2):
+        assert_close(enc.lstm_h[k].detach().cpu(), ref.lstm_h[k].detach(), 2e-5, 2e-6, "state %d" % k)
+    w = torch.randn(bs, T, H)
+    (y * w.cuda()).sum().backward()
+    (yr * w).sum().backward()
+    assert_close(xg.grad.cpu(), xr.grad, 1e-4, 1e-6, "dx")
+    for (k, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
+        assert_close(p.grad.cpu(), q.grad, 1e-4, 1e-5 * max(float(q.grad.abs().max()), 1e-9), "d" + k)
