@@ -349,58 +349,12 @@ __device__ __forceinline__ void stage_pair_wt(float* w2t, float* w1t, const floa
   }
 }
 
-// One 16-pair tile: given the recomputed activations (h1, h2 post-ReLU) and dz3 = d(loss)/d(f_ij) (C layout,
-// exact zeros for invalid pairs), back-propagate through fc.4 / fc.2 and add this tile's contribution to all
-// weight gradients.  w2t / w1t: TRANSPOSED LDS images fc.4.weight^T [64 in][68] / fc.2.weight^T [32 in][68] (the
-// A operands of the two data-gradient products as float4s); scr: this wave's transposition scratch.
-__device__ __forceinline__ void pair_tile_bwd(PairGrad& G, float* scr, const float* w2t, const float* w1t,
-                                              const f32x4 h1[2], const f32x4 h2[4], const f32x4 dz3[4], float f0,
-                                              float f1, float f2, int ln, int lg SW_STAMP_PARAM) {
-  // dW3 += dz3 h2^T (k = pairs): both operands through the transposition scratch
+// Second half of a tile's backward: given dh2 = d(loss)/d(pre-activation of fc.2) (C layout, ReLU' applied, exact zeros for
+// invalid pairs): dW2 += dh2 h1^T, dh1 = (W1^T dh2) relu'(h1), dW1 / db1 += dh1 [feat | 1].
+__device__ __forceinline__ void pair_tile_bwd_tail(PairGrad& G, float* scr, const float* w1t, const f32x4 h1[2],
+                                                   const f32x4 dh2[4], float f0, float f1, float f2, int ln,
+                                                   int lg SW_STAMP_PARAM) {
   f32x4 ta[4], tb[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) tr_put(scr + t * 16 * SW_SOC_TLD, dz3[t], ln, lg);
-  wave_lds_fence();
-#pragma unroll
-  for (int t = 0; t < 4; ++t) ta[t] = tr_get(scr + t * 16 * SW_SOC_TLD, ln, lg);
-  wave_lds_fence();
-#pragma unroll
-  for (int t = 0; t < 4; ++t) tr_put(scr + t * 16 * SW_SOC_TLD, h2[t], ln, lg);
-  wave_lds_fence();
-#pragma unroll
-  for (int t = 0; t < 4; ++t) tb[t] = tr_get(scr + t * 16 * SW_SOC_TLD, ln, lg);
-  wave_lds_fence();
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-#pragma unroll
-    for (int mo = 0; mo < 4; ++mo) {
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) G.acc3[mo][kt] = SW_MFMA(ta[mo][r], tb[kt][r], G.acc3[mo][kt]);
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < 4; ++t) G.b3s[t] += (ta[t][0] + ta[t][1]) + (ta[t][2] + ta[t][3]);
-  // dh2 = (W2^T dz3) * relu'(h2): A operand = W2[16mo+4lg+r][16mt+ln], one float4 per (mt, mo) from the transposed image
-  f32x4 dh2[4];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) dh2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int mo = 0; mo < 4; ++mo) {
-    f32x4 wt[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) wt[mt] = ld4(w2t + (16 * mt + ln) * SW_SOC_WTLD + 16 * mo + 4 * lg);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) dh2[mt] = SW_MFMA(wt[mt][r], dz3[mo][r], dh2[mt]);
-    }
-  }
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dh2[mt][r] = h2[mt][r] > 0.f ? dh2[mt][r] : 0.f;
-  }
-  SW_STAMP(3);
   // dW2 += dh2 h1^T
 #pragma unroll
   for (int t = 0; t < 4; ++t) tr_put(scr + t * 16 * SW_SOC_TLD, dh2[t], ln, lg);
@@ -463,6 +417,117 @@ __device__ __forceinline__ void pair_tile_bwd(PairGrad& G, float* scr, const flo
     }
   }
   wave_lds_fence();
+}
+
+// One 16-pair tile: given the recomputed activations (h1, h2 post-ReLU) and dz3 = d(loss)/d(f_ij) (C layout,
+// exact zeros for invalid pairs), back-propagate through fc.4 / fc.2 and add this tile's contribution to all
+// weight gradients.  w2t / w1t: TRANSPOSED LDS images fc.4.weight^T [64 in][68] / fc.2.weight^T [32 in][68] (the
+// A operands of the two data-gradient products as float4s); scr: this wave's transposition scratch.
+__device__ __forceinline__ void pair_tile_bwd(PairGrad& G, float* scr, const float* w2t, const float* w1t,
+                                              const f32x4 h1[2], const f32x4 h2[4], const f32x4 dz3[4], float f0,
+                                              float f1, float f2, int ln, int lg SW_STAMP_PARAM) {
+  // dW3 += dz3 h2^T (k = pairs): both operands through the transposition scratch
+  f32x4 ta[4], tb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) tr_put(scr + t * 16 * SW_SOC_TLD, dz3[t], ln, lg);
+  wave_lds_fence();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) ta[t] = tr_get(scr + t * 16 * SW_SOC_TLD, ln, lg);
+  wave_lds_fence();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) tr_put(scr + t * 16 * SW_SOC_TLD, h2[t], ln, lg);
+  wave_lds_fence();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) tb[t] = tr_get(scr + t * 16 * SW_SOC_TLD, ln, lg);
+  wave_lds_fence();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) G.acc3[mo][kt] = SW_MFMA(ta[mo][r], tb[kt][r], G.acc3[mo][kt]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) G.b3s[t] += (ta[t][0] + ta[t][1]) + (ta[t][2] + ta[t][3]);
+  // dh2 = (W2^T dz3) * relu'(h2): A operand = W2[16mo+4lg+r][16mt+ln], one float4 per (mt, mo) from the transposed image
+  f32x4 dh2[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) dh2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int mo = 0; mo < 4; ++mo) {
+    f32x4 wt[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) wt[mt] = ld4(w2t + (16 * mt + ln) * SW_SOC_WTLD + 16 * mo + 4 * lg);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) dh2[mt] = SW_MFMA(wt[mt][r], dz3[mo][r], dh2[mt]);
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dh2[mt][r] = h2[mt][r] > 0.f ? dh2[mt][r] : 0.f;
+  }
+  SW_STAMP(3);
+  pair_tile_bwd_tail(G, scr, w1t, h1, dh2, f0, f1, f2, ln, lg SW_STAMP_ARG);
+}
+
+// ---- the rank-1 structure of the attention's gradient -------------------------------------------------------------
+// sigma_ij = <f_ij, Wh_j>  =>  dz3_ij = d(loss)/d(f_ij) = dsigma_ij Wh_j: for the 16 pairs (i, j = 16 jb + ln) of a tile the
+// 64-vector is the SAME per column j for every i, only its scale dsigma_ij changes.  Two of the four matrix products of a
+// tile's backward therefore factor over the i loop of a j block:
+//   dh2_ij = relu'(h2_ij) . (W3^T dz3_ij) = relu'(h2_ij) . dsigma_ij v_j,   v_j = W3^T Wh_j   (once per block: pair_block_v)
+//   dW3 = sum_ij dz3_ij h2_ij^T = sum_j Wh_j Q_j^T,   Q_j = sum_i dsigma_ij h2_ij             (VALU per tile, then once per
+//   db3 = sum_ij dz3_ij = sum_j Wh_j sd_j,            sd_j = sum_i dsigma_ij                    block: pair_block_dw3)
+// 128 of a tile's 288 MFMAs and the two largest transpositions become 32 vector FMAs.  (Re-associated sums: the results
+// differ from the per-pair order in the last bits, like every split-K order in this library.)
+__device__ __forceinline__ void pair_block_v(const float* w2t, const f32x4 whj[4], f32x4 v[4], int ln, int lg) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) v[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int mo = 0; mo < 4; ++mo) {
+    f32x4 wt[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) wt[mt] = ld4(w2t + (16 * mt + ln) * SW_SOC_WTLD + 16 * mo + 4 * lg);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) v[mt] = SW_MFMA(wt[mt][r], whj[mo][r], v[mt]);
+    }
+  }
+}
+__device__ __forceinline__ void pair_block_dw3(PairGrad& G, float* scr, const f32x4 whj[4], const f32x4 Q[4], float sd, int ln,
+                                               int lg) {
+  f32x4 ta[4], tb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) tr_put(scr + t * 16 * SW_SOC_TLD, whj[t], ln, lg);
+  wave_lds_fence();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) ta[t] = tr_get(scr + t * 16 * SW_SOC_TLD, ln, lg);
+  wave_lds_fence();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) tr_put(scr + t * 16 * SW_SOC_TLD, Q[t], ln, lg);
+  wave_lds_fence();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) tb[t] = tr_get(scr + t * 16 * SW_SOC_TLD, ln, lg);
+  wave_lds_fence();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) G.acc3[mo][kt] = SW_MFMA(ta[mo][r], tb[kt][r], G.acc3[mo][kt]);
+    }
+  }
+  // ta[t][r] = Wh[unit 16t + ln][agent 4lg + r of the block]; sd of that agent sits in lane 4lg + r (any lane group)
+  float sdT[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sdT[r] = __shfl(sd, 4 * lg + r);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    G.b3s[t] += fmaf(ta[t][0], sdT[0], ta[t][1] * sdT[1]) + fmaf(ta[t][2], sdT[2], ta[t][3] * sdT[3]);
 }
 
 // Workgroup partial = sum of its 4 waves' PairGrad in a fixed order through LDS (`red`: SW_SOC_PART floats,
@@ -614,6 +679,12 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
         whj[mo] = ld4(&wh[jc * 68 + 16 * mo + 4 * lg]);
         accw[mo] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
+      // per block: v_j = W3^T Wh_j; per tile dh2 = relu'(h2) dsigma v_j on the VALU, Q_j / sd_j accumulate for dW3 / db3
+      f32x4 vj[4], Q[4];
+      float sd = 0.f;
+      pair_block_v(w2t, whj, vj, ln, lg);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) Q[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
       for (int i = wave; i < n; i += 4) {
         float f0, f1, f2;
         pair_feat(ld4(&x4[i * 4]), xj, f0, f1, f2);
@@ -621,19 +692,29 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
         pair_l1(w0b, lg, f0, f1, f2, h1);
         pair_l23(W, b12, b12 + 64, lg, h1, h2, f);
         const float dsv = valid ? dsg[i * sa + jc] : 0.f;   // invalid lanes contribute exact zeros everywhere below
-        f32x4 dz3[4];
+        f32x4 dh2[4];
+        sd += dsv;
 #pragma unroll
         for (int mo = 0; mo < 4; ++mo) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             accw[mo][r] = fmaf(dsv, f[mo][r], accw[mo][r]);
-            dz3[mo][r] = dsv * whj[mo][r];
+            Q[mo][r] = fmaf(dsv, h2[mo][r], Q[mo][r]);
+            dh2[mo][r] = h2[mo][r] > 0.f ? dsv * vj[mo][r] : 0.f;
           }
         }
         SW_STAMP(2);
-        pair_tile_bwd(G, scr, w2t, w1t, h1, h2, dz3, f0, f1, f2, ln, lg SW_STAMP_ARG);
+        SW_STAMP(3);
+        pair_tile_bwd_tail(G, scr, w1t, h1, dh2, f0, f1, f2, ln, lg SW_STAMP_ARG);
         SW_STAMP(5);
       }
+      {
+        f32x4 whr[4];     // re-read: keeps 16 registers out of the tile loop
+#pragma unroll
+        for (int mo = 0; mo < 4; ++mo) whr[mo] = ld4(&wh[jc * 68 + 16 * mo + 4 * lg]);
+        pair_block_dw3(G, scr, whr, Q, sd, ln, lg);
+      }
+      wave_lds_fence();
 #pragma unroll
       for (int mo = 0; mo < 4; ++mo) st4(scr + ln * 68 + 16 * mo + 4 * lg, accw[mo]);
       __syncthreads();
