@@ -56,6 +56,25 @@ __device__ __forceinline__ void load_pair_w_img(PairW& W, const float* __restric
   }
 }
 
+// fc.2 alone (the kernels that never form f_ij = fc.4(..) explicitly, see "the attention never needs f_ij" below)
+struct PairW1 {
+  f32x4 w1[4][2];         // fc.2.weight[16mt + ln][16j + 4lg ..]   (64 x 32)
+};
+__device__ __forceinline__ void load_pair_w1(PairW1& W, const float* emb_w, int ln, int lg) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) W.w1[mt][j] = ld4(emb_w + swp::EMB_W1 + (16 * mt + ln) * 32 + 16 * j + 4 * lg);
+  }
+}
+__device__ __forceinline__ void load_pair_w1_img(PairW1& W, const float* __restrict__ img, int lane) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) W.w1[mt][j] = ld4(img + swimg::OP_E1 + ((mt * 2 + j) * 64 + lane) * 4);
+  }
+}
+
 // [dist, bearing, dca] of the ordered pair (i, j): dp = p_i - p_j, dv = v_i - v_j (train.py:232-234);
 // eps placement as train.py:212,225.  The diagonal gives (0, 0, 0).
 __device__ __forceinline__ void pair_feat(f32x4 si, f32x4 sj, float& f0, float& f1, float& f2) {
@@ -105,6 +124,21 @@ __device__ __forceinline__ void pair_l23(const PairW& W, const float* b1, const 
 #pragma unroll
       for (int mo = 0; mo < 4; ++mo) f[mo] = SW_MFMA(W.w2[mo][k][r], h2[k][r], f[mo]);
     }
+  }
+}
+
+// layer 2 alone: h2 = relu(fc.2 h1 + b1), C layout
+__device__ __forceinline__ void pair_l2(const PairW1& W, const float* b1, int lg, const f32x4 h1[2], f32x4 h2[4]) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    f32x4 acc = ld4(b1 + 16 * mt + 4 * lg);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = SW_MFMA(W.w1[mt][j][r], h1[j][r], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h2[mt][r] = fmaxf(acc[r], 0.f);
   }
 }
 
@@ -186,6 +220,43 @@ __device__ __forceinline__ void scene_prologue(float* smem, const SocL& Ls, cons
   stage_pair_consts(smem, Ls, emb_w);
   scene_load_h_wh(smem, Ls, h, att_w, s0, n);
 }
+// ---- the attention never needs f_ij explicitly ---------------------------------------------------------------------
+// f_ij = fc.4(h2_ij) = W3 h2_ij + b3 enters the model only through sigma_ij = <f_ij, Wh_j> (train.py:166-170), and
+//      <W3 h2_ij + b3, Wh_j> = <h2_ij, v_j> + c_j,     v_j = W3^T Wh_j,  c_j = <b3, Wh_j>
+// - one 64 x 64 product per AGENT instead of one per PAIR (64 of the 98 MFMAs of a pair tile's forward).  Backward the same
+// identity gives dWh_j = sum_i dsigma_ij f_ij = W3 Q_j + b3 sd_j with the Q_j / sd_j of pair_block_dw3.
+// Turns the scene's Wh rows (LDS [a16][68]) into v_j IN PLACE, c_j in column 64 of row j.
+__device__ __forceinline__ void scene_wh_to_v(float* smem, const SocL& Ls, const float* emb_w, int n) {
+  float* wh = smem + Ls.wh;
+  const float* b3 = smem + Ls.b12 + 64;
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  f32x4 w3t[4];     // A operand: W3[m = 16j + 4lg + r][k = 16 wave + ln] (wave w owns the units k = 16w .. 16w+15 of v)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w3t[j][r] = emb_w[swp::EMB_W2 + (16 * j + 4 * lg + r) * 64 + 16 * wave + ln];
+  }
+  const int nt = (n + 15) >> 4;
+  f32x4 acc[4];
+#pragma unroll
+  for (int at = 0; at < 4; ++at) {
+    acc[at] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (at < nt) acc[at] = tile_mm_reg<4>(w3t, &wh[(16 * at + ln) * 68 + 4 * lg], acc[at]);
+  }
+  float c = 0.f;
+  if ((int)threadIdx.x < n) {
+    for (int u = 0; u < 64; u += 4) {
+      const f32x4 x = ld4(&wh[threadIdx.x * 68 + u]), y = ld4(&b3[u]);
+      c = fmaf(x[0], y[0], c); c = fmaf(x[1], y[1], c); c = fmaf(x[2], y[2], c); c = fmaf(x[3], y[3], c);
+    }
+  }
+  sw_barrier();     // every wave has read the Wh rows
+#pragma unroll
+  for (int at = 0; at < 4; ++at)
+    if (at < nt) st4(&wh[(16 * at + ln) * 68 + 16 * wave + 4 * lg], acc[at]);
+  if ((int)threadIdx.x < n) wh[threadIdx.x * 68 + 64] = c;
+  sw_barrier();
+}
 // softmax over the scene for every agent i (train.py:172, one wave per row) then
 // S_i = sum_j a_ij h_j (train.py:173: pools the raw hidden states)
 __device__ __forceinline__ void scene_softmax_pool(float* smem, const SocL& Ls, int s0, int n, float* S_out, float* attn) {
@@ -248,29 +319,30 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_fwd_kernel(
     return;
   }
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
-  PairW W;     // requested first: the weights arrive under the scene prologue
-  if (simg) load_pair_w_img(W, simg, lane);
-  else load_pair_w(W, emb_w, ln, lg);
+  PairW1 W;    // requested first: the weights arrive under the scene prologue
+  if (simg) load_pair_w1_img(W, simg, lane);
+  else load_pair_w1(W, emb_w, ln, lg);
   scene_prologue(smem, Ls, obsv, To, h, emb_w, att_w, s0, n);
+  scene_wh_to_v(smem, Ls, emb_w, n);     // `wh` rows now hold v_j | c_j: sigma_ij = <h2_ij, v_j> + c_j, fc.4 is never run
   const int P = n * n;
   for (int pt = wave; pt * 16 < P; pt += 4) {
     int p = min(pt * 16 + ln, P - 1);
     int i = p / n, j = p - i * n;
     float f0, f1, f2;
     pair_feat(ld4(&x4[i * 4]), ld4(&x4[j * 4]), f0, f1, f2);
-    f32x4 h1[2], h2[4], f[4];
+    f32x4 h1[2], h2[4];
     pair_l1(w0b, lg, f0, f1, f2, h1);
-    pair_l23(W, b12, b12 + 64, lg, h1, h2, f);
+    pair_l2(W, b12, lg, h1, h2);
     float part = 0.f;
 #pragma unroll
     for (int mo = 0; mo < 4; ++mo) {
       f32x4 w = ld4(&wh[j * 68 + 16 * mo + 4 * lg]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) part = fmaf(f[mo][r], w[r], part);
+      for (int r = 0; r < 4; ++r) part = fmaf(h2[mo][r], w[r], part);
     }
     part += __shfl_xor(part, 16);
     part += __shfl_xor(part, 32);
-    if (lg == 0 && pt * 16 + ln < P) sig[i * sa + j] = (i == j) ? -1000.0f : part;  // train.py:170
+    if (lg == 0 && pt * 16 + ln < P) sig[i * sa + j] = (i == j) ? -1000.0f : part + wh[j * 68 + 64];  // train.py:170
   }
   sw_barrier();
   scene_softmax_pool(smem, Ls, s0, n, S_out, attn);
@@ -618,8 +690,13 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
 
   // ---- once per workgroup: weights ------------------------------------------------------------
   stage_pair_wt(w2t, w1t, emb_w);
-  PairW W;
-  load_pair_w(W, emb_w, ln, lg);
+  PairW1 W;
+  load_pair_w1(W, emb_w, ln, lg);
+  // fc.4 itself is only needed for dWh_j = W3 Q_j + b3 sd_j, once per j block: wave w forms the units 16w .. 16w+15
+  f32x4 w2own[4];     // A operand: W3[m = 16 wave + ln][k = 16kt + 4lg + r]
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) w2own[kt] = ld4(emb_w + swp::EMB_W2 + (16 * wave + ln) * 64 + 16 * kt + 4 * lg);
+  const f32x4 b3own = ld4(emb_w + swp::EMB_B2 + 16 * wave + 4 * lg);
   PairGrad G;
   pair_grad_zero(G);
 #ifdef SW_PHASE_STAMPS
@@ -673,12 +750,9 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
       const bool valid = j < n;
       const int jc = min(j, n - 1);
       const f32x4 xj = ld4(&x4[jc * 4]);
-      f32x4 whj[4], accw[4];
+      f32x4 whj[4];
 #pragma unroll
-      for (int mo = 0; mo < 4; ++mo) {
-        whj[mo] = ld4(&wh[jc * 68 + 16 * mo + 4 * lg]);
-        accw[mo] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int mo = 0; mo < 4; ++mo) whj[mo] = ld4(&wh[jc * 68 + 16 * mo + 4 * lg]);
       // per block: v_j = W3^T Wh_j; per tile dh2 = relu'(h2) dsigma v_j on the VALU, Q_j / sd_j accumulate for dW3 / db3
       f32x4 vj[4], Q[4];
       float sd = 0.f;
@@ -688,9 +762,9 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
       for (int i = wave; i < n; i += 4) {
         float f0, f1, f2;
         pair_feat(ld4(&x4[i * 4]), xj, f0, f1, f2);
-        f32x4 h1[2], h2[4], f[4];
+        f32x4 h1[2], h2[4];
         pair_l1(w0b, lg, f0, f1, f2, h1);
-        pair_l23(W, b12, b12 + 64, lg, h1, h2, f);
+        pair_l2(W, b12, lg, h1, h2);
         const float dsv = valid ? dsg[i * sa + jc] : 0.f;   // invalid lanes contribute exact zeros everywhere below
         f32x4 dh2[4];
         sd += dsv;
@@ -698,7 +772,6 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
         for (int mo = 0; mo < 4; ++mo) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            accw[mo][r] = fmaf(dsv, f[mo][r], accw[mo][r]);
             Q[mo][r] = fmaf(dsv, h2[mo][r], Q[mo][r]);
             dh2[mo][r] = h2[mo][r] > 0.f ? dsv * vj[mo][r] : 0.f;
           }
@@ -715,16 +788,32 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
         pair_block_dw3(G, scr, whr, Q, sd, ln, lg);
       }
       wave_lds_fence();
+      // dWh_j = sum_i dsigma_ij f_ij = W3 Q_j + b3 sd_j with Q_j, sd_j summed over the 4 waves (fixed order) through their
+      // scratch tiles; wave w forms the output units 16w .. 16w+15 of the block's 16 agents (16 MFMAs)
 #pragma unroll
-      for (int mo = 0; mo < 4; ++mo) st4(scr + ln * 68 + 16 * mo + 4 * lg, accw[mo]);
+      for (int mo = 0; mo < 4; ++mo) st4(scr + ln * 68 + 16 * mo + 4 * lg, Q[mo]);
+      if (lg == 0) scr[ln * 68 + 64] = sd;
       __syncthreads();
-      for (int e = threadIdx.x; e < 16 * 64; e += blockDim.x) {
-        const int jj = e >> 6, u = e & 63, j2 = 16 * jb + jj;
+      {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          const float* q = scr_all + ln * 68 + 16 * kt + 4 * lg;
+          const f32x4 bq = (ld4(q) + ld4(q + SW_SOC_SCR)) + (ld4(q + 2 * SW_SOC_SCR) + ld4(q + 3 * SW_SOC_SCR));
+          acc = SW_MFMA(w2own[kt][0], bq[0], acc);
+          acc1 = SW_MFMA(w2own[kt][1], bq[1], acc1);
+          acc = SW_MFMA(w2own[kt][2], bq[2], acc);
+          acc1 = SW_MFMA(w2own[kt][3], bq[3], acc1);
+        }
+        const float* qs = scr_all + ln * 68 + 64;
+        const float sds = (qs[0] + qs[SW_SOC_SCR]) + (qs[2 * SW_SOC_SCR] + qs[3 * SW_SOC_SCR]);
+        f32x4 out = acc + acc1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[r] = fmaf(b3own[r], sds, out[r]);
+        const int j2 = 16 * jb + ln;
         if (j2 < n) {
-          const float* q = scr_all + jj * 68 + u;
-          const float acc = (q[0] + q[SW_SOC_SCR]) + (q[2 * SW_SOC_SCR] + q[3 * SW_SOC_SCR]);
-          dwh[j2 * 68 + u] = acc;
-          dwh_rows[(size_t)(s0 + j2) * 64 + u] = acc;
+          st4(&dwh[j2 * 68 + 16 * wave + 4 * lg], out);
+          st4(dwh_rows + (size_t)(s0 + j2) * 64 + 16 * wave + 4 * lg, out);
         }
       }
       __syncthreads();   // the scratch tiles go back to the transpositions of the next block
