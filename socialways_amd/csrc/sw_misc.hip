@@ -189,7 +189,7 @@ extern "C" size_t sw_workspace_floats(int ws_id, int B, int To, int Tp, int nb, 
     case SW_WS_DSAVE: return sw_dsave_floats(B, To, Tp, nb < 1 ? 1 : nb);
     case SW_WS_DDELTA: return sw_ddelta_floats(B, To, Tp, nb < 1 ? 1 : nb);
     case SW_WS_WGRAD: return SW_WG_WS_FLOATS;
-    case SW_WS_PAIRS: return (size_t)B * 64 + (size_t)(P < 0 ? 0 : P) * 324;  // dWh rows + pair rows (small-scene path; 64 per pair otherwise)
+    case SW_WS_PAIRS: return (size_t)B * 200 + (size_t)(P < 0 ? 0 : P) * 196;  // per-agent rows (dWh | Wh | Q | sd) + pair rows of the small-scene path (sw_social.hip)
   }
   return 0;
 }

@@ -858,29 +858,30 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
 // ---- variant for SMALL scenes: per-pair rows + deferred GEMM --------------------------------------
 // With a handful of pair tiles per scene (8-agent scenes: one tile per wave) the in-register
 // accumulation above cannot amortise its fixed costs (weight staging, the 4-wave partial reduction, a
-// 25 KB partial per scene); there the backward leaves per-pair rows (f, dz3, h2, dh2 [64], h1, dh1
-// [32], feat [4] = 324 floats per pair) for the grouped weight-gradient GEMM of sw_wgrad.hip instead.
+// 25 KB partial per scene); there the backward leaves per-pair rows (h2, dh2 [64], h1, dh1 [32], feat [4] = 196
+// floats per pair) and per-AGENT rows (Wh_j, Q_j [64], sd_j) for the grouped weight-gradient GEMM of sw_wgrad.hip:
+// dW3 = sum_j Wh_j Q_j^T and db3 = sum_j Wh_j sd_j run over B rows, not over P (pair_block_dw3 has the algebra).
 struct PairRows {
-  float *f, *dz3, *h2, *dh2, *h1, *dh1, *feat;
+  float *h2, *dh2, *h1, *dh1, *feat;
 };
 __host__ __device__ inline PairRows pair_rows(float* base, long long P) {
   PairRows r;
-  r.f = base;
-  r.dz3 = r.f + 64 * P;
-  r.h2 = r.dz3 + 64 * P;
+  r.h2 = base;
   r.dh2 = r.h2 + 64 * P;
   r.h1 = r.dh2 + 64 * P;
   r.dh1 = r.h1 + 32 * P;
   r.feat = r.dh1 + 32 * P;
   return r;
 }
-#define SW_PAIR_ROW_FLOATS 324
+#define SW_PAIR_ROW_FLOATS 196
+#define SW_AGENT_ROW_FLOATS 200      // per agent in the pair workspace: dWh | Wh | Q [64 each] | sd [4] | pad [4]
 
 __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_rows_kernel(
     const float* __restrict__ obsv, int To, const float* __restrict__ h, const int* __restrict__ scene_off,
     const long long* __restrict__ pair_off, const float* __restrict__ emb_w, const float* __restrict__ att_w,
     const float* __restrict__ attn, const float* __restrict__ dS, float* __restrict__ dh,
-    float* __restrict__ dwh_rows, PairRows pr, int a16, const float* __restrict__ simg) {
+    float* __restrict__ dwh_rows, float* __restrict__ wh_rows, float* __restrict__ q_rows, float* __restrict__ sd_rows,
+    PairRows pr, int a16, const float* __restrict__ simg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SocL Ls = soc_lds(a16);
   const int sa = Ls.sa;
@@ -893,10 +894,18 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_rows_kernel(
   float* dsl = smem + Ls.ds;
   float* dsg = smem + Ls.dsg;
   float* dwh = smem + Ls.dwh;
+  float* vv = dwh;             // v_j = W3^T Wh_j [a16][68] during the pair loop (dWh is formed after it)
+  float* qq = hs;              // Q_j | sd_j [a16][68] behind the pair loop (h is last read by the softmax backward)
   const int s0 = scene_off[blockIdx.x], n = scene_off[blockIdx.x + 1] - s0;
   if (n <= 0 || n > SW_AMAX) return;
-  if (n == 1) {  // S = 0 constant: no gradient anywhere; dWh row is zero
-    if (threadIdx.x < 16) st4(dwh_rows + (size_t)s0 * 64 + 4 * threadIdx.x, f32x4{0.f, 0.f, 0.f, 0.f});
+  if (n == 1) {  // S = 0 constant: no gradient anywhere; the agent's rows are zero
+    if (threadIdx.x < 16) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      st4(dwh_rows + (size_t)s0 * 64 + 4 * threadIdx.x, z);
+      st4(wh_rows + (size_t)s0 * 64 + 4 * threadIdx.x, z);
+      st4(q_rows + (size_t)s0 * 64 + 4 * threadIdx.x, z);
+      if (threadIdx.x == 0) st4(sd_rows + (size_t)s0 * 4, z);
+    }
     return;
   }
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
@@ -905,34 +914,34 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_rows_kernel(
   long long _tprev = clock64();
 #endif
   // the pair-MLP weights (registers, L2 latency) are requested first: they arrive under the scene prologue
-  PairW W;
-  f32x4 w2T[4][4];  // fc.4.weight^T: [mt][mo][r] = W2[16mo + 4lg + r][16mt + ln]
+  PairW1 W;
   f32x4 w1T[2][4];  // fc.2.weight^T: [jt][mt][r] = W1[16mt + 4lg + r][16jt + ln]
   f32x4 wT[4];      // attention W^T for the dh rows: W[k = 16kt + 4lg + r][u = 16 wave + ln]
+  f32x4 w3t[4];     // fc.4.weight^T rows of this wave's units (v_j): W3[m = 16mo + 4lg + r][k = 16 wave + ln]
+  f32x4 w2own[4];   // fc.4.weight rows of this wave's units (dWh_j): W3[m = 16 wave + ln][k = 16kt + 4lg + r]
   if (simg) {       // operand-layout images of the step: every load instruction reads 1 KB of consecutive memory
-    load_pair_w_img(W, simg, lane);
+    load_pair_w1_img(W, simg, lane);
 #pragma unroll
     for (int mo = 0; mo < 4; ++mo) {
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) w2T[mt][mo] = ld4(simg + swimg::OP_E2T + ((mt * 4 + mo) * 64 + lane) * 4);
       w1T[0][mo] = ld4(simg + swimg::OP_E1T + ((0 * 4 + mo) * 64 + lane) * 4);
       w1T[1][mo] = ld4(simg + swimg::OP_E1T + ((1 * 4 + mo) * 64 + lane) * 4);
+      w3t[mo] = ld4(simg + swimg::OP_E2T + ((wave * 4 + mo) * 64 + lane) * 4);
+      w2own[mo] = ld4(simg + swimg::OP_E2 + ((wave * 4 + mo) * 64 + lane) * 4);
     }
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) wT[kt] = ld4(simg + swimg::OP_ATT_T + ((wave * 4 + kt) * 64 + lane) * 4);
   } else {
-    load_pair_w(W, emb_w, ln, lg);
+    load_pair_w1(W, emb_w, ln, lg);
 #pragma unroll
     for (int mo = 0; mo < 4; ++mo) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float* row2 = emb_w + swp::EMB_W2 + (16 * mo + 4 * lg + r) * 64 + ln;
         const float* row1 = emb_w + swp::EMB_W1 + (16 * mo + 4 * lg + r) * 32 + ln;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) w2T[mt][mo][r] = row2[16 * mt];
         w1T[0][mo][r] = row1[0];
         w1T[1][mo][r] = row1[16];
+        w3t[mo][r] = emb_w[swp::EMB_W2 + (16 * mo + 4 * lg + r) * 64 + 16 * wave + ln];
       }
+      w2own[mo] = ld4(emb_w + swp::EMB_W2 + (16 * wave + ln) * 64 + 16 * mo + 4 * lg);
     }
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -940,14 +949,21 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_rows_kernel(
       for (int r = 0; r < 4; ++r) wT[kt][r] = att_w[swp::ATT_W + (16 * kt + 4 * lg + r) * 64 + 16 * wave + ln];
     }
   }
+  const f32x4 b3own = ld4(emb_w + swp::EMB_B2 + 16 * wave + 4 * lg);
   scene_prologue(smem, Ls, obsv, To, h, emb_w, att_w, s0, n);
   for (int i = threadIdx.x; i < n * 16; i += blockDim.x) {
     int a = i >> 4, q = i & 15;
     st4(&dsl[a * 68 + 4 * q], ld4(dS + (size_t)(s0 + a) * 64 + 4 * q));
+    st4(wh_rows + (size_t)(s0 + a) * 64 + 4 * q, ld4(&wh[a * 68 + 4 * q]));     // Wh rows for dW3 / db3 (deferred GEMM)
   }
   for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
     int i = e / n, j = e - i * n;
     sig[i * sa + j] = attn[(size_t)(s0 + i) * SW_AMAX + j];
+  }
+  const int nt = (n + 15) >> 4;
+  for (int at = 0; at < nt; ++at) {     // v_j = W3^T Wh_j: wave w the units 16w .. 16w+15
+    const f32x4 acc = tile_mm_reg<4>(w3t, &wh[(16 * at + ln) * 68 + 4 * lg], f32x4{0.f, 0.f, 0.f, 0.f});
+    st4(&vv[(16 * at + ln) * 68 + 16 * wave + 4 * lg], acc);
   }
   sw_barrier();
   SW_STAMP(0);
@@ -968,7 +984,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_rows_kernel(
   }
   sw_barrier();
   SW_STAMP(1);
-  // ---- pair tiles: recompute the MLP, back-propagate, leave rows for the deferred GEMMs --------
+  // ---- pair tiles: recompute the MLP up to h2, back-propagate, leave rows for the deferred GEMMs --------
   const int P = n * n;
   for (int pt = wave; pt * 16 < P; pt += 4) {
     const bool valid = pt * 16 + ln < P;
@@ -976,32 +992,16 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_rows_kernel(
     int i = p / n, j = p - i * n;
     float f0, f1, f2;
     pair_feat(ld4(&x4[i * 4]), ld4(&x4[j * 4]), f0, f1, f2);
-    f32x4 h1[2], h2[4], f[4];
+    f32x4 h1[2], h2[4];
     pair_l1(w0b, lg, f0, f1, f2, h1);
-    pair_l23(W, b12, b12 + 64, lg, h1, h2, f);
+    pair_l2(W, b12, lg, h1, h2);
     const float dsv = valid ? dsg[i * sa + j] : 0.f;
-    f32x4 dz3[4];
-#pragma unroll
-    for (int mo = 0; mo < 4; ++mo) {
-      f32x4 w = ld4(&wh[j * 68 + 16 * mo + 4 * lg]);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dz3[mo][r] = dsv * w[r];
-    }
-    f32x4 dh2[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) dh2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int mo = 0; mo < 4; ++mo) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) dh2[mt] = SW_MFMA(w2T[mt][mo][r], dz3[mo][r], dh2[mt]);
-      }
-    }
+    f32x4 dh2[4];     // relu'(h2) . dsigma_ij v_j
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
+      const f32x4 v = ld4(&vv[j * 68 + 16 * mt + 4 * lg]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dh2[mt][r] = h2[mt][r] > 0.f ? dh2[mt][r] : 0.f;
+      for (int r = 0; r < 4; ++r) dh2[mt][r] = h2[mt][r] > 0.f ? dsv * v[r] : 0.f;
     }
     f32x4 dh1[2];
     dh1[0] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1023,8 +1023,6 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_rows_kernel(
       const size_t row = (size_t)(p0 + p);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        st4(pr.f + row * 64 + 16 * mt + 4 * lg, f[mt]);
-        st4(pr.dz3 + row * 64 + 16 * mt + 4 * lg, dz3[mt]);
         st4(pr.h2 + row * 64 + 16 * mt + 4 * lg, h2[mt]);
         st4(pr.dh2 + row * 64 + 16 * mt + 4 * lg, dh2[mt]);
       }
@@ -1039,13 +1037,32 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_rows_kernel(
   SW_STAMP(2);
   __syncthreads();  // pair rows of this scene are visible to the whole workgroup (same CU)
   SW_STAMP(3);
-  // dWh_j = sum_i dsigma_ij f_ij
+  // Q_j = sum_i dsigma_ij h2_ij, sd_j = sum_i dsigma_ij (reads the h2 rows back)
   for (int e = threadIdx.x; e < n * 64; e += blockDim.x) {
     int j = e >> 6, u = e & 63;
     float acc = 0.f;
-    for (int i = 0; i < n; ++i) acc = fmaf(dsg[i * sa + j], pr.f[(size_t)(p0 + i * n + j) * 64 + u], acc);
-    dwh[j * 68 + u] = acc;
-    dwh_rows[(size_t)(s0 + j) * 64 + u] = acc;
+    for (int i = 0; i < n; ++i) acc = fmaf(dsg[i * sa + j], pr.h2[(size_t)(p0 + i * n + j) * 64 + u], acc);
+    qq[j * 68 + u] = acc;
+    q_rows[(size_t)(s0 + j) * 64 + u] = acc;
+  }
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    float acc = 0.f;
+    for (int i = 0; i < n; ++i) acc += dsg[i * sa + j];
+    qq[j * 68 + 64] = acc;
+    st4(sd_rows + (size_t)(s0 + j) * 4, f32x4{acc, 0.f, 0.f, 0.f});
+  }
+  sw_barrier();
+  // dWh_j = sum_i dsigma_ij f_ij = W3 Q_j + b3 sd_j: wave w the units 16w .. 16w+15
+  for (int at = 0; at < nt; ++at) {
+    f32x4 out = tile_mm_reg<4>(w2own, &qq[(16 * at + ln) * 68 + 4 * lg], f32x4{0.f, 0.f, 0.f, 0.f});
+    const int j = 16 * at + ln;
+    const float sds = qq[min(j, n - 1) * 68 + 64];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = fmaf(b3own[r], sds, out[r]);
+    if (j < n) {
+      st4(&dwh[j * 68 + 16 * wave + 4 * lg], out);
+      st4(dwh_rows + (size_t)(s0 + j) * 64 + 16 * wave + 4 * lg, out);
+    }
   }
   sw_barrier();
   SW_STAMP(6);
@@ -1702,9 +1719,13 @@ extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, con
       if (int rc = set_lds((const void*)social_pool_bwd_rows_kernel, soc_lds(SW_AMAX).bwd_total * 4)) return rc;
       attr2 = true;
     }
-    PairRows pr = pair_rows(pair_ws + (size_t)B * 64, P);
+    float* wh_rows = pair_ws + (size_t)B * 64;
+    float* q_rows = pair_ws + (size_t)B * 128;
+    float* sd_rows = pair_ws + (size_t)B * 192;
+    PairRows pr = pair_rows(pair_ws + (size_t)B * SW_AGENT_ROW_FLOATS, P);
     SW_LAUNCH(social_pool_bwd_rows_kernel, dim3(S), dim3(SW_THREADS), soc_lds(a16).bwd_total * 4, st, obsv, To, h,
-                       scene_off, pair_off, emb_w, att_w, attn, dS, dh, dwh_rows, pr, a16, sw_soc_images_for(emb_w, att_w));
+                       scene_off, pair_off, emb_w, att_w, attn, dS, dh, dwh_rows, wh_rows, q_rows, sd_rows, pr, a16,
+                       sw_soc_images_for(emb_w, att_w));
     SW_CHECK_LAUNCH("social_pool_bwd_rows_kernel");
     WgBatch wr_local;
     WgBatch& wr = defer ? *wg_pending(defer) : wr_local;
@@ -1712,7 +1733,9 @@ extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, con
     int rc_r = 0;
     rc_r |= wg_add(wr, dwh_rows, 64, h, 64, B, 64, 64, d_att_w + swp::ATT_W, 64, d_att_w + swp::ATT_B, nullptr, 0);
     if (P > 0) {
-      rc_r |= wg_add(wr, pr.dz3, 64, pr.h2, 64, (int)P, 64, 64, d_emb_w + swp::EMB_W2, 64, d_emb_w + swp::EMB_B2, nullptr, 0);
+      // dW3 = sum_j Wh_j Q_j^T, db3 = sum_j Wh_j sd_j: B rows (the bias as a one-column problem: its "act" is sd)
+      rc_r |= wg_add(wr, wh_rows, 64, q_rows, 64, B, 64, 64, d_emb_w + swp::EMB_W2, 64, nullptr, nullptr, 0);
+      rc_r |= wg_add(wr, wh_rows, 64, sd_rows, 4, B, 64, 1, d_emb_w + swp::EMB_B2, 1, nullptr, nullptr, 0);
       rc_r |= wg_add(wr, pr.dh2, 64, pr.h1, 32, (int)P, 64, 32, d_emb_w + swp::EMB_W1, 32, d_emb_w + swp::EMB_B1, nullptr, 0);
       rc_r |= wg_add(wr, pr.dh1, 32, pr.feat, 4, (int)P, 32, 3, d_emb_w + swp::EMB_W0, 3, d_emb_w + swp::EMB_B0, nullptr, 0);
     }
