@@ -101,6 +101,21 @@ __device__ __forceinline__ void pair_l1(const float* w0b, int lg, float f0, floa
     }
   }
 }
+// layer 1 on the matrix cores: K = 4 = (f0, f1, f2, 1) against (w0, w1, w2, bias) - 2 MFMAs instead of 8 LDS operand
+// reads + 32 FMAs per lane; the result tile IS the B-operand layout above.  wa[t] = w0b[16t + ln][lg] (loop invariant).
+__device__ __forceinline__ void pair_l1_load(const float* w0b, int ln, int lg, float wa[2]) {
+  wa[0] = w0b[ln * 4 + lg];
+  wa[1] = w0b[(16 + ln) * 4 + lg];
+}
+__device__ __forceinline__ void pair_l1m(const float wa[2], int lg, float f0, float f1, float f2, f32x4 h1[2]) {
+  const float bv = lg == 0 ? f0 : (lg == 1 ? f1 : (lg == 2 ? f2 : 1.0f));
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const f32x4 acc = SW_MFMA(wa[t], bv, (f32x4{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h1[t][r] = fmaxf(acc[r], 0.f);
+  }
+}
 // layers 2, 3 on the matrix cores; pre-activations of layer 2 are returned post-ReLU in h2
 __device__ __forceinline__ void pair_l23(const PairW& W, const float* b1, const float* b2, int lg,
                                          const f32x4 h1[2], f32x4 h2[4], f32x4 f[4]) {
@@ -324,6 +339,8 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_fwd_kernel(
   else load_pair_w1(W, emb_w, ln, lg);
   scene_prologue(smem, Ls, obsv, To, h, emb_w, att_w, s0, n);
   scene_wh_to_v(smem, Ls, emb_w, n);     // `wh` rows now hold v_j | c_j: sigma_ij = <h2_ij, v_j> + c_j, fc.4 is never run
+  float w0a[2];
+  pair_l1_load(w0b, ln, lg, w0a);
   const int P = n * n;
   for (int pt = wave; pt * 16 < P; pt += 4) {
     int p = min(pt * 16 + ln, P - 1);
@@ -331,7 +348,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_fwd_kernel(
     float f0, f1, f2;
     pair_feat(ld4(&x4[i * 4]), ld4(&x4[j * 4]), f0, f1, f2);
     f32x4 h1[2], h2[4];
-    pair_l1(w0b, lg, f0, f1, f2, h1);
+    pair_l1m(w0a, lg, f0, f1, f2, h1);
     pair_l2(W, b12, lg, h1, h2);
     float part = 0.f;
 #pragma unroll
@@ -745,6 +762,8 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
     // rows in HBM, no second pass), and x_j / Wh_j are loop invariants.  Per block: 4 wave partials (i = wave,
     // wave + 4, ..) summed in a fixed order through the waves' scratch tiles.
     const int nJB = (n + 15) >> 4;
+    float w0a[2];
+    pair_l1_load(w0b, ln, lg, w0a);
     for (int jb = 0; jb < nJB; ++jb) {
       const int j = 16 * jb + ln;
       const bool valid = j < n;
@@ -763,7 +782,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_kernel(
         float f0, f1, f2;
         pair_feat(ld4(&x4[i * 4]), xj, f0, f1, f2);
         f32x4 h1[2], h2[4];
-        pair_l1(w0b, lg, f0, f1, f2, h1);
+        pair_l1m(w0a, lg, f0, f1, f2, h1);
         pair_l2(W, b12, lg, h1, h2);
         const float dsv = valid ? dsg[i * sa + jc] : 0.f;   // invalid lanes contribute exact zeros everywhere below
         f32x4 dh2[4];
@@ -985,6 +1004,8 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_rows_kernel(
   sw_barrier();
   SW_STAMP(1);
   // ---- pair tiles: recompute the MLP up to h2, back-propagate, leave rows for the deferred GEMMs --------
+  float w0a[2];
+  pair_l1_load(w0b, ln, lg, w0a);
   const int P = n * n;
   for (int pt = wave; pt * 16 < P; pt += 4) {
     const bool valid = pt * 16 + ln < P;
@@ -993,7 +1014,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_rows_kernel(
     float f0, f1, f2;
     pair_feat(ld4(&x4[i * 4]), ld4(&x4[j * 4]), f0, f1, f2);
     f32x4 h1[2], h2[4];
-    pair_l1(w0b, lg, f0, f1, f2, h1);
+    pair_l1m(w0a, lg, f0, f1, f2, h1);
     pair_l2(W, b12, lg, h1, h2);
     const float dsv = valid ? dsg[i * sa + j] : 0.f;
     f32x4 dh2[4];     // relu'(h2) . dsigma_ij v_j
