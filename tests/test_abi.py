@@ -103,7 +103,7 @@ def test_workspace_sizes():
     B, To, Tp = 2048, 8, 12
     assert L.workspace_floats(L.WS_GSAVE, B, To, Tp) == B * ((To + Tp - 1) * 388 + Tp * 280)
     assert L.workspace_floats(L.WS_GDELTA, B, To, Tp) == B * ((To + Tp - 1) * 256 + Tp * 284 + 160)
-    assert L.workspace_floats(L.WS_PAIRS, B, To, Tp, 1, 16384) == B * 64 + 16384 * 324
+    assert L.workspace_floats(L.WS_PAIRS, B, To, Tp, 1, 16384) == B * 200 + 16384 * 196   # per-agent rows dWh | Wh | Q | sd, pair rows h2 | dh2 | h1 | dh1 | feat
     assert L.workspace_floats(L.WS_DSAVE, B, To, Tp, 2) > L.workspace_floats(L.WS_DSAVE, B, To, Tp, 1)
 
 

@@ -173,6 +173,10 @@ def test_smaller_hidden_sizes_are_zero_padded_with_the_reference_initialisation(
     mask = torch.cat([torch.nn.functional.pad(m.pad_mask(), (0, (-m.pad_mask().numel()) % 4))
                       for m in (G.attention, G.feature_embedder, G.encoder, G.decoder)])
     assert torch.equal(opt2.m, opt.m * mask) and torch.equal(opt2.v, opt.v * mask)
-    for bad in (128, 20, 0):
+    for bad in (20, 0):
         with pytest.raises(sw.SocialWaysHipError):
             sw.EncoderLstm(bad, 1)
+    from socialways_amd import generic
+    assert isinstance(sw.EncoderLstm(128, 1), generic.EncoderLstm)      # above 64 units: the generic-width module
+    with pytest.raises(sw.SocialWaysHipError, match="generic"):
+        sw.DecoderFC(128 + 128 + 64)
