@@ -428,7 +428,7 @@ def main():
             lg = Leg("m1", dev, None, 1, 0, "weak", 0, 1, use_variety_loss="fixed", variety_k=20, use_l2_loss=True)
             n, w = 40, 6
             d = short_leg(lg, n, w)
-            other["m1_variety_k20"] = {"workload": "m1 + best-of-20 variety loss (use_variety_loss='fixed'): generator batch 40 960 agents",
+            other["m1_variety_k20"] = {"workload": "m1 + best-of-20 variety loss (use_variety_loss='fixed'): decode loop on 40 960 agent copies, encoder and social block once on the 2 048 agents",
                                        "steps": n, "steps_s": n / d, "ms_per_step": 1e3 * d / n}
             del lg
 

@@ -222,6 +222,98 @@ def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d
            L.ptr(d_enc), L.ptr(d_dec), 0, L.ptr(wgrad), L.ptr(tmp), pending, L.stream())
 
 
+class GenCtxK:
+    """Context of K rollouts that share the observation encoding (gen_forward_k)."""
+    __slots__ = ("one", "K", "obsv_k", "noise_k", "S_k", "gsave_k")
+
+
+def gen_forward_k(enc_w, emb_w, att_w, dec_w, obsv, noise_k, scenes, n_next, use_social, K, ws, tag="gv"):
+    """K rollouts of predict() on the SAME observations with K noise draws (the best-of-K variety term, train.py:527-536
+    with its intended semantics): EncoderLstm over the observed steps and the social pooling do not depend on z, so they run
+    ONCE on the B agents; only the decode loop runs on the K*B copies (copy k = rows [k*B, (k+1)*B)).
+    Returns pred_hat_4d (K*B, n_next, 4) and the context for gen_backward_k."""
+    L.require_gpu(obsv)
+    obsv = obsv.contiguous()
+    noise_k = noise_k.contiguous()
+    B, To = obsv.shape[0], obsv.shape[1]
+    KB = K * B
+    if noise_k.shape != (KB, 32):
+        raise ValueError("noise must be (K * B, 32)")
+    dev = obsv.device
+    st = L.stream()
+    hT, cT = torch.empty(B, 64, device=dev), torch.empty(B, 64, device=dev)
+    gsave_1 = ws.get(tag + ".gsave1", L.workspace_floats(L.WS_GSAVE, B, To, n_next))
+    gsave_k = ws.get(tag + ".gsave", L.workspace_floats(L.WS_GSAVE, KB, To, n_next))
+    Ta = To + n_next - 1
+    L.call("sw_enc_lstm_fwd_aux", L.ptr(obsv), 0, L.ptr(enc_w), None, None, B, To, L.ptr(hT), L.ptr(cT), None,
+           L.ptr(gsave_1), gsave_1.data_ptr() + 4 * Ta * B * 384, 0, None, None, 0, st)
+    attn = wh = ml = None
+    if use_social:
+        S = torch.empty(B, 64, device=dev)
+        attn = torch.empty(B, L.AMAX, device=dev)
+        if scenes.NB:
+            wh, ml = torch.empty(B, 64, device=dev), torch.empty(B, 2, device=dev)
+        L.call("sw_social_pool_fwd_aux", L.ptr(obsv), To, L.ptr(hT), L.ptr(scenes.scene_off), scenes.S, B, scenes.amax,
+               L.ptr(emb_w), L.ptr(att_w), L.ptr(S), L.ptr(attn), L.ptr(scenes.big_blocks), scenes.NB, L.ptr(wh), L.ptr(ml),
+               None, None, 0, st)
+    else:
+        S = torch.zeros(B, 64, device=dev)
+    # the K copies: state / pooled context / last observed point of every agent, and the saved LSTM row of the last observed
+    # step in the K*B layout (the decode BPTT and the weight-gradient rows of decode step 0 read c / h of step To - 1 there)
+    obsv_k, hT_k, cT_k, S_k = obsv.repeat(K, 1, 1), hT.repeat(K, 1), cT.repeat(K, 1), S.repeat(K, 1)
+    row = gsave_1[(To - 1) * B * 384: To * B * 384].view(1, B, 384)
+    gsave_k[(To - 1) * KB * 384: To * KB * 384].view(K, B, 384).copy_(row.expand(K, B, 384))
+    pred4 = torch.empty(KB, n_next, 4, device=dev)
+    L.call("sw_dec_rollout_fwd_aux", L.ptr(obsv_k), To, L.ptr(noise_k), L.ptr(S_k), L.ptr(hT_k), L.ptr(cT_k), L.ptr(enc_w),
+           L.ptr(dec_w), KB, n_next, L.ptr(pred4), None, None, L.ptr(gsave_k), None, 0.0, None, None, None, st)
+    one = GenCtx()
+    one.obsv, one.noise, one.scenes, one.hT, one.cT, one.S, one.attn = obsv, noise_k[:B], scenes, hT, cT, S, attn
+    one.gsave, one.B, one.To, one.Tp, one.use_social, one.wh, one.ml = gsave_1, B, To, n_next, use_social, wh, ml
+    ctx = GenCtxK()
+    ctx.one, ctx.K, ctx.obsv_k, ctx.noise_k, ctx.S_k, ctx.gsave_k = one, K, obsv_k, noise_k, S_k, gsave_k
+    return pred4, ctx
+
+
+def gen_backward_k(enc_w, emb_w, att_w, dec_w, ctx, dpred4_k, d_enc, d_emb, d_att, d_dec, ws, tag="gv", aux=None):
+    """Backward of gen_forward_k: decode BPTT on the K*B copies, their gradients w.r.t. the shared state / pooled context
+    summed over the copies (back-propagation is linear in the upstream gradient), then the social block and the observation
+    BPTT ONCE on the B agents.  Weight gradients: the decode phase's problems over K*B rows (sw_gen_wgrad part 1), the
+    observation phase's over B rows on top (part 2)."""
+    one, K = ctx.one, ctx.K
+    dev = dpred4_k.device
+    B, To, Tp = one.B, one.To, one.Tp
+    KB = K * B
+    dpred4_k = dpred4_k.contiguous()
+    gdelta_k = ws.get(tag + ".gdelta", L.workspace_floats(L.WS_GDELTA, KB, To, Tp))
+    gdelta_1 = ws.get(tag + ".gdelta1", L.workspace_floats(L.WS_GDELTA, B, To, Tp))
+    wgrad = ws.get("wgrad", L.workspace_floats(L.WS_WGRAD, B, To, Tp))
+    tmp = ws.get(tag + ".dwx", 2048)
+    dh_k, dc_k, dS_k = (torch.empty(KB, 64, device=dev) for _ in range(3))
+    L.call("sw_dec_rollout_bwd_aux", L.ptr(dpred4_k), L.ptr(enc_w), L.ptr(dec_w), L.ptr(ctx.gsave_k), KB, To, Tp,
+           L.ptr(gdelta_k), L.ptr(dh_k), L.ptr(dc_k), L.ptr(dS_k), L.ptr(aux[0]) if aux else None,
+           L.ptr(aux[1]) if aux else None, L.ptr(aux[2]) if aux else None, aux[1].numel() if aux else 0, L.stream())
+    dhT, dcT, dS = (t.view(K, B, 64).sum(0) for t in (dh_k, dc_k, dS_k))
+    L.call("sw_gen_wgrad", L.ptr(enc_w), L.ptr(dec_w), L.ptr(ctx.gsave_k), L.ptr(gdelta_k), L.ptr(ctx.noise_k), L.ptr(ctx.S_k),
+           KB, To, Tp, L.ptr(d_enc), L.ptr(d_dec), 1, L.ptr(wgrad), L.ptr(tmp), None, L.stream())
+    pending = None
+    if one.use_social and (one.scenes.P > 0 or one.scenes.NB > 0):
+        sc = one.scenes
+        pending = ws.wgrad_batch
+        pws = ws.get("pairs", L.workspace_floats(L.WS_PAIRS, B, To, Tp, 1, sc.P))
+        bigp = ws.get("bigpart", sc.big_rows * 128) if sc.NB else None
+        L.call("sw_social_pool_bwd", L.ptr(one.obsv), To, L.ptr(one.hT), L.ptr(sc.scene_off), L.ptr(sc.pair_off), sc.S,
+               B, sc.amax, sc.P, L.ptr(emb_w), L.ptr(att_w), L.ptr(one.attn), L.ptr(dS), L.ptr(dhT), L.ptr(d_emb),
+               L.ptr(d_att), L.ptr(pws), L.ptr(wgrad), L.ptr(sc.big_blocks), sc.NB, L.ptr(one.wh), L.ptr(one.ml),
+               L.ptr(one.S), L.ptr(bigp), pending, L.stream())
+    else:
+        d_emb.zero_()
+        d_att.zero_()
+    L.call("sw_enc_lstm_bwd", L.ptr(enc_w), L.ptr(one.gsave), None, L.ptr(dhT), L.ptr(dcT), None, B, To, 0,
+           L.ptr(gdelta_1), None, None, L.stream())
+    L.call("sw_gen_wgrad", L.ptr(enc_w), L.ptr(dec_w), L.ptr(one.gsave), L.ptr(gdelta_1), L.ptr(one.noise), L.ptr(one.S), B, To, Tp,
+           L.ptr(d_enc), L.ptr(d_dec), 2, L.ptr(wgrad), L.ptr(tmp), pending, L.stream())
+
+
 class DiscCtx:
     __slots__ = ("dsave", "B", "To", "Tp", "nb")
 

@@ -610,11 +610,9 @@ class SocialWaysTrainer:
         if KV > 1:
             # best-of-K variety term: the K rollouts are K copies of the scenes in one batch; copy 0 (the step's own z)
             # is the prediction every other loss term and the ADE/FDE sums see
-            sb1 = np.stack([np.cumsum(scenes.sizes) - scenes.sizes, np.cumsum(scenes.sizes)], axis=1)
-            scenes_k = ops.SceneIndex.get(np.concatenate([sb1 + k * B for k in range(KV)]), KV * B, dev)
-            pred_hat_k, gctx = ops.gen_forward(enc._flat, emb._flat, att._flat, dec._flat, obsv.repeat(KV, 1, 1),
-                                               torch.cat([noise, self._vnoise]), scenes_k, Tp, G.use_social, save=True,
-                                               ws=ws, tag="gv")
+            # (the encoder over the observed steps and the social pooling do not depend on z: once for all K copies)
+            pred_hat_k, gctx = ops.gen_forward_k(enc._flat, emb._flat, att._flat, dec._flat, obsv,
+                                                 torch.cat([noise, self._vnoise]), scenes, Tp, G.use_social, KV, ws=ws)
             pred_hat = pred_hat_k[:B]
             out[U + 2].zero_()
             L.call("sw_ade_fde", L.ptr(pred_hat), L.ptr(pred), B, Tp, 1.0 / float(ss), L.ptr(out[U + 2]),
@@ -682,15 +680,19 @@ class SocialWaysTrainer:
         # the grouped GEMM and the composition back-propagation; the latter reads the step-start weight snapshot of the
         # image buffer).  Without social problems in the launch the attention / embedder weights would miss their
         # (zero-gradient) update: torch's kernel then.
-        fuse = (self._fuse_g_adam and self._gimg is not None and isinstance(self.predictor_optimizer, PackedAdam)
+        fuse = (KV == 1 and self._fuse_g_adam and self._gimg is not None and isinstance(self.predictor_optimizer, PackedAdam)
                 and self.predictor_optimizer.fusable and not (self.world > 1 or self._force_dist)
                 and (not G.use_social or gctx.scenes.P > 0 or gctx.scenes.NB > 0))
         adam = None
         if fuse:
             opt = self.predictor_optimizer
             adam = (G._flat_all, G._gflat_all) + opt.fused_args(None if steps is None else steps[U + 1])
-        ops.gen_backward(enc._flat, emb._flat, att._flat, dec._flat, gctx, dpred, enc._gflat, emb._gflat, att._gflat,
-                         dec._gflat, ws=ws, aux=restore, tag="gv" if KV > 1 else "g", adam=adam)
+        if KV > 1:
+            ops.gen_backward_k(enc._flat, emb._flat, att._flat, dec._flat, gctx, dpred, enc._gflat, emb._gflat, att._gflat,
+                               dec._gflat, ws=ws, aux=restore)
+        else:
+            ops.gen_backward(enc._flat, emb._flat, att._flat, dec._flat, gctx, dpred, enc._gflat, emb._gflat, att._gflat,
+                             dec._gflat, ws=ws, aux=restore, tag="g", adam=adam)
         yield G._gflat_all
         if not fuse:
             self.predictor_optimizer.step() if steps is None else self.predictor_optimizer.step(steps[U + 1])
