@@ -92,6 +92,31 @@ def test_scenes_larger_than_64_agents_backward(sizes):
             assert_close(p.grad.cpu(), want, 3e-4, (3e-4 if B > 150 else 3e-5) * max(float(want.abs().max()), 1e-12), "%s.%s" % (name, k))
 
 
+@pytest.mark.parametrize("sizes", [[17, 33, 20, 48, 64, 16], [31, 2, 47, 63, 1], [15, 9, 2, 1, 12, 3], [16, 16, 32]])
+def test_social_block_without_the_last_embedder_layer_per_pair(sizes):
+    """The kernels never form f_ij = fc.4(h2_ij) (sigma_ij = <h2_ij, W3^T Wh_j> + <b3, Wh_j>, dW3 / db3 /
+    dWh through Q_j = sum_i dsigma_ij h2_ij).  Rollout and every generator gradient against the oracle's autograd (which does
+    form f_ij) on scene sizes on both sides of the 16-agent blocks: ragged dense scenes (in-register weight gradients) and
+    small scenes (pair rows + per-agent rows for the deferred GEMM), single-agent scenes in between."""
+    import socialways_amd as sw
+    t = sw.synth_tracks(len(sizes), sizes, seed=15)
+    tr, orc = pair(12)
+    B = int(np.sum(sizes))
+    obsv = torch.from_numpy(t["obsvs"]).cuda()
+    sb = np.asarray(t["batches"])
+    torch.manual_seed(18)
+    z, cot = torch.rand(B, 32), torch.randn(B, 12, 4) * 0.1
+    out = tr.G(obsv, z.cuda(), 12, sb)
+    out.backward(cot.cuda())
+    ref = orc.predict(obsv.cpu(), z, 12, sb)
+    ref.backward(cot)
+    assert_close(out.detach().cpu(), ref.detach(), 3e-5, 3e-6, "rollout")
+    for name in ("attention", "feature_embedder", "encoder", "decoder"):
+        for (k, p), (_, q) in zip(getattr(tr.G, name).named_parameters(), getattr(orc, name).named_parameters()):
+            want = q.grad if q.grad is not None else torch.zeros_like(q)
+            assert_close(p.grad.cpu(), want, 3e-4, 3e-5 * max(float(want.abs().max()), 1e-12), "%s.%s" % (name, k))
+
+
 def test_training_step_with_large_scenes_matches_oracle():
     """One whole GAN step on a packed batch that holds 100- and 70-agent scenes next to small ones."""
     import socialways_amd as sw
