@@ -7,36 +7,76 @@
 #include "sw_common.h"
 #include "sw_wgrad.h"
 
-// ---- y[r][n] (+)= bias[n] + sum_k x[r][k] w[k w_rs + n w_cs]: a small row-times-matrix product with free strides on w
-//      (W or W^T).  One thread per output element; the products the modules need are a few MFLOP.
+// ---- y[r][n] (+)= bias[n] + sum_k x[r][k] w[k w_rs + n w_cs]: a row-times-matrix product with free strides on w
+//      (W or W^T).  One wave = 16 rows x (up to) 64 output columns on the matrix cores, operands straight from global
+//      memory (clamped addresses, masked values: no load under a branch); the generic-width path (generic.py) spends most
+//      of its time here - the first version (one thread per output element) ran 33 ms of a 40 ms step at 128 hidden units.
 __global__ __launch_bounds__(256) void rows_gemm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                         int w_rs, int w_cs, const float* __restrict__ bias, long long R,
                                                         int K, int N, float* __restrict__ y, int ldy, int accumulate) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= R * N) return;
-  const long long r = e / N;
-  const int n = (int)(e - r * N);
-  const float* xr = x + r * ldx;
-  const float* wn = w + (size_t)n * w_cs;
-  float a0 = bias ? bias[n] : 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int k = 0;
-  for (; k + 3 < K; k += 4) {
-    a0 = fmaf(xr[k], wn[(size_t)k * w_rs], a0);
-    a1 = fmaf(xr[k + 1], wn[(size_t)(k + 1) * w_rs], a1);
-    a2 = fmaf(xr[k + 2], wn[(size_t)(k + 2) * w_rs], a2);
-    a3 = fmaf(xr[k + 3], wn[(size_t)(k + 3) * w_rs], a3);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 15, lg = lane >> 4;
+  const int ncb = (N + 63) >> 6;
+  const long long g = (long long)blockIdx.x * 4 + wave;
+  const long long rt = g / ncb;
+  const int n0 = (int)(g - rt * ncb) * 64;
+  if (rt * 16 >= R) return;
+  const long long row = rt * 16 + ln;
+  const bool rv = row < R;
+  const float* xr = x + (rv ? row : R - 1) * ldx;
+  // C layout: acc[t][q] = y[row ln][n0 + 16t + 4lg + q]
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + 16 * t + 4 * lg + q;
+      acc[t][q] = (bias && n < N) ? bias[n] : 0.f;
+    }
   }
-  for (; k < K; ++k) a0 = fmaf(xr[k], wn[(size_t)k * w_rs], a0);
-  const float v = (a0 + a1) + (a2 + a3);
-  float* dst = y + r * ldy + n;
-  *dst = accumulate ? *dst + v : v;
+  size_t wn[4];      // column offsets of the lane's A operands: output column n0 + 16t + ln (clamped)
+  bool nv[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int n = n0 + 16 * t + ln;
+    nv[t] = n < N;
+    wn[t] = (size_t)(nv[t] ? n : N - 1) * w_cs;
+  }
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    float bv[4], av[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kk = k0 + 4 * lg + q, kc = kk < K ? kk : K - 1;
+      bv[q] = xr[kc];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) av[t][q] = w[(size_t)kc * w_rs + wn[t]];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool kv = k0 + 4 * lg + q < K;
+      const float b = (kv && rv) ? bv[q] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = SW_MFMA((kv && nv[t]) ? av[t][q] : 0.f, b, acc[t]);
+    }
+  }
+  if (!rv) return;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + 16 * t + 4 * lg + q;
+      if (n < N) {
+        float* dst = y + row * ldy + n;
+        *dst = accumulate ? *dst + acc[t][q] : acc[t][q];
+      }
+    }
+  }
 }
 extern "C" int sw_rows_gemm(const float* x, int ldx, const float* w, int w_rs, int w_cs, const float* bias, long long R, int K,
                             int N, float* y, int ldy, int accumulate, void* stream) {
   if (!x || !w || !y || R < 0 || K < 1 || N < 1 || ldx < K || ldy < N) return SW_EARG;
   if (R == 0) return SW_OK;
-  const long long n = R * N;
-  SW_LAUNCH(rows_gemm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, w, w_rs,
+  const long long waves = ((R + 15) / 16) * ((N + 63) / 64);
+  SW_LAUNCH(rows_gemm_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, w, w_rs,
                      w_cs, bias, R, K, N, y, ldy, accumulate);
   SW_CHECK_LAUNCH("rows_gemm_kernel");
   return SW_OK;

@@ -1,6 +1,6 @@
 """Scratch: what the staging launch spends its time on (eager launches bracketed by HIP events)."""
 import ctypes, sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import socialways_amd as sw
 from socialways_amd import _lib as L

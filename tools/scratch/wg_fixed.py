@@ -1,6 +1,6 @@
 """Scratch: fixed cost of a weight-gradient job (one problem, 64 workgroups, rows per wave swept); -DSW_WG_STAMP variant."""
 import ctypes, sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from socialways_amd import _lib as L
 dev = torch.device("cuda:0")

@@ -1,6 +1,6 @@
 """Scratch: per-workgroup start / end stamps of the generator's weight-gradient launch (variant built with -DSW_WG_STAMP)."""
 import ctypes, sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import bench
 from socialways_amd import _lib as L
