@@ -229,9 +229,11 @@ class Leg:
                 i += 1
 
     def prime(self):
-        """Untimed: the first 3 calls of a launch shape run eagerly / capture the graphs - both shapes (KG steps per
-        launch and single steps) are primed so that no capture falls into a timed region."""
-        for rep in range(3):
+        """Untimed: the first 3 calls of a launch shape run eagerly / capture the graphs - every shape (KG steps per
+        launch, the 2-step and single-step launches of the ramp) is primed so that no capture falls into a timed region,
+        and called twice more so that BOTH alternating executables of a shape have been launched once (the first launch of
+        an executable costs ~2 ms on this runtime: the first timed region used to carry two of them)."""
+        for rep in range(5):
             if self.KG > 1:
                 self.run_steps(0, self.KG)
                 self.last = self.tr.step_many([self.draw(j) for j in range(2)], self.sb, self.data.ss, global_B=self.Bg,
