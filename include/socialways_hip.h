@@ -90,9 +90,11 @@ int sw_enc_lstm_bwd(const float* enc_w, const float* act, const float* c0, const
  * listed by the caller as blocks of 16 query agents, big_blocks = int32 [NB][8] records
  *   { scene, i0, partial row base of the block, partial row base of its scene, blocks in the scene,
  *     block index in the scene, 0, 0 }
- * (partial rows: 128 floats each, sum over big scenes of blocks*agents rows - used by the backward), and
- * run as row-block kernels with an online softmax; wh_ws [B,64] receives W h + b, ml [B,2] the softmax
- * statistics (running max, normaliser) the backward needs.  Amax = largest scene NOT in big_blocks.     */
+ * (partial rows: 132 floats each, sum over big scenes of blocks*agents rows - used by the backward), and
+ * run as row-block kernels with an online softmax; wh_ws (132 B floats) receives W h + b [B,64], then
+ * v = W3^T (W h + b) [B,64] and c = <b3, W h + b> [B] - what the attention needs of the embedder's last layer fc.4
+ * (weight W3, bias b3), which is never run per pair; ml [B,2] the softmax statistics (running max, normaliser)
+ * the backward needs.  Amax = largest scene NOT in big_blocks.                                         */
 int sw_social_pool_fwd(const float* obsv /*[B,To,2]*/, int To, const float* h /*[B,64]*/,
                        const int* scene_off, int S, int B, int Amax /*<= 64*/,
                        const float* emb_w, const float* att_w, float* S_out /*[B,64]*/,
@@ -160,7 +162,7 @@ int sw_social_pool_bwd(const float* obsv, int To, const float* h, const int* sce
                        const float* emb_w, const float* att_w, const float* attn, const float* dS,
                        float* dh, float* d_emb_w, float* d_att_w, float* pair_ws, float* wgrad_ws,
                        /* scenes above 64 agents (see sw_social_pool_fwd): the forward's big_blocks, wh_ws, ml, its
-                        * output S_pool, and big_part_ws = 128 floats per partial row (blocks*agents rows per scene) */
+                        * output S_pool, and big_part_ws = 132 floats per partial row (blocks*agents rows per scene) */
                        const int* big_blocks /*or NULL*/, int NB, const float* wh_ws, const float* ml,
                        const float* S_pool, float* big_part_ws,
                        sw_wgrad_batch* defer /*NULL: reduce the weight gradients now; else leave the problems in the

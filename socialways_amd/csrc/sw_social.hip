@@ -1123,31 +1123,49 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_bwd_rows_kernel(
 //             blocks in the scene, block index in the scene, 0, 0 }.
 // ---------------------------------------------------------------------------------------------
 #define SW_BIG_REC 8
+#define SW_BIG_PROW 132   // floats per partial row of the row-block backward: Q_j [64] | sum_i a_ij dS_i [64] | sd_j, pad [4]
 __device__ __forceinline__ f32x4 agent_x4(const float* obsv, int To, int a) {
   const float* p = obsv + ((size_t)a * To + To - 2) * 2;  // last two observed points -> (p, v)
   return f32x4{p[2], p[3], p[2] - p[0], p[3] - p[1]};
 }
 
-// Wh = W h + b for the 16 agents of a block (one MFMA tile per wave: units 16w..)
+// Wh = W h + b for the 16 agents of a block (one MFMA tile per wave: units 16w..), and what the attention needs of fc.4:
+// v_j = W3^T Wh_j, c_j = <b3, Wh_j> (scene_wh_to_v has the algebra).  wh / vv [B][64], cc [B].
+#define SW_BIG_WH_FLOATS 132      // per agent in wh_ws: Wh [64] | v [64] | c [1] + pad (three arrays of B rows)
 __global__ __launch_bounds__(SW_THREADS) void social_wh_kernel(const float* __restrict__ h, const int* __restrict__ scene_off,
                                                                const int* __restrict__ blocks, const float* __restrict__ att_w,
-                                                               float* __restrict__ wh) {
+                                                               const float* __restrict__ emb_w, float* __restrict__ wh,
+                                                               float* __restrict__ vv, float* __restrict__ cc) {
+  __shared__ __attribute__((aligned(16))) float tile[16][68];
   const int* rec = blocks + (size_t)blockIdx.x * SW_BIG_REC;
   const int s0 = scene_off[rec[0]], n = scene_off[rec[0] + 1] - s0, i0 = rec[1];
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
   const int a = s0 + min(i0 + ln, n - 1);
-  f32x4 wr[4];
+  f32x4 wr[4], w3t[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) wr[j] = ld4(att_w + swp::ATT_W + (16 * wave + ln) * 64 + 16 * j + 4 * lg);
+  for (int j = 0; j < 4; ++j) {
+    wr[j] = ld4(att_w + swp::ATT_W + (16 * wave + ln) * 64 + 16 * j + 4 * lg);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w3t[j][r] = emb_w[swp::EMB_W2 + (16 * j + 4 * lg + r) * 64 + 16 * wave + ln];
+  }
   f32x4 acc = ld4(att_w + swp::ATT_B + 16 * wave + 4 * lg);
   acc = tile_mm_reg<4>(wr, h + (size_t)a * 64 + 4 * lg, acc);
   if (i0 + ln < n) st4(wh + (size_t)a * 64 + 16 * wave + 4 * lg, acc);
+  st4(&tile[ln][16 * wave + 4 * lg], acc);
+  __syncthreads();
+  const f32x4 v = tile_mm_reg<4>(w3t, &tile[ln][4 * lg], f32x4{0.f, 0.f, 0.f, 0.f});
+  if (i0 + ln < n) st4(vv + (size_t)a * 64 + 16 * wave + 4 * lg, v);
+  if (threadIdx.x < 16 && i0 + (int)threadIdx.x < n) {
+    float c = 0.f;
+    for (int u = 0; u < 64; ++u) c = fmaf(emb_w[swp::EMB_B2 + u], tile[threadIdx.x][u], c);
+    cc[s0 + i0 + threadIdx.x] = c;
+  }
 }
 
 __global__ __launch_bounds__(SW_THREADS) void social_big_fwd_kernel(
-    const float* __restrict__ obsv, int To, const float* __restrict__ h, const float* __restrict__ wh,
-    const int* __restrict__ scene_off, const int* __restrict__ blocks, const float* __restrict__ emb_w,
-    float* __restrict__ S_out, float* __restrict__ ml) {
+    const float* __restrict__ obsv, int To, const float* __restrict__ h, const float* __restrict__ vv,
+    const float* __restrict__ cc, const int* __restrict__ scene_off, const int* __restrict__ blocks,
+    const float* __restrict__ emb_w, float* __restrict__ S_out, float* __restrict__ ml) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SocL Ls = soc_lds(16);
   const float* w0b = smem + Ls.w0b;
@@ -1156,8 +1174,8 @@ __global__ __launch_bounds__(SW_THREADS) void social_big_fwd_kernel(
   const int* rec = blocks + (size_t)blockIdx.x * SW_BIG_REC;
   const int s0 = scene_off[rec[0]], n = scene_off[rec[0] + 1] - s0, i0 = rec[1];
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
-  PairW W;
-  load_pair_w(W, emb_w, ln, lg);
+  PairW1 W;
+  load_pair_w1(W, emb_w, ln, lg);
   sw_barrier();
   for (int q = 0; q < 4; ++q) {
     const int i = i0 + 4 * wave + q;
@@ -1170,18 +1188,19 @@ __global__ __launch_bounds__(SW_THREADS) void social_big_fwd_kernel(
       const int jc = min(j, n - 1);
       float f0, f1, f2;
       pair_feat(xi, agent_x4(obsv, To, s0 + jc), f0, f1, f2);
-      f32x4 h1[2], h2[4], f[4];
+      f32x4 h1[2], h2[4];
       pair_l1(w0b, lg, f0, f1, f2, h1);
-      pair_l23(W, b12, b12 + 64, lg, h1, h2, f);
-      float part = 0.f;
+      pair_l2(W, b12, lg, h1, h2);
+      float part = 0.f;     // sigma_ij = <h2_ij, v_j> + c_j (fc.4 is never run per pair)
 #pragma unroll
       for (int mo = 0; mo < 4; ++mo) {
-        f32x4 w = ld4(wh + (size_t)(s0 + jc) * 64 + 16 * mo + 4 * lg);
+        f32x4 w = ld4(vv + (size_t)(s0 + jc) * 64 + 16 * mo + 4 * lg);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) part = fmaf(f[mo][r], w[r], part);
+        for (int r = 0; r < 4; ++r) part = fmaf(h2[mo][r], w[r], part);
       }
       part += __shfl_xor(part, 16);
       part += __shfl_xor(part, 32);
+      part += cc[s0 + jc];
       const float sg = !jv ? -INFINITY : (jc == i ? -1000.0f : part);   // train.py:170
       float tmax = sg;
 #pragma unroll
@@ -1206,6 +1225,21 @@ __global__ __launch_bounds__(SW_THREADS) void social_big_fwd_kernel(
   }
 }
 
+// layer 2 alone with fc.2.weight read from its row-major LDS image
+__device__ __forceinline__ void pair_l2_lds(const float* w1s, const float* b1, int ln, int lg, const f32x4 h1[2], f32x4 h2[4]) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    f32x4 acc = ld4(b1 + 16 * mt + 4 * lg);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const f32x4 w = ld4(w1s + (16 * mt + ln) * SW_SOC_W1LD + 16 * j + 4 * lg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = SW_MFMA(w[r], h1[j][r], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h2[mt][r] = fmaxf(acc[r], 0.f);
+  }
+}
 // layers 2, 3 with the weights read from the row-major LDS images (the row-block backward has no registers
 // to spare for a register-resident copy next to the gradient accumulators)
 __device__ __forceinline__ void pair_l23_lds(const float* w1s, const float* w2s, const float* b1, const float* b2, int ln,
@@ -1246,9 +1280,9 @@ __device__ __forceinline__ void pair_l23_lds(const float* w1s, const float* w2s,
 // partial row (128 floats) per (block, j); social_big_finish_kernel adds the blocks of a scene.
 __global__ __launch_bounds__(SW_THREADS) void social_big_bwd_kernel(
     const float* __restrict__ obsv, int To, const float* __restrict__ h, const float* __restrict__ wh,
-    const int* __restrict__ scene_off, const int* __restrict__ blocks, const float* __restrict__ emb_w,
-    const float* __restrict__ S_pool, const float* __restrict__ ml, const float* __restrict__ dS,
-    float* __restrict__ part_rows, SocPart part, int slice0) {
+    const float* __restrict__ vv, const float* __restrict__ cc, const int* __restrict__ scene_off,
+    const int* __restrict__ blocks, const float* __restrict__ emb_w, const float* __restrict__ S_pool,
+    const float* __restrict__ ml, const float* __restrict__ dS, float* __restrict__ part_rows, SocPart part, int slice0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SocL Ls = soc_lds(16);
   const float* w0b = smem + Ls.w0b;
@@ -1256,8 +1290,8 @@ __global__ __launch_bounds__(SW_THREADS) void social_big_bwd_kernel(
   float* w2s = smem + Ls.fwd_total;                   // fc.4.weight [64][68]
   float* w1s = w2s + 64 * SW_SOC_W2LD;                // fc.2.weight [64][36]
   float* scr_all = w1s + 64 * SW_SOC_W1LD;            // [4 waves][4 tiles][16][20]
-  float* jred = scr_all + 4 * SW_SOC_SCR;             // [16 j][128]: dWh | sum a dS of the current j tile
-  float* w2t = jred + 16 * 128;                       // fc.4.weight^T [64][68] | fc.2.weight^T [32][68]
+  float* jred = scr_all + 4 * SW_SOC_SCR;             // [16 j][SW_BIG_PROW]: Q | sum a dS | sd of the current j tile
+  float* w2t = jred + 16 * SW_BIG_PROW;               // fc.4.weight^T [64][68] | fc.2.weight^T [32][68]
   float* w1t = w2t + 64 * SW_SOC_WTLD;
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
   float* scr = scr_all + wave * SW_SOC_SCR;
@@ -1296,12 +1330,14 @@ __global__ __launch_bounds__(SW_THREADS) void social_big_bwd_kernel(
     const bool jv = j < n;
     const int jc = min(j, n - 1);
     const f32x4 xj = agent_x4(obsv, To, s0 + jc);
-    f32x4 whj[4], hj[4], dwh_acc[4], dhj_acc[4];
+    f32x4 vj[4], hj[4], Q[4], dhj_acc[4];     // Q_j = sum_i dsigma_ij h2_ij (-> dW3, dWh_j), see pair_block_dw3
+    float sd = 0.f;
+    const float cj = cc[s0 + jc];
 #pragma unroll
     for (int mo = 0; mo < 4; ++mo) {
-      whj[mo] = ld4(wh + (size_t)(s0 + jc) * 64 + 16 * mo + 4 * lg);
+      vj[mo] = ld4(vv + (size_t)(s0 + jc) * 64 + 16 * mo + 4 * lg);
       hj[mo] = ld4(h + (size_t)(s0 + jc) * 64 + 16 * mo + 4 * lg);
-      dwh_acc[mo] = f32x4{0.f, 0.f, 0.f, 0.f};
+      Q[mo] = f32x4{0.f, 0.f, 0.f, 0.f};
       dhj_acc[mo] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll 1
@@ -1313,9 +1349,9 @@ __global__ __launch_bounds__(SW_THREADS) void social_big_bwd_kernel(
       const float Dq = q == 0 ? Di[0] : (q == 1 ? Di[1] : (q == 2 ? Di[2] : Di[3]));
       float f0, f1, f2;
       pair_feat(xq, xj, f0, f1, f2);
-      f32x4 h1[2], h2[4], f[4];
+      f32x4 h1[2], h2[4];
       pair_l1(w0b, lg, f0, f1, f2, h1);
-      pair_l23_lds(w1s, w2s, b12, b12 + 64, ln, lg, h1, h2, f);
+      pair_l2_lds(w1s, b12, ln, lg, h1, h2);
       float part_s = 0.f, da = 0.f;
       f32x4 dsi[4];
 #pragma unroll
@@ -1323,7 +1359,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_big_bwd_kernel(
         dsi[mo] = ld4(dS + (size_t)(s0 + i) * 64 + 16 * mo + 4 * lg);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          part_s = fmaf(f[mo][r], whj[mo][r], part_s);
+          part_s = fmaf(h2[mo][r], vj[mo][r], part_s);
           da = fmaf(dsi[mo][r], hj[mo][r], da);
         }
       }
@@ -1331,37 +1367,49 @@ __global__ __launch_bounds__(SW_THREADS) void social_big_bwd_kernel(
       part_s += __shfl_xor(part_s, 32);
       da += __shfl_xor(da, 16);
       da += __shfl_xor(da, 32);
-      const float sg = jc == i ? -1000.0f : part_s;                       // train.py:170
+      const float sg = jc == i ? -1000.0f : part_s + cj;                  // train.py:170
       const float a = jv ? expf(sg - mq) * rlq : 0.f;
       const float dsv = a * (da - Dq);                                     // softmax backward; 0 for invalid lanes
-      f32x4 dz3[4];
+      f32x4 dh2[4];
+      sd += dsv;
 #pragma unroll
       for (int mo = 0; mo < 4; ++mo) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          dz3[mo][r] = dsv * whj[mo][r];
-          dwh_acc[mo][r] = fmaf(dsv, f[mo][r], dwh_acc[mo][r]);
+          Q[mo][r] = fmaf(dsv, h2[mo][r], Q[mo][r]);
+          dh2[mo][r] = h2[mo][r] > 0.f ? dsv * vj[mo][r] : 0.f;
           dhj_acc[mo][r] = fmaf(a, dsi[mo][r], dhj_acc[mo][r]);
         }
       }
-      pair_tile_bwd(G, scr, w2t, w1t, h1, h2, dz3, f0, f1, f2, ln, lg SW_STAMP_ARG);
+      pair_tile_bwd_tail(G, scr, w1t, h1, dh2, f0, f1, f2, ln, lg SW_STAMP_ARG);
+    }
+    {     // dW3 += Wh Q^T, db3 += Wh sd over the block's 16 agents (this wave's rows)
+      f32x4 whj[4];
+#pragma unroll
+      for (int mo = 0; mo < 4; ++mo) whj[mo] = ld4(wh + (size_t)(s0 + jc) * 64 + 16 * mo + 4 * lg);
+      pair_block_dw3(G, scr, whj, Q, sd, ln, lg);
+      wave_lds_fence();
     }
     // sum the 4 waves' j-tile partials in a fixed order, then one partial row per agent j of the tile
     for (int w = 0; w < 4; ++w) {
       if (wave == w) {
 #pragma unroll
         for (int mo = 0; mo < 4; ++mo) {
-          float* a0 = jred + ln * 128 + 16 * mo + 4 * lg;
-          st4(a0, w == 0 ? dwh_acc[mo] : ld4(a0) + dwh_acc[mo]);
+          float* a0 = jred + ln * SW_BIG_PROW + 16 * mo + 4 * lg;
+          st4(a0, w == 0 ? Q[mo] : ld4(a0) + Q[mo]);
           st4(a0 + 64, w == 0 ? dhj_acc[mo] : ld4(a0 + 64) + dhj_acc[mo]);
+        }
+        if (lg == 0) {
+          float* a1 = jred + ln * SW_BIG_PROW + 128;
+          *a1 = w == 0 ? sd : *a1 + sd;
         }
       }
       sw_barrier();
     }
     const int jn = min(16, n - j0);
-    for (int e = threadIdx.x; e < jn * 32; e += blockDim.x) {
-      const int jr = e >> 5, c4 = e & 31;
-      st4(part_rows + ((size_t)prow0 + j0 + jr) * 128 + 4 * c4, ld4(jred + jr * 128 + 4 * c4));
+    for (int e = threadIdx.x; e < jn * 33; e += blockDim.x) {
+      const int jr = e / 33, c4 = e - jr * 33;     // 132 floats per row: Q [64] | sum a dS [64] | sd, pad [4]
+      st4(part_rows + ((size_t)prow0 + j0 + jr) * SW_BIG_PROW + 4 * c4, ld4(jred + jr * SW_BIG_PROW + 4 * c4));
     }
     sw_barrier();
   }
@@ -1372,26 +1420,37 @@ __global__ __launch_bounds__(SW_THREADS) void social_big_bwd_kernel(
 __global__ __launch_bounds__(SW_THREADS) void social_big_finish_kernel(const int* __restrict__ scene_off,
                                                                        const int* __restrict__ blocks,
                                                                        const float* __restrict__ att_w,
+                                                                       const float* __restrict__ emb_w,
                                                                        const float* __restrict__ part_rows,
                                                                        float* __restrict__ dh, float* __restrict__ dwh_rows) {
-  __shared__ float dwh[16][68];
+  __shared__ float dwh[16][68], qs[16][68];
   const int* rec = blocks + (size_t)blockIdx.x * SW_BIG_REC;
   const int s0 = scene_off[rec[0]], n = scene_off[rec[0] + 1] - s0, j0 = rec[1], srow0 = rec[3], nblk = rec[4];
   const int jn = min(16, n - j0);
   float dhj[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int q = 0, e = threadIdx.x; q < 4; ++q, e += 256) {   // 16 x 64 elements, 4 per thread
+  for (int q = 0, e = threadIdx.x; q < 4; ++q, e += 256) {   // 16 x 64 elements, 4 per thread: Q_j, sum a dS over the blocks
     const int jr = e >> 6, u = e & 63;
-    float sw = 0.f, sh = 0.f;
+    float sw = 0.f, sh = 0.f, ss = 0.f;
     if (jr < jn) {
       for (int k = 0; k < nblk; ++k) {
-        const float* row = part_rows + ((size_t)srow0 + (size_t)k * n + j0 + jr) * 128;
+        const float* row = part_rows + ((size_t)srow0 + (size_t)k * n + j0 + jr) * SW_BIG_PROW;
         sw += row[u];
         sh += row[64 + u];
+        if (u == 0) ss += row[128];
       }
-      dwh_rows[(size_t)(s0 + j0 + jr) * 64 + u] = sw;
     }
-    dwh[jr][u] = sw;
+    qs[jr][u] = sw;
+    if (u == 0) qs[jr][64] = ss;
     dhj[q] = sh;
+  }
+  __syncthreads();
+  for (int q = 0, e = threadIdx.x; q < 4; ++q, e += 256) {   // dWh_j = W3 Q_j + b3 sd_j (pair_block_dw3 has the algebra)
+    const int jr = e >> 6, u = e & 63;
+    float acc = emb_w[swp::EMB_B2 + u] * qs[jr][64];
+    const float* w3 = emb_w + swp::EMB_W2 + u * 64;
+    for (int k = 0; k < 64; ++k) acc = fmaf(w3[k], qs[jr][k], acc);
+    dwh[jr][u] = acc;
+    if (jr < jn) dwh_rows[(size_t)(s0 + j0 + jr) * 64 + u] = acc;
   }
   __syncthreads();
   for (int q = 0, e = threadIdx.x; q < 4; ++q, e += 256) {
@@ -1690,11 +1749,12 @@ extern "C" int sw_social_pool_fwd_aux(const float* obsv, int To, const float* h,
                      sw_soc_images_for(emb_w, att_w));
   SW_CHECK_LAUNCH("social_pool_fwd_kernel");
   if (NB > 0) {   // scenes above SW_AMAX agents
+    // wh_ws: Wh [B][64] | v [B][64] | c [B] (+ pad): SW_BIG_WH_FLOATS per agent
     SW_LAUNCH(social_wh_kernel, dim3(NB), dim3(SW_THREADS), 0, (hipStream_t)stream, h, scene_off, big_blocks, att_w,
-                       wh_ws);
+                       emb_w, wh_ws, wh_ws + (size_t)B * 64, wh_ws + (size_t)B * 128);
     SW_CHECK_LAUNCH("social_wh_kernel");
     SW_LAUNCH(social_big_fwd_kernel, dim3(NB), dim3(SW_THREADS), soc_lds(16).fwd_total * 4, (hipStream_t)stream,
-                       obsv, To, h, wh_ws, scene_off, big_blocks, emb_w, S_out, ml);
+                       obsv, To, h, wh_ws + (size_t)B * 64, wh_ws + (size_t)B * 128, scene_off, big_blocks, emb_w, S_out, ml);
     SW_CHECK_LAUNCH("social_big_fwd_kernel");
   }
   return SW_OK;
@@ -1723,7 +1783,7 @@ extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, con
   const int a16 = Amax < 16 ? 16 : ((Amax + 15) & ~15);
   const int extra = SW_SOC_WT + 4 * SW_SOC_SCR;       // scene kernel: transposed weight images + scratch
   const int lds = (soc_lds(a16).bwd_total + extra) * 4;
-  const int lds_big = (soc_lds(16).fwd_total + 64 * SW_SOC_W2LD + 64 * SW_SOC_W1LD + 4 * SW_SOC_SCR + 16 * 128 + SW_SOC_WT) * 4;
+  const int lds_big = (soc_lds(16).fwd_total + 64 * SW_SOC_W2LD + 64 * SW_SOC_W1LD + 4 * SW_SOC_SCR + 16 * SW_BIG_PROW + SW_SOC_WT) * 4;
   static_assert(SW_SOC_WT + 4 * SW_SOC_SCR >= SW_SOC_PART, "epilogue staging area");
   static_assert(64 * SW_SOC_W2LD + 64 * SW_SOC_W1LD + 4 * SW_SOC_SCR >= SW_SOC_PART, "epilogue staging area (row-block kernel)");
   static bool attr = false;
@@ -1779,10 +1839,11 @@ extern "C" int sw_social_pool_bwd(const float* obsv, int To, const float* h, con
   if (rc_add) return SW_ESHAPE;
   SocPart part{wgrad_ws + wb.p[i3].ws_off, wgrad_ws + wb.p[i2].ws_off, wgrad_ws + wb.p[i1].ws_off};
   if (NB > 0) {   // scenes above SW_AMAX agents: fills dh / dwh_rows of their agents
-    SW_LAUNCH(social_big_bwd_kernel, dim3(NB), dim3(SW_THREADS), lds_big, st, obsv, To, h, wh_ws, scene_off,
-                       big_blocks, emb_w, S_pool, ml, dS, big_part_ws, part, G);
+    SW_LAUNCH(social_big_bwd_kernel, dim3(NB), dim3(SW_THREADS), lds_big, st, obsv, To, h, wh_ws,
+                       wh_ws + (size_t)B * 64, wh_ws + (size_t)B * 128, scene_off, big_blocks, emb_w, S_pool, ml, dS,
+                       big_part_ws, part, G);
     SW_CHECK_LAUNCH("social_big_bwd_kernel");
-    SW_LAUNCH(social_big_finish_kernel, dim3(NB), dim3(SW_THREADS), 0, st, scene_off, big_blocks, att_w,
+    SW_LAUNCH(social_big_finish_kernel, dim3(NB), dim3(SW_THREADS), 0, st, scene_off, big_blocks, att_w, emb_w,
                        big_part_ws, dh, dwh_rows);
     SW_CHECK_LAUNCH("social_big_finish_kernel");
   }

@@ -156,7 +156,7 @@ def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_soc
         S = torch.empty(B, 64, device=dev)
         attn = torch.empty(B, L.AMAX, device=dev) if save else None
         if scenes.NB:          # scenes above AMAX agents: W h + b per agent and the softmax statistics of every row
-            wh = torch.empty(B, 64, device=dev)
+            wh = torch.empty(B * 132, device=dev)       # Wh | v | c rows of the row-block kernels (sw_social_pool_fwd)
             ml = torch.empty(B, 2, device=dev) if save else None
         L.call("sw_social_pool_fwd_aux", L.ptr(obsv), To, L.ptr(hT), L.ptr(scenes.scene_off), scenes.S, B, scenes.amax,
                L.ptr(emb_w), L.ptr(att_w), L.ptr(S), L.ptr(attn), L.ptr(scenes.big_blocks), scenes.NB, L.ptr(wh), L.ptr(ml),
@@ -202,7 +202,7 @@ def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d
         sc = ctx.scenes
         pending = ws.wgrad_batch
         pws = ws.get("pairs", L.workspace_floats(L.WS_PAIRS, B, To, Tp, 1, sc.P))
-        bigp = ws.get("bigpart", sc.big_rows * 128) if sc.NB else None      # scenes above AMAX agents: per-block partial rows
+        bigp = ws.get("bigpart", sc.big_rows * 132) if sc.NB else None      # scenes above AMAX agents: per-block partial rows
         L.call("sw_social_pool_bwd", L.ptr(ctx.obsv), To, L.ptr(ctx.hT), L.ptr(sc.scene_off), L.ptr(sc.pair_off), sc.S,
                B, sc.amax, sc.P, L.ptr(emb_w), L.ptr(att_w), L.ptr(ctx.attn), L.ptr(dS), L.ptr(dhT), L.ptr(d_emb),
                L.ptr(d_att), L.ptr(pws), L.ptr(wgrad), L.ptr(sc.big_blocks), sc.NB, L.ptr(ctx.wh), L.ptr(ctx.ml),
@@ -252,7 +252,7 @@ def gen_forward_k(enc_w, emb_w, att_w, dec_w, obsv, noise_k, scenes, n_next, use
         S = torch.empty(B, 64, device=dev)
         attn = torch.empty(B, L.AMAX, device=dev)
         if scenes.NB:
-            wh, ml = torch.empty(B, 64, device=dev), torch.empty(B, 2, device=dev)
+            wh, ml = torch.empty(B * 132, device=dev), torch.empty(B, 2, device=dev)
         L.call("sw_social_pool_fwd_aux", L.ptr(obsv), To, L.ptr(hT), L.ptr(scenes.scene_off), scenes.S, B, scenes.amax,
                L.ptr(emb_w), L.ptr(att_w), L.ptr(S), L.ptr(attn), L.ptr(scenes.big_blocks), scenes.NB, L.ptr(wh), L.ptr(ml),
                None, None, 0, st)
@@ -300,7 +300,7 @@ def gen_backward_k(enc_w, emb_w, att_w, dec_w, ctx, dpred4_k, d_enc, d_emb, d_at
         sc = one.scenes
         pending = ws.wgrad_batch
         pws = ws.get("pairs", L.workspace_floats(L.WS_PAIRS, B, To, Tp, 1, sc.P))
-        bigp = ws.get("bigpart", sc.big_rows * 128) if sc.NB else None
+        bigp = ws.get("bigpart", sc.big_rows * 132) if sc.NB else None
         L.call("sw_social_pool_bwd", L.ptr(one.obsv), To, L.ptr(one.hT), L.ptr(sc.scene_off), L.ptr(sc.pair_off), sc.S,
                B, sc.amax, sc.P, L.ptr(emb_w), L.ptr(att_w), L.ptr(one.attn), L.ptr(dS), L.ptr(dhT), L.ptr(d_emb),
                L.ptr(d_att), L.ptr(pws), L.ptr(wgrad), L.ptr(sc.big_blocks), sc.NB, L.ptr(one.wh), L.ptr(one.ml),
