@@ -45,17 +45,6 @@ __device__ __forceinline__ void load_pair_w(PairW& W, const float* emb_w, int ln
   }
 }
 
-// the same from the operand-layout images of the step (swimg::OP_E1 / OP_E2): a wave's load = 1 KB of consecutive memory
-__device__ __forceinline__ void load_pair_w_img(PairW& W, const float* __restrict__ img, int lane) {
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) W.w1[mt][j] = ld4(img + swimg::OP_E1 + ((mt * 2 + j) * 64 + lane) * 4);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) W.w2[mt][k] = ld4(img + swimg::OP_E2 + ((mt * 4 + k) * 64 + lane) * 4);
-  }
-}
-
 // fc.2 alone (the kernels that never form f_ij = fc.4(..) explicitly, see "the attention never needs f_ij" below)
 struct PairW1 {
   f32x4 w1[4][2];         // fc.2.weight[16mt + ln][16j + 4lg ..]   (64 x 32)
@@ -368,13 +357,13 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_fwd_kernel(
 // ---------------------------------------------------------------------------------------------
 // Backward.  Inputs carry no gradient (tracks are data); gradients flow to h (through the pooling
 // and through W h), to W/b of the attention and to the pair MLP.  The pair MLP forward is
-// recomputed per 16-pair tile and its WEIGHT GRADIENTS ARE ACCUMULATED IN REGISTERS across all tiles
-// (and scenes) a wave processes: per tile the operands (dz3, h2, dh2, h1) are transposed through a
-// small per-wave LDS scratch into "k = pair" MFMA layout and 96 more MFMAs update the 64x64 / 64x32
-// accumulators.  Writing per-pair rows for a deferred GEMM instead costs 324 floats per pair - 2.7 GB
-// per step at 512 x 64-agent scenes.  One partial (6400 floats) per workgroup goes to the wgrad
-// workspace and is reduced in fixed order by wgrad_reduce_kernel.  Only f_ij (64 floats per pair) is
-// still written: dWh_j = sum_i dsigma_ij f_ij needs it after all pairs of the scene are done.
+// recomputed per 16-pair tile up to h2 (f_ij is never formed: "the attention never needs f_ij" above,
+// "the rank-1 structure" below) and its WEIGHT GRADIENTS ARE ACCUMULATED IN REGISTERS across all tiles
+// (and scenes) a wave processes: per tile dh2 and h1 are transposed through a small per-wave LDS scratch
+// into "k = pair" MFMA layout and 64 MFMAs update dW2 / produce dh1; per j block 64 more update dW3 from
+// Wh and Q.  Writing per-pair rows for a deferred GEMM instead cost 324 floats per pair - 2.7 GB per step
+// at 512 x 64-agent scenes.  One partial (6400 floats) per workgroup goes to the wgrad workspace and is
+// reduced in fixed order by wgrad_reduce_kernel.  No per-pair data reaches HBM.
 // ---------------------------------------------------------------------------------------------
 #define SW_SOC_W2LD 68   // LDS row strides of the row-major fc.4 / fc.2 weight images (forward of the row-block kernel)
 #define SW_SOC_W1LD 36
@@ -506,61 +495,6 @@ __device__ __forceinline__ void pair_tile_bwd_tail(PairGrad& G, float* scr, cons
     }
   }
   wave_lds_fence();
-}
-
-// One 16-pair tile: given the recomputed activations (h1, h2 post-ReLU) and dz3 = d(loss)/d(f_ij) (C layout,
-// exact zeros for invalid pairs), back-propagate through fc.4 / fc.2 and add this tile's contribution to all
-// weight gradients.  w2t / w1t: TRANSPOSED LDS images fc.4.weight^T [64 in][68] / fc.2.weight^T [32 in][68] (the
-// A operands of the two data-gradient products as float4s); scr: this wave's transposition scratch.
-__device__ __forceinline__ void pair_tile_bwd(PairGrad& G, float* scr, const float* w2t, const float* w1t,
-                                              const f32x4 h1[2], const f32x4 h2[4], const f32x4 dz3[4], float f0,
-                                              float f1, float f2, int ln, int lg SW_STAMP_PARAM) {
-  // dW3 += dz3 h2^T (k = pairs): both operands through the transposition scratch
-  f32x4 ta[4], tb[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) tr_put(scr + t * 16 * SW_SOC_TLD, dz3[t], ln, lg);
-  wave_lds_fence();
-#pragma unroll
-  for (int t = 0; t < 4; ++t) ta[t] = tr_get(scr + t * 16 * SW_SOC_TLD, ln, lg);
-  wave_lds_fence();
-#pragma unroll
-  for (int t = 0; t < 4; ++t) tr_put(scr + t * 16 * SW_SOC_TLD, h2[t], ln, lg);
-  wave_lds_fence();
-#pragma unroll
-  for (int t = 0; t < 4; ++t) tb[t] = tr_get(scr + t * 16 * SW_SOC_TLD, ln, lg);
-  wave_lds_fence();
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-#pragma unroll
-    for (int mo = 0; mo < 4; ++mo) {
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) G.acc3[mo][kt] = SW_MFMA(ta[mo][r], tb[kt][r], G.acc3[mo][kt]);
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < 4; ++t) G.b3s[t] += (ta[t][0] + ta[t][1]) + (ta[t][2] + ta[t][3]);
-  // dh2 = (W2^T dz3) * relu'(h2): A operand = W2[16mo+4lg+r][16mt+ln], one float4 per (mt, mo) from the transposed image
-  f32x4 dh2[4];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) dh2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int mo = 0; mo < 4; ++mo) {
-    f32x4 wt[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) wt[mt] = ld4(w2t + (16 * mt + ln) * SW_SOC_WTLD + 16 * mo + 4 * lg);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) dh2[mt] = SW_MFMA(wt[mt][r], dz3[mo][r], dh2[mt]);
-    }
-  }
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dh2[mt][r] = h2[mt][r] > 0.f ? dh2[mt][r] : 0.f;
-  }
-  SW_STAMP(3);
-  pair_tile_bwd_tail(G, scr, w1t, h1, dh2, f0, f1, f2, ln, lg SW_STAMP_ARG);
 }
 
 // ---- the rank-1 structure of the attention's gradient -------------------------------------------------------------
@@ -1240,37 +1174,6 @@ __device__ __forceinline__ void pair_l2_lds(const float* w1s, const float* b1, i
     for (int r = 0; r < 4; ++r) h2[mt][r] = fmaxf(acc[r], 0.f);
   }
 }
-// layers 2, 3 with the weights read from the row-major LDS images (the row-block backward has no registers
-// to spare for a register-resident copy next to the gradient accumulators)
-__device__ __forceinline__ void pair_l23_lds(const float* w1s, const float* w2s, const float* b1, const float* b2, int ln,
-                                             int lg, const f32x4 h1[2], f32x4 h2[4], f32x4 f[4]) {
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    f32x4 acc = ld4(b1 + 16 * mt + 4 * lg);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const f32x4 w = ld4(w1s + (16 * mt + ln) * SW_SOC_W1LD + 16 * j + 4 * lg);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc = SW_MFMA(w[r], h1[j][r], acc);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) h2[mt][r] = fmaxf(acc[r], 0.f);
-  }
-#pragma unroll
-  for (int mo = 0; mo < 4; ++mo) f[mo] = ld4(b2 + 16 * mo + 4 * lg);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    f32x4 w[4];
-#pragma unroll
-    for (int mo = 0; mo < 4; ++mo) w[mo] = ld4(w2s + (16 * mo + ln) * SW_SOC_W2LD + 16 * k + 4 * lg);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int mo = 0; mo < 4; ++mo) f[mo] = SW_MFMA(w[mo][r], h2[k][r], f[mo]);
-    }
-  }
-}
-
 // Backward of one 16-query-agent block of a large scene.  For every j tile (outer loop) the wave visits its
 // <= 4 rows i (inner loop): recompute f_ij and sigma_ij, a_ij = e^(sigma_ij - m_i) / l_i,
 // dsigma_ij = a_ij (<dS_i, h_j> - <dS_i, S_i>), back-propagate the pair MLP and accumulate its weight gradients
