@@ -29,9 +29,10 @@ for _ in range(N):
 torch.cuda.synchronize()
 out = (ctypes.c_longlong * 8)()
 lib.sw_debug_soc_stamps(out, 0)
-names = {0: "scene prologue (x4, h, Wh, dS, a)", 1: "softmax backward", 2: "tile: features, fc.0 (VALU), fc.2, fc.4 forward, dz3",
-         3: "tile: dW3 (transposes + 64 MFMA), dh2 (64 MFMA)", 4: "tile: dW2 (32), dh1 (32)", 5: "tile: dW1 (VALU)",
-         6: "per j-block: dWh partial sums", 7: "dh rows"}
+names = {0: "scene prologue (x4, h, Wh, dS, a)", 1: "softmax backward",
+         2: "tile: features, fc.0, fc.2 forward, Q_j / dh2 on the VALU (no fc.4 per pair)",
+         3: "tile: (was dW3 + dh2: 128 MFMAs per tile - now per j block)", 4: "tile: dW2 (32), dh1 (32)", 5: "tile: dW1 (VALU)",
+         6: "per j-block: v_j, dW3 += Wh Q^T, dWh_j = W3 Q_j + b3 sd_j", 7: "dh rows"}
 tiles = 64 * 4 / 4.0      # tiles of wave 0 per scene
 tot = sum(out[k] for k in range(8)) / N
 for k in range(8):
