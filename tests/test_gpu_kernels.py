@@ -495,3 +495,31 @@ def test_disc_update_in_one_launch_equals_forward_plus_backward(B, obs_pre, To):
     for name, a, b in zip(names, res[0], res[1]):
         assert torch.equal(a, b), "%s: max |diff| %.3e" % (name, float((a - b).abs().max()))
     assert float(res[1][5].abs().max()) > 0 and not torch.equal(res[1][6], w0)
+
+
+@pytest.mark.parametrize("R,K,N", [(37, 5, 3), (2048, 48, 32), (130, 160, 80), (16, 64, 256), (1000, 4, 130), (1, 1, 1)])
+def test_rows_gemm_on_the_matrix_cores_any_shape_and_stride(R, K, N):
+    """sw_rows_gemm (y = x W^T + b with W (N, K), and y (+)= dy W through the transposed strides): the generic-width path's
+    matrix product, one wave per 16 rows x 64 columns; shapes that are multiples of nothing, padded row strides, accumulation."""
+    from socialways_amd import _lib as L
+    g = torch.Generator().manual_seed(R * 131 + K * 7 + N)
+    ldx, ldy = K + 3, N + 5
+    x = torch.randn(R, ldx, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.3
+    b = torch.randn(N, generator=g)
+    y0 = torch.randn(R, ldy, generator=g)
+    xd, Wd, bd = x.cuda(), W.cuda().contiguous(), b.cuda()
+    # forward form: w element (k, n) at w[k + n K]
+    y = y0.cuda().clone()
+    L.call("sw_rows_gemm", L.ptr(xd), ldx, L.ptr(Wd), 1, K, L.ptr(bd), R, K, N, L.ptr(y), ldy, 0, L.stream())
+    want = x[:, :K].double() @ W.double().t() + b.double()
+    assert_close(y[:, :N].cpu(), want.float(), 2e-5, 2e-6 * max(float(want.abs().max()), 1.0), "y = x W^T + b")
+    assert torch.equal(y[:, N:].cpu(), y0[:, N:]), "columns beyond N untouched"
+    # backward form, accumulating: dx (+)= dy W, w element (k = n of W, n = k of W) at w[k K + n]
+    dy = torch.randn(R, ldy, generator=g)
+    dx0 = torch.randn(R, ldx, generator=g)
+    dx = dx0.cuda().clone()
+    L.call("sw_rows_gemm", L.ptr(dy.cuda()), ldy, L.ptr(Wd), K, 1, None, R, N, K, L.ptr(dx), ldx, 1, L.stream())
+    want = dx0[:, :K].double() + dy[:, :N].double() @ W.double()
+    assert_close(dx[:, :K].cpu(), want.float(), 2e-5, 2e-6 * max(float(want.abs().max()), 1.0), "dx += dy W")
+    assert torch.equal(dx[:, K:].cpu(), dx0[:, K:])
