@@ -310,6 +310,11 @@ def main():
     gc.collect()
     gc.disable()
     leg.prime()
+    # The runtime's one-time stalls (16-55 ms host blocks seen in the FIRST timed region of a young process in ~1 of 10 runs,
+    # never in 180 later regions: tools/scratch/hiccup.py) are let happen in untimed steps: ~0.4 s of the same graph launches
+    # in front of the W warmup steps.  Reported as config.settle_steps.
+    SETTLE = int(os.environ.get("SW_BENCH_SETTLE_STEPS", "1000")) // KG * KG
+    leg.run_steps(0, SETTLE)
     leg.run_steps(0, args.warmup)
     dt = max_over_ranks(leg.timed(fence, args.warmup, args.steps))          # THE timed region: exactly K steps
     reps = [max_over_ranks(leg.timed(fence, args.warmup + (r + 1) * args.steps, args.steps)) for r in range(REPEATS)]
@@ -486,7 +491,7 @@ def main():
                                    ("%s-strong: ONE packed batch of %d scenes x %d agents (reference --batch-size %d) sharded "
                                     "scene-aligned over %d ranks; use_social=True, n_unrolling_steps=1, info loss on"
                                     % (args.workload, leg.S_global, A, leg.Bg, world)),
-                       "global_batch_scenes": leg.S_global, "parallelism": "dp%d" % world, "steps_per_graph_launch": KG,
+                       "global_batch_scenes": leg.S_global, "parallelism": "dp%d" % world, "steps_per_graph_launch": KG, "settle_steps": SETTLE,
                        "collectives": collectives, "rccl_ranks": (world if pg is not None else None),
                        "allreduces_per_step": (3 if pg is not None else 0),
                        "replicas_identical": replicas_identical,
