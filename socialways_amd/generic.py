@@ -22,12 +22,10 @@ here with the same parity guarantees, not for throughput.  No CPU fallback: CPU 
 """
 import copy
 
-import numpy as np
 import torch
 import torch.nn as nn
 
 from . import _lib as L
-from . import ops
 from .model import _scene_index, _wgrad_ws, get_traj_4d
 from .trainer import SocialWaysTrainer
 
