@@ -164,6 +164,7 @@ static bool wg_shape_ok(int N, int K) {   // every 64-column block of delta / ac
 int wg_add(WgBatch& b, const float* delta, int ldd, const float* act, int lda, int R, int N, int K, float* dW,
            int ldw, float* db, float* db2, int accumulate) {
   if (N > 256 || (ldd & 3) || (lda & 3)) return SW_ESHAPE;
+  if ((long long)R * ldd >= (1LL << 31) || (long long)R * lda >= (1LL << 31)) return SW_ESHAPE;   // 32-bit element offsets in the kernel
   // column blocks of <= 64 REAL act columns; the ones column (bias gradient) rides with the last block on the VALU
   // (it used to open a block of its own whenever K was a multiple of 64: every delta row read again for a row sum)
   if (K < 1) return SW_ESHAPE;
@@ -203,6 +204,7 @@ int wg_add_tail(WgBatch& b, const float* delta, int ldd, const float* act, int l
                 int accumulate) {
   if (N > 256 || (ldd & 3) || (lda & 3) || (lda2 & 3) || K != 64 || K2 != 4 || b.np >= SW_WG_MAXP)   // the tail runs on the
     return SW_ESHAPE;                                                                                  // VALU: 4 columns, float4 rows
+  if ((long long)R * ldd >= (1LL << 31) || (long long)R * lda >= (1LL << 31) || (long long)R * lda2 >= (1LL << 31)) return SW_ESHAPE;
   WgProblem& P = b.p[b.np++];
   P.delta = delta; P.ldd = ldd; P.act = act; P.lda = lda; P.R = R; P.N = N; P.K = K; P.ones = db ? 1 : 0;
   P.dW = dW; P.ldw = ldw; P.db = db; P.db2 = db ? db2 : nullptr; P.accumulate = accumulate; P.pre = 0;

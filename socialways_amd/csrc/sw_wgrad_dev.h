@@ -90,9 +90,15 @@ __device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const fl
 #else
     const int rc = min(r0 + lg, rmax);
 #endif
-    wg_ldv<NA>(av, dbase + (size_t)rc * ldd + acol);
-    wg_ldv<KR>(bv, abase + (size_t)max(rc, row0) * lda + bcol);     // rows below row0 have no `act` operand
-    if constexpr (K2 > 0) xv = ld4(abase2 + (size_t)rc * lda2);      // the row's tail columns (same address for 16 lanes)
+    // 32-bit element offsets (the host rejects a problem whose rows x stride reach 2^31): one multiply-add per load
+    // instead of a 64-bit multiply-add + shift-add
+    wg_ldv<NA>(av, dbase + (unsigned)(rc * ldd + acol));
+    if constexpr (K2 > 0) {
+      wg_ldv<KR>(bv, abase + (unsigned)(max(rc, row0) * lda + bcol));   // rows below row0 have no `act` operand
+      xv = ld4(abase2 + (unsigned)(rc * lda2));                          // the row's tail columns (same address for 16 lanes)
+    } else {
+      wg_ldv<KR>(bv, abase + (unsigned)(rc * lda + bcol));              // (row0 = 0 without a tail segment)
+    }
   };
 #pragma unroll
   for (int q = 0; q < DEPTH - 1; ++q) load(rbeg + 4 * q, a[q], b[q], xq[q]);
@@ -113,12 +119,17 @@ __device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const fl
       if constexpr (K2 > 0) asm volatile("" : "+v"(xq[q]));
       const int rr = r + 4 * q + lg;
       const float rs = rr < rend ? 1.0f : 0.0f;
-      const float rs0 = rr >= row0 ? 1.0f : 0.0f;
       float av[NA], bv[KT];
 #pragma unroll
       for (int i = 0; i < NA; ++i) av[i] = a[q][i] * rs;
+      if constexpr (K2 > 0) {       // only problems with a tail segment have rows without an `act` operand (row0 > 0)
+        const float rs0 = rr >= row0 ? 1.0f : 0.0f;
 #pragma unroll
-      for (int kt = 0; kt < KR; ++kt) bv[kt] = b[q][kt] * rs0;
+        for (int kt = 0; kt < KR; ++kt) bv[kt] = b[q][kt] * rs0;
+      } else {
+#pragma unroll
+        for (int kt = 0; kt < KR; ++kt) bv[kt] = b[q][kt];
+      }
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
 #pragma unroll
