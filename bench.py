@@ -4,6 +4,7 @@
                     [--no-cpu-baseline] [--no-other-workloads]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          (no launcher: the N ranks are started by self_launch() the same way)
 
 One "step" = the body of the reference's train() for one packed batch (train.py:458-554): generator
 rollout with the pairwise social block, 2 discriminator updates, 1 generator update (LSGAN + InfoGAN
@@ -162,6 +163,58 @@ def cpu_baseline(tracks, S, A, To, Tp, budget_s=10.0):
     return res
 
 
+def self_launch(n):
+    """`python bench.py --gpus N ...` without a launcher's environment (WORLD_SIZE unset): re-run this command line as
+    N ranks of ONE node under torch.distributed.run - one process per GPU, rendezvous on 127.0.0.1 at a free port -
+    and return its exit code; rank 0 of that job prints the JSON line.  RCCL needs every rank on its own device, so a
+    box with fewer than N GPUs is refused here (SW_BENCH_BACKEND=gloo lets ranks share devices: a plumbing rehearsal,
+    never a measurement)."""
+    import socket
+    import subprocess
+    backend = os.environ.get("SW_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and "--launch-check" not in sys.argv and torch.cuda.device_count() < n:
+        print("bench.py: --gpus %d needs %d visible GPUs (found %d); RCCL ranks cannot share a device"
+              % (n, n, torch.cuda.device_count()), file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "8")      # the launcher would set 1: z is drawn on the host every step
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(world, rank, args):
+    """--launch-check: the N-rank launch, rendezvous, barrier and max-over-ranks plumbing of this file with NO training
+    step (runs without a GPU, gloo): rank 0 prints one JSON line with value null - a rehearsal of the driver's command,
+    not a measurement."""
+    backend = os.environ.get("SW_BENCH_BACKEND", "gloo" if not torch.cuda.is_available() else "nccl")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            torch.distributed.init_process_group(backend)
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        torch.distributed.barrier()
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        ranks_seen = int(t.item())
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    else:
+        ranks_seen = 1
+    if rank == 0:
+        print(json.dumps({"metric": "launch check (no training step ran)", "value": None, "unit": "steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "launch_check": True, "backend": backend,
+                          "ranks_seen": ranks_seen}), flush=True)
+    return 0
+
+
 class Leg:
     """One workload on this rank: trainer, resident synthetic batches and the stepping closures."""
 
@@ -260,20 +313,25 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained leg")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only launch / rendezvous / reduce over the N ranks (no GPU needed), print a JSON line with value null")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))        # plain `python bench.py --gpus N`: start the N ranks ourselves
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                         % (args.gpus, args.gpus))
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit("--gpus %d but the launcher's WORLD_SIZE is %d" % (args.gpus, world))
+    if args.launch_check:
+        return launch_check(world, rank, args)
     ndev = torch.cuda.device_count()
     local = local % max(ndev, 1)               # SW_BENCH_BACKEND=gloo lets several ranks share one GPU (plumbing test)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    pg = None
+    pg, backend = None, None
     if world > 1 or os.environ.get("SW_FORCE_DIST", "") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -425,7 +483,9 @@ def main():
                                      "steps": n, "steps_s": n / d, "ms_per_step": 1e3 * d / n,
                                      "delta_us_per_step": 1e3 * (1e3 * d / n - 1e3 * dt / args.steps),
                                      "collectives": "in-graph" if lg.tr._graph_collectives else "between graph segments",
-                                     "implied_weak_scaling_ceiling": (dt / args.steps) / (d / n)}
+                                     # plain-path time / 1-rank-group time: what the DP step STRUCTURE costs with no peer
+                                     # on the wire - says nothing about N > 1 (no wire latency is in it)
+                                     "plain_over_dp1_time_ratio": (dt / args.steps) / (d / n)}
                 lg.tr.release_graphs()
                 del lg
                 torch.distributed.destroy_process_group()
@@ -493,6 +553,7 @@ def main():
                                     % (args.workload, leg.S_global, A, leg.Bg, world)),
                        "global_batch_scenes": leg.S_global, "parallelism": "dp%d" % world, "steps_per_graph_launch": KG, "settle_steps": SETTLE,
                        "collectives": collectives, "rccl_ranks": (world if pg is not None else None),
+                       "backend": backend,       # "nccl" = RCCL; "gloo" = ranks sharing devices, a rehearsal, not a measurement
                        "allreduces_per_step": (3 if pg is not None else 0),
                        "replicas_identical": replicas_identical,
                        "step_alg_gflop": fl["step"] / 1e9,

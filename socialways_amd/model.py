@@ -461,11 +461,13 @@ class EmbedSocialFeatures(_Packed):
 class EncoderLstm(_Packed):
     _GRP = L.GRP_ENC
 
-    def __new__(cls, hidden_size=64, n_layers=2, device=None):
+    def __new__(cls, hidden_size=None, n_layers=2, device=None):
         # The fused kernels are built for ONE layer of <= 64 units (what train.py:82 constructs).  The class signature's
         # default of 2 stacked layers (train.py:246) and wider encoders are served by the generic-width module: same
         # parameters / state_dict keys / initialisation, its steps run layer by layer through the C-ABI pieces.
-        if cls is EncoderLstm and (n_layers != 1 or hidden_size > 64):
+        # copy.deepcopy / pickle / torch.load rebuild an object with cls.__new__(cls) and NO arguments: that is not a
+        # constructor call and must give a bare instance of THIS class (hidden_size is None only on that path).
+        if cls is EncoderLstm and hidden_size is not None and (n_layers != 1 or hidden_size > 64):
             from . import generic
             return generic.EncoderLstm(hidden_size, n_layers, device)
         return super().__new__(cls)

@@ -163,7 +163,8 @@ class SocialWaysTrainer:
     def __new__(cls, n_next=None, hidden_size=64, *args, **kw):
         """Widths above the fused kernels' 64 units and latent-code counts other than 2 (train.py:42-44, 65) train on
         the generic-width path (generic.py: the same model layer by layer, same public surface)."""
-        if cls is SocialWaysTrainer and (int(hidden_size) > 64 or int(kw.get("n_latent_codes", 2)) != 2):
+        nl = kw.get("n_latent_codes", args[6] if len(args) > 6 else 2)      # positional slot 9 of __init__'s signature
+        if cls is SocialWaysTrainer and (int(hidden_size) > 64 or int(nl) != 2):
             from .generic import GenericTrainer
             return object.__new__(GenericTrainer)
         return object.__new__(cls)

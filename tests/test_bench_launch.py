@@ -1,0 +1,59 @@
+"""The driver's plain command `python bench.py --gpus N --steps K --warmup W` must start its own N ranks (one process
+per GPU under torch.distributed.run, 127.0.0.1, a free port) and have rank 0 print exactly one JSON line.
+CPU leg: the launch / rendezvous / reduce plumbing alone (`--launch-check`, gloo, no training step).
+GPU leg: the whole data-parallel bench with 2 gloo ranks sharing the test box's one GPU - a rehearsal of the N > 1
+command line, not a measurement (RCCL wants one device per rank; the 2-device RCCL tests are in test_gpu_trainer.py)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra, timeout):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)                       # the driver's N = 1 form of the command: no launcher environment
+    env.update(env_extra)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, cwd=ROOT, timeout=timeout,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, lines
+
+
+@pytest.mark.timeout(300)
+def test_plain_command_launches_its_own_ranks():
+    p, lines = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--launch-check"], {"SW_BENCH_BACKEND": "gloo"}, 280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["launch_check"] is True and rec["value"] is None
+
+
+@pytest.mark.timeout(120)
+def test_world_size_mismatch_is_refused():
+    p, lines = _run(["--gpus", "4", "--launch-check"], {"WORLD_SIZE": "2", "RANK": "0", "SW_BENCH_BACKEND": "gloo"}, 100)
+    assert p.returncode != 0 and not lines
+    assert "WORLD_SIZE" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_two_rank_bench_line_on_one_box():
+    """`python bench.py --gpus 2 --steps 4 --warmup 2` with SW_BENCH_BACKEND=gloo (both ranks on cuda:0): exit 0, one
+    JSON line, n_gpus = 2, three all-reduces per step, replicas bit-identical after the run."""
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    p, lines = _run(["--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-other-workloads",
+                     "--no-sustained"], {"SW_BENCH_BACKEND": backend, "SW_BENCH_SETTLE_STEPS": "8"}, 850)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["steps"] == 4
+    cfg = rec["config"]
+    assert cfg["rccl_ranks"] == 2 and cfg["allreduces_per_step"] == 3 and cfg["replicas_identical"] is True
+    assert cfg["backend"] == backend
+    assert rec["value"] > 0 and abs(rec["value"] - 2 * 1e3 / rec["ms_per_step"]) < 1e-6 * rec["value"]

@@ -180,3 +180,29 @@ def test_smaller_hidden_sizes_are_zero_padded_with_the_reference_initialisation(
     assert isinstance(sw.EncoderLstm(128, 1), generic.EncoderLstm)      # above 64 units: the generic-width module
     with pytest.raises(sw.SocialWaysHipError, match="generic"):
         sw.DecoderFC(128 + 128 + 64)
+
+
+def test_fused_encoder_survives_deepcopy_and_pickle():
+    """copy / pickle rebuild a module through cls.__new__(cls) without arguments: the fused EncoderLstm must come back as
+    itself (not as the generic-width module its constructor dispatches to for 2 layers / wide sizes), consuming no RNG."""
+    import copy
+    import io
+    import socialways_amd as sw
+    from socialways_amd import generic, model
+    torch.manual_seed(3)
+    enc = model.EncoderLstm(64, 1)
+    st = torch.get_rng_state()
+    twin = copy.deepcopy(enc)
+    assert type(twin) is model.EncoderLstm and torch.equal(torch.get_rng_state(), st)
+    assert all(torch.equal(a, b) for a, b in zip(enc.state_dict().values(), twin.state_dict().values()))
+    buf = io.BytesIO()
+    torch.save(enc, buf)
+    buf.seek(0)
+    assert type(torch.load(buf, weights_only=False)) is model.EncoderLstm
+    g = copy.deepcopy(model.Generator(64, 1, use_social=True))
+    assert type(g.encoder) is model.EncoderLstm
+    # explicit constructor calls still dispatch: the class default of 2 layers and wide encoders are generic-width modules
+    assert type(model.EncoderLstm(64)) is generic.EncoderLstm and type(model.EncoderLstm(128, 1)) is generic.EncoderLstm
+    # n_latent_codes given positionally reaches the generic trainer like the keyword does
+    t = sw.SocialWaysTrainer.__new__(sw.SocialWaysTrainer, 12, 64, 1e-4, 1e-3, 1, True, True, 0.5, 3)
+    assert type(t) is generic.GenericTrainer
