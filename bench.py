@@ -47,8 +47,11 @@ WORKLOADS = {   # name -> (scenes per GPU step, agents per scene, To, Tp)
     "m1": (256, 8, 8, 12),     # BASELINE metric shape: --batch-size 2048
     "c2": (32, 8, 8, 12),      # BASELINE config 2: --batch-size 256
     "c4": (512, 64, 8, 12),    # dense crowd: 32768 agents, 2.1M pairs
+    # BASELINE config 3's SHAPE (ETH-hotel: <= 8 agents per scene; the recordings themselves are not in the image): one
+    # packed batch of 2048 agents in scenes of 1..8 agents (data.ragged_scene_sizes), A = None marks the ragged layout
+    "c3_ragged": (None, None, 8, 12),
 }
-OTHER_STEPS = {"m1": (100, 12), "c2": (100, 12), "c4": (24, 8)}     # (steps, warm-up) of a short leg
+OTHER_STEPS = {"m1": (100, 12), "c2": (100, 12), "c4": (24, 8), "c3_ragged": (100, 12)}     # (steps, warm-up) of a short leg
 PEAK_HBM_BPS = 8.0e12          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_FP32_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / VALU fp32 peak
 N_BATCHES = 8                  # distinct packed batches cycled through
@@ -227,6 +230,20 @@ class Leg:
         torch.manual_seed(0)                      # identical replicas on every rank
         np.random.seed(0)
         self.tr = sw.SocialWaysTrainer(Tp, use_social=True, device=dev, process_group=pg, **trainer_kw)
+        if A is None:      # ragged layout: every packed batch has the same scene sizes (one graph layout), different tracks
+            sizes = sw.ragged_scene_sizes(2048, 8, seed=77)
+            tracks = sw.synth_tracks(len(sizes) * N_BATCHES, sizes * N_BATCHES, To, Tp, seed=1234 + rank)
+            self.tracks = tracks
+            self.data = sw.SceneDataset(tracks["obsvs"], tracks["preds"], tracks["batches"], device=dev)
+            self.S_local, self.B = len(sizes), int(np.sum(sizes))
+            self.Bg, self.S_global, self.row0, self.stride = self.B * world, len(sizes) * world, 0, self.B
+            self.P = int(sum(a * a for a in sizes if a > 1))
+            self.sb = np.asarray(tracks["batches"][:len(sizes)], dtype=np.int64)
+            self.sizes = sizes
+            self.last = None
+            self._zring = [torch.empty(self.B, self.tr.noise_len) for _ in range(2 * max(KG, 1) + 2)]
+            self._zi = 0
+            return
         if scaling == "strong":
             # the same global dataset on every rank; this rank's rows = its scene-aligned shard of every packed batch
             Sg = global_scenes
@@ -307,7 +324,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="m1", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="m1", choices=[k for k in sorted(WORKLOADS) if WORKLOADS[k][1] is not None])   # c3_ragged: a side leg only
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--global-scenes", type=int, default=2048, help="--scaling strong: scenes of the ONE global packed batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -461,7 +478,10 @@ def main():
             d = short_leg(lg, n, w)
             fl_o = alg_flops(lg.B, lg.P, lg.To, lg.Tp)
             S_o, A_o = WORKLOADS[name][:2]
-            other[name] = {"workload": "%d scenes x %d agents x %d+%d" % (S_o, A_o, lg.To, lg.Tp), "steps": n, "warmup": w,
+            wl = ("%d scenes x %d agents x %d+%d" % (S_o, A_o, lg.To, lg.Tp)) if A_o is not None else \
+                 ("%d scenes of 1..8 agents (%d agents, %d in-scene pairs, %d single-agent scenes) x %d+%d: the SHAPE of a real "
+                  "ETH/UCY packed batch, synthetic tracks" % (lg.S_local, lg.B, lg.P, sum(a == 1 for a in lg.sizes), lg.To, lg.Tp))
+            other[name] = {"workload": wl, "steps": n, "warmup": w,
                            "steps_s": n / d, "ms_per_step": 1e3 * d / n, "step_alg_gflop": fl_o["step"] / 1e9,
                            "step_frac_of_fp32_peak": fl_o["step"] / (d / n) / (PEAK_FP32_TFLOPS * 1e12)}
             del lg
@@ -502,6 +522,29 @@ def main():
             other["m1_variety_k20"] = {"workload": "m1 + best-of-20 variety loss (use_variety_loss='fixed'): decode loop on 40 960 agent copies, encoder and social block once on the 2 048 agents",
                                        "steps": n, "steps_s": n / d, "ms_per_step": 1e3 * d / n}
             del lg
+            # the evaluation pass test() exists for - K = 20 sampled futures per held-out scene, min / avg ADE
+            # and FDE (train.py:563-616) - on the m1-shaped recording's held-out fifth (scenes folded into rollout launches)
+            torch.cuda.empty_cache()
+            import socialways_amd as sw
+            torch.manual_seed(0)
+            tr_e = sw.SocialWaysTrainer(Tp, use_social=True, device=dev)
+            tk = sw.synth_tracks(1280, 8, To, Tp, seed=4321)
+            data_e = sw.SceneDataset(tk["obsvs"], tk["preds"], tk["batches"], device=dev)
+            tr_e.test(data_e, 20)
+            fence()
+            t_best = float("inf")
+            for _ in range(3):
+                t0 = time.perf_counter()
+                res_e = tr_e.test(data_e, 20)
+                fence()
+                t_best = min(t_best, time.perf_counter() - t0)
+            n_sc = len(data_e.test_batches)
+            other["test_k20"] = {"workload": "test(): K = 20 sampled futures for each of %d held-out scenes x 8 agents (%d agents), "
+                                             "min / avg ADE and FDE; scenes folded into launches of <= %d agent copies"
+                                             % (n_sc, data_e.n_test_samples, tr_e.TEST_CHUNK),
+                                 "seconds": t_best, "scenes_s": n_sc / t_best, "rollouts_s": 20 * data_e.n_test_samples / t_best,
+                                 "ade_avg_min": [res_e[0], res_e[2]], "fde_avg_min": [res_e[1], res_e[3]]}
+            del tr_e, data_e
 
     if rank == 0:
         S = leg.S_local

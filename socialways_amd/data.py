@@ -100,6 +100,18 @@ def synth_tracks(n_scenes, agents, n_past=8, n_next=12, seed=1234):
     return dict(obsvs=track[:, :n_past], preds=track[:, n_past:], times=times, batches=batches)
 
 
+def ragged_scene_sizes(n_agents=2048, max_agents=8, seed=77):
+    """Scene sizes of a real-shaped packed batch: ETH/UCY recordings hold 1..8 pedestrians per timestamp and
+    train.py:446-461 packs whole scenes up to --batch-size agents; uniform 1..max_agents until the batch holds exactly
+    `n_agents` agents (single-agent scenes included)."""
+    rng = np.random.default_rng(seed)
+    sizes = []
+    while sum(sizes) < n_agents:
+        sizes.append(int(rng.integers(1, max_agents + 1)))
+    sizes[-1] -= sum(sizes) - n_agents
+    return [a for a in sizes if a > 0]
+
+
 def toy_tracks(n_samples=768, n_conditions=8, n_modes=3, n_per_batch=6, seed=30):
     """The toy multi-modal set of create_toy.py:11-54 + its npz packing (:162-187): 4-point tracks
     (2 observed + 2 to predict) approaching the origin from `n_conditions` directions and turning

@@ -794,49 +794,69 @@ class SocialWaysTrainer:
         return torch.zeros(self.n_unrolling_steps + 3, 3, device=self.device, dtype=torch.float64)
 
     # ------------------------------------------------------------------------------------------
+    TEST_CHUNK = 16384      # agent copies (K x agents) per rollout launch of test(): scenes are folded up to this many
+
     def test(self, data, n_gen_samples=20, linear=False, write_to_file=None, just_one=False, collect=None):
         """test() (train.py:563-616): K sampled futures per held-out scene, avg / min-over-K ADE & FDE,
         optional prediction npz ('<epoch>-<t>.npz': timestamp, obsvs, preds_our, preds_gtt, preds_lnr,
         all denormalised - the schema visualize.py / calc_statistics.py read).  The K rollouts of a
         scene are independent given the noise, so they run as ONE batch of K*n agents with K copies
-        of the scene (identical results, K times fewer launches)."""
+        of the scene, and consecutive held-out scenes are folded into the same launch (block-diagonal social
+        block: a scene's rollout does not depend on its neighbours in the batch) up to TEST_CHUNK agent copies:
+        identical rollouts, one launch sequence and one host sync per chunk instead of per scene.  The noise is
+        drawn scene by scene, K draws of (n, noise_len) each, in the reference's order (train.py:584)."""
         ss, dev, K = data.ss, self.device, n_gen_samples
-        ade_avg = fde_avg = ade_min = fde_min = 0.0
-        for ii, batch_i in enumerate(data.test_batches):
-            obsv = data.obsv[batch_i[0]:batch_i[1]]
-            pred = data.pred[batch_i[0]:batch_i[1]]
-            bs = int(batch_i[1] - batch_i[0])
+        sums = torch.zeros(4, dtype=torch.float64, device=dev)          # ade_avg, fde_avg, ade_min, fde_min
+        batches = [(int(b[0]), int(b[1])) for b in data.test_batches]
+        if just_one:
+            batches = batches[:1]
+        i = 0
+        while i < len(batches):
+            j, tot = i + 1, batches[i][1] - batches[i][0]
+            while (j < len(batches) and batches[j][0] == batches[j - 1][1]
+                   and (tot + batches[j][1] - batches[j][0]) * K <= self.TEST_CHUNK):
+                tot += batches[j][1] - batches[j][0]
+                j += 1
+            lo, hi = batches[i][0], batches[j - 1][1]
+            obsv, pred = data.obsv[lo:hi], data.pred[lo:hi]
+            n = hi - lo
             with torch.no_grad():
                 linear_preds = predict_cv(obsv, self.n_next)
                 if linear and not write_to_file:
                     preds_k = linear_preds.unsqueeze(0)
                     errs = torch.pow((linear_preds[:, :, :2] - pred) / ss, 2).sum(dim=2, keepdim=True).sqrt().unsqueeze(0)
                 else:
-                    noise = torch.cat([torch.rand(bs, self.noise_len) for _ in range(K)]).to(dev)   # train.py:584
-                    sb = np.stack([np.arange(K) * bs, (np.arange(K) + 1) * bs], axis=1)
-                    ph = self.G(obsv.repeat(K, 1, 1), noise, self.n_next, sb).view(K, bs, self.n_next, 4)
+                    # copy k of scene s sits at rows k * n + (scene rows): K copies of the chunk, each copy its scenes
+                    noise = torch.empty(K, n, self.noise_len)
+                    for a, b in batches[i:j]:
+                        for k in range(K):
+                            noise[k, a - lo:b - lo] = torch.rand(b - a, self.noise_len)      # train.py:584, scene by scene
+                    sb1 = np.asarray([[a - lo, b - lo] for a, b in batches[i:j]], dtype=np.int64)
+                    sb = np.concatenate([sb1 + k * n for k in range(K)])
+                    ph = self.G(obsv.repeat(K, 1, 1), noise.view(K * n, -1).to(dev), self.n_next, sb).view(K, n, self.n_next, 4)
                     preds_k = ph
                     errs = torch.pow((ph[:, :, :, :2] - pred.unsqueeze(0)) / ss, 2).sum(dim=3, keepdim=True).sqrt()
                 if write_to_file or collect is not None:
                     sc = data.scale
-                    t = data.times[batch_i[0]] if data.times is not None else ii
-                    rec = dict(timestamp=t, obsvs=sc.denormalize(obsv[:, :, :2].cpu().numpy()),
-                               preds_our=sc.denormalize(preds_k[:, :, :, :2].cpu().numpy()),
-                               preds_gtt=sc.denormalize(pred[:, :, :2].cpu().numpy()),
-                               preds_lnr=sc.denormalize(linear_preds[:, :, :2].cpu().numpy()))
-                    if collect is not None:
-                        collect.append(rec)
-                    if write_to_file:
-                        os.makedirs(write_to_file, exist_ok=True)
-                        np.savez(os.path.join(write_to_file, str(self.epoch) + '-' + str(t) + '.npz'), **rec)
-                fde_min += errs[:, :, -1].min(0, keepdim=True)[0].sum().item()
-                ade_min += errs.mean(2).min(0, keepdim=True)[0].sum().item()
-                fde_avg += errs[:, :, -1].mean(0, keepdim=True).sum().item()
-                ade_avg += errs.mean(2).mean(0, keepdim=True).sum().item()
-            if just_one:
-                break
+                    for si, (a, b) in enumerate(batches[i:j]):
+                        t = data.times[a] if data.times is not None else i + si
+                        r = slice(a - lo, b - lo)
+                        rec = dict(timestamp=t, obsvs=sc.denormalize(obsv[r, :, :2].cpu().numpy()),
+                                   preds_our=sc.denormalize(preds_k[:, r, :, :2].cpu().numpy()),
+                                   preds_gtt=sc.denormalize(pred[r, :, :2].cpu().numpy()),
+                                   preds_lnr=sc.denormalize(linear_preds[r, :, :2].cpu().numpy()))
+                        if collect is not None:
+                            collect.append(rec)
+                        if write_to_file:
+                            os.makedirs(write_to_file, exist_ok=True)
+                            np.savez(os.path.join(write_to_file, str(self.epoch) + '-' + str(t) + '.npz'), **rec)
+                e = errs.double()
+                sums += torch.stack([e.mean(2).mean(0).sum(), e[:, :, -1].mean(0).sum(),
+                                     e.mean(2).min(0)[0].sum(), e[:, :, -1].min(0)[0].sum()])
+            i = j
         n = data.n_test_samples
-        return ade_avg / n, fde_avg / n, ade_min / n, fde_min / n
+        ade_avg, fde_avg, ade_min, fde_min = (sums / n).tolist()
+        return ade_avg, fde_avg, ade_min, fde_min
 
     # ------------------------------------------------------------------------------------------
     def checkpoint(self, epoch=None):

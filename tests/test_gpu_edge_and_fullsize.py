@@ -259,10 +259,16 @@ def _step_vs_oracle(S, A, seed, grads_rtol, frac_ok=0.999):
     (relative to each tensor's largest entry: fp32 sums over up to 2.1 M pairs on both sides) and the weights after
     Adam (elementwise within ~lr, see tests/test_gpu_trainer.py::check_weights)."""
     import socialways_amd as sw
-    t = sw.synth_tracks(S + 2, A, 8, 12, seed=seed)
+    if np.isscalar(A):
+        t = sw.synth_tracks(S + 2, A, 8, 12, seed=seed)
+        B = S * A
+    else:                      # ragged: per-scene agent counts
+        assert len(A) == S
+        t = sw.synth_tracks(S, list(A), 8, 12, seed=seed)
+        B = int(np.sum(A))
     data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
     tr, orc = pair(12)
-    B, sb = S * A, data.the_batches[:S]
+    sb = data.the_batches[:S]
     torch.manual_seed(4)
     noise = torch.rand(B, 32)
     rec = {}
@@ -310,6 +316,22 @@ def _step_vs_oracle(S, A, seed, grads_rtol, frac_ok=0.999):
             close = float((d <= 0.05 * lr + 1e-6 * ref[k].abs()).float().mean())
             assert close >= frac_ok, "%s.%s: only %.4f of the elements within 5 %% of lr" % (name, k, close)
     return tr, data, sb, B
+
+
+def test_m1_training_step_gradients_and_weights_match_oracle():
+    """The BASELINE metric shape itself (256 scenes x 8 agents = 2 048 agents: exactly 128 agent tiles, the one-launch
+    discriminator update, weight-gradient jobs sized for <= 256 CUs): gradients at identical weights and the weights after
+    the step, as for c2 / c4."""
+    _step_vs_oracle(256, 8, 11, 2e-4)
+
+
+def test_c3_ragged_real_shaped_step_matches_oracle():
+    """A packed batch shaped like the real recordings: ~455 scenes of 1..8 agents (single-agent scenes included), 2 048
+    agents - tiles that straddle scenes, half-empty social tiles, scenes that own no pairs."""
+    import socialways_amd as sw
+    sizes = sw.ragged_scene_sizes(2048, 8, seed=77)
+    assert min(sizes) == 1 and max(sizes) == 8 and sum(sizes) == 2048
+    _step_vs_oracle(len(sizes), sizes, 13, 2e-4)
 
 
 def test_c2_training_step_matches_oracle():
