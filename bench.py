@@ -112,6 +112,20 @@ def kernel_src_sha16():
     return h.hexdigest()[:16]
 
 
+def pmc_record(workload, weak=True):
+    """The committed PMC pass of this workload (profiles/r*_pmc_<workload>.json, newest round first) IF it was taken with
+    exactly these kernel sources (sha256 of csrc/*.h*); else None.  It carries HBM bytes per launch / per step and the
+    EXECUTED matrix FLOP per launch / per step (64 x SQ_VALU_MFMA_BUSY_CYCLES, tools/pmc_traffic.py)."""
+    sha = kernel_src_sha16()
+    for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % workload)), reverse=True):
+        rec = json.load(open(pmc))
+        meta = rec.get("_meta", {})
+        if meta.get("kernel_src_sha16") == sha and weak:
+            rec["_file"] = os.path.relpath(pmc, ROOT)
+            return rec
+    return None
+
+
 def _time_oracle(orc, obsv, pred, sb, noise, ss, budget_s, max_steps):
     orc.train_step(obsv, pred, sb, 0.05, 0.95, noise, ss)               # warm-up
     n, t0 = 0, time.perf_counter()
@@ -483,7 +497,13 @@ def main():
                   "ETH/UCY packed batch, synthetic tracks" % (lg.S_local, lg.B, lg.P, sum(a == 1 for a in lg.sizes), lg.To, lg.Tp))
             other[name] = {"workload": wl, "steps": n, "warmup": w,
                            "steps_s": n / d, "ms_per_step": 1e3 * d / n, "step_alg_gflop": fl_o["step"] / 1e9,
+                           # reference-formulation FLOPs / time: CREDITS work the kernels eliminate algebraically
                            "step_frac_of_fp32_peak": fl_o["step"] / (d / n) / (PEAK_FP32_TFLOPS * 1e12)}
+            rec_o = pmc_record(name)
+            ex = rec_o and rec_o.get("_step", {}).get("mfma_flop_per_step")
+            # matrix FLOP the kernels really issued per step (SQ counter pass of these sources) / this leg's time
+            other[name]["step_executed_mfma_gflop"] = ex / 1e9 if ex else None
+            other[name]["step_frac_executed"] = ex / (d / n) / (PEAK_FP32_TFLOPS * 1e12) if ex else None
             del lg
         # The data-parallel step structure at N = 1 - the only scaling evidence a 1-GPU box can give: the same workload on a
         # 1-rank RCCL group (SW_FORCE_DIST: all three all-reduces are issued, the Adam updates run behind them as kernels
@@ -566,17 +586,19 @@ def main():
         achieved = (top["alg_gflop_per_step"] or float("nan")) * 1e9 / (top["us_per_step"] * 1e-6) / 1e12
         # HBM traffic: from the committed PMC pass (separate --pmc runs, tools/collect_profiles.sh) - valid only for the
         # kernel sources it was taken with (same sha) and this workload; otherwise null
-        traffic, step_traffic, traffic_src = None, None, None
+        traffic, step_traffic, traffic_src, step_exec = None, None, None, None
         sha = kernel_src_sha16()
-        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % args.workload)), reverse=True):
-            rec = json.load(open(pmc))
-            meta = rec.get("_meta", {})
-            if meta.get("kernel_src_sha16") == sha and args.scaling == "weak":
-                by_kernel = {v.get("kernel", "").replace("void ", "").split("<")[0]: v for k, v in rec.items() if not k.startswith("_")}
-                traffic = by_kernel.get(top["name"], {}).get("hbm_bytes_per_launch")
-                step_traffic = rec.get("_step", {}).get("hbm_bytes_per_step")
-                traffic_src = {"file": os.path.relpath(pmc, ROOT), "commit": meta.get("commit"), "kernel_src_sha16": sha}
-                break
+        rec = pmc_record(args.workload, args.scaling == "weak")
+        if rec is not None:
+            by_kernel = {v.get("kernel", "").replace("void ", "").split("<")[0]: v for k, v in rec.items() if not k.startswith("_")}
+            traffic = by_kernel.get(top["name"], {}).get("hbm_bytes_per_launch")
+            step_traffic = rec.get("_step", {}).get("hbm_bytes_per_step")
+            step_exec = rec.get("_step", {}).get("mfma_flop_per_step")
+            traffic_src = {"file": rec["_file"], "commit": rec.get("_meta", {}).get("commit"), "kernel_src_sha16": sha}
+            for r in rows:      # EXECUTED matrix work next to the reference-formulation credit, per kernel
+                ex = by_kernel.get(r["name"], {}).get("mfma_flop_per_launch")
+                r["executed_mfma_gflop_per_step"] = ex * r["launches_per_step"] / 1e9 if ex is not None else None
+                r["frac_executed"] = (ex * r["launches_per_step"] / (r["us_per_step"] * 1e-6) / (PEAK_FP32_TFLOPS * 1e12)) if ex is not None else None
         if traffic_src is None:
             traffic_src = {"file": None, "kernel_src_sha16": sha,
                            "note": "no PMC pass under profiles/ matches these kernel sources / this workload"}
@@ -619,6 +641,13 @@ def main():
                          # for the kernel's own duration; `frac` is computed from the RAW times (conservative)
                          "event_overhead_us": event_overhead_us,
                          "eager_step_kernel_us": sum(r["us_per_step"] for r in rows),
+                         # `frac` / step_frac_of_fp32_peak count the REFERENCE formulation's FLOPs and so credit work
+                         # the kernels eliminate; *_executed = matrix FLOP really issued (64 x SQ_VALU_MFMA_BUSY_CYCLES of the
+                         # committed SQ pass of these kernel sources) over the same measured times: pipe USE, never above 1
+                         "step_frac_reference_formulation": fl["step"] / per_step / (PEAK_FP32_TFLOPS * 1e12),
+                         "step_executed_mfma_gflop": (step_exec / 1e9) if step_exec else None,
+                         "step_frac_executed": (step_exec / per_step / (PEAK_FP32_TFLOPS * 1e12)) if step_exec else None,
+                         "frac_executed": top.get("frac_executed"),
                          "traffic": traffic, "step_traffic": step_traffic,
                          "step_traffic_vs_algorithmic": (step_traffic / alg_bytes(B, To, Tp)) if step_traffic else None,
                          "traffic_source": traffic_src,

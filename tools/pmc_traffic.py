@@ -4,7 +4,11 @@ half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) - vali
 reads (saved LSTM rows + a1/a2) are 58 MB by construction vs 2 x 27.4 MB counted.
 `_step` = per-step totals: sum over kernels of (mean bytes per launch) x (launches per step; counted against the one
 dec_rollout_fwd launch every step has).
-    python tools/pmc_traffic.py fetch.db write.db out.json"""
+Optional 4th argument: the SQ pass (SQ_VALU_MFMA_BUSY_CYCLES summed over the SIMDs).  A SIMD's matrix pipe retires 64 fp32
+FLOP per busy cycle (v_mfma_f32_16x16x4_f32: 2048 FLOP per 32-cycle issue slot), so EXECUTED matrix FLOP per launch = 64 x
+busy cycles - what the kernels really issued, next to the reference-formulation FLOP counts of bench.kernel_alg_flops (which
+credit work the kernels eliminate algebraically).  VALU arithmetic (gate non-linearities, tail columns) is not in it.
+    python tools/pmc_traffic.py fetch.db write.db out.json [sq.db]"""
 import glob
 import hashlib
 import json
@@ -36,7 +40,9 @@ abi = {"dec_rollout_bwd_kernel": "sw_dec_rollout_bwd", "dec_rollout_fwd_kernel":
        "social_pool_bwd_rows_kernel": "sw_social_pool_bwd_rows", "stage_step_kernel": "sw_stage_step",
        "enc_compose_bwd_kernel": "enc_compose_bwd"}
 steps = max(nf.get("dec_rollout_fwd_kernel", 1), 1)
-out, step_bytes, step_k = {}, 0.0, {}
+mfma, nm = mean_counter(sys.argv[4], "SQ_VALU_MFMA_BUSY_CYCLES") if len(sys.argv) > 4 else ({}, {})
+sq_steps = max(nm.get("dec_rollout_fwd_kernel", 1), 1)
+out, step_bytes, step_k, step_mfma = {}, 0.0, {}, 0.0
 for k in sorted(set(fetch) | set(write)):
     if "at::" in k or "rocclr" in k or k in ("spin_kernel", "nop_kernel", "traj4d_kernel", "gen_images_kernel", "disc_images_kernel"):
         continue            # torch's own kernels and helpers that are not part of a replayed step
@@ -48,16 +54,24 @@ for k in sorted(set(fetch) | set(write)):
                  "hbm_bytes_per_launch": int(per_launch), "launches_per_step": round(lps, 3)}
     step_bytes += per_launch * lps
     step_k[k] = int(per_launch * lps)
+    if k in mfma:
+        out[name]["mfma_busy_cycles_per_launch"] = int(mfma[k])
+        out[name]["mfma_flop_per_launch"] = int(64 * mfma[k])
+        step_mfma += 64 * mfma[k] * nm[k] / sq_steps
 out["_step"] = {"hbm_bytes_per_step": int(step_bytes), "by_kernel": step_k, "steps_counted": steps}
+if mfma:
+    out["_step"]["mfma_flop_per_step"] = int(step_mfma)
 # identity of the kernel sources this pass was taken with: bench.py reports `roofline.traffic` only while they match
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 h = hashlib.sha256()
 for f in sorted(glob.glob(os.path.join(root, "socialways_amd", "csrc", "*.h*"))):
     h.update(open(f, "rb").read())
-try:
-    commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
-except Exception:
-    commit = os.environ.get("SW_COMMIT", "unknown")
+commit = os.environ.get("SW_COMMIT")          # the GPU box has no .git: tools/collect_profiles.sh is given the commit
+if not commit:
+    try:
+        commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        commit = "unknown"
 out["_meta"] = {"kernel_src_sha16": h.hexdigest()[:16], "commit": commit,
                 "units": "FETCH_SIZE / WRITE_SIZE in KiB; hbm_bytes_per_launch = (2 FETCH + WRITE) * 1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md)"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
