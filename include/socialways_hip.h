@@ -406,6 +406,43 @@ int sw_attn_pairs_bwd(const float* f, const float* wh, const float* h, const flo
 int sw_adam_packed(float* w, const float* g, float* m, float* v, long long n, const float* step, double lr, double beta1,
                    double beta2, double eps, int disc_Tp, void* stream);
 
+/* ---- WIDE path (socialways_amd/wide.py, csrc/sw_wide.hip): the model at hidden sizes H > 64, H % 16 == 0 (train.py:42-44,
+ *      76-81) as one launch per LSTM step and per decoder / head layer over all agents, explicit backward, deferred
+ *      weight gradients.  Replaces, per call, the stock-PyTorch ops behind nn.Linear / nn.LSTM / nn.LeakyReLU / nn.ReLU of
+ *      train.py:153-335 (forward and autograd backward).  All buffers row-major fp32, row strides in floats.            */
+/* y[r][n] = epi(sum_k x[r][k] w[n][k] + bias[n] + cin[r][n]; aux[r][n]); x element (r,k) at x + r*x_rs + k*x_cs, w element
+ * (n,k) at w + n*w_rs + k*w_cs; epi 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 / 4: multiply by ReLU' / LeakyReLU'(0.2) taken from
+ * the sign of aux (the layer's saved activation).  bias / cin / aux may be NULL.                                         */
+int sw_wide_gemm(const float* x, long long x_rs, int x_cs, const float* w, long long w_rs, int w_cs, const float* bias,
+                 const float* cin, int cin_ld, const float* aux, int aux_ld, long long R, int K, int N, float* y, int y_ld, int epi,
+                 void* stream);
+/* one nn.LSTM step on all B agents: pre = Wx x4 + b1 (+ b2) + Whh h_prev (Wx [4H][4], Whh [4H][H], gate blocks i f g o),
+ * gates [B][4H] = activated gates, c_out / h_out the new state (h also to h_out2 if given); h_prev / c_prev NULL = zeros */
+int sw_wide_lstm_fwd(const float* x4, int x_ld, const float* h_prev, int hp_ld, const float* c_prev, const float* Wx,
+                     const float* b1, const float* b2, const float* Whh, int B, int H, float* gates, float* c_out, float* h_out,
+                     int h_ld, float* h_out2, int h2_ld, void* stream);
+/* its backward: dh = dh_ext + dh_ext2 + dg_next WhhT^T (WhhT [H][4H]; any of the three may be NULL), cell backward with the
+ * saved gates / c / c_prev -> dgates [B][4H] (pre-activation gradients) and dc_out [B][H]                               */
+int sw_wide_lstm_bwd(const float* dh_ext, int dhe_ld, const float* dh_ext2, int dhe2_ld, const float* dg_next, const float* WhhT,
+                     const float* gates, const float* c, const float* c_prev, const float* dc_in, int B, int H, float* dgates,
+                     float* dc_out, void* stream);
+/* last decoder layer + integration of a decode step (train.py:330, 422-424): v = a3 W4^T + b4 (W4 [2][D3]), p += v,
+ * pred4_i[b*pred_ld] = x4_tm[b*4] = (p, v).  Backward of the step: dx4 = dg WxT^T (dg [B][H4] = dgates of the re-fed encoder
+ * step or NULL, WxT [4][H4]), dp_run += dpred.p + dx4.p, dv[b] = (dpred.v + dx4.v + dp_run, 0, 0), dz3 [B][D3] = dv W4       */
+int sw_wide_out_fwd(const float* a3, int D3, const float* W4, const float* b4, float* p, int B, float* pred4_i, int pred_ld,
+                    float* x4_tm, void* stream);
+int sw_wide_out_bwd(const float* dpred4_i, int pred_ld, const float* dg, const float* WxT, int H4, float* dp_run, int B, float* dv,
+                    const float* W4, int D3, float* dz3, void* stream);
+/* out[r][c] = sum_t in[t*t_stride + r*in_ld + c] */
+int sw_wide_sum_steps(const float* in, long long t_stride, int in_ld, int T, long long R, int C, float* out, int out_ld,
+                      void* stream);
+/* transposed copies of ntab matrices of one packed buffer: tab (device, ntab x {src offset, rows, cols, dst offset} int32, in
+ * floats), total_tiles = sum over the matrices of ceil(rows/32) ceil(cols/32); dst[dst_off + c*rows + r] = src[src_off + r*cols + c] */
+int sw_wide_transpose(const float* src, const int* tab, int ntab, int total_tiles, float* dst, void* stream);
+/* n weight-gradient problems dW[N][K] = delta^T act, db = column sums (desc: n x {delta, ldd, act, lda, R, N, K, dW, ldw, db}
+ * as 64-bit host values) through the grouped split-K GEMM; wgrad_ws = sw_workspace_floats(SW_WS_WGRAD, ...) floats       */
+int sw_wide_wgrad(const long long* desc, int n, float* wgrad_ws, void* stream);
+
 /* ---- measurement aids.  sw_kernel_timing(1): every kernel launch of the library is bracketed by two HIP events on its
  *      own stream (never inside a graph capture) until sw_kernel_timing(0); sw_kernel_timing_read(buf, cap) waits for
  *      the device and writes one line "kernel calls total_us" per kernel, returning the bytes needed.  sw_debug_spin

@@ -1,0 +1,625 @@
+// sw_wide.hip - the WIDE path: the reference's model at hidden sizes above the fused kernels' 64 units (`--hidden-size`,
+// train.py:42-44, 76-81: encoder / social / discriminator width H, noise H/2, decoder 2.5H -> 2.5H -> 1.25H -> 0.625H -> 2)
+// as TIME-STEP-level kernels: one launch per LSTM step (gate products + cell in one kernel) and per decoder layer
+// (product + bias + activation, or product + activation derivative on the way back), over all agents of the packed
+// batch at once, driven by socialways_amd/wide.py with an explicit backward pass (time-major saved rows, deferred
+// weight gradients through the grouped split-K GEMM of sw_wgrad.hip) and captured into one hipGraph per step.
+//
+// Why not the fused design: at 128 units W_hh alone is 256 KB - it fills the 512 registers per lane of a 4-wave
+// workgroup - and the decoder's 320 x 320 + 160 x 320 weights (600 KB) fit neither registers nor the 160 KB LDS next to
+// it, so a sequence kernel would stream 600 KB per tile and step from L2.  Here every product runs over the whole batch
+// (2048 agents = 32 row blocks x N / 64 column blocks of workgroups), weights are read once per workgroup through L1 /
+// L2, and the recurrence is carried by kernel boundaries.  Same tiling convention as the rest of the library
+// (sw_common.h): D[16 units][16 agents] += W[16 units][K] X[K][16 agents] on v_mfma_f32_16x16x4_f32, a wave owns 16
+// agents x 64 units (4 accumulators), lanes fetch float4s of their weight / activation rows (k = 16 j + 4 lg + r).
+#include "../../include/socialways_hip.h"
+#include "sw_common.h"
+#include "sw_wgrad.h"
+
+namespace {
+enum { EPI_NONE = 0, EPI_RELU = 1, EPI_LRELU = 2, EPI_DRELU = 3, EPI_DLRELU = 4 };
+
+__device__ __forceinline__ float epi_apply(float v, int epi, float aux) {
+  switch (epi) {
+    case EPI_RELU: return fmaxf(v, 0.f);
+    case EPI_LRELU: return sw_lrelu(v);
+    case EPI_DRELU: return aux > 0.f ? v : 0.f;
+    case EPI_DLRELU: return aux > 0.f ? v : 0.2f * v;
+  }
+  return v;
+}
+
+// y[r][n] = epi( sum_k x[r][k] w[n][k] + bias[n] + cin[r][n] ; aux[r][n] )
+//   x element (r, k) at x + r x_rs + k x_cs, w element (n, k) at w + n w_rs + k w_cs.  XV / WV: the operand has unit k
+//   stride, a row stride that is a multiple of 4 and K % 4 == 0 -> float4 loads (the model's layers); otherwise scalar
+//   loads with free strides (the 3-wide pair features, transposed operands of the small composition products).
+//   OV: N % 4 == 0 and every row stride of y / cin / aux a multiple of 4 -> float4 epilogue.
+template <bool XV, bool WV, bool OV>
+__global__ __launch_bounds__(256) void wide_gemm_kernel(const float* __restrict__ x, long long x_rs, int x_cs,
+                                                        const float* __restrict__ w, long long w_rs, int w_cs,
+                                                        const float* __restrict__ bias, const float* __restrict__ cin,
+                                                        int cin_ld, const float* __restrict__ aux, int aux_ld, long long R,
+                                                        int K, int N, float* __restrict__ y, int y_ld, int epi) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 15, lg = lane >> 4;
+  const int ncb = (N + 63) >> 6;
+  const long long rb = blockIdx.x / ncb;
+  const int n0 = (int)(blockIdx.x - rb * ncb) * 64;
+  const long long r0 = rb * 64 + 16 * wave;
+  if (r0 >= R) return;
+  const long long row = r0 + ln;
+  const bool rv = row < R;
+  const float* xr = x + (rv ? row : R - 1) * x_rs;
+  const int nt = min(4, (N - n0 + 15) >> 4);        // live 16-unit tiles of this column block (wave-uniform)
+  const float* wr[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) wr[t] = w + (long long)min(n0 + 16 * t + ln, N - 1) * w_rs;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + 16 * t + 4 * lg + q;
+      acc[t][q] = (bias && n < N) ? bias[n] : 0.f;
+    }
+  }
+  // Operands of k-step j (16 columns): one float4 of the lane's activation row and of each of its 4 weight rows.  Three
+  // k-steps are in flight: the loads of step j + 2 are issued before the 16 matrix instructions of step j (a wave alone on
+  // its SIMD - these grids are a few hundred workgroups - has nothing else to hide the L2 round trip behind).  Loads are
+  // unconditional from clamped addresses; a k-step beyond K contributes zeros (its activation operand is masked).
+  auto load = [&](int k0, f32x4& xv, f32x4 (&wv)[4]) {
+    const int kk = k0 + 4 * lg;
+    if constexpr (XV) {
+      xv = ld4(xr + min(kk, K - 4));
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xv[q] = xr[(long long)min(kk + q, K - 1) * x_cs];
+    }
+    if constexpr (WV) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) wv[t] = ld4(wr[t] + min(kk, K - 4));
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wv[t][q] = wr[t][(long long)min(kk + q, K - 1) * w_cs];
+    }
+  };
+  auto mma = [&](int k0, f32x4 xv, const f32x4 (&wv)[4]) {
+    if (k0 >= K) return;                             // wave-uniform; no memory operation inside
+    const int kk = k0 + 4 * lg;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float b = kk + q < K ? xv[q] : 0.f;
+      acc[0] = SW_MFMA(wv[0][q], b, acc[0]);
+      if (nt > 1) acc[1] = SW_MFMA(wv[1][q], b, acc[1]);
+      if (nt > 2) acc[2] = SW_MFMA(wv[2][q], b, acc[2]);
+      if (nt > 3) acc[3] = SW_MFMA(wv[3][q], b, acc[3]);
+    }
+  };
+  f32x4 xa, xb, xc, wa[4], wb[4], wc[4];
+  load(0, xa, wa);
+  load(16, xb, wb);
+  for (int k0 = 0; k0 < K; k0 += 48) {
+    load(k0 + 32, xc, wc);
+    mma(k0, xa, wa);
+    load(k0 + 48, xa, wa);
+    mma(k0 + 16, xb, wb);
+    load(k0 + 64, xb, wb);
+    mma(k0 + 32, xc, wc);
+  }
+  if (!rv) return;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int n = n0 + 16 * t + 4 * lg;
+    if (n >= N) continue;
+    if constexpr (OV) {
+      f32x4 v = acc[t];
+      if (cin) v = v + ld4(cin + row * cin_ld + n);
+      if (epi != EPI_NONE) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (epi >= EPI_DRELU) a = ld4(aux + row * aux_ld + n);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = epi_apply(v[q], epi, a[q]);
+      }
+      st4(y + row * y_ld + n, v);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (n + q < N) {
+          float v = acc[t][q];
+          if (cin) v += cin[row * cin_ld + n + q];
+          v = epi_apply(v, epi, epi >= EPI_DRELU ? aux[row * aux_ld + n + q] : 0.f);
+          y[row * y_ld + n + q] = v;
+        }
+      }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// LDS-staged product core.  Lanes of an MFMA operand hold one ROW each (16 rows x 64-byte pieces per load instruction): read
+// like that from global memory a wave instruction is 64 separate 16-byte accesses for the address unit, and the first
+// version of these kernels - operands straight from global memory, three k-steps in flight - ran at 12 us for a
+// 2048 x 320 x 320 product that holds 4.4 us of matrix instructions (rocprofv3: bound by address processing, not by
+// latency: the prefetch depth changed nothing).  So a workgroup stages 64-column chunks of its activation rows (16 AT
+// agents) and of its 64 weight rows into LDS with COALESCED loads (a wave instruction = 4 rows x 256 contiguous bytes),
+// double-buffered (the global loads of chunk c + 1 are in flight under the products of chunk c, one barrier per chunk),
+// and the waves read their row-per-lane operands from LDS (row stride 68 floats).
+//   AT agent tiles per workgroup, wave -> agent tile wave % AT, unit group wave / AT of UT unit tiles each (4 / AT groups x
+//   UT tiles = the 4 unit tiles of the 64 staged weight rows).  acc[UT] in/out.
+//   xrow(i): pointer to activation row i of the tile (0 .. 16 AT - 1, clamped by the caller), wrow(i): weight row i (0..63).
+// Requires K % 4 == 0, 16-byte aligned rows.
+// ---------------------------------------------------------------------------------------------------------------------------
+#define WIDE_LDS 68
+template <int AT>
+struct WideSmem {
+  float xs[2][16 * AT][WIDE_LDS];
+  float ws[2][64][WIDE_LDS];
+};
+template <int AT, int UT, class XRow, class WRow>
+__device__ __forceinline__ void wide_core(WideSmem<AT>& sm, XRow xrow, WRow wrow, int K, f32x4 (&acc)[UT]) {
+  static_assert((4 / AT) * UT == 4, "4 unit tiles per workgroup");
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, ln = lane & 15, lg = lane >> 4;
+  const int c4 = t & 15, rr = t >> 4;
+  const int at = wave % AT, ug = wave / AT;
+  constexpr int NX = AT;          // float4s of the activation tile per thread (16 AT rows x 16 float4 / 256 threads)
+  const float* xp[NX];
+  const float* wp[4];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xp[i] = xrow(rr + 16 * i) + 4 * c4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wp[i] = wrow(rr + 16 * i) + 4 * c4;
+  const int nch = (K + 63) >> 6;
+  // TWO chunks of global loads in flight (register stages A, B): at 32 matrix instructions per wave and chunk (0.45 us) one
+  // chunk ahead did not cover the L2 round trip - the backward LSTM step (K = 4H, 8 chunks) ran latency-bound at 1.2 us per
+  // chunk.  Loads are unconditional (the last chunk is re-fetched by the prefetches beyond the end).
+  f32x4 xa[NX], wa[4], xb[NX], wb[4];
+  auto gload = [&](int c, f32x4 (&xr)[NX], f32x4 (&wr)[4]) {
+    const int kc = min(64 * min(c, nch - 1) + 4 * c4, K - 4);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xr[i] = ld4(xp[i] + kc - 4 * c4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wr[i] = ld4(wp[i] + kc - 4 * c4);
+  };
+  auto lstore = [&](int c, int buf, const f32x4 (&xr)[NX], const f32x4 (&wr)[4]) {
+    const bool kv = 64 * c + 4 * c4 < K;       // columns beyond K: zeros (arithmetic on the loaded value, not a conditional load)
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NX; ++i) st4(&sm.xs[buf][rr + 16 * i][4 * c4], kv ? xr[i] : z);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st4(&sm.ws[buf][rr + 16 * i][4 * c4], kv ? wr[i] : z);
+  };
+  auto compute = [&](int c) {
+    const int buf = c & 1;
+    const int nj = min(4, (K - 64 * c + 15) >> 4);
+    for (int j = 0; j < nj; ++j) {
+      const f32x4 b = ld4(&sm.xs[buf][16 * at + ln][16 * j + 4 * lg]);
+      f32x4 a[UT];
+#pragma unroll
+      for (int u = 0; u < UT; ++u) a[u] = ld4(&sm.ws[buf][16 * (ug * UT + u) + ln][16 * j + 4 * lg]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int u = 0; u < UT; ++u) acc[u] = SW_MFMA(a[u][q], b[q], acc[u]);
+    }
+  };
+  gload(0, xa, wa);
+  gload(1, xb, wb);
+  lstore(0, 0, xa, wa);
+  gload(2, xa, wa);
+  __syncthreads();
+  // invariant at the top of an iteration for chunk c (even): LDS[c & 1] holds chunk c, stage B chunk c + 1, stage A chunk c + 2
+  for (int c = 0; c < nch; c += 2) {
+    compute(c);
+    lstore(c + 1, (c + 1) & 1, xb, wb);
+    gload(c + 3, xb, wb);
+    __syncthreads();
+    if (c + 1 < nch) compute(c + 1);
+    lstore(c + 2, c & 1, xa, wa);
+    gload(c + 4, xa, wa);
+    __syncthreads();
+  }
+}
+
+// y = epi(x W^T + bias + cin; aux) on the staged core: workgroup = 32 rows x 64 columns, wave = 16 rows x 32 columns.
+template <bool OV>
+__global__ __launch_bounds__(256) void wide_gemm_lds_kernel(const float* __restrict__ x, long long x_rs, const float* __restrict__ w,
+                                                            long long w_rs, const float* __restrict__ bias,
+                                                            const float* __restrict__ cin, int cin_ld, const float* __restrict__ aux,
+                                                            int aux_ld, long long R, int K, int N, float* __restrict__ y, int y_ld,
+                                                            int epi) {
+  __shared__ WideSmem<2> sm;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 15, lg = lane >> 4;
+  const int ncb = (N + 63) >> 6;
+  const long long rb = blockIdx.x / ncb;
+  const int n0 = (int)(blockIdx.x - rb * ncb) * 64;
+  const long long r0 = rb * 32;
+  const int at = wave & 1, ug = wave >> 1;
+  f32x4 acc[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + 16 * (2 * ug + u) + 4 * lg + q;
+      acc[u][q] = (bias && n < N) ? bias[n] : 0.f;
+    }
+  wide_core<2, 2>(sm, [&](int i) { return x + min(r0 + i, R - 1) * x_rs; },
+                  [&](int i) { return w + (long long)min(n0 + i, N - 1) * w_rs; }, K, acc);
+  const long long row = r0 + 16 * at + ln;
+  if (row >= R) return;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int n = n0 + 16 * (2 * ug + u) + 4 * lg;
+    if (n >= N) continue;
+    if constexpr (OV) {
+      f32x4 v = acc[u];
+      if (cin) v = v + ld4(cin + row * cin_ld + n);
+      if (epi != EPI_NONE) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (epi >= EPI_DRELU) a = ld4(aux + row * aux_ld + n);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = epi_apply(v[q], epi, a[q]);
+      }
+      st4(y + row * y_ld + n, v);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (n + q < N) {
+          float v = acc[u][q];
+          if (cin) v += cin[row * cin_ld + n + q];
+          v = epi_apply(v, epi, epi >= EPI_DRELU ? aux[row * aux_ld + n + q] : 0.f);
+          y[row * y_ld + n + q] = v;
+        }
+      }
+    }
+  }
+}
+
+// One LSTM step for all agents (nn.LSTM gate order i f g o, train.py:254, 278):
+//   pre = Wx x4 + b1 (+ b2) + Whh h_prev ; c' = f c + i g ; h' = o tanh(c')
+// Wx [4H][4] is the 4-d input's matrix (the encoder's composed W_ih W_embed, the discriminator's W_ih), Whh [4H][H].
+// A wave owns 16 agents x 16 hidden units of all four gates (the cell update is lane-local); a workgroup = 4 waves = 64
+// agents of one unit block (its weight rows are shared through L1).
+__global__ __launch_bounds__(256) void wide_lstm_fwd_kernel(const float* __restrict__ x4, int x_ld, const float* __restrict__ h_prev,
+                                                            int hp_ld, const float* __restrict__ c_prev,
+                                                            const float* __restrict__ Wx, const float* __restrict__ b1,
+                                                            const float* __restrict__ b2, const float* __restrict__ Whh,
+                                                            int B, int H, float* __restrict__ gates, float* __restrict__ c_out,
+                                                            float* __restrict__ h_out, int h_ld, float* __restrict__ h_out2,
+                                                            int h2_ld) {
+  __shared__ WideSmem<4> sm;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 15, lg = lane >> 4;
+  const int nub = H >> 4;
+  const int rb = blockIdx.x / nub, u0 = (blockIdx.x - rb * nub) * 16;
+  const int r0 = rb * 64;
+  const int row = r0 + 16 * wave + ln;
+  const bool rv = row < B;
+  const int rc = rv ? row : B - 1;
+  f32x4 acc[4];
+  const float xb = x4[(size_t)rc * x_ld + lg];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 b = ld4(b1 + g * H + u0 + 4 * lg);
+    if (b2) b = b + ld4(b2 + g * H + u0 + 4 * lg);
+    acc[g] = SW_MFMA(Wx[(size_t)(g * H + u0 + ln) * 4 + lg], xb, b);
+  }
+  if (h_prev)      // staged weight row i = gate i / 16, unit u0 + i % 16; all waves of the workgroup take part (barriers inside)
+    wide_core<4, 4>(sm, [&](int i) { return h_prev + (size_t)min(r0 + i, B - 1) * hp_ld; },
+                    [&](int i) { return Whh + ((size_t)(i >> 4) * H + u0 + (i & 15)) * H; }, H, acc);
+  if (!rv) return;
+  f32x4 cp = {0.f, 0.f, 0.f, 0.f};
+  if (c_prev) cp = ld4(c_prev + (size_t)row * H + u0 + 4 * lg);
+  f32x4 gi, gf, gg, go, cn, hn;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    gi[q] = sw_sigmoid(acc[0][q]);
+    gf[q] = sw_sigmoid(acc[1][q]);
+    gg[q] = sw_tanh(acc[2][q]);
+    go[q] = sw_sigmoid(acc[3][q]);
+    cn[q] = fmaf(gf[q], cp[q], gi[q] * gg[q]);
+    hn[q] = go[q] * sw_tanh(cn[q]);
+  }
+  float* gr = gates + (size_t)row * 4 * H + u0 + 4 * lg;
+  st4(gr, gi);
+  st4(gr + H, gf);
+  st4(gr + 2 * H, gg);
+  st4(gr + 3 * H, go);
+  st4(c_out + (size_t)row * H + u0 + 4 * lg, cn);
+  st4(h_out + (size_t)row * h_ld + u0 + 4 * lg, hn);
+  if (h_out2) st4(h_out2 + (size_t)row * h2_ld + u0 + 4 * lg, hn);
+}
+
+// Backward of one LSTM step for all agents: dh = dh_ext + dgates_{t+1} Whh (the recurrent path; WhhT [H][4H] is the
+// transposed matrix), then the element-wise cell backward -> dgates_t (pre-activation gradients, the rows the weight
+// gradients contract over) and dc_{t-1}.  A wave owns 16 agents x 16 units; a workgroup = the 4 unit tiles of one
+// 64-unit block for the same 16 agents (the dgates rows are shared through L1).
+__global__ __launch_bounds__(256) void wide_lstm_bwd_kernel(const float* __restrict__ dh_ext, int dhe_ld,
+                                                            const float* __restrict__ dh_ext2, int dhe2_ld,
+                                                            const float* __restrict__ dg_next, const float* __restrict__ WhhT,
+                                                            const float* __restrict__ gates, const float* __restrict__ c,
+                                                            const float* __restrict__ c_prev, const float* __restrict__ dc_in,
+                                                            int B, int H, float* __restrict__ dgates, float* __restrict__ dc_out) {
+  __shared__ WideSmem<2> sm;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 15, lg = lane >> 4;
+  const int nub = (H + 63) >> 6;
+  const int rb = blockIdx.x / nub, ub = (blockIdx.x - rb * nub) * 64;
+  const int r0 = rb * 32;
+  const int at = wave & 1, ug = wave >> 1;
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (dg_next)
+    wide_core<2, 2>(sm, [&](int i) { return dg_next + (size_t)min(r0 + i, B - 1) * 4 * H; },
+                    [&](int i) { return WhhT + (size_t)min(ub + i, H - 1) * 4 * H; }, 4 * H, acc);
+  const int row = r0 + 16 * at + ln;
+  if (row >= B) return;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int u0 = ub + 16 * (2 * ug + u);
+    if (u0 >= H) continue;
+    f32x4 dh = acc[u];
+    const size_t e = (size_t)row * H + u0 + 4 * lg;
+    if (dh_ext) dh = dh + ld4(dh_ext + (size_t)row * dhe_ld + u0 + 4 * lg);
+    if (dh_ext2) dh = dh + ld4(dh_ext2 + (size_t)row * dhe2_ld + u0 + 4 * lg);
+    const float* gr = gates + (size_t)row * 4 * H + u0 + 4 * lg;
+    const f32x4 gi = ld4(gr), gf = ld4(gr + H), gg = ld4(gr + 2 * H), go = ld4(gr + 3 * H), ct = ld4(c + e);
+    f32x4 cp = {0.f, 0.f, 0.f, 0.f}, dc = cp;
+    if (c_prev) cp = ld4(c_prev + e);
+    if (dc_in) dc = ld4(dc_in + e);
+    f32x4 di, df, dg, dO, dcp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float tc = sw_tanh(ct[q]);
+      const float dct = fmaf(dh[q] * go[q], 1.0f - tc * tc, dc[q]);
+      di[q] = dct * gg[q] * gi[q] * (1.0f - gi[q]);
+      df[q] = dct * cp[q] * gf[q] * (1.0f - gf[q]);
+      dg[q] = dct * gi[q] * (1.0f - gg[q] * gg[q]);
+      dO[q] = dh[q] * tc * go[q] * (1.0f - go[q]);
+      dcp[q] = dct * gf[q];
+    }
+    float* dq = dgates + (size_t)row * 4 * H + u0 + 4 * lg;
+    st4(dq, di);
+    st4(dq + H, df);
+    st4(dq + 2 * H, dg);
+    st4(dq + 3 * H, dO);
+    st4(dc_out + e, dcp);
+  }
+}
+
+// Last decoder layer + position integration of a decode step (train.py:330, 422-424): v = a3 W4^T + b4 (2 outputs, K = D3:
+// a dot product per agent - 16 lanes per agent, shuffle tree), p_i = p_{i-1} + v_i; the prediction row (p, v) agent-major
+// and the 4-d input of the re-fed encoder step time-major.  One launch instead of a product, an integration and two copies.
+__global__ __launch_bounds__(256) void wide_out_fwd_kernel(const float* __restrict__ a3, int D3, const float* __restrict__ W4,
+                                                           const float* __restrict__ b4, float* __restrict__ p, int B,
+                                                           float* __restrict__ pred4_i, int pred_ld, float* __restrict__ x4_tm) {
+  const int b = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+  const int bc = min(b, B - 1);
+  float vx = 0.f, vy = 0.f;
+  for (int k = l; k < D3; k += 16) {
+    const float a = a3[(size_t)bc * D3 + k];
+    vx = fmaf(a, W4[k], vx);
+    vy = fmaf(a, W4[D3 + k], vy);
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    vx += __shfl_xor(vx, o);
+    vy += __shfl_xor(vy, o);
+  }
+  if (b >= B || l != 0) return;
+  vx += b4[0];
+  vy += b4[1];
+  const float px = p[2 * b] + vx, py = p[2 * b + 1] + vy;
+  p[2 * b] = px;
+  p[2 * b + 1] = py;
+  const f32x4 r = {px, py, vx, vy};
+  st4(pred4_i + (size_t)b * pred_ld, r);
+  if (x4_tm) st4(x4_tm + (size_t)b * 4, r);
+}
+// ... and the backward of that step: dx4 = dgates_t Wx (the re-fed encoder step's input gradient, K = 4H: a dot product per
+// agent and component against WxT [4][4H]), d p_i = dpred.p + dx4.p + d p_{i+1}, d v_i = dpred.v + dx4.v + d p_i, and
+// dz3 = dv W4 (rank 2).  16 lanes per agent.
+__global__ __launch_bounds__(256) void wide_out_bwd_kernel(const float* __restrict__ dpred4_i, int pred_ld,
+                                                           const float* __restrict__ dg, const float* __restrict__ WxT, int H4,
+                                                           float* __restrict__ dp_run, int B, float* __restrict__ dv,
+                                                           const float* __restrict__ W4, int D3, float* __restrict__ dz3) {
+  const int b = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+  const int bc = min(b, B - 1);
+  f32x4 g = ld4(dpred4_i + (size_t)bc * pred_ld);
+  if (dg) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const float* dr = dg + (size_t)bc * H4;
+    for (int k = 4 * l; k < H4; k += 64) {
+      const f32x4 d = ld4(dr + k), w0 = ld4(WxT + k), w1 = ld4(WxT + H4 + k), w2 = ld4(WxT + 2 * H4 + k), w3 = ld4(WxT + 3 * H4 + k);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s0 = fmaf(d[q], w0[q], s0);
+        s1 = fmaf(d[q], w1[q], s1);
+        s2 = fmaf(d[q], w2[q], s2);
+        s3 = fmaf(d[q], w3[q], s3);
+      }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      s0 += __shfl_xor(s0, o);
+      s1 += __shfl_xor(s1, o);
+      s2 += __shfl_xor(s2, o);
+      s3 += __shfl_xor(s3, o);
+    }
+    g = g + f32x4{s0, s1, s2, s3};
+  }
+  const float dpx = g[0] + dp_run[2 * bc], dpy = g[1] + dp_run[2 * bc + 1];
+  const float dvx = g[2] + dpx, dvy = g[3] + dpy;
+  if (b >= B) return;
+  for (int k = l; k < D3; k += 16) dz3[(size_t)b * D3 + k] = fmaf(dvx, W4[k], dvy * W4[D3 + k]);
+  if (l == 0) {
+    dp_run[2 * b] = dpx;
+    dp_run[2 * b + 1] = dpy;
+    st4(dv + (size_t)b * 4, f32x4{dvx, dvy, 0.f, 0.f});
+  }
+}
+
+// out[r][c] = sum_t in[t][r][c] (fixed order), 2-d blocks with row strides
+__global__ __launch_bounds__(256) void wide_sum_steps_kernel(const float* __restrict__ in, long long t_stride, int in_ld, int T,
+                                                             long long R, int C, float* __restrict__ out, int out_ld) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= R * C) return;
+  const long long r = e / C;
+  const int cc = (int)(e - r * C);
+  float s = 0.f;
+  for (int t = 0; t < T; ++t) s += in[t * t_stride + r * in_ld + cc];
+  out[r * out_ld + cc] = s;
+}
+// dst[tab.dst + c rows + r] = src[tab.src + r cols + c] for every matrix of the table (int4: src offset, rows, cols, dst
+// offset; all in floats): the transposed copies the backward products read (dx = dy W wants W^T rows), one launch for all
+// matrices of a module.  One workgroup per 32 x 32 tile, through LDS (coalesced on both sides).
+__global__ __launch_bounds__(256) void wide_transpose_kernel(const float* __restrict__ src, const int4* __restrict__ tab, int ntab,
+                                                             float* __restrict__ dst) {
+  __shared__ float tile[32][33];
+  int b = blockIdx.x, m = 0;
+  for (; m < ntab; ++m) {
+    const int tiles = ((tab[m].y + 31) >> 5) * ((tab[m].z + 31) >> 5);
+    if (b < tiles) break;
+    b -= tiles;
+  }
+  if (m >= ntab) return;
+  const int4 T = tab[m];
+  const int tc = (T.z + 31) >> 5;
+  const int r0 = (b / tc) * 32, c0 = (b % tc) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < T.y && c0 + tx < T.z) tile[i][tx] = src[T.x + (size_t)(r0 + i) * T.z + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < T.z && r0 + tx < T.y) dst[T.w + (size_t)(c0 + i) * T.y + r0 + tx] = tile[tx][i];
+}
+}  // namespace
+
+extern "C" int sw_wide_transpose(const float* src, const int* tab /*device, ntab x 4*/, int ntab, int total_tiles, float* dst,
+                                 void* stream) {
+  if (!src || !tab || !dst || ntab < 1 || total_tiles < 1) return SW_EARG;
+  SW_LAUNCH(wide_transpose_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, src, (const int4*)tab, ntab, dst);
+  SW_CHECK_LAUNCH("wide_transpose_kernel");
+  return SW_OK;
+}
+
+extern "C" int sw_wide_gemm(const float* x, long long x_rs, int x_cs, const float* w, long long w_rs, int w_cs, const float* bias,
+                            const float* cin, int cin_ld, const float* aux, int aux_ld, long long R, int K, int N, float* y,
+                            int y_ld, int epi, void* stream) {
+  if (!x || !w || !y || R < 0 || K < 1 || N < 1 || y_ld < N || epi < 0 || epi > 4 || (epi >= 3 && !aux) || (cin && cin_ld < N) ||
+      (aux && aux_ld < N))
+    return SW_EARG;
+  if (R == 0) return SW_OK;
+  const long long blocks = ((R + 63) / 64) * ((N + 63) / 64);
+  if (blocks > 0x7fffffffLL) return SW_ESHAPE;
+  auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  const bool xv = x_cs == 1 && (x_rs & 3) == 0 && (K & 3) == 0 && al(x);
+  const bool wv = w_cs == 1 && (w_rs & 3) == 0 && (K & 3) == 0 && al(w);
+  const bool ov = (N & 3) == 0 && (y_ld & 3) == 0 && al(y) && (!cin || ((cin_ld & 3) == 0 && al(cin))) &&
+                  (!aux || ((aux_ld & 3) == 0 && al(aux)));
+  hipStream_t st = (hipStream_t)stream;
+  if (xv && wv && R >= 16) {      // the model's layers: LDS-staged core, 32 x 64 tiles
+    const long long blocks2 = ((R + 31) / 32) * ((N + 63) / 64);
+    if (blocks2 > 0x7fffffffLL) return SW_ESHAPE;
+    if (ov) SW_LAUNCH((wide_gemm_lds_kernel<true>), dim3((unsigned)blocks2), dim3(256), 0, st, x, x_rs, w, w_rs, bias, cin, cin_ld, aux,
+                      aux_ld, R, K, N, y, y_ld, epi);
+    else SW_LAUNCH((wide_gemm_lds_kernel<false>), dim3((unsigned)blocks2), dim3(256), 0, st, x, x_rs, w, w_rs, bias, cin, cin_ld, aux,
+                   aux_ld, R, K, N, y, y_ld, epi);
+    SW_CHECK_LAUNCH("wide_gemm_lds_kernel");
+    return SW_OK;
+  }
+  // everything else (3-wide pair features, the K = 1 / 2 products of the heads, transposed operands of the small
+  // composition products, a handful of rows): operands straight from global memory with free strides
+  const dim3 grid((unsigned)blocks), block(256);
+#define WIDE_GEMM(XV, WV, OV)                                                                                              \
+  SW_LAUNCH((wide_gemm_kernel<XV, WV, OV>), grid, block, 0, st, x, x_rs, x_cs, w, w_rs, w_cs, bias, cin, cin_ld, aux, aux_ld, \
+            R, K, N, y, y_ld, epi)
+  if (xv && wv && ov) WIDE_GEMM(true, true, true);
+  else if (xv && wv) WIDE_GEMM(true, true, false);
+  else if (xv && ov) WIDE_GEMM(true, false, true);
+  else if (wv && ov) WIDE_GEMM(false, true, true);
+  else WIDE_GEMM(false, false, false);
+#undef WIDE_GEMM
+  SW_CHECK_LAUNCH("wide_gemm_kernel");
+  return SW_OK;
+}
+
+extern "C" int sw_wide_lstm_fwd(const float* x4, int x_ld, const float* h_prev, int hp_ld, const float* c_prev, const float* Wx,
+                                const float* b1, const float* b2, const float* Whh, int B, int H, float* gates, float* c_out,
+                                float* h_out, int h_ld, float* h_out2, int h2_ld, void* stream) {
+  if (!x4 || !Wx || !b1 || !Whh || !gates || !c_out || !h_out || B < 1 || H < 16 || (H & 15) || x_ld < 4 || h_ld < H ||
+      (h_ld & 3) || (h_prev && (hp_ld < H || (hp_ld & 3))) || (h_out2 && (h2_ld < H || (h2_ld & 3))))
+    return SW_EARG;
+  SW_LAUNCH(wide_lstm_fwd_kernel, dim3((unsigned)(((B + 63) / 64) * (H / 16))), dim3(256), 0, (hipStream_t)stream, x4, x_ld,
+            h_prev, hp_ld, c_prev, Wx, b1, b2, Whh, B, H, gates, c_out, h_out, h_ld, h_out2, h2_ld);
+  SW_CHECK_LAUNCH("wide_lstm_fwd_kernel");
+  return SW_OK;
+}
+
+extern "C" int sw_wide_lstm_bwd(const float* dh_ext, int dhe_ld, const float* dh_ext2, int dhe2_ld, const float* dg_next,
+                                const float* WhhT, const float* gates, const float* c, const float* c_prev, const float* dc_in,
+                                int B, int H, float* dgates, float* dc_out, void* stream) {
+  if (!gates || !c || !dgates || !dc_out || B < 1 || H < 16 || (H & 15) || (dg_next && !WhhT) ||
+      (dh_ext && (dhe_ld < H || (dhe_ld & 3))) || (dh_ext2 && (dhe2_ld < H || (dhe2_ld & 3))))
+    return SW_EARG;
+  SW_LAUNCH(wide_lstm_bwd_kernel, dim3((unsigned)(((B + 31) / 32) * ((H + 63) / 64))), dim3(256), 0, (hipStream_t)stream, dh_ext,
+            dhe_ld, dh_ext2, dhe2_ld, dg_next, WhhT, gates, c, c_prev, dc_in, B, H, dgates, dc_out);
+  SW_CHECK_LAUNCH("wide_lstm_bwd_kernel");
+  return SW_OK;
+}
+
+extern "C" int sw_wide_out_fwd(const float* a3, int D3, const float* W4, const float* b4, float* p, int B, float* pred4_i,
+                               int pred_ld, float* x4_tm, void* stream) {
+  if (!a3 || !W4 || !b4 || !p || !pred4_i || B < 1 || D3 < 1 || (pred_ld & 3)) return SW_EARG;
+  SW_LAUNCH(wide_out_fwd_kernel, dim3((B + 15) / 16), dim3(256), 0, (hipStream_t)stream, a3, D3, W4, b4, p, B, pred4_i, pred_ld,
+            x4_tm);
+  SW_CHECK_LAUNCH("wide_out_fwd_kernel");
+  return SW_OK;
+}
+extern "C" int sw_wide_out_bwd(const float* dpred4_i, int pred_ld, const float* dg, const float* WxT, int H4, float* dp_run, int B,
+                               float* dv, const float* W4, int D3, float* dz3, void* stream) {
+  if (!dpred4_i || !dp_run || !dv || !W4 || !dz3 || B < 1 || D3 < 1 || (pred_ld & 3) || (dg && (!WxT || H4 < 64 || (H4 & 63))))
+    return SW_EARG;
+  SW_LAUNCH(wide_out_bwd_kernel, dim3((B + 15) / 16), dim3(256), 0, (hipStream_t)stream, dpred4_i, pred_ld, dg, WxT, H4, dp_run, B,
+            dv, W4, D3, dz3);
+  SW_CHECK_LAUNCH("wide_out_bwd_kernel");
+  return SW_OK;
+}
+extern "C" int sw_wide_sum_steps(const float* in, long long t_stride, int in_ld, int T, long long R, int C, float* out,
+                                 int out_ld, void* stream) {
+  if (!in || !out || T < 1 || R < 1 || C < 1 || in_ld < C || out_ld < C) return SW_EARG;
+  SW_LAUNCH(wide_sum_steps_kernel, dim3((unsigned)((R * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, t_stride, in_ld,
+            T, R, C, out, out_ld);
+  SW_CHECK_LAUNCH("wide_sum_steps_kernel");
+  return SW_OK;
+}
+
+// Weight gradients of a whole backward pass: n problems dW[N][K] = delta^T act, db[N] = column sums of delta, through the
+// grouped split-K GEMM (sw_wgrad.hip) - as few launches as its 24-problem batches allow.  desc = n x 10 host values
+// (pointers as integers): delta, ldd, act, lda, R, N, K, dW, ldw, db (0: no bias).
+extern "C" int sw_wide_wgrad(const long long* desc, int n, float* wgrad_ws, void* stream) {
+  if (!desc || n < 1 || !wgrad_ws) return SW_EARG;
+  WgBatch b;
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < n; ++i) {
+    const long long* d = desc + 10 * (size_t)i;
+    const float* delta = (const float*)(uintptr_t)d[0];
+    const float* act = (const float*)(uintptr_t)d[2];
+    float* dW = (float*)(uintptr_t)d[7];
+    float* db = (float*)(uintptr_t)d[9];
+    const int ldd = (int)d[1], lda = (int)d[3], R = (int)d[4], N = (int)d[5], K = (int)d[6], ldw = (int)d[8];
+    if (!delta || !act || !dW || R < 1 || N < 1 || K < 1) return SW_EARG;
+    for (int n0 = 0; n0 < N; n0 += 256) {
+      const int nn = N - n0 < 256 ? N - n0 : 256;
+      WgBatch trial = b;
+      int rc = wg_add(trial, delta + n0, ldd, act, lda, R, nn, K, dW + (size_t)n0 * ldw, ldw, db ? db + n0 : nullptr, nullptr, 0);
+      if (rc == SW_ESHAPE && b.np > 0) {        // the batch is full: launch it and start the next one with this problem
+        if (int r2 = wg_launch(b, wgrad_ws, st)) return r2;
+        b = WgBatch();
+        trial = WgBatch();
+        rc = wg_add(trial, delta + n0, ldd, act, lda, R, nn, K, dW + (size_t)n0 * ldw, ldw, db ? db + n0 : nullptr, nullptr, 0);
+      }
+      if (rc) return rc;
+      b = trial;
+    }
+  }
+  return wg_launch(b, wgrad_ws, st);
+}

@@ -166,6 +166,12 @@ class SocialWaysTrainer:
         nl = kw.get("n_latent_codes", args[6] if len(args) > 6 else 2)      # positional slot 9 of __init__'s signature
         if cls is SocialWaysTrainer and (int(hidden_size) > 64 or int(nl) != 2):
             from .generic import GenericTrainer
+            from .wide import WideTrainer
+            # widths that are multiples of 32: the wide path (time-step-level kernels, explicit backward, one hipGraph per
+            # step); anything else the reference accepts: the layer-by-layer generic path under torch's tape
+            if os.environ.get("SW_WIDE", "1") != "0" and WideTrainer.supports(hidden_size, nl, kw.get("use_variety_loss", False),
+                                                                              kw.get("process_group")):
+                return object.__new__(WideTrainer)
             return object.__new__(GenericTrainer)
         return object.__new__(cls)
 

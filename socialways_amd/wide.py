@@ -1,0 +1,525 @@
+"""The WIDE path: `--hidden-size` above the fused kernels' 64 units (train.py:42-44, 76-81), H % 32 == 0, and any latent-code
+count >= 2 (train.py:65), as an explicit forward / backward ENGINE over time-step-level kernels (csrc/sw_wide.hip):
+
+    one launch per LSTM step          sw_wide_lstm_fwd / _bwd   gate products + cell (+ the recurrent dh product) fused
+    one launch per decoder / head     sw_wide_gemm              product + bias + LeakyReLU / ReLU forward, product x
+    layer                                                       activation derivative on the way back
+    weight gradients                  sw_wide_wgrad             every matrix of a backward pass in one or two launches of
+                                                                the grouped split-K GEMM over the time-major saved rows
+    Adam                              sw_adam_packed            one launch per optimizer over a packed parameter buffer
+
+- no autograd tape: the backward pass is written out like the fused trainer's (same saved-row layout idea: time-major
+[t][agent][...] rows, deferred weight gradients), and the whole training step (~400 launches) is captured into ONE hipGraph
+per batch layout and replayed.  Same modules, construction order (= initial weights), state_dict keys and optimizer
+state_dicts as train.py:153-335, 370-385; results match the layer-by-layer generic path (generic.py, kept for widths that
+are not multiples of 32 and as the cross-check of this engine) and the oracle to the usual tolerances.
+
+torch is used for memory (buffers, slicing, broadcast copies of S / z into the decoder's input rows, weight transposes, the
+Linear-only restore of train.py:541-542); arithmetic runs in the library's kernels.  No CPU fallback.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .generic import Discriminator, Generator, GenericTrainer
+from .model import _scene_index
+from .trainer import PackedAdam
+
+EPI_NONE, EPI_RELU, EPI_LRELU, EPI_DRELU, EPI_DLRELU = 0, 1, 2, 3, 4
+
+
+def _p(t):
+    return None if t is None else (t if isinstance(t, int) else t.data_ptr())
+
+
+def gemm(x, x_rs, w, w_rs, bias, R, K, N, y, y_ld, epi=EPI_NONE, cin=None, cin_ld=0, aux=None, aux_ld=0, x_cs=1, w_cs=1):
+    """y[r][n] = epi(sum_k x[r][k] w[n][k] + bias[n] + cin[r][n]; aux[r][n]) (sw_wide_gemm); tensors or raw pointers."""
+    L.call("sw_wide_gemm", _p(x), x_rs, x_cs, _p(w), w_rs, w_cs, _p(bias), _p(cin), cin_ld, _p(aux), aux_ld, R, K, N, _p(y), y_ld,
+           epi, L.stream())
+
+
+def _off(t, floats):
+    """Pointer `floats` floats into tensor t."""
+    return t.data_ptr() + 4 * int(floats)
+
+
+class _Flat:
+    """The parameters of a list of modules as views of ONE packed fp32 buffer (each tensor on a 4-float boundary), their
+    .grad as views of a second one: one Adam launch, one all-reduce, transposes by offset."""
+
+    def __init__(self, params, device):
+        self.params = list(params)
+        offs, n = [], 0
+        for p in self.params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        self.flat = torch.zeros(n, device=device)
+        self.gflat = torch.zeros(n, device=device)
+        self.slices = []
+        for p, o in zip(self.params, offs):
+            k = p.numel()
+            self.flat[o:o + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + k].view(p.shape)
+            p.grad = self.gflat[o:o + k].view(p.shape)
+            self.slices.append((o, k, tuple(p.shape)))
+        self.off = {id(p): o for p, o in zip(self.params, offs)}
+
+    def g(self, p):
+        """The gradient view of parameter p (re-attached if something set .grad to None)."""
+        o = self.off[id(p)]
+        v = self.gflat[o:o + p.numel()].view(p.shape)
+        p.grad = v
+        return v
+
+
+class WideTrainer(GenericTrainer):
+    """train() / test() / checkpoint (train.py:439-668) at hidden sizes above 64 on the wide path.  Same public surface
+    as SocialWaysTrainer (step, step_many, train_epoch, test, checkpoint, load_checkpoint, losses_from)."""
+
+    @staticmethod
+    def supports(hidden_size, n_latent_codes=2, use_variety_loss=False, process_group=None):
+        return (int(hidden_size) % 32 == 0 and int(hidden_size) >= 32 and int(n_latent_codes) >= 2 and not use_variety_loss
+                and process_group is None)
+
+    def __init__(self, n_next, hidden_size=128, lr_g=1e-4, lr_d=1e-3, n_unrolling_steps=1, use_social=True, use_info_loss=True,
+                 loss_info_w=0.5, n_latent_codes=2, device="cuda", process_group=None, use_l2_loss=False,
+                 use_variety_loss=False, loss_l2_w=0.5, use_graph=None, **_ignored):
+        if not self.supports(hidden_size, n_latent_codes, use_variety_loss, process_group):
+            raise L.SocialWaysHipError("wide path: hidden_size % 32 == 0, n_latent_codes >= 2, single process, no variety loss")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.SocialWaysHipError("socialways_amd runs on MI355X only (no CPU fallback)")
+        self.n_next, self.noise_len = n_next, hidden_size // 2
+        self.n_unrolling_steps, self.use_info_loss, self.loss_info_w = n_unrolling_steps, use_info_loss, loss_info_w
+        self.use_l2_loss, self.use_variety_loss, self.loss_l2_w = use_l2_loss, False, loss_l2_w
+        self.n_latent_codes = n_latent_codes
+        self.H = H = int(hidden_size)
+        # construction order = train.py:370-385 (RNG -> init mapping, optimizer parameter order)
+        self.G = Generator(H, 1, use_social=use_social).to(self.device)
+        self.D = Discriminator(n_next, H, n_latent_codes).to(self.device)
+        self.gp = _Flat(self.G.predictor_params(), self.device)
+        self.dp = _Flat(self.D.parameters(), self.device)
+        self.predictor_optimizer = PackedAdam(self.gp.flat, self.gp.gflat, self.gp.slices, lr_g)
+        self.D_optimizer = PackedAdam(self.dp.flat, self.dp.gflat, self.dp.slices, lr_d)
+        self.pg, self.world, self.rank, self.epoch = None, 1, 0, 0
+        self.use_graph = True if use_graph is None else bool(use_graph)
+        self.last_variety = None
+        self._ws = {}            # workspaces per (B, To, P)
+        self._graphs = {}        # captured steps per (B, To, scene layout, switches)
+        self._seen = {}
+        # Linear-only mask of D.load() (train.py:311-316): 1 for nn.Linear parameters
+        m = torch.zeros_like(self.dp.flat)
+        for name, p in self.D.named_parameters():
+            if "lstm" not in name:
+                o = self.dp.off[id(p)]
+                m[o:o + p.numel()] = 1.0
+        self._lin_mask = m > 0
+        self._d_backup = torch.zeros_like(self.dp.flat)
+        # transposed copies of the weight matrices (the backward products dx = dy W read W^T rows): ONE launch per module
+        # (sw_wide_transpose) through a device table of (source offset, rows, cols, destination offset)
+        enc, dec, emb, att = self.G.encoder, self.G.decoder.fc1, self.G.feature_embedder.fc, self.G.attention.W
+        self.gT, self._gT_args = self._transpose_table(self.gp, dict(
+            whh=enc.lstm.weight_hh_l0, w1=dec[0].weight, w2=dec[2].weight, w3=dec[4].weight, w4=dec[5].weight,
+            e1=emb[2].weight, e2=emb[4].weight, att=att.weight))
+        Dm = self.D
+        self.dT, self._dT_args = self._transpose_table(self.dp, dict(
+            whh=Dm.obsv_encoder_lstm.weight_hh_l0, of0=Dm.obsv_encoder_fc[0].weight, of1=Dm.obsv_encoder_fc[2].weight,
+            pe0=Dm.pred_encoder[0].weight, pe1=Dm.pred_encoder[2].weight, cl0=Dm.classifier[0].weight,
+            cl1=Dm.classifier[2].weight, la0=Dm.latent_decoder[0].weight, la1=Dm.latent_decoder[2].weight))
+        nl = n_latent_codes                     # reported sums: the info term's mean runs over B * nl elements (losses_from)
+        k = np.ones((n_unrolling_steps + 3, 3))
+        k[:n_unrolling_steps + 2, 1] = 2.0 / nl
+        self._kres = torch.from_numpy(k).to(self.device)
+
+    def _transpose_table(self, fl, mats):
+        tab, views, off, tiles = [], {}, 0, 0
+        for name, p in mats.items():
+            r, c = p.shape
+            tab.append((fl.off[id(p)], r, c, off))
+            views[name] = (off, c, r)
+            off += (r * c + 3) // 4 * 4
+            tiles += ((r + 31) // 32) * ((c + 31) // 32)
+        buf = torch.zeros(off, device=self.device)
+        out = {name: buf[o:o + a * b].view(a, b) for name, (o, a, b) in views.items()}
+        tab_d = torch.tensor(tab, dtype=torch.int32).to(self.device)
+        return out, (fl.flat, tab_d, len(tab), tiles, buf)
+
+    def _transposes(self, args):
+        src, tab, n, tiles, dst = args
+        L.call("sw_wide_transpose", L.ptr(src), L.ptr(tab), n, tiles, L.ptr(dst), L.stream())
+
+    # ---- buffers -----------------------------------------------------------------------------------------------------------
+    def _buffers(self, B, To, P):
+        key = (B, To, P)
+        w = self._ws.get(key)
+        if w is not None:
+            return w
+        H, Tp, dev = self.H, self.n_next, self.device
+        Z, D1 = H // 2, 2 * H + H // 2
+        D2, D3 = D1 // 2, D1 // 4
+        Ta = To + Tp - 1
+        nl, nlp = self.n_latent_codes, (self.n_latent_codes + 3) // 4 * 4
+        z = lambda *s: torch.zeros(*s, device=dev)
+        # the fake and the real future of a D update are the two halves of ONE [2B][4 Tp] buffer: the rollout writes its
+        # prediction rows into the first, get_traj_4d the real rows into the second; D's pred_encoder reads them in place
+        px = z(2 * B, 4 * Tp)
+        w = dict(
+            obsv=z(B, To, 2), pred=z(B, Tp, 2), noise=z(B, Z), targets=z(2), o4=z(B, To, 4), px=px,
+            pred4=px[:B].view(B, Tp, 4), p4=px[B:].view(B, Tp, 4),
+            x4=z(Ta + 1, B, 4), hs=z(Ta + 1, B, H), cs=z(Ta, B, H), gates=z(Ta, B, 4 * H),
+            Wx=z(4 * H, 4), WxT=z(4, 4 * H), bxc=z(4 * H),
+            feat=z(max(P, 1), 4), f1=z(max(P, 1), 32), f2=z(max(P, 1), 64), f3=z(max(P, 1), H), wh=z(B, H), attn=z(max(P, 1)),
+            S=z(B, H), cat=z(Tp, B, D1), a1=z(Tp, B, D1), a2=z(Tp, B, D2), a3=z(Tp, B, D3), pcur=z(B, 2),
+            # generator backward
+            dgates=z(Ta, B, 4 * H), dc=z(B, H), dx4=z(B, 4), dprun=z(B, 2), dv=z(Tp, B, 4), dz3=z(Tp, B, D3), dz2=z(Tp, B, D2),
+            dz1=z(Tp, B, D1), dhcat=z(B, H), dsz=z(Tp, B, H), dS=z(B, H), dhT=z(B, H), dsig=z(max(P, 1)),
+            df3=z(max(P, 1), H), df2=z(max(P, 1), 64), df1=z(max(P, 1), 32), dwh=z(B, H), dh_att=z(B, H),
+            dWx=z(4 * H, 4), dbx=z(4 * H),
+            # discriminator
+            d_hs=z(To + 1, B, H), d_cs=z(To, B, H), d_gates=z(To, B, 4 * H), o1=z(B, H // 2),
+            q1=z(2 * B, H // 2), both=z(2 * B, H), c1=z(2 * B, H // 2), l1=z(2 * B, H // 2),
+            label=z(2 * B, 1), code=z(2 * B, nl), dlab=z(2 * B, 4), dcod=z(2 * B, nlp), dc1=z(2 * B, H // 2),
+            dl1=z(2 * B, H // 2), dboth=z(2 * B, H), dq1=z(2 * B, H // 2), docode=z(B, H // 2), do1=z(B, H // 2),
+            d_dhT=z(B, H), d_dgates=z(To, B, 4 * H), d_dc=z(B, H), dpx=z(B, 4 * Tp),
+            sums=z(self.n_unrolling_steps + 3, 3), ade_scr=z(3 * L.RED_BLOCKS),
+            wgrad=torch.empty(L.workspace_floats(L.WS_WGRAD, 1, 2, 1), device=dev),
+            res=torch.zeros(self.n_unrolling_steps + 3, 3, dtype=torch.float64, device=dev),
+        )
+        self._ws[key] = w
+        return w
+
+    # ---- pieces ------------------------------------------------------------------------------------------------------------
+    def _wgrad(self, w, problems):
+        """problems: (delta, ldd, act, lda, R, N, K, dW, ldw, db) with tensors or raw pointers."""
+        arr = (ctypes.c_longlong * (10 * len(problems)))()
+        for i, pr in enumerate(problems):
+            for j, v in enumerate(pr):
+                arr[10 * i + j] = 0 if v is None else (int(v) if isinstance(v, (int, np.integer)) else v.data_ptr())
+        L.call("sw_wide_wgrad", ctypes.cast(arr, ctypes.c_void_p), len(problems), L.ptr(w["wgrad"]), L.stream())
+
+    def _gen_forward(self, w, sc, B, To):
+        """predict() (train.py:392-432): observation encoding, social pooling, Tp decode steps with the re-fed encoder."""
+        H, Tp, st = self.H, self.n_next, L.stream()
+        Z, D1 = H // 2, 2 * H + H // 2
+        D2, D3 = D1 // 2, D1 // 4
+        G = self.G
+        enc, dec = G.encoder, G.decoder.fc1
+        wih, whh = enc.lstm.weight_ih_l0, enc.lstm.weight_hh_l0
+        # composed input matrix Wx = W_ih W_embed [4H][4], bxc = W_ih b_embed + b_ih (no non-linearity between embed and the
+        # LSTM, train.py:266-268); b_hh is added by the step kernel
+        gemm(wih, H, enc.embed.weight, 1, None, 4 * H, H, 4, w["Wx"], 4, w_cs=4)
+        gemm(wih, H, enc.embed.bias, 1, None, 4 * H, H, 1, w["bxc"], 1, cin=enc.lstm.bias_ih_l0, cin_ld=1)
+        # ... and its transpose [4][4H] (the rows of dx4 = dgates Wx in the backward pass)
+        gemm(enc.embed.weight, 1, wih, H, None, 4, H, 4 * H, w["WxT"], 4 * H, x_cs=4)
+        x4, hs, cs, gates, cat = w["x4"], w["hs"], w["cs"], w["gates"], w["cat"]
+        x4[:To].copy_(w["o4"].transpose(0, 1))
+
+        def lstm(t, h2=None, h2_ld=0):
+            L.call("sw_wide_lstm_fwd", L.ptr(x4[t]), 4, L.ptr(hs[t]) if t > 0 else None, H, L.ptr(cs[t - 1]) if t > 0 else None,
+                   L.ptr(w["Wx"]), L.ptr(w["bxc"]), L.ptr(enc.lstm.bias_hh_l0), L.ptr(whh), B, H, L.ptr(gates[t]),
+                   L.ptr(cs[t]), L.ptr(hs[t + 1]), H, _p(h2), h2_ld, st)
+
+        for t in range(To):
+            lstm(t, cat[0] if t == To - 1 else None, D1)
+        hT = hs[To]
+        if G.use_social and sc.P > 0:
+            if sc.NB:
+                raise L.SocialWaysHipError("wide path: scenes above %d agents are not supported" % L.AMAX)
+            emb, att = G.feature_embedder.fc, G.attention.W
+            P = sc.P
+            L.call("sw_pair_features", L.ptr(w["o4"][:, -1].contiguous()), L.ptr(sc.scene_off), L.ptr(sc.pair_off), sc.S,
+                   L.ptr(w["feat"]), st)
+            gemm(w["feat"], 4, emb[0].weight, 3, emb[0].bias, P, 3, 32, w["f1"], 32, EPI_RELU)
+            gemm(w["f1"], 32, emb[2].weight, 32, emb[2].bias, P, 32, 64, w["f2"], 64, EPI_RELU)
+            gemm(w["f2"], 64, emb[4].weight, 64, emb[4].bias, P, 64, H, w["f3"], H)
+            gemm(hT, H, att.weight, H, att.bias, B, H, H, w["wh"], H)
+            L.call("sw_attn_pairs_fwd", L.ptr(w["f3"]), L.ptr(w["wh"]), L.ptr(hT), L.ptr(sc.scene_off), L.ptr(sc.pair_off),
+                   sc.S, B, H, H, L.ptr(w["attn"]), L.ptr(w["S"]), st)
+        else:
+            w["S"].zero_()
+        cat[:, :, H:2 * H] = w["S"]
+        cat[:, :, 2 * H:] = w["noise"]
+        w["pcur"].copy_(w["obsv"][:, -1])
+        for i in range(Tp):
+            gemm(cat[i], D1, dec[0].weight, D1, dec[0].bias, B, D1, D1, w["a1"][i], D1, EPI_LRELU)
+            gemm(w["a1"][i], D1, dec[2].weight, D1, dec[2].bias, B, D1, D2, w["a2"][i], D2, EPI_LRELU)
+            gemm(w["a2"][i], D2, dec[4].weight, D2, dec[4].bias, B, D2, D3, w["a3"][i], D3)
+            L.call("sw_wide_out_fwd", L.ptr(w["a3"][i]), D3, L.ptr(dec[5].weight), L.ptr(dec[5].bias), L.ptr(w["pcur"]), B,
+                   _off(w["pred4"], 4 * i), 4 * Tp, L.ptr(x4[To + i]), st)
+            if i + 1 < Tp:                      # the step after the last decode is dead compute (train.py:430)
+                lstm(To + i, cat[i + 1], D1)
+        return w["pred4"]
+
+    def _gen_backward(self, w, sc, B, To, dpred4):
+        """Backward of predict() from d(loss)/d(pred_hat_4d) [B][Tp][4]: data gradients step by step, then every weight
+        gradient of the generator as deferred products over the saved rows."""
+        H, Tp, st = self.H, self.n_next, L.stream()
+        Z, D1 = H // 2, 2 * H + H // 2
+        D2, D3 = D1 // 2, D1 // 4
+        Ta = To + Tp - 1
+        G, gp = self.G, self.gp
+        enc, dec = G.encoder, G.decoder.fc1
+        whh = enc.lstm.weight_hh_l0
+        self._transposes(self._gT_args)
+        gT = self.gT
+        gates, cs, hs, dg = w["gates"], w["cs"], w["hs"], w["dgates"]
+        w["dprun"].zero_()
+        have_dc = False
+
+        def lstm_bwd(t, dh_ext, dhe_ld, dh_ext2=None, dhe2_ld=0):
+            nonlocal have_dc
+            L.call("sw_wide_lstm_bwd", _p(dh_ext), dhe_ld, _p(dh_ext2), dhe2_ld, L.ptr(dg[t + 1]) if t + 1 < Ta else None,
+                   L.ptr(gT["whh"]), L.ptr(gates[t]), L.ptr(cs[t]), L.ptr(cs[t - 1]) if t > 0 else None,
+                   L.ptr(w["dc"]) if have_dc else None, B, H, L.ptr(dg[t]), L.ptr(w["dc"]), st)
+            have_dc = True
+
+        for i in range(Tp - 1, -1, -1):
+            t_in = To + i                      # the LSTM step that consumed x4 = (p_i, v_i)
+            dgt = None
+            if i + 1 < Tp:
+                # h of step t_in feeds decode step i + 1 (dhcat) and LSTM step t_in + 1 (dgates of t_in + 1)
+                lstm_bwd(t_in, w["dhcat"], H)
+                dgt = dg[t_in]
+            # dx4 = dgates Wx, the position / velocity chain and dz3 = dv W4 (fc4: linear, no activation) in one launch
+            L.call("sw_wide_out_bwd", _off(dpred4, 4 * i), 4 * Tp, _p(dgt), L.ptr(w["WxT"]), 4 * H, L.ptr(w["dprun"]), B,
+                   L.ptr(w["dv"][i]), L.ptr(dec[5].weight), D3, L.ptr(w["dz3"][i]), st)
+            gemm(w["dz3"][i], D3, gT["w3"], D3, None, B, D3, D2, w["dz2"][i], D2, EPI_DLRELU, aux=w["a2"][i], aux_ld=D2)
+            gemm(w["dz2"][i], D2, gT["w2"], D2, None, B, D2, D1, w["dz1"][i], D1, EPI_DLRELU, aux=w["a1"][i], aux_ld=D1)
+            gemm(w["dz1"][i], D1, gT["w1"], D1, None, B, D1, H, w["dhcat"], H)                      # d cat[:, :H] = d h_{To-1+i}
+        # dS = sum over the steps of dz1 W1[:, H:2H] (z is an input: no gradient wanted): one product over all Tp B rows, then
+        # the sum over the steps
+        gemm(w["dz1"], D1, _off(gT["w1"], H * D1), D1, None, Tp * B, D1, H, w["dsz"], H)
+        L.call("sw_wide_sum_steps", L.ptr(w["dsz"]), B * H, H, Tp, B, H, L.ptr(w["dS"]), H, st)
+        problems = []
+        hT = hs[To]
+        dh2, dh2_ld = None, 0
+        if G.use_social and sc.P > 0:
+            emb, att = G.feature_embedder.fc, G.attention.W
+            P = sc.P
+            L.call("sw_attn_pairs_bwd", L.ptr(w["f3"]), L.ptr(w["wh"]), L.ptr(hT), L.ptr(w["attn"]), L.ptr(w["dS"]),
+                   L.ptr(sc.scene_off), L.ptr(sc.pair_off), sc.S, B, H, H, L.ptr(w["dsig"]), L.ptr(w["df3"]), L.ptr(w["dwh"]),
+                   L.ptr(w["dh_att"]), st)
+            gemm(w["df3"], H, gT["e2"], H, None, P, H, 64, w["df2"], 64, EPI_DRELU, aux=w["f2"], aux_ld=64)
+            gemm(w["df2"], 64, gT["e1"], 64, None, P, 64, 32, w["df1"], 32, EPI_DRELU, aux=w["f1"], aux_ld=32)
+            gemm(w["dwh"], H, gT["att"], H, None, B, H, H, w["dh_att"], H, cin=w["dh_att"], cin_ld=H)   # += dwh W_att
+            dh2, dh2_ld = w["dh_att"], H
+            problems += [(w["df1"], 32, w["feat"], 4, P, 32, 3, gp.g(emb[0].weight), 3, gp.g(emb[0].bias)),
+                         (w["df2"], 64, w["f1"], 32, P, 64, 32, gp.g(emb[2].weight), 32, gp.g(emb[2].bias)),
+                         (w["df3"], H, w["f2"], 64, P, H, 64, gp.g(emb[4].weight), 64, gp.g(emb[4].bias)),
+                         (w["dwh"], H, hT, H, B, H, H, gp.g(att.weight), H, gp.g(att.bias))]
+        else:
+            for p in list(G.feature_embedder.parameters()) + list(G.attention.parameters()):
+                gp.g(p).zero_()
+        # observation steps: h_{To-1} feeds decode step 0 (dhcat), LSTM step To (dgates of To) and the social block
+        for t in range(To - 1, -1, -1):
+            if t == To - 1:
+                lstm_bwd(t, w["dhcat"], H, dh2, dh2_ld)
+            else:
+                lstm_bwd(t, None, 0)
+        # weight gradients: LSTM (W_hh against h_{t-1}: hs[t], zero slab first; the composed input matrix against x4)
+        problems += [(dg, 4 * H, hs, H, Ta * B, 4 * H, H, gp.g(whh), H, gp.g(enc.lstm.bias_hh_l0)),
+                     (dg, 4 * H, w["x4"], 4, Ta * B, 4 * H, 4, w["dWx"], 4, w["dbx"]),
+                     (w["dz1"], D1, w["cat"], D1, Tp * B, D1, D1, gp.g(dec[0].weight), D1, gp.g(dec[0].bias)),
+                     (w["dz2"], D2, w["a1"], D1, Tp * B, D2, D1, gp.g(dec[2].weight), D1, gp.g(dec[2].bias)),
+                     (w["dz3"], D3, w["a2"], D2, Tp * B, D3, D2, gp.g(dec[4].weight), D2, gp.g(dec[4].bias)),
+                     (w["dv"], 4, w["a3"], D3, Tp * B, 2, D3, gp.g(dec[5].weight), D3, gp.g(dec[5].bias))]
+        self._wgrad(w, problems)
+        # back through the composition Wx = W_ih W_e, bxc = W_ih b_e + b_ih:
+        #   dW_ih = dWx W_e^T + dbx b_e^T, dW_e = W_ih^T dWx, db_e = W_ih^T dbx, db_ih = dbx (= db_hh, written above)
+        wih = enc.lstm.weight_ih_l0
+        gemm(w["dWx"], 4, enc.embed.weight, 4, None, 4 * H, 4, H, gp.g(wih), H)
+        gemm(w["dbx"], 1, enc.embed.bias, 1, None, 4 * H, 1, H, gp.g(wih), H, cin=gp.g(wih), cin_ld=H)
+        gemm(wih, 1, w["dWx"], 1, None, H, 4 * H, 4, gp.g(enc.embed.weight), 4, x_cs=H, w_cs=4)
+        gemm(wih, 1, w["dbx"], 1, None, H, 4 * H, 1, gp.g(enc.embed.bias), 1, x_cs=H)
+        gp.g(enc.lstm.bias_ih_l0).copy_(w["dbx"])
+
+    def _disc_forward(self, w, B, To, nb):
+        """Discriminator.forward (train.py:294-309) on nb future branches sharing the observation encoding; rows of branch k
+        at [k B, (k + 1) B) of w["px"] (0: the rollout's prediction, 1: the real future)."""
+        H, Tp, st, D = self.H, self.n_next, L.stream(), self.D
+        H2, nl = H // 2, self.n_latent_codes
+        lstm = D.obsv_encoder_lstm
+        x4, hs, cs, gates = w["x4"], w["d_hs"], w["d_cs"], w["d_gates"]
+        for t in range(To):
+            L.call("sw_wide_lstm_fwd", L.ptr(x4[t]), 4, L.ptr(hs[t]) if t > 0 else None, H, L.ptr(cs[t - 1]) if t > 0 else None,
+                   L.ptr(lstm.weight_ih_l0), L.ptr(lstm.bias_ih_l0), L.ptr(lstm.bias_hh_l0), L.ptr(lstm.weight_hh_l0), B, H,
+                   L.ptr(gates[t]), L.ptr(cs[t]), L.ptr(hs[t + 1]), H, None, 0, st)
+        of, pe, cl, la = D.obsv_encoder_fc, D.pred_encoder, D.classifier, D.latent_decoder
+        R = nb * B
+        gemm(hs[To], H, of[0].weight, H, of[0].bias, B, H, H2, w["o1"], H2, EPI_LRELU)
+        for k in range(nb):      # obsv_code into the first half of `both`, once per branch
+            gemm(w["o1"], H2, of[2].weight, H2, of[2].bias, B, H2, H2, _off(w["both"], k * B * H), H)
+        gemm(w["px"], 4 * Tp, pe[0].weight, 4 * Tp, pe[0].bias, R, 4 * Tp, H2, w["q1"], H2, EPI_LRELU)
+        gemm(w["q1"], H2, pe[2].weight, H2, pe[2].bias, R, H2, H2, _off(w["both"], H2), H)
+        gemm(w["both"], H, cl[0].weight, H, cl[0].bias, R, H, H2, w["c1"], H2, EPI_LRELU)
+        gemm(w["c1"], H2, cl[2].weight, H2, cl[2].bias, R, H2, 1, w["label"], 1)
+        gemm(w["both"], H, la[0].weight, H, la[0].bias, R, H, H2, w["l1"], H2, EPI_LRELU)
+        gemm(w["l1"], H2, la[2].weight, H2, la[2].bias, R, H2, nl, w["code"], nl)
+
+    def _disc_heads_backward(self, w, B, nb, want_dpred):
+        """Backward of the heads from dlab / dcod: every delta the weight gradients need, optionally d/d(pred) of branch 0."""
+        H, Tp, D = self.H, self.n_next, self.D
+        H2, nl, nlp = H // 2, self.n_latent_codes, (self.n_latent_codes + 3) // 4 * 4
+        of, pe, cl, la = D.obsv_encoder_fc, D.pred_encoder, D.classifier, D.latent_decoder
+        R = nb * B
+        self._transposes(self._dT_args)
+        dT = self.dT
+        gemm(w["dlab"], 4, dT["cl1"], 1, None, R, 1, H2, w["dc1"], H2, EPI_DLRELU, aux=w["c1"], aux_ld=H2)
+        gemm(w["dcod"], nlp, dT["la1"], nl, None, R, nl, H2, w["dl1"], H2, EPI_DLRELU, aux=w["l1"], aux_ld=H2)
+        gemm(w["dc1"], H2, dT["cl0"], H2, None, R, H2, H, w["dboth"], H)
+        gemm(w["dl1"], H2, dT["la0"], H2, None, R, H2, H, w["dboth"], H, cin=w["dboth"], cin_ld=H)
+        gemm(_off(w["dboth"], H2), H, dT["pe1"], H2, None, R, H2, H2, w["dq1"], H2, EPI_DLRELU, aux=w["q1"], aux_ld=H2)
+        if want_dpred:
+            gemm(w["dq1"], H2, dT["pe0"], H2, None, B, H2, 4 * Tp, w["dpx"], 4 * Tp)
+
+    def _disc_backward(self, w, B, To):
+        """Backward of a D update (both branches): heads, observation path, LSTM through time, weight gradients."""
+        H, Tp, st, D, dp = self.H, self.n_next, L.stream(), self.D, self.dp
+        H2, nl, nlp = H // 2, self.n_latent_codes, (self.n_latent_codes + 3) // 4 * 4
+        of, pe, cl, la = D.obsv_encoder_fc, D.pred_encoder, D.classifier, D.latent_decoder
+        lstm = D.obsv_encoder_lstm
+        dT = self.dT
+        self._disc_heads_backward(w, B, 2, False)
+        # obsv_code feeds both branches: its gradient is the sum over the branches
+        L.call("sw_wide_sum_steps", L.ptr(w["dboth"]), B * H, H, 2, B, H2, L.ptr(w["docode"]), H2, st)
+        gemm(w["docode"], H2, dT["of1"], H2, None, B, H2, H2, w["do1"], H2, EPI_DLRELU, aux=w["o1"], aux_ld=H2)
+        gemm(w["do1"], H2, dT["of0"], H2, None, B, H2, H, w["d_dhT"], H)
+        hs, cs, gates, dg = w["d_hs"], w["d_cs"], w["d_gates"], w["d_dgates"]
+        for t in range(To - 1, -1, -1):
+            L.call("sw_wide_lstm_bwd", L.ptr(w["d_dhT"]) if t == To - 1 else None, H, None, 0,
+                   L.ptr(dg[t + 1]) if t + 1 < To else None, L.ptr(dT["whh"]), L.ptr(gates[t]), L.ptr(cs[t]),
+                   L.ptr(cs[t - 1]) if t > 0 else None, L.ptr(w["d_dc"]) if t + 1 < To else None, B, H, L.ptr(dg[t]),
+                   L.ptr(w["d_dc"]), st)
+        g = dp.g
+        R = 2 * B
+        self._wgrad(w, [
+            (dg, 4 * H, hs, H, To * B, 4 * H, H, g(lstm.weight_hh_l0), H, g(lstm.bias_hh_l0)),
+            (dg, 4 * H, w["x4"], 4, To * B, 4 * H, 4, g(lstm.weight_ih_l0), 4, g(lstm.bias_ih_l0)),
+            (w["do1"], H2, hs[To], H, B, H2, H, g(of[0].weight), H, g(of[0].bias)),
+            (w["docode"], H2, w["o1"], H2, B, H2, H2, g(of[2].weight), H2, g(of[2].bias)),
+            (w["dq1"], H2, w["px"], 4 * Tp, R, H2, 4 * Tp, g(pe[0].weight), 4 * Tp, g(pe[0].bias)),
+            (_off(w["dboth"], H2), H, w["q1"], H2, R, H2, H2, g(pe[2].weight), H2, g(pe[2].bias)),
+            (w["dc1"], H2, w["both"], H, R, H2, H, g(cl[0].weight), H, g(cl[0].bias)),
+            (w["dlab"], 4, w["c1"], H2, R, 1, H2, g(cl[2].weight), H2, g(cl[2].bias)),
+            (w["dl1"], H2, w["both"], H, R, H2, H, g(la[0].weight), H, g(la[0].bias)),
+            (w["dcod"], nlp, w["l1"], H2, R, nl, H2, g(la[2].weight), H2, g(la[2].bias)),
+        ])
+
+    def _sq(self, a, lda, b, ldb, targets, t_idx, R, C, gscale, out, da, ldda):
+        L.call("sw_sqdiff", _p(a), lda, _p(b), ldb, _p(targets), int(t_idx), R, C, float(gscale), _p(out), _p(da), ldda, L.stream())
+
+    # ---- the step ------------------------------------------------------------------------------------------------------------
+    def _step_device(self, w, sc, B, To, ss):
+        """Device-only body of train.py:458-554 on the staged inputs of `w` (capturable)."""
+        U, Tp, nl, H = self.n_unrolling_steps, self.n_next, self.n_latent_codes, self.H
+        nlp = (nl + 3) // 4 * 4
+        Bg = float(B)
+        wi = self.loss_info_w if self.use_info_loss else 0.0
+        sums, z, tg = w["sums"], w["noise"], w["targets"]
+        L.call("sw_traj_4d", L.ptr(w["obsv"]), L.ptr(w["pred"]), B, To, Tp, L.ptr(w["o4"]), L.ptr(w["p4"]), L.stream())
+        fake = self._gen_forward(w, sc, B, To)        # the three predict() calls of a step are identical
+        for u in range(U + 1):                           # train.py:476-499
+            self._disc_forward(w, B, To, 2)
+            self._sq(w["label"], 1, None, 0, tg, 0, B, 1, 2.0 / Bg, _off(sums, 3 * u), w["dlab"], 4)
+            self._sq(_off(w["label"], B), 1, None, 0, tg, 1, B, 1, 2.0 / Bg, _off(sums, 3 * u + 2), _off(w["dlab"], 4 * B), 4)
+            self._sq(w["code"], nl, z, H // 2, None, 0, B, nl, wi * 2.0 / (nl * Bg), _off(sums, 3 * u + 1), w["dcod"], nlp)
+            self._disc_backward(w, B, To)
+            self.D_optimizer.step()
+            if u == 0 and U > 0:
+                self._d_backup.copy_(self.dp.flat)       # deepcopy(D) after the first update (train.py:498-499)
+        # ---- generator update (train.py:503-539) ----
+        self._disc_forward(w, B, To, 1)
+        self._sq(w["label"], 1, None, 0, tg, 1, B, 1, 2.0 / Bg, _off(sums, 3 * (U + 1)), w["dlab"], 4)
+        self._sq(w["code"], nl, z, H // 2, None, 0, B, nl, wi * 2.0 / (nl * Bg), _off(sums, 3 * (U + 1) + 1), w["dcod"], nlp)
+        self._disc_heads_backward(w, B, 1, True)
+        dpred4 = w["dpx"]
+        if self.use_l2_loss:                             # train.py:525-526
+            L.call("sw_l2_grad", L.ptr(fake), L.ptr(w["pred"]), B, Tp, 0, B, self.loss_l2_w / (Bg * Tp), L.ptr(dpred4), L.stream())
+        self._gen_backward(w, sc, B, To, dpred4)
+        self.predictor_optimizer.step()
+        if U > 0:                                        # D.load(backup): Linear layers only (train.py:311-316, 541-542)
+            torch.where(self._lin_mask, self._d_backup, self.dp.flat, out=self.dp.flat)
+        sums[U + 2].zero_()
+        L.call("sw_ade_fde", L.ptr(fake), L.ptr(w["pred"]), B, Tp, 1.0 / float(ss), L.ptr(sums[U + 2]), L.ptr(w["ade_scr"]), L.stream())
+        # the reported sums (SocialWaysTrainer.step()'s layout): the info term's mean runs over B * nl elements
+        torch.mul(sums.double(), self._kres, out=w["res"])
+
+    def step(self, obsv, pred, sub_batches, zeros_val, ones_val, noise, ss=1.0, global_B=None, out=None, global_row0=0,
+             variety_noise=None):
+        """One packed batch (train.py:458-554).  Returns the (U+3, 3) float64 sums of SocialWaysTrainer.step()."""
+        dev = self.device
+        B, To = obsv.shape[0], obsv.shape[1]
+        if global_B is not None and float(global_B) != B:
+            raise L.SocialWaysHipError("wide path: single process only")
+        sc = _scene_index(sub_batches, B, dev)
+        w = self._buffers(B, To, sc.P)
+        w["obsv"].copy_(obsv)
+        w["pred"].copy_(pred)
+        w["noise"].copy_(noise.to(dev, non_blocking=True))
+        w["targets"].copy_(torch.tensor([float(zeros_val), float(ones_val)], dtype=torch.float32))
+        # the captured step bakes the Adam step indices' ADDRESSES in (PackedAdam.step_t) - their values advance on the host
+        key = (B, To, sc.key, float(ss), self.use_l2_loss, self.use_info_loss, self.n_unrolling_steps)
+        n_seen = self._seen.get(key, 0)
+        self._seen[key] = n_seen + 1
+        if not self.use_graph or n_seen < 2:           # two eager steps of a layout first (allocations, caches)
+            self._step_device(w, sc, B, To, ss)
+        else:
+            g = self._graphs.get(key)
+            if g is None:
+                g = self._capture(key, w, sc, B, To, ss)
+            self._replay(g)
+        self.last_pred_hat = w["pred4"]
+        return w["res"].clone()
+
+    # The optimizers count their updates on the host (PackedAdam.t -> step_t.fill_) - inside a captured graph that fill is
+    # replayed with the value of capture time.  A captured step therefore reads the update indices from two device scalars
+    # that the host sets before every replay.
+    def _capture(self, key, w, sc, B, To, ss):
+        torch.cuda.synchronize()
+        dopt, gopt = self.D_optimizer, self.predictor_optimizer
+        steps_d = [torch.zeros((), device=self.device) for _ in range(self.n_unrolling_steps + 1)]
+        step_g = torch.zeros((), device=self.device)
+        real_d, real_g = dopt.step, gopt.step
+        it = iter(steps_d)
+        dopt.step = lambda st=None: real_d(next(it))
+        gopt.step = lambda st=None: real_g(step_g)
+        graph = torch.cuda.CUDAGraph()
+        t_d, t_g = dopt.t, gopt.t
+        for k, s in enumerate(steps_d):
+            s.fill_(float(t_d + k + 1))
+        step_g.fill_(float(t_g + 1))
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        try:
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    self._step_device(w, sc, B, To, ss)
+        finally:
+            dopt.step, gopt.step = real_d, real_g
+        torch.cuda.current_stream().wait_stream(side)
+        g = dict(graph=graph, steps_d=steps_d, step_g=step_g, fresh=True)
+        self._graphs[key] = g
+        return g
+
+    def _replay(self, g):
+        dopt, gopt = self.D_optimizer, self.predictor_optimizer
+        for k, s in enumerate(g["steps_d"]):
+            s.fill_(float(dopt.t + k + 1))
+        g["step_g"].fill_(float(gopt.t + 1))
+        g["graph"].replay()
+        dopt.t += len(g["steps_d"])
+        gopt.t += 1
+        dopt.step_t.fill_(float(dopt.t))
+        gopt.step_t.fill_(float(gopt.t))
+
+    def release_graphs(self):
+        self._graphs.clear()
+
+    def load_checkpoint(self, ck):
+        r = super().load_checkpoint(ck)
+        for fl in (self.gp, self.dp):          # load_state_dict copies in place: the views still alias the packed buffers
+            for p in fl.params:
+                assert p.data_ptr() == fl.flat.data_ptr() + 4 * fl.off[id(p)], "parameter left its packed buffer"
+        return r

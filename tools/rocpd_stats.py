@@ -17,7 +17,7 @@ tot = sum(sum(v[skip:]) for v in agg.values())
 print("%-72s %7s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
 for name, v in sorted(agg.items(), key=lambda kv: -sum(kv[1][skip:])):
     v = v[skip:] or [0]
-    short = name.split("(")[0][:72]
+    short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:72]
     print("%-72s %7d %12.1f %10.2f %10.2f %10.2f %6.2f" % (short, len(v), sum(v) / 1e3, sum(v) / len(v) / 1e3,
                                                          min(v) / 1e3, max(v) / 1e3, 100.0 * sum(v) / max(tot, 1)))
 print("total kernel time %.1f us over %d dispatches; wall span %.1f us" % (tot / 1e3, len(rows),
