@@ -205,4 +205,4 @@ def test_fused_encoder_survives_deepcopy_and_pickle():
     assert type(model.EncoderLstm(64)) is generic.EncoderLstm and type(model.EncoderLstm(128, 1)) is generic.EncoderLstm
     # n_latent_codes given positionally reaches the generic trainer like the keyword does
     t = sw.SocialWaysTrainer.__new__(sw.SocialWaysTrainer, 12, 64, 1e-4, 1e-3, 1, True, True, 0.5, 3)
-    assert type(t) is generic.GenericTrainer
+    assert isinstance(t, generic.GenericTrainer)        # the wide / generic-width family, not the fused 64-unit trainer
