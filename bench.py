@@ -542,6 +542,42 @@ def main():
             other["m1_variety_k20"] = {"workload": "m1 + best-of-20 variety loss (use_variety_loss='fixed'): decode loop on 40 960 agent copies, encoder and social block once on the 2 048 agents",
                                        "steps": n, "steps_s": n / d, "ms_per_step": 1e3 * d / n}
             del lg
+            # `--hidden-size 128` (train.py:42-44): the WIDE path (wide.py: time-step-level kernels, explicit backward, one
+            # hipGraph per step) on the metric shape; the generic path's layer-by-layer form ran 42 steps/s here in round 3
+            for Hw in (128, 96):
+                torch.cuda.empty_cache()
+                import socialways_amd as sw
+                torch.manual_seed(0)
+                np.random.seed(0)
+                tr_w = sw.SocialWaysTrainer(Tp, hidden_size=Hw, use_social=True, device=dev)
+                S_w, A_w = WORKLOADS["m1"][:2]
+                tk = sw.synth_tracks(S_w * 2, A_w, To, Tp, seed=99)
+                dw = sw.SceneDataset(tk["obsvs"], tk["preds"], tk["batches"], device=dev)
+                Bw, sbw = S_w * A_w, np.stack([np.arange(S_w) * A_w, (np.arange(S_w) + 1) * A_w], axis=1).astype(np.int64)
+                zb = torch.empty(Bw, Hw // 2).pin_memory()
+
+                def wstep(i):
+                    a = (i % 2) * Bw
+                    torch.rand(zb.shape, out=zb)
+                    return tr_w.step(dw.obsv[a:a + Bw], dw.pred[a:a + Bw], sbw, np.random.uniform(0, 0.1), np.random.uniform(0.9, 1.0),
+                                     zb, dw.ss)
+                for i in range(6):
+                    last_w = wstep(i)
+                n_w, t_best = 60, float("inf")
+                for rep in range(3):
+                    fence()
+                    t0 = time.perf_counter()
+                    for i in range(n_w):
+                        last_w = wstep(i)
+                    fence()
+                    t_best = min(t_best, time.perf_counter() - t0)
+                assert torch.isfinite(last_w).all(), "non-finite losses (hidden size %d)" % Hw
+                other["m1_hidden%d" % Hw] = {
+                    "workload": "m1 at --hidden-size %d (decoder %d-%d-%d-%d-2, noise %d): %s" % (
+                        Hw, 5 * Hw // 2, 5 * Hw // 2, 5 * Hw // 4, 5 * Hw // 8, Hw // 2, type(tr_w).__name__),
+                    "steps": n_w, "steps_s": n_w / t_best, "ms_per_step": 1e3 * t_best / n_w}
+                tr_w.release_graphs()
+                del tr_w, dw
             # the evaluation pass test() exists for - K = 20 sampled futures per held-out scene, min / avg ADE
             # and FDE (train.py:563-616) - on the m1-shaped recording's held-out fifth (scenes folded into rollout launches)
             torch.cuda.empty_cache()

@@ -222,35 +222,37 @@ __device__ __forceinline__ void wide_core(WideSmem<AT>& sm, XRow xrow, WRow wrow
   }
 }
 
-// y = epi(x W^T + bias + cin; aux) on the staged core: workgroup = 32 rows x 64 columns, wave = 16 rows x 32 columns.
-template <bool OV>
+// y = epi(x W^T + bias + cin; aux) on the staged core: workgroup = 16 AT rows x 64 columns (AT = 2: wave = 16 rows x 32
+// columns; AT = 1: 16 rows x 16 columns - twice the workgroups, for products that would leave half of the chip idle).
+template <int AT, bool OV>
 __global__ __launch_bounds__(256) void wide_gemm_lds_kernel(const float* __restrict__ x, long long x_rs, const float* __restrict__ w,
                                                             long long w_rs, const float* __restrict__ bias,
                                                             const float* __restrict__ cin, int cin_ld, const float* __restrict__ aux,
                                                             int aux_ld, long long R, int K, int N, float* __restrict__ y, int y_ld,
                                                             int epi) {
-  __shared__ WideSmem<2> sm;
+  constexpr int UT = AT;
+  __shared__ WideSmem<AT> sm;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 15, lg = lane >> 4;
   const int ncb = (N + 63) >> 6;
   const long long rb = blockIdx.x / ncb;
   const int n0 = (int)(blockIdx.x - rb * ncb) * 64;
-  const long long r0 = rb * 32;
-  const int at = wave & 1, ug = wave >> 1;
-  f32x4 acc[2];
+  const long long r0 = rb * 16 * AT;
+  const int at = wave % AT, ug = wave / AT;
+  f32x4 acc[UT];
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < UT; ++u)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int n = n0 + 16 * (2 * ug + u) + 4 * lg + q;
+      const int n = n0 + 16 * (UT * ug + u) + 4 * lg + q;
       acc[u][q] = (bias && n < N) ? bias[n] : 0.f;
     }
-  wide_core<2, 2>(sm, [&](int i) { return x + min(r0 + i, R - 1) * x_rs; },
-                  [&](int i) { return w + (long long)min(n0 + i, N - 1) * w_rs; }, K, acc);
+  wide_core<AT, UT>(sm, [&](int i) { return x + min(r0 + i, R - 1) * x_rs; },
+                    [&](int i) { return w + (long long)min(n0 + i, N - 1) * w_rs; }, K, acc);
   const long long row = r0 + 16 * at + ln;
   if (row >= R) return;
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int n = n0 + 16 * (2 * ug + u) + 4 * lg;
+  for (int u = 0; u < UT; ++u) {
+    const int n = n0 + 16 * (UT * ug + u) + 4 * lg;
     if (n >= N) continue;
     if constexpr (OV) {
       f32x4 v = acc[u];
@@ -334,27 +336,31 @@ __global__ __launch_bounds__(256) void wide_lstm_fwd_kernel(const float* __restr
 // transposed matrix), then the element-wise cell backward -> dgates_t (pre-activation gradients, the rows the weight
 // gradients contract over) and dc_{t-1}.  A wave owns 16 agents x 16 units; a workgroup = the 4 unit tiles of one
 // 64-unit block for the same 16 agents (the dgates rows are shared through L1).
+template <int AT>       // agent tiles per workgroup: 2 (32 agents x 64 units) or 1 (16 x 64: twice the workgroups for small batches)
 __global__ __launch_bounds__(256) void wide_lstm_bwd_kernel(const float* __restrict__ dh_ext, int dhe_ld,
                                                             const float* __restrict__ dh_ext2, int dhe2_ld,
                                                             const float* __restrict__ dg_next, const float* __restrict__ WhhT,
                                                             const float* __restrict__ gates, const float* __restrict__ c,
                                                             const float* __restrict__ c_prev, const float* __restrict__ dc_in,
                                                             int B, int H, float* __restrict__ dgates, float* __restrict__ dc_out) {
-  __shared__ WideSmem<2> sm;
+  constexpr int UT = AT;          // unit tiles per wave (4 / AT unit groups x UT = 4)
+  __shared__ WideSmem<AT> sm;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 15, lg = lane >> 4;
   const int nub = (H + 63) >> 6;
   const int rb = blockIdx.x / nub, ub = (blockIdx.x - rb * nub) * 64;
-  const int r0 = rb * 32;
-  const int at = wave & 1, ug = wave >> 1;
-  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const int r0 = rb * 16 * AT;
+  const int at = wave % AT, ug = wave / AT;
+  f32x4 acc[UT];
+#pragma unroll
+  for (int u = 0; u < UT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (dg_next)
-    wide_core<2, 2>(sm, [&](int i) { return dg_next + (size_t)min(r0 + i, B - 1) * 4 * H; },
-                    [&](int i) { return WhhT + (size_t)min(ub + i, H - 1) * 4 * H; }, 4 * H, acc);
+    wide_core<AT, UT>(sm, [&](int i) { return dg_next + (size_t)min(r0 + i, B - 1) * 4 * H; },
+                      [&](int i) { return WhhT + (size_t)min(ub + i, H - 1) * 4 * H; }, 4 * H, acc);
   const int row = r0 + 16 * at + ln;
   if (row >= B) return;
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int u0 = ub + 16 * (2 * ug + u);
+  for (int u = 0; u < UT; ++u) {
+    const int u0 = ub + 16 * (UT * ug + u);
     if (u0 >= H) continue;
     f32x4 dh = acc[u];
     const size_t e = (size_t)row * H + u0 + 4 * lg;
@@ -516,13 +522,20 @@ extern "C" int sw_wide_gemm(const float* x, long long x_rs, int x_cs, const floa
   const bool ov = (N & 3) == 0 && (y_ld & 3) == 0 && al(y) && (!cin || ((cin_ld & 3) == 0 && al(cin))) &&
                   (!aux || ((aux_ld & 3) == 0 && al(aux)));
   hipStream_t st = (hipStream_t)stream;
-  if (xv && wv && R >= 16) {      // the model's layers: LDS-staged core, 32 x 64 tiles
-    const long long blocks2 = ((R + 31) / 32) * ((N + 63) / 64);
-    if (blocks2 > 0x7fffffffLL) return SW_ESHAPE;
-    if (ov) SW_LAUNCH((wide_gemm_lds_kernel<true>), dim3((unsigned)blocks2), dim3(256), 0, st, x, x_rs, w, w_rs, bias, cin, cin_ld, aux,
-                      aux_ld, R, K, N, y, y_ld, epi);
-    else SW_LAUNCH((wide_gemm_lds_kernel<false>), dim3((unsigned)blocks2), dim3(256), 0, st, x, x_rs, w, w_rs, bias, cin, cin_ld, aux,
-                   aux_ld, R, K, N, y, y_ld, epi);
+  if (xv && wv && R >= 16) {      // the model's layers: LDS-staged core, 32 x 64 tiles (16 x 64 while those leave CUs idle)
+    const long long b2 = ((R + 31) / 32) * ((N + 63) / 64), b1 = ((R + 15) / 16) * ((N + 63) / 64);
+    if (b1 > 0x7fffffffLL) return SW_ESHAPE;
+#define WIDE_LDS_GEMM(AT, OV, NB)                                                                                              \
+  SW_LAUNCH((wide_gemm_lds_kernel<AT, OV>), dim3((unsigned)(NB)), dim3(256), 0, st, x, x_rs, w, w_rs, bias, cin, cin_ld, aux, aux_ld, \
+            R, K, N, y, y_ld, epi)
+    if (b2 >= 384) {
+      if (ov) WIDE_LDS_GEMM(2, true, b2);
+      else WIDE_LDS_GEMM(2, false, b2);
+    } else {
+      if (ov) WIDE_LDS_GEMM(1, true, b1);
+      else WIDE_LDS_GEMM(1, false, b1);
+    }
+#undef WIDE_LDS_GEMM
     SW_CHECK_LAUNCH("wide_gemm_lds_kernel");
     return SW_OK;
   }
@@ -560,8 +573,13 @@ extern "C" int sw_wide_lstm_bwd(const float* dh_ext, int dhe_ld, const float* dh
   if (!gates || !c || !dgates || !dc_out || B < 1 || H < 16 || (H & 15) || (dg_next && !WhhT) ||
       (dh_ext && (dhe_ld < H || (dhe_ld & 3))) || (dh_ext2 && (dhe2_ld < H || (dhe2_ld & 3))))
     return SW_EARG;
-  SW_LAUNCH(wide_lstm_bwd_kernel, dim3((unsigned)(((B + 31) / 32) * ((H + 63) / 64))), dim3(256), 0, (hipStream_t)stream, dh_ext,
-            dhe_ld, dh_ext2, dhe2_ld, dg_next, WhhT, gates, c, c_prev, dc_in, B, H, dgates, dc_out);
+  const int nub = (H + 63) / 64;
+  if (((B + 31) / 32) * nub >= 512)      // enough workgroups for the chip at 32 agents each
+    SW_LAUNCH((wide_lstm_bwd_kernel<2>), dim3((unsigned)(((B + 31) / 32) * nub)), dim3(256), 0, (hipStream_t)stream, dh_ext, dhe_ld,
+              dh_ext2, dhe2_ld, dg_next, WhhT, gates, c, c_prev, dc_in, B, H, dgates, dc_out);
+  else
+    SW_LAUNCH((wide_lstm_bwd_kernel<1>), dim3((unsigned)(((B + 15) / 16) * nub)), dim3(256), 0, (hipStream_t)stream, dh_ext, dhe_ld,
+              dh_ext2, dhe2_ld, dg_next, WhhT, gates, c, c_prev, dc_in, B, H, dgates, dc_out);
   SW_CHECK_LAUNCH("wide_lstm_bwd_kernel");
   return SW_OK;
 }

@@ -15,10 +15,14 @@ for a seed -, state_dict keys and shapes as train.py:153-335), evaluated LAYER B
 
 - each wrapped in a torch.autograd.Function, so torch's tape does the bookkeeping of the backward pass (as it does for the
 stand-alone sub-modules of model.py) and torch.optim.Adam the update (north_star: "Host code stays Python on
-PyTorch-ROCm for glue and the Adam step").  Every floating-point operation of the model runs in a HIP kernel; torch is
-used for memory, concatenation / slicing, the tape and Adam.  This path is launch-bound (hundreds of small launches per
-step) and an order of magnitude slower than the fused path: it exists so that every width the reference accepts trains
-here with the same parity guarantees, not for throughput.  No CPU fallback: CPU tensors raise.
+PyTorch-ROCm for glue and the Adam step").  The matrix products, LSTM cells, activations, pair features, attention and loss
+terms run in the library's kernels; torch supplies memory, concatenation / slicing, the tape - and a few element-wise
+operations of its own: the sum of the two gate pre-activation products, the position integration p += v, the scaling of
+the loss gradients, the loss sum and both Adam steps.  This path is launch-bound (over a thousand small launches per step
+under the tape): 42 steps/s at 128 units on the metric shape.  Widths that are multiples of 32 train on the WIDE path instead
+(wide.py: the same modules, explicit backward over time-step-level kernels, one hipGraph per step - 10 x faster); this file
+remains for every other width the reference accepts, as the module classes of both, and as the cross-check of the wide
+engine (tests).  No CPU fallback: CPU tensors raise.
 """
 import copy
 
@@ -64,20 +68,27 @@ class _Lin(torch.autograd.Function):
             if R:
                 L.call("sw_rows_gemm", L.ptr(dy), N, L.ptr(W), K, 1, None, R, N, K, L.ptr(dx), ldx, 0, L.stream())
         if ctx.needs_input_grad[1]:
-            dW = torch.zeros(N, K, device=dev)
-            db = torch.zeros(N, device=dev)
+            # the grouped GEMM reads delta / activation rows as float4s and cuts them into whole lane vectors: row strides and
+            # the contracted / output widths are padded to multiples of 4 with zeros (widths like 50 = 0.625 x 80 units)
+            N4, K4 = (N + 3) // 4 * 4, (K + 3) // 4 * 4
+            dWp = torch.zeros(N4, K4, device=dev)
+            dbp = torch.zeros(N4, device=dev)
             if R:
                 d4 = dy
-                if N % 4:            # the grouped GEMM reads delta rows as float4s: pad the row stride to a multiple of 4
-                    d4 = torch.zeros(R, (N + 3) // 4 * 4, device=dev)
+                if N4 != N:
+                    d4 = torch.zeros(R, N4, device=dev)
                     d4[:, :N] = dy
-                if ldx % 4:
-                    raise L.SocialWaysHipError("generic linear layer: input row stride %d is not a multiple of 4" % ldx)
+                x4 = x
+                if ldx % 4 or K4 > ldx:
+                    x4 = torch.zeros(R, max(K4, (ldx + 3) // 4 * 4), device=dev)
+                    x4[:, :K] = x[:, :K]
                 ws = _wgrad_ws(dev)
-                for n0 in range(0, N, 256):        # sw_linear_wgrad takes up to 256 output rows per call
-                    n1 = min(N, n0 + 256)
-                    L.call("sw_linear_wgrad", d4.data_ptr() + 4 * n0, d4.shape[1], L.ptr(x), ldx, R, n1 - n0, K,
-                           dW.data_ptr() + 4 * n0 * K, K, db.data_ptr() + 4 * n0, L.ptr(ws), 0, L.stream())
+                for n0 in range(0, N4, 256):       # sw_linear_wgrad takes up to 256 output rows per call
+                    n1 = min(N4, n0 + 256)
+                    L.call("sw_linear_wgrad", d4.data_ptr() + 4 * n0, d4.shape[1], L.ptr(x4), x4.shape[1], R, n1 - n0, K4,
+                           dWp.data_ptr() + 4 * n0 * K4, K4, dbp.data_ptr() + 4 * n0, L.ptr(ws), 0, L.stream())
+            dW = dWp[:N, :K].contiguous() if (N4 != N or K4 != K) else dWp
+            db = dbp[:N].contiguous() if N4 != N else dbp
             if not ctx.has_b:
                 db = None
         return dx, dW, db
@@ -371,11 +382,21 @@ class GenericTrainer(SocialWaysTrainer):
 
     def __init__(self, n_next, hidden_size=64, lr_g=1e-4, lr_d=1e-3, n_unrolling_steps=1, use_social=True, use_info_loss=True,
                  loss_info_w=0.5, n_latent_codes=2, device="cuda", process_group=None, use_l2_loss=False,
-                 use_variety_loss=False, loss_l2_w=0.5, **_ignored):
+                 use_variety_loss=False, loss_l2_w=0.5, **perf_only):
+        # options of the fused trainer that change speed, not results, are accepted and have no effect here; anything else
+        # is a mistake worth hearing about
+        unknown = set(perf_only) - {"variety_k", "use_graph", "fused_adam"}
+        if unknown:
+            raise TypeError("unexpected keyword arguments: %s" % sorted(unknown))
         if process_group is not None:
             raise L.SocialWaysHipError("generic-width path: single process only")
         if use_variety_loss:
             raise L.SocialWaysHipError("generic-width path: use_variety_loss is not implemented")
+        if int(n_latent_codes) < 2:
+            # train.py:486, 516 compare code_hat.squeeze() of shape (B,) with noise[:, :1] of shape (B, 1): nn.MSELoss
+            # broadcasts them to (B, B).  That accident is not reproduced here - and not silently replaced by another loss
+            raise L.SocialWaysHipError("n_latent_codes = 1: the reference's info loss broadcasts (B,) against (B, 1) into a "
+                                       "(B, B) mean (train.py:486, 516); not supported - use >= 2 latent codes")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise L.SocialWaysHipError("socialways_amd runs on MI355X only (no CPU fallback)")

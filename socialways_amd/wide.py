@@ -85,7 +85,10 @@ class WideTrainer(GenericTrainer):
 
     def __init__(self, n_next, hidden_size=128, lr_g=1e-4, lr_d=1e-3, n_unrolling_steps=1, use_social=True, use_info_loss=True,
                  loss_info_w=0.5, n_latent_codes=2, device="cuda", process_group=None, use_l2_loss=False,
-                 use_variety_loss=False, loss_l2_w=0.5, use_graph=None, **_ignored):
+                 use_variety_loss=False, loss_l2_w=0.5, use_graph=None, **perf_only):
+        unknown = set(perf_only) - {"variety_k", "fused_adam"}
+        if unknown:
+            raise TypeError("unexpected keyword arguments: %s" % sorted(unknown))
         if not self.supports(hidden_size, n_latent_codes, use_variety_loss, process_group):
             raise L.SocialWaysHipError("wide path: hidden_size % 32 == 0, n_latent_codes >= 2, single process, no variety loss")
         self.device = torch.device(device)

@@ -499,11 +499,11 @@ def test_smaller_hidden_sizes_run_zero_padded_and_match_the_oracle(H, tmp_path):
     assert torch.equal(a, b) and torch.equal(tr.G._flat_all, tr2.G._flat_all) and torch.equal(tr.D._flat, tr2.D._flat)
 
 
-@pytest.mark.parametrize("H,nl", [(128, 2), (96, 2), (64, 3)])
+@pytest.mark.parametrize("H,nl", [(128, 2), (96, 2), (64, 3), (80, 2)])      # 80 units (decoder 200 / 100 / 50): generic path
 def test_wider_networks_train_on_the_generic_path_and_match_the_oracle(H, nl, tmp_path):
     """`--hidden-size` above the fused kernels' 64 units (train.py:42-44, 76-81) and latent-code counts other than 2
-    (train.py:65): SocialWaysTrainer hands these to the generic-width path (socialways_amd/generic.py - the same model
-    layer by layer through the C ABI).  Same initial weights as the reference draws, two whole GAN steps against the
+    (train.py:65): SocialWaysTrainer hands these to the wide path (socialways_amd/wide.py: time-step-level kernels, explicit
+    backward; these three widths are multiples of 32) - a subclass of the generic-width trainer (socialways_amd/generic.py).  Same initial weights as the reference draws, two whole GAN steps against the
     oracle built with that width (9 MSE terms, rollout, ADE/FDE, the generator's gradients of the first step, the
     weights after both steps), a checkpoint in the reference's format and a resume from the file."""
     import socialways_amd as sw
@@ -556,6 +556,52 @@ def test_wider_networks_train_on_the_generic_path_and_match_the_oracle(H, nl, tm
     # evaluation on the generic path: test() of train.py:563-616
     res = tr.test(data, n_gen_samples=3)
     assert all(np.isfinite(res))
+
+
+def test_wide_path_equals_generic_path_and_graph_replay_equals_eager():
+    """The wide engine (wide.py: time-step-level kernels, explicit backward) against the layer-by-layer generic path under
+    torch's tape (generic.py) on the same modules: reported sums, rollout, EVERY gradient of the generator, the weights
+    of G and D after each of three steps; then its hipGraph-replayed step against its eager step, bit for bit.  Widths
+    that are not multiples of 32 stay on the generic path."""
+    import socialways_amd as sw
+    from socialways_amd.generic import GenericTrainer
+    from socialways_amd.wide import WideTrainer
+    H = 128
+    assert type(sw.SocialWaysTrainer(12, hidden_size=H, device="cuda:0")) is WideTrainer
+    assert type(sw.SocialWaysTrainer(12, hidden_size=80, device="cuda:0")) is GenericTrainer
+    torch.manual_seed(7)
+    a = WideTrainer(12, hidden_size=H, device="cuda:0", use_graph=False)
+    torch.manual_seed(7)
+    b = GenericTrainer(12, hidden_size=H, device="cuda:0")
+    t = sw.synth_tracks(8, [5, 1, 9, 16, 3, 2, 2, 2], 8, 12, seed=5)
+    data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
+    B, sb = 36, data.the_batches[:6]
+    gen = torch.Generator().manual_seed(2)
+    for it in range(3):
+        noise = torch.rand(B, H // 2, generator=gen)
+        ra = a.step(data.obsv[:B], data.pred[:B], sb, 0.03, 0.94, noise, data.ss)
+        rb = b.step(data.obsv[:B], data.pred[:B], sb, 0.03, 0.94, noise, data.ss)
+        assert_close(ra.cpu(), rb.cpu(), 2e-6, 1e-9, "reported sums, step %d" % it)
+        assert_close(a.last_pred_hat.cpu(), b.last_pred_hat.cpu(), 1e-5, 1e-6, "rollout, step %d" % it)
+        for (n, p), (_, q) in zip(a.G.named_parameters(), b.G.named_parameters()):
+            assert_close(p.grad.cpu(), q.grad.cpu(), 1e-4, 1e-4 * max(float(q.grad.abs().max()), 1e-12), "dG %s, step %d" % (n, it))
+        for (n, p), (_, q) in zip(list(a.G.named_parameters()) + list(a.D.named_parameters()),
+                                  list(b.G.named_parameters()) + list(b.D.named_parameters())):
+            lr = 1e-3 if n in dict(a.D.named_parameters()) else 1e-4
+            dpq = (p.detach() - q.detach()).abs()
+            assert float(dpq.max()) <= 2.2 * lr * (it + 1), n        # Adam: sign flips of noise-level gradients
+            assert float((dpq <= 0.1 * lr).float().mean()) > 0.98, n
+    torch.manual_seed(7)
+    c = WideTrainer(12, hidden_size=H, device="cuda:0", use_graph=True)
+    torch.manual_seed(7)
+    d = WideTrainer(12, hidden_size=H, device="cuda:0", use_graph=False)
+    gen = torch.Generator().manual_seed(3)
+    for it in range(6):           # eager, eager, capture + replay, replay x 3
+        noise = torch.rand(B, H // 2, generator=gen)
+        rc = c.step(data.obsv[:B], data.pred[:B], sb, 0.01 * it, 0.94, noise, data.ss)
+        rd = d.step(data.obsv[:B], data.pred[:B], sb, 0.01 * it, 0.94, noise, data.ss)
+        assert torch.equal(rc, rd) and torch.equal(c.gp.flat, d.gp.flat) and torch.equal(c.dp.flat, d.dp.flat), it
+    assert len(c._graphs) == 1 and c.D_optimizer.t == 12 and c.predictor_optimizer.t == 6
 
 
 def test_unsupported_module_widths_say_where_to_go():
