@@ -4,12 +4,17 @@
 //
 // The reference builds dense (B,B,3) / (B,B,64) tensors over all agents of the packed batch and
 // then reads only the in-scene blocks; here one workgroup owns one scene and only
-// its n^2 ordered pairs are ever formed.  Per 16-pair tile (one wave):
-//   features (VALU, per lane)  ->  3->32 ReLU (VALU, produced directly in MFMA B-operand layout)
-//   ->  32->64 ReLU  ->  64->64 on the matrix cores, the output registers of one layer being
-//   the B operands of the next (no LDS round trip: the K order of sw_common.h is chosen so that
-//   C/D layout == B layout)  ->  score = <f_ij, W h_j> by a 4-lane shuffle reduction.
-// Pair embeddings never touch HBM in the forward pass.
+// its n^2 ordered pairs are ever formed.  EmbedSocialFeatures ends in a LINEAR layer (f_ij = W3 h2_ij + b3,
+// train.py:183-188) and AttentionPooling uses f_ij only inside sigma_ij = <f_ij, Wh_j> (train.py:166-170), so
+//     sigma_ij = <h2_ij, v_j> + c_j,   v_j = W3^T Wh_j,  c_j = <b3, Wh_j>        (per AGENT j: scene_wh_to_v)
+// and the 64 -> 64 layer is never run per pair, forward or backward.  Per 16-pair tile (one wave):
+//   features (VALU, per lane)  ->  3->32 ReLU as two K = 4 matrix instructions on (f0, f1, f2, 1) x (w0, w1, w2, bias)
+//   ->  32->64 ReLU on the matrix cores, the output registers of one layer being the B operands of the
+//   next (no LDS round trip: the K order of sw_common.h is chosen so that C/D layout == B layout)
+//   ->  score = <h2_ij, v_j> + c_j by a 4-lane shuffle reduction (pair_block_v).
+// Backward: dh2_ij = relu'(h2_ij) dsigma_ij v_j; dW3 = sum_j Wh_j Q_j^T, db3 = sum_j Wh_j sd_j, dWh_j = W3 Q_j + b3 sd_j with
+// Q_j = sum_i dsigma_ij h2_ij, sd_j = sum_i dsigma_ij (pair_block_dw3).  The stand-alone module API (sw_embed_features) still
+// returns f_ij.  Pair embeddings never touch HBM in the forward pass.
 #include "../../include/socialways_hip.h"
 #include "sw_common.h"
 #include "sw_wgrad.h"
