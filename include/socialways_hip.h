@@ -406,6 +406,20 @@ int sw_attn_pairs_bwd(const float* f, const float* wh, const float* h, const flo
 int sw_adam_packed(float* w, const float* g, float* m, float* v, long long n, const float* step, double lr, double beta1,
                    double beta2, double eps, int disc_Tp, void* stream);
 
+/* sw_enc_lstm_bwd with the masked copy of sw_dec_rollout_bwd_aux (dst[i] = mask[i] > 0 ? src[i] : dst[i]) done by extra
+ * workgroups of the launch                                                                                            */
+int sw_enc_lstm_bwd_aux(const float* enc_w, const float* act, const float* c0, const float* dhT, const float* dcT,
+                        const float* dy, int B, int T, int t0, float* dgates, float* dh0, float* dc0, const float* aux_src,
+                        float* aux_dst, const float* aux_mask, long long aux_n, void* stream);
+/* sw_disc_dpred (generator phase of train.py:510-523: D forward on obsv [B,To,2] / pred4 + the backward of its prediction
+ * heads, loss gradients formed in the kernel, per-tile loss sums to loss_part) and sw_dec_rollout_bwd in ONE launch: the
+ * pass is tile-local and the decode BPTT of the same 16 agents is its only consumer.  dpred4 [B,Tp,4] = scratch that
+ * receives d(g_loss)/d(pred4).  Same results as the two calls, bit for bit.                                           */
+int sw_dec_rollout_bwd_dfuse(const float* obsv, const float* pred4, const float* d_w, const float* targets, int t_idx,
+                             const float* z, float g_label, float g_code, float* loss_part, float* dpred4, const float* enc_w,
+                             const float* dec_w, const float* gsave, int B, int To, int Tp, float* gdelta, float* dhT, float* dcT,
+                             float* dS_pool, void* stream);
+
 /* ---- WIDE path (socialways_amd/wide.py, csrc/sw_wide.hip): the model at hidden sizes H > 64, H % 16 == 0 (train.py:42-44,
  *      76-81) as one launch per LSTM step and per decoder / head layer over all agents, explicit backward, deferred
  *      weight gradients.  Replaces, per call, the stock-PyTorch ops behind nn.Linear / nn.LSTM / nn.LeakyReLU / nn.ReLU of

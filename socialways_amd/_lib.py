@@ -44,6 +44,9 @@ PROTOTYPES = {
     "sw_gen_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "sw_gen_wgrad_adam": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                ctypes.c_longlong, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp]),
+    "sw_enc_lstm_bwd_aux": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "sw_dec_rollout_bwd_dfuse": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp,
+                                      _vp]),
     "sw_rows_gemm": (_i, [_vp, _i, _vp, _i, _i, _vp, ctypes.c_longlong, _i, _i, _vp, _i, _i, _vp]),
     "sw_linear_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "sw_embed_features_bwd": (_i, [_vp, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp]),

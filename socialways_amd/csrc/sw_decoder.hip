@@ -12,10 +12,10 @@
 //     between layers through small LDS tiles (one barrier per layer).
 #include "../../include/socialways_hip.h"
 #include "sw_lstm_dev.h"
+#include "sw_disc_dev.h"
 #include <type_traits>
 
-namespace {
-constexpr int LD64 = sw_ld(64);    // 68
+namespace {     // (LD64 = sw_ld(64) = 68 comes with sw_disc_dev.h)
 constexpr int LD160 = sw_ld(160);  // 164
 constexpr int LD80 = sw_ld(80);    // 84
 constexpr int LD96 = sw_ld(96);    // 100
@@ -486,11 +486,24 @@ struct BwdLds {
 static_assert(16 * SW_GLD >= 16 * LD160 && 16 * SW_GLD >= 1280 + 176, "aliases of dgbuf");
 }  // namespace
 
+// DFUSE: the generator-phase discriminator pass of the tile (D forward on the tile's prediction + the backward of its
+// prediction heads down to d(g_loss)/d(pred_hat), train.py:510-523) runs IN FRONT of the tile's decode BPTT, in the same
+// workgroup: the pass is tile-local and this BPTT is its only consumer - one graph node (~4 us of boundary) less per step.
+struct DecDiscFuse {
+  const float* obsv;      // [B][To][2]
+  const float* pred_hat;  // [B][Tp][4]
+  const float* d_w;       // packed D weights (after its last update of the step)
+  const float* dimg;      // D's weight images or null
+  DiscLoss gl;
+  float* dpred;           // [B][Tp][4] scratch: d(g_loss)/d(pred_hat), written and re-read by the same workgroup
+};
+template <bool DFUSE>
 __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
     const float* __restrict__ dpred4, const float* __restrict__ enc_w, const float* __restrict__ dec_w,
     const float* __restrict__ gsave, int B, int To, int Tp, float* __restrict__ gdelta,
     float* __restrict__ dhT, float* __restrict__ dcT, float* __restrict__ dS_pool, const float* __restrict__ aux_src,
-    float* __restrict__ aux_dst, const float* __restrict__ aux_mask, long long aux_n, const float* __restrict__ gimg) {
+    float* __restrict__ aux_dst, const float* __restrict__ aux_mask, long long aux_n, const float* __restrict__ gimg,
+    DecDiscFuse df) {
   // Workgroups beyond the agent tiles run an auxiliary masked copy dst[i] = mask[i] > 0 ? src[i] : dst[i]
   // (the training step's D.load(backup), train.py:541-542, on CUs this latency-bound launch leaves idle)
   {
@@ -503,6 +516,11 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
     }
   }
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if constexpr (DFUSE) {
+    disc_fwd_tile(smem, blockIdx.x, gridDim.x, df.obsv, To, 0, df.pred_hat, nullptr, 1, df.d_w, B, Tp, nullptr, nullptr, nullptr,
+                  nullptr, nullptr, 0, 0, nullptr, 1, df.gl, df.dpred, df.dimg);
+    __syncthreads();      // the tile's d/d(pred) rows are in memory (this workgroup wrote them) and the LDS is free again
+  }
   constexpr int LD128 = BwdLds::LD128, LD16 = BwdLds::LD16;
   float* dgbuf = smem + BwdLds::dgbuf;
   float* dz1buf = smem + BwdLds::dz1buf;
@@ -872,6 +890,12 @@ extern "C" int sw_dec_rollout_fwd(const float* obsv, int To, const float* z, con
                                 ade_part, nullptr, nullptr, stream);
 }
 
+static int set_lds_bwd(const void* fn, int bytes, int& have) {
+  if (have >= bytes) return SW_OK;
+  if (int rc = set_lds(fn, bytes)) return rc;
+  have = bytes;
+  return SW_OK;
+}
 extern "C" int sw_dec_rollout_bwd_aux(const float* dpred4, const float* enc_w, const float* dec_w,
                                       const float* gsave, int B, int To, int Tp, float* gdelta, float* dhT,
                                       float* dcT, float* dS_pool, const float* aux_src, float* aux_dst,
@@ -880,17 +904,44 @@ extern "C" int sw_dec_rollout_bwd_aux(const float* dpred4, const float* enc_w, c
     return SW_EARG;
   if (aux_n < 0 || (aux_n > 0 && (!aux_src || !aux_dst || !aux_mask))) return SW_EARG;
   if (B == 0) return SW_OK;
-  static bool attr = false;
-  if (!attr) {
-    if (int rc = set_lds((const void*)dec_rollout_bwd_kernel, BwdLds::total * 4)) return rc;
-    attr = true;
-  }
+  static int have = 0;
+  if (int rc = set_lds_bwd((const void*)dec_rollout_bwd_kernel<false>, BwdLds::total * 4, have)) return rc;
   const int tiles = (B + SW_TILE - 1) / SW_TILE;
   int extra = aux_n > 0 ? (int)((aux_n + SW_THREADS - 1) / SW_THREADS) : 0;
   if (extra > 64) extra = 64;
-  SW_LAUNCH(dec_rollout_bwd_kernel, dim3(tiles + extra), dim3(SW_THREADS), BwdLds::total * 4, (hipStream_t)stream,
+  SW_LAUNCH(dec_rollout_bwd_kernel<false>, dim3(tiles + extra), dim3(SW_THREADS), BwdLds::total * 4, (hipStream_t)stream,
                      dpred4, enc_w, dec_w, gsave, B, To, Tp, gdelta, dhT, dcT, dS_pool, aux_src, aux_dst, aux_mask, aux_n,
-                     sw_gen_images_for(enc_w, dec_w));
+                     sw_gen_images_for(enc_w, dec_w), DecDiscFuse{});
+  SW_CHECK_LAUNCH("dec_rollout_bwd_kernel");
+  return SW_OK;
+}
+
+// sw_disc_dpred + sw_dec_rollout_bwd in ONE launch (generator phase of a training step, train.py:510-538): every
+// workgroup first runs D's forward on its tile's prediction and the backward of the prediction heads (as sw_disc_dpred:
+// loss gradients of train.py:512-523 formed in the kernel, per-tile loss sums to loss_part), then the decode BPTT of that
+// tile from the d/d(pred) rows it has just written to `dpred4` (scratch).  Same results as the two calls, bit for bit.
+extern "C" int sw_dec_rollout_bwd_dfuse(const float* obsv, const float* pred4, const float* d_w, const float* targets, int t_idx,
+                                        const float* z, float g_label, float g_code, float* loss_part, float* dpred4,
+                                        const float* enc_w, const float* dec_w, const float* gsave, int B, int To, int Tp,
+                                        float* gdelta, float* dhT, float* dcT, float* dS_pool, void* stream) {
+  if (!obsv || !pred4 || !d_w || !targets || !z || t_idx < 0 || !dpred4 || !enc_w || !dec_w || !gsave || !gdelta || !dhT || !dcT ||
+      B < 0 || To < 2 || Tp < 1)
+    return SW_EARG;
+  if (Tp > 64) return SW_ESHAPE;
+  if (B == 0) return SW_OK;
+  int lds = head_lds_b(Tp, head_lds(Tp, 2 * 16 * SW_HLD + 1280).total).total * 4;
+  if (lds < BwdLds::total * 4) lds = BwdLds::total * 4;
+  if (lds > 163840) return SW_ESHAPE;
+  static int have = 0;
+  if (int rc = set_lds_bwd((const void*)dec_rollout_bwd_kernel<true>, lds, have)) return rc;
+  DecDiscFuse df;
+  df.obsv = obsv; df.pred_hat = pred4; df.d_w = d_w; df.dimg = sw_disc_images_for(d_w, Tp).img;
+  df.gl = DiscLoss{targets, z, t_idx, t_idx, g_label, g_code, 1, loss_part};
+  df.dpred = dpred4;
+  const int tiles = (B + SW_TILE - 1) / SW_TILE;
+  SW_LAUNCH(dec_rollout_bwd_kernel<true>, dim3(tiles), dim3(SW_THREADS), lds, (hipStream_t)stream, dpred4, enc_w, dec_w, gsave, B, To,
+            Tp, gdelta, dhT, dcT, dS_pool, (const float*)nullptr, (float*)nullptr, (const float*)nullptr, 0LL,
+            sw_gen_images_for(enc_w, dec_w), df);
   SW_CHECK_LAUNCH("dec_rollout_bwd_kernel");
   return SW_OK;
 }

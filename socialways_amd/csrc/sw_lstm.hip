@@ -96,7 +96,19 @@ template <bool DY>
 __global__ __launch_bounds__(SW_THREADS) void enc_lstm_bwd_kernel(
     const float* __restrict__ whh, const float* __restrict__ act, const float* __restrict__ c0,
     const float* __restrict__ dhT, const float* __restrict__ dcT, const float* __restrict__ dy, int B, int T,
-    int t0, float* __restrict__ dgates, float* __restrict__ dh0, float* __restrict__ dc0, const float* __restrict__ gimg) {
+    int t0, float* __restrict__ dgates, float* __restrict__ dh0, float* __restrict__ dc0, const float* __restrict__ gimg,
+    const float* __restrict__ aux_src, float* __restrict__ aux_dst, const float* __restrict__ aux_mask, long long aux_n) {
+  // Workgroups beyond the agent tiles run an auxiliary masked copy dst[i] = mask[i] > 0 ? src[i] : dst[i] (the training
+  // step's D.load(backup), train.py:541-542, when the decode BPTT launch - its usual place - also reads D's weights)
+  {
+    const int tiles = (B + SW_TILE - 1) / SW_TILE;
+    if ((int)blockIdx.x >= tiles) {
+      const long long stride = (long long)(gridDim.x - tiles) * SW_THREADS;
+      for (long long i = (long long)(blockIdx.x - tiles) * SW_THREADS + threadIdx.x; i < aux_n; i += stride)
+        if (aux_mask[i] > 0.f) aux_dst[i] = aux_src[i];
+      return;
+    }
+  }
   __shared__ __attribute__((aligned(16))) float dgbuf[2][SW_TILE * SW_GLD];
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
   const int u0 = wave * 16;
@@ -242,18 +254,28 @@ extern "C" int sw_enc_lstm_fwd(const float* x, int x_mode, const float* enc_w, c
   return sw_enc_lstm_fwd_aux(x, x_mode, enc_w, h0, c0, B, T, hT, cT, y, act, x4s, t0, nullptr, nullptr, 0, stream);
 }
 
+extern "C" int sw_enc_lstm_bwd_aux(const float* enc_w, const float* act, const float* c0, const float* dhT,
+                                   const float* dcT, const float* dy, int B, int T, int t0, float* dgates,
+                                   float* dh0, float* dc0, const float* aux_src, float* aux_dst, const float* aux_mask,
+                                   long long aux_n, void* stream) {
+  if (!enc_w || !act || !dgates || B < 0 || T < 1 || t0 < 0) return SW_EARG;
+  if (aux_n < 0 || (aux_n > 0 && (!aux_src || !aux_dst || !aux_mask))) return SW_EARG;
+  if (B == 0) return SW_OK;
+  const float* gimg = sw_gen_images_for(enc_w, nullptr);
+  const int tiles = (B + SW_TILE - 1) / SW_TILE;
+  int extra = aux_n > 0 ? (int)((aux_n + SW_THREADS - 1) / SW_THREADS) : 0;
+  if (extra > 64) extra = 64;
+  if (dy)
+    SW_LAUNCH(enc_lstm_bwd_kernel<true>, dim3(tiles + extra), dim3(SW_THREADS), 0, (hipStream_t)stream, enc_w + swp::ENC_WHH, act, c0,
+              dhT, dcT, dy, B, T, t0, dgates, dh0, dc0, gimg, aux_src, aux_dst, aux_mask, aux_n);
+  else
+    SW_LAUNCH(enc_lstm_bwd_kernel<false>, dim3(tiles + extra), dim3(SW_THREADS), 0, (hipStream_t)stream, enc_w + swp::ENC_WHH, act, c0,
+              dhT, dcT, dy, B, T, t0, dgates, dh0, dc0, gimg, aux_src, aux_dst, aux_mask, aux_n);
+  SW_CHECK_LAUNCH("enc_lstm_bwd_kernel");
+  return SW_OK;
+}
 extern "C" int sw_enc_lstm_bwd(const float* enc_w, const float* act, const float* c0, const float* dhT,
                                const float* dcT, const float* dy, int B, int T, int t0, float* dgates,
                                float* dh0, float* dc0, void* stream) {
-  if (!enc_w || !act || !dgates || B < 0 || T < 1 || t0 < 0) return SW_EARG;
-  if (B == 0) return SW_OK;
-  const float* gimg = sw_gen_images_for(enc_w, nullptr);
-  if (dy)
-    SW_LAUNCH(enc_lstm_bwd_kernel<true>, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS), 0,
-                       (hipStream_t)stream, enc_w + swp::ENC_WHH, act, c0, dhT, dcT, dy, B, T, t0, dgates, dh0, dc0, gimg);
-  else
-    SW_LAUNCH(enc_lstm_bwd_kernel<false>, dim3((B + SW_TILE - 1) / SW_TILE), dim3(SW_THREADS), 0,
-                       (hipStream_t)stream, enc_w + swp::ENC_WHH, act, c0, dhT, dcT, dy, B, T, t0, dgates, dh0, dc0, gimg);
-  SW_CHECK_LAUNCH("enc_lstm_bwd_kernel");
-  return SW_OK;
+  return sw_enc_lstm_bwd_aux(enc_w, act, c0, dhT, dcT, dy, B, T, t0, dgates, dh0, dc0, nullptr, nullptr, nullptr, 0, stream);
 }

@@ -5,6 +5,8 @@ These are thin host wrappers: they own the workspaces (torch allocator), put the
 include/socialways_hip.h in order on the current stream and nothing else.  Both the autograd
 Functions of model.py and the fused training step of trainer.py go through them.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -176,7 +178,11 @@ def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_soc
     return pred4, ctx
 
 
-def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d_dec, ws=None, tag="g", aux=None, adam=None):
+DFUSE = os.environ.get("SW_DFUSE", "1") != "0"     # A/B switch: generator-phase D pass inside the decode BPTT launch
+
+
+def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d_dec, ws=None, tag="g", aux=None, adam=None,
+                 dfuse=None):
     """Backward of predict(): decode BPTT -> social block -> obs BPTT -> ONE grouped weight-gradient GEMM launch
     (the social block's problems ride in it).  d_* are the packed gradient buffers (overwritten).
     aux = (src, dst, mask): masked copy dst = mask > 0 ? src : dst done by idle workgroups of the decode BPTT
@@ -184,19 +190,31 @@ def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d
     CUs from the latency-bound chain and every cross-stream edge of a captured graph costs 5-10 us.)
     adam = (w_all, g_all, m, v, step scalar, lr, beta1, beta2, eps): the kernels that finish the gradients also apply
     the generator's Adam update (sw_gen_wgrad_adam; the four weight / gradient buffers are views of w_all / g_all)."""
-    dev = dpred4.device
+    dev = ctx.obsv.device
     ws = ws or default_ws(dev)
     B, To, Tp = ctx.B, ctx.To, ctx.Tp
-    dpred4 = dpred4.contiguous()
     gdelta = ws.get(tag + ".gdelta", L.workspace_floats(L.WS_GDELTA, B, To, Tp))
     wgrad = ws.get("wgrad", L.workspace_floats(L.WS_WGRAD, B, To, Tp))
     tmp = ws.get(tag + ".dwx", 2048)
     dhT = torch.empty(B, 64, device=dev)
     dcT = torch.empty(B, 64, device=dev)
     dS = torch.empty(B, 64, device=dev)
-    L.call("sw_dec_rollout_bwd_aux", L.ptr(dpred4), L.ptr(enc_w), L.ptr(dec_w), L.ptr(ctx.gsave), B, To, Tp,
-           L.ptr(gdelta), L.ptr(dhT), L.ptr(dcT), L.ptr(dS), L.ptr(aux[0]) if aux else None, L.ptr(aux[1]) if aux else None,
-           L.ptr(aux[2]) if aux else None, aux[1].numel() if aux else 0, L.stream())
+    aux_late = None
+    if dfuse is not None:
+        # dfuse = (d_w, pred_hat, targets, t_idx, z, g_label, g_code, loss_part): the generator-phase D pass (disc_dpred) runs
+        # inside the decode BPTT launch, tile by tile; that launch READS D's weights, so the masked copy that restores them
+        # (aux) moves to the observation BPTT launch
+        d_w, pred_hat, targets, t_idx, z, g_label, g_code, loss_part = dfuse
+        dscr = ws.get(tag + ".dpred", B * Tp * 4)
+        L.call("sw_dec_rollout_bwd_dfuse", L.ptr(ctx.obsv), L.ptr(pred_hat), L.ptr(d_w), L.ptr(targets), int(t_idx), L.ptr(z),
+               g_label, g_code, L.ptr(loss_part), L.ptr(dscr), L.ptr(enc_w), L.ptr(dec_w), L.ptr(ctx.gsave), B, To, Tp,
+               L.ptr(gdelta), L.ptr(dhT), L.ptr(dcT), L.ptr(dS), L.stream())
+        aux_late = aux
+    else:
+        dpred4 = dpred4.contiguous()
+        L.call("sw_dec_rollout_bwd_aux", L.ptr(dpred4), L.ptr(enc_w), L.ptr(dec_w), L.ptr(ctx.gsave), B, To, Tp,
+               L.ptr(gdelta), L.ptr(dhT), L.ptr(dcT), L.ptr(dS), L.ptr(aux[0]) if aux else None, L.ptr(aux[1]) if aux else None,
+               L.ptr(aux[2]) if aux else None, aux[1].numel() if aux else 0, L.stream())
     pending = None
     if ctx.use_social and (ctx.scenes.P > 0 or ctx.scenes.NB > 0):
         sc = ctx.scenes
@@ -210,8 +228,9 @@ def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d
     else:
         d_emb.zero_()
         d_att.zero_()
-    L.call("sw_enc_lstm_bwd", L.ptr(enc_w), L.ptr(ctx.gsave), None, L.ptr(dhT), L.ptr(dcT), None, B, To, 0,
-           L.ptr(gdelta), None, None, L.stream())
+    L.call("sw_enc_lstm_bwd_aux", L.ptr(enc_w), L.ptr(ctx.gsave), None, L.ptr(dhT), L.ptr(dcT), None, B, To, 0,
+           L.ptr(gdelta), None, None, L.ptr(aux_late[0]) if aux_late else None, L.ptr(aux_late[1]) if aux_late else None,
+           L.ptr(aux_late[2]) if aux_late else None, aux_late[1].numel() if aux_late else 0, L.stream())
     if adam is not None:
         w_all, g_all, m, v, step, lr, b1, b2, eps = adam
         L.call("sw_gen_wgrad_adam", L.ptr(enc_w), L.ptr(dec_w), L.ptr(ctx.gsave), L.ptr(gdelta), L.ptr(ctx.noise), L.ptr(ctx.S),

@@ -662,7 +662,12 @@ class SocialWaysTrainer:
                     self._disc_images()        # an update the image table did not see (torch's Adam): scatter again
         # ---- generator update (train.py:503-539) ----------------------------------------------------
         # D forward on the prediction + backward of its heads down to d(g_loss)/d(pred_hat), one launch, nothing saved
-        dpred = ops.disc_dpred(D._flat, obsv, pred_hat, targets, 1, noise, g_label, g_code, loss_part=out[U + 1])
+        # ... which is tile-local and feeds only the decode BPTT of the same tile: in the plain step (no extra terms on
+        # d/d(pred_hat)) it runs inside that launch (ops.gen_backward(dfuse=...): one graph node less)
+        dfuse = None
+        if (ops.DFUSE and KV == 1 and not self.use_l2_loss and self.use_variety_loss is False and obsv.shape[2] == 2):
+            dfuse = (D._flat, pred_hat, targets, 1, noise, g_label, g_code, out[U + 1])
+        dpred = None if dfuse else ops.disc_dpred(D._flat, obsv, pred_hat, targets, 1, noise, g_label, g_code, loss_part=out[U + 1])
         if self.use_l2_loss:                                                 # train.py:525-526
             L.call("sw_l2_grad", L.ptr(pred_hat), L.ptr(pred), B, Tp, 0, B, self.loss_l2_w / (Bg * Tp), L.ptr(dpred), L.stream())
         if self.use_variety_loss is True:                                    # train.py:527-536 as written
@@ -699,7 +704,7 @@ class SocialWaysTrainer:
                                dec._gflat, ws=ws, aux=restore)
         else:
             ops.gen_backward(enc._flat, emb._flat, att._flat, dec._flat, gctx, dpred, enc._gflat, emb._gflat, att._gflat,
-                             dec._gflat, ws=ws, aux=restore, tag="g", adam=adam)
+                             dec._gflat, ws=ws, aux=restore, tag="g", adam=adam, dfuse=dfuse)
         yield G._gflat_all
         if not fuse:
             self.predictor_optimizer.step() if steps is None else self.predictor_optimizer.step(steps[U + 1])
