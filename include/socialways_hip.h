@@ -453,6 +453,20 @@ int sw_wide_sum_steps(const float* in, long long t_stride, int in_ld, int T, lon
 /* transposed copies of ntab matrices of one packed buffer: tab (device, ntab x {src offset, rows, cols, dst offset} int32, in
  * floats), total_tiles = sum over the matrices of ceil(rows/32) ceil(cols/32); dst[dst_off + c*rows + r] = src[src_off + r*cols + c] */
 int sw_wide_transpose(const float* src, const int* tab, int ntab, int total_tiles, float* dst, void* stream);
+/* MFMA operand images of ntab matrices of one packed buffer (tab: device, ntab x {src offset, R, K, dst offset, transposed,
+ * 0} int32; the image of Mx [R][K] - M or, transposed, M^T of M [K][R] - holds the float4 Mx[16t + (l & 15)][16j + 4(l >> 4)..]
+ * at dst offset + ((t K/16 + j) 64 + l) 4); total_float4 = sum of R K / 4                                              */
+int sw_wide_opimage(const float* src, const int* tab, int ntab, long long total_float4, float* dst, void* stream);
+/* LSTM SEQUENCE kernels (hidden sizes 64 and 128: sw_wide_lstm_seq_supported): T steps of sw_wide_lstm_fwd / _bwd in one
+ * launch per 16-agent tile, W_hh / W_hh^T register-resident from their operand images.  x4 [T][B][4], gates [T][B][4H],
+ * cs [T][B][H], hs [T+1][B][H] (slab 0 = h_0, c_0 = 0), h_last2 = optional second copy of h_T.  Backward: dh_ext (+ dh_ext2)
+ * = gradient w.r.t. h_{T-1} from outside, dg_init [B][4H] = dgates of the step behind the sequence or NULL, dc_init [B][H]
+ * = gradient w.r.t. c_{T-1} from that step or NULL; writes dgates [T][B][4H].                                          */
+int sw_wide_lstm_seq_supported(int H);
+int sw_wide_lstm_seq_fwd(const float* x4, const float* Wx, const float* b1, const float* b2, const float* whh_img, int B, int H, int T,
+                         float* gates, float* cs, float* hs, float* h_last2, int h2_ld, void* stream);
+int sw_wide_lstm_seq_bwd(const float* dh_ext, int dhe_ld, const float* dh_ext2, int dhe2_ld, const float* dg_init, const float* dc_init,
+                         const float* whhT_img, const float* gates, const float* cs, int B, int H, int T, float* dgates, void* stream);
 /* n weight-gradient problems dW[N][K] = delta^T act, db = column sums (desc: n x {delta, ldd, act, lda, R, N, K, dW, ldw, db}
  * as 64-bit host values) through the grouped split-K GEMM; wgrad_ws = sw_workspace_floats(SW_WS_WGRAD, ...) floats       */
 int sw_wide_wgrad(const long long* desc, int n, float* wgrad_ws, void* stream);

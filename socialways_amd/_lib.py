@@ -96,6 +96,10 @@ PROTOTYPES = {
     "sw_wide_sum_steps": (_i, [_vp, _ll, _i, _i, _ll, _i, _vp, _i, _vp]),
     "sw_wide_wgrad": (_i, [_vp, _i, _vp, _vp]),
     "sw_wide_transpose": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "sw_wide_opimage": (_i, [_vp, _vp, _i, _ll, _vp, _vp]),
+    "sw_wide_lstm_seq_supported": (_i, [_i]),
+    "sw_wide_lstm_seq_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "sw_wide_lstm_seq_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "sw_kernel_timing": (_i, [_i]),
     "sw_kernel_timing_read": (_i, [ctypes.c_char_p, _i]),
     "sw_debug_spin": (_i, [ctypes.c_double, _vp]),

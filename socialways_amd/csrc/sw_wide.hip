@@ -497,6 +497,236 @@ __global__ __launch_bounds__(256) void wide_transpose_kernel(const float* __rest
   for (int i = ty; i < 32; i += 8)
     if (c0 + i < T.z && r0 + tx < T.y) dst[T.w + (size_t)(c0 + i) * T.y + r0 + tx] = tile[tx][i];
 }
+
+// MFMA A-operand IMAGES of weight matrices (as swimg::OP_* of the fused path, sw_common.h): for a matrix Mx [R][K] - M
+// itself or its transpose - the float4 of (row tile t, k-step j, lane l) = Mx[16 t + (l & 15)][16 j + 4 (l >> 4) .. + 3] at
+// dst + ((t K/16 + j) 64 + l) 4, so that a wave loads a tile's operand as 1 KB of consecutive memory.  The LSTM sequence
+// kernels below hold W_hh (forward) / W_hh^T (BPTT) in registers for a whole sequence and load them from these images.
+// table entry (6 ints): src offset, R, K, dst offset, transposed (Mx = M^T, M is [K][R]), -.  One thread per float4.
+__global__ __launch_bounds__(256) void wide_opimage_kernel(const float* __restrict__ src, const int* __restrict__ tab, int ntab,
+                                                           float* __restrict__ dst) {
+  long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+  int m = 0;
+  for (; m < ntab; ++m) {
+    const long long n4 = (long long)tab[6 * m + 1] * tab[6 * m + 2] / 4;
+    if (f < n4) break;
+    f -= n4;
+  }
+  if (m >= ntab) return;
+  const int so = tab[6 * m], K = tab[6 * m + 2], dofs = tab[6 * m + 3], tr = tab[6 * m + 4], R = tab[6 * m + 1];
+  const int KJ = K >> 4;
+  const int l = (int)(f & 63);
+  const long long tj = f >> 6;
+  const int t = (int)(tj / KJ), j = (int)(tj - (long long)t * KJ);
+  const int r = 16 * t + (l & 15), k = 16 * j + 4 * (l >> 4);
+  f32x4 v;
+  if (!tr) v = ld4(src + so + (size_t)r * K + k);
+  else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = src[so + (size_t)(k + q) * R + r];
+  }
+  st4(dst + dofs + 4 * f, v);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// LSTM SEQUENCE kernels for H = 64 NU (NU = 1, 2): the T steps of one observation sequence in ONE launch per 16-agent tile,
+// W_hh (forward) / W_hh^T (BPTT) register-resident for the whole sequence - at 128 units that is 256 of the 512 registers a
+// lane owns at one wave per SIMD -, h / dgates exchanged through LDS tiles, one barrier per step: the design of
+// enc_lstm_fwd/bwd_kernel (sw_lstm.hip) at twice the width.  Replaces T launches of wide_lstm_fwd / _bwd (9.5 / 13.7 us each)
+// by 4.1 us per step.  Wave w owns the unit tiles NU w .. NU w + NU - 1 of all four gates.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int NU>
+__global__ __launch_bounds__(256) void wide_lstm_seq_fwd_kernel(const float* __restrict__ x4 /*[T][B][4]*/,
+                                                                const float* __restrict__ Wx, const float* __restrict__ b1,
+                                                                const float* __restrict__ b2, const float* __restrict__ whh_img,
+                                                                int B, int T, float* __restrict__ gates /*[T][B][4H]*/,
+                                                                float* __restrict__ cs /*[T][B][H]*/,
+                                                                float* __restrict__ hs /*[T+1][B][H], slab 0 = h_0*/,
+                                                                float* __restrict__ h_last2, int h2_ld) {
+  constexpr int H = 64 * NU, KJ = H / 16, HLD = H + 4, UT = 4 * NU;     // UT unit tiles per gate
+  __shared__ __attribute__((aligned(16))) float hbuf[2][16 * HLD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 15, lg = lane >> 4;
+  const int a0 = blockIdx.x * 16;
+  const int b = min(a0 + ln, B - 1);          // padding lanes of the last tile: replicas of agent B - 1 (same values, same rows)
+  f32x4 whh[4][NU][KJ];
+  float wx[4][NU];
+  f32x4 bias[4][NU];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      const int tile = g * UT + NU * wave + k;
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) whh[g][k][j] = ld4(whh_img + (((size_t)tile * KJ + j) * 64 + lane) * 4);
+      const int u0 = 16 * (NU * wave + k);
+      wx[g][k] = Wx[(size_t)(g * H + u0 + ln) * 4 + lg];
+      bias[g][k] = ld4(b1 + g * H + u0 + 4 * lg);
+      if (b2) bias[g][k] = bias[g][k] + ld4(b2 + g * H + u0 + 4 * lg);
+    }
+  f32x4 c[NU], h[NU];
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    c[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    h[k] = ld4(hs + (size_t)b * H + 16 * (NU * wave + k) + 4 * lg);      // h_0 (zeros for the model's sequences)
+    st4(&hbuf[0][ln * HLD + 16 * (NU * wave + k) + 4 * lg], h[k]);
+  }
+  float xa = x4[(size_t)b * 4 + lg];
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const float xb = xa;
+    xa = x4[((size_t)min(t + 1, T - 1) * B + b) * 4 + lg];             // the next step's input, in flight under this step
+    const float* hrow = &hbuf[t & 1][ln * HLD + 4 * lg];
+    f32x4 acc[4][NU];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int k = 0; k < NU; ++k) acc[g][k] = SW_MFMA(wx[g][k], xb, bias[g][k]);
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+      const f32x4 hv = ld4(hrow + 16 * j);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int k = 0; k < NU; ++k) acc[g][k] = SW_MFMA(whh[g][k][j][q], hv[q], acc[g][k]);
+    }
+    float* grow = gates + ((size_t)t * B + b) * 4 * H + 4 * lg;
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      const int u0 = 16 * (NU * wave + k);
+      f32x4 gi, gf, gg, go;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        gi[q] = sw_sigmoid(acc[0][k][q]);
+        gf[q] = sw_sigmoid(acc[1][k][q]);
+        gg[q] = sw_tanh(acc[2][k][q]);
+        go[q] = sw_sigmoid(acc[3][k][q]);
+        c[k][q] = fmaf(gf[q], c[k][q], gi[q] * gg[q]);
+        h[k][q] = go[q] * sw_tanh(c[k][q]);
+      }
+      st4(&hbuf[(t + 1) & 1][ln * HLD + u0 + 4 * lg], h[k]);
+      st4(grow + u0, gi);
+      st4(grow + H + u0, gf);
+      st4(grow + 2 * H + u0, gg);
+      st4(grow + 3 * H + u0, go);
+      st4(cs + ((size_t)t * B + b) * H + u0 + 4 * lg, c[k]);
+      st4(hs + ((size_t)(t + 1) * B + b) * H + u0 + 4 * lg, h[k]);
+    }
+    sw_barrier();
+  }
+  if (h_last2) {
+#pragma unroll
+    for (int k = 0; k < NU; ++k) st4(h_last2 + (size_t)b * h2_ld + 16 * (NU * wave + k) + 4 * lg, h[k]);
+  }
+}
+
+// BPTT of a sequence: for t = T-1 .. 0: dh_t = [t == T-1: dh_ext + dh_ext2] + W_hh^T dgates_{t+1} (dgates_T = dg_init or none),
+// cell backward with the saved rows -> dgates_t (to memory through an LDS tile, one agent row per store instruction, and
+// kept in LDS as the next step's operand), dc carried in registers (dc_T = dc_init or 0).
+template <int NU>
+__global__ __launch_bounds__(256) void wide_lstm_seq_bwd_kernel(const float* __restrict__ dh_ext, int dhe_ld,
+                                                                const float* __restrict__ dh_ext2, int dhe2_ld,
+                                                                const float* __restrict__ dg_init, const float* __restrict__ dc_init,
+                                                                const float* __restrict__ whhT_img, const float* __restrict__ gates,
+                                                                const float* __restrict__ cs, int B, int T,
+                                                                float* __restrict__ dgates) {
+  constexpr int H = 64 * NU, K = 4 * H, KJ = K / 16, GLD = K + 4;
+  __shared__ __attribute__((aligned(16))) float dgbuf[2][16 * GLD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 15, lg = lane >> 4;
+  const int a0 = blockIdx.x * 16;
+  const int b = min(a0 + ln, B - 1);
+  f32x4 wT[NU][KJ];
+#pragma unroll
+  for (int k = 0; k < NU; ++k)
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) wT[k][j] = ld4(whhT_img + (((size_t)(NU * wave + k) * KJ + j) * 64 + lane) * 4);
+  f32x4 dc[NU], dh[NU];
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const int u0 = 16 * (NU * wave + k);
+    dc[k] = dc_init ? ld4(dc_init + (size_t)b * H + u0 + 4 * lg) : f32x4{0.f, 0.f, 0.f, 0.f};
+    dh[k] = dh_ext ? ld4(dh_ext + (size_t)b * dhe_ld + u0 + 4 * lg) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (dh_ext2) dh[k] = dh[k] + ld4(dh_ext2 + (size_t)b * dhe2_ld + u0 + 4 * lg);
+  }
+  // dgates_T (the step behind the sequence, if any) into the tile the first iteration reads: a wave copies 4 agents' rows
+  {
+    float* tile = dgbuf[T & 1];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int a = 4 * wave + q, bb = min(a0 + a, B - 1);
+      for (int c4 = lane; c4 < K / 4; c4 += 64)
+        st4(tile + a * GLD + 4 * c4, dg_init ? ld4(dg_init + (size_t)bb * K + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+  }
+  __syncthreads();
+  for (int t = T - 1; t >= 0; --t) {
+    // the saved rows of step t are requested FIRST: their round trip runs under the 256 matrix instructions below
+    f32x4 gi[NU], gf[NU], gg[NU], go[NU], ct[NU], cp[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      const int u0 = 16 * (NU * wave + k);
+      const float* gr = gates + ((size_t)t * B + b) * K + u0 + 4 * lg;
+      gi[k] = ld4(gr); gf[k] = ld4(gr + H); gg[k] = ld4(gr + 2 * H); go[k] = ld4(gr + 3 * H);
+      ct[k] = ld4(cs + ((size_t)t * B + b) * H + u0 + 4 * lg);
+      cp[k] = ld4(cs + ((size_t)max(t - 1, 0) * B + b) * H + u0 + 4 * lg);      // unconditional; zeroed below for t = 0
+    }
+    // recurrent part: dh += W_hh^T dgates_{t+1} from the LDS tile (zeros when nothing follows)
+    {
+      const float* drow = &dgbuf[(t + 1) & 1][ln * GLD + 4 * lg];
+      f32x4 acc[NU], acc1[NU];
+#pragma unroll
+      for (int k = 0; k < NU; ++k) acc[k] = acc1[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j0 = 0; j0 < KJ; j0 += 8) {
+        f32x4 d[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = ld4(drow + 16 * (j0 + j));
+#pragma unroll
+        for (int j = 0; j < 8; j += 2)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < NU; ++k) {
+              acc[k] = SW_MFMA(wT[k][j0 + j][q], d[j][q], acc[k]);
+              acc1[k] = SW_MFMA(wT[k][j0 + j + 1][q], d[j + 1][q], acc1[k]);
+            }
+      }
+#pragma unroll
+      for (int k = 0; k < NU; ++k) dh[k] = dh[k] + (acc[k] + acc1[k]);
+    }
+    float* tile = dgbuf[t & 1];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      const int u0 = 16 * (NU * wave + k);
+      if (t == 0) cp[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 di, df, dg, dO;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float tc = sw_tanh(ct[k][q]);
+        const float dct = fmaf(dh[k][q] * go[k][q], 1.0f - tc * tc, dc[k][q]);
+        di[q] = dct * gg[k][q] * gi[k][q] * (1.0f - gi[k][q]);
+        df[q] = dct * cp[k][q] * gf[k][q] * (1.0f - gf[k][q]);
+        dg[q] = dct * gi[k][q] * (1.0f - gg[k][q] * gg[k][q]);
+        dO[q] = dh[k][q] * tc * go[k][q] * (1.0f - go[k][q]);
+        dc[k][q] = dct * gf[k][q];
+      }
+      float* tr = tile + ln * GLD + u0 + 4 * lg;
+      st4(tr, di);
+      st4(tr + H, df);
+      st4(tr + 2 * H, dg);
+      st4(tr + 3 * H, dO);
+      dh[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    sw_barrier();      // LDS only: a full __syncthreads() would also drain the 32 KB of dgates rows stored in the previous step
+    // dgates_t rows to memory from the tile: a wave writes 4 agents' rows, consecutive lanes consecutive float4s
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int a = 4 * wave + q, bb = min(a0 + a, B - 1);
+      for (int c4 = lane; c4 < K / 4; c4 += 64) st4(dgates + ((size_t)t * B + bb) * K + 4 * c4, ld4(tile + a * GLD + 4 * c4));
+    }
+  }
+}
 }  // namespace
 
 extern "C" int sw_wide_transpose(const float* src, const int* tab /*device, ntab x 4*/, int ntab, int total_tiles, float* dst,
@@ -504,6 +734,49 @@ extern "C" int sw_wide_transpose(const float* src, const int* tab /*device, ntab
   if (!src || !tab || !dst || ntab < 1 || total_tiles < 1) return SW_EARG;
   SW_LAUNCH(wide_transpose_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, src, (const int4*)tab, ntab, dst);
   SW_CHECK_LAUNCH("wide_transpose_kernel");
+  return SW_OK;
+}
+
+extern "C" int sw_wide_opimage(const float* src, const int* tab /*device, ntab x 6*/, int ntab, long long total_float4, float* dst,
+                               void* stream) {
+  if (!src || !tab || !dst || ntab < 1 || total_float4 < 1) return SW_EARG;
+  SW_LAUNCH(wide_opimage_kernel, dim3((unsigned)((total_float4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, tab, ntab, dst);
+  SW_CHECK_LAUNCH("wide_opimage_kernel");
+  return SW_OK;
+}
+
+extern "C" int sw_wide_lstm_seq_supported(int H) { return H == 64 || H == 128 ? 1 : 0; }
+
+extern "C" int sw_wide_lstm_seq_fwd(const float* x4, const float* Wx, const float* b1, const float* b2, const float* whh_img, int B,
+                                    int H, int T, float* gates, float* cs, float* hs, float* h_last2, int h2_ld, void* stream) {
+  if (!x4 || !Wx || !b1 || !whh_img || !gates || !cs || !hs || B < 1 || T < 1 || (h_last2 && (h2_ld < H || (h2_ld & 3)))) return SW_EARG;
+  if (!sw_wide_lstm_seq_supported(H)) return SW_ESHAPE;
+  const dim3 grid((B + 15) / 16), block(256);
+  if (H == 64)
+    SW_LAUNCH((wide_lstm_seq_fwd_kernel<1>), grid, block, 0, (hipStream_t)stream, x4, Wx, b1, b2, whh_img, B, T, gates, cs, hs, h_last2,
+              h2_ld);
+  else
+    SW_LAUNCH((wide_lstm_seq_fwd_kernel<2>), grid, block, 0, (hipStream_t)stream, x4, Wx, b1, b2, whh_img, B, T, gates, cs, hs, h_last2,
+              h2_ld);
+  SW_CHECK_LAUNCH("wide_lstm_seq_fwd_kernel");
+  return SW_OK;
+}
+
+extern "C" int sw_wide_lstm_seq_bwd(const float* dh_ext, int dhe_ld, const float* dh_ext2, int dhe2_ld, const float* dg_init,
+                                    const float* dc_init, const float* whhT_img, const float* gates, const float* cs, int B, int H,
+                                    int T, float* dgates, void* stream) {
+  if (!whhT_img || !gates || !cs || !dgates || B < 1 || T < 1 || (dh_ext && (dhe_ld < H || (dhe_ld & 3))) ||
+      (dh_ext2 && (dhe2_ld < H || (dhe2_ld & 3))))
+    return SW_EARG;
+  if (!sw_wide_lstm_seq_supported(H)) return SW_ESHAPE;
+  const dim3 grid((B + 15) / 16), block(256);
+  if (H == 64)
+    SW_LAUNCH((wide_lstm_seq_bwd_kernel<1>), grid, block, 0, (hipStream_t)stream, dh_ext, dhe_ld, dh_ext2, dhe2_ld, dg_init, dc_init,
+              whhT_img, gates, cs, B, T, dgates);
+  else
+    SW_LAUNCH((wide_lstm_seq_bwd_kernel<2>), grid, block, 0, (hipStream_t)stream, dh_ext, dhe_ld, dh_ext2, dhe2_ld, dg_init, dc_init,
+              whhT_img, gates, cs, B, T, dgates);
+  SW_CHECK_LAUNCH("wide_lstm_seq_bwd_kernel");
   return SW_OK;
 }
 

@@ -131,6 +131,11 @@ class WideTrainer(GenericTrainer):
             whh=Dm.obsv_encoder_lstm.weight_hh_l0, of0=Dm.obsv_encoder_fc[0].weight, of1=Dm.obsv_encoder_fc[2].weight,
             pe0=Dm.pred_encoder[0].weight, pe1=Dm.pred_encoder[2].weight, cl0=Dm.classifier[0].weight,
             cl1=Dm.classifier[2].weight, la0=Dm.latent_decoder[0].weight, la1=Dm.latent_decoder[2].weight))
+        # hidden sizes 64 / 128: the observation sequences run as LSTM SEQUENCE kernels (W_hh / W_hh^T register-resident for
+        # the whole sequence, loaded from operand-layout images made once per weight update: sw_wide_opimage)
+        self.seq = bool(L.load().sw_wide_lstm_seq_supported(H))
+        self.gI, self._gI_args = self._image_table(self.gp, enc.lstm.weight_hh_l0)
+        self.dI, self._dI_args = self._image_table(self.dp, Dm.obsv_encoder_lstm.weight_hh_l0)
         nl = n_latent_codes                     # reported sums: the info term's mean runs over B * nl elements (losses_from)
         k = np.ones((n_unrolling_steps + 3, 3))
         k[:n_unrolling_steps + 2, 1] = 2.0 / nl
@@ -148,6 +153,19 @@ class WideTrainer(GenericTrainer):
         out = {name: buf[o:o + a * b].view(a, b) for name, (o, a, b) in views.items()}
         tab_d = torch.tensor(tab, dtype=torch.int32).to(self.device)
         return out, (fl.flat, tab_d, len(tab), tiles, buf)
+
+    def _image_table(self, fl, whh):
+        """Operand images of W_hh [4H][H] (forward) and of its transpose [H][4H] (BPTT)."""
+        n = whh.numel()
+        o = fl.off[id(whh)]
+        R, K = whh.shape
+        tab = torch.tensor([[o, R, K, 0, 0, 0], [o, K, R, n, 1, 0]], dtype=torch.int32).to(self.device)
+        buf = torch.zeros(2 * n, device=self.device)
+        return dict(whh=buf[:n], whhT=buf[n:]), (fl.flat, tab, 2, 2 * n // 4, buf)
+
+    def _images(self, args):
+        src, tab, n, n4, dst = args
+        L.call("sw_wide_opimage", L.ptr(src), L.ptr(tab), n, n4, L.ptr(dst), L.stream())
 
     def _transposes(self, args):
         src, tab, n, tiles, dst = args
@@ -224,8 +242,13 @@ class WideTrainer(GenericTrainer):
                    L.ptr(w["Wx"]), L.ptr(w["bxc"]), L.ptr(enc.lstm.bias_hh_l0), L.ptr(whh), B, H, L.ptr(gates[t]),
                    L.ptr(cs[t]), L.ptr(hs[t + 1]), H, _p(h2), h2_ld, st)
 
-        for t in range(To):
-            lstm(t, cat[0] if t == To - 1 else None, D1)
+        if self.seq:
+            self._images(self._gI_args)
+            L.call("sw_wide_lstm_seq_fwd", L.ptr(x4), L.ptr(w["Wx"]), L.ptr(w["bxc"]), L.ptr(enc.lstm.bias_hh_l0), L.ptr(self.gI["whh"]),
+                   B, H, To, L.ptr(gates), L.ptr(cs), L.ptr(hs), L.ptr(cat[0]), D1, st)
+        else:
+            for t in range(To):
+                lstm(t, cat[0] if t == To - 1 else None, D1)
         hT = hs[To]
         if G.use_social and sc.P > 0:
             if sc.NB:
@@ -316,11 +339,15 @@ class WideTrainer(GenericTrainer):
             for p in list(G.feature_embedder.parameters()) + list(G.attention.parameters()):
                 gp.g(p).zero_()
         # observation steps: h_{To-1} feeds decode step 0 (dhcat), LSTM step To (dgates of To) and the social block
-        for t in range(To - 1, -1, -1):
-            if t == To - 1:
-                lstm_bwd(t, w["dhcat"], H, dh2, dh2_ld)
-            else:
-                lstm_bwd(t, None, 0)
+        if self.seq:
+            L.call("sw_wide_lstm_seq_bwd", L.ptr(w["dhcat"]), H, _p(dh2), dh2_ld, L.ptr(dg[To]) if To < Ta else None,
+                   L.ptr(w["dc"]) if have_dc else None, L.ptr(self.gI["whhT"]), L.ptr(gates), L.ptr(cs), B, H, To, L.ptr(dg), st)
+        else:
+            for t in range(To - 1, -1, -1):
+                if t == To - 1:
+                    lstm_bwd(t, w["dhcat"], H, dh2, dh2_ld)
+                else:
+                    lstm_bwd(t, None, 0)
         # weight gradients: LSTM (W_hh against h_{t-1}: hs[t], zero slab first; the composed input matrix against x4)
         problems += [(dg, 4 * H, hs, H, Ta * B, 4 * H, H, gp.g(whh), H, gp.g(enc.lstm.bias_hh_l0)),
                      (dg, 4 * H, w["x4"], 4, Ta * B, 4 * H, 4, w["dWx"], 4, w["dbx"]),
@@ -345,7 +372,11 @@ class WideTrainer(GenericTrainer):
         H2, nl = H // 2, self.n_latent_codes
         lstm = D.obsv_encoder_lstm
         x4, hs, cs, gates = w["x4"], w["d_hs"], w["d_cs"], w["d_gates"]
-        for t in range(To):
+        if self.seq:
+            self._images(self._dI_args)
+            L.call("sw_wide_lstm_seq_fwd", L.ptr(x4), L.ptr(lstm.weight_ih_l0), L.ptr(lstm.bias_ih_l0), L.ptr(lstm.bias_hh_l0),
+                   L.ptr(self.dI["whh"]), B, H, To, L.ptr(gates), L.ptr(cs), L.ptr(hs), None, 0, st)
+        for t in range(0 if self.seq else To):
             L.call("sw_wide_lstm_fwd", L.ptr(x4[t]), 4, L.ptr(hs[t]) if t > 0 else None, H, L.ptr(cs[t - 1]) if t > 0 else None,
                    L.ptr(lstm.weight_ih_l0), L.ptr(lstm.bias_ih_l0), L.ptr(lstm.bias_hh_l0), L.ptr(lstm.weight_hh_l0), B, H,
                    L.ptr(gates[t]), L.ptr(cs[t]), L.ptr(hs[t + 1]), H, None, 0, st)
@@ -390,7 +421,10 @@ class WideTrainer(GenericTrainer):
         gemm(w["docode"], H2, dT["of1"], H2, None, B, H2, H2, w["do1"], H2, EPI_DLRELU, aux=w["o1"], aux_ld=H2)
         gemm(w["do1"], H2, dT["of0"], H2, None, B, H2, H, w["d_dhT"], H)
         hs, cs, gates, dg = w["d_hs"], w["d_cs"], w["d_gates"], w["d_dgates"]
-        for t in range(To - 1, -1, -1):
+        if self.seq:
+            L.call("sw_wide_lstm_seq_bwd", L.ptr(w["d_dhT"]), H, None, 0, None, None, L.ptr(self.dI["whhT"]), L.ptr(gates), L.ptr(cs),
+                   B, H, To, L.ptr(dg), st)
+        for t in range(-1 if self.seq else To - 1, -1, -1):
             L.call("sw_wide_lstm_bwd", L.ptr(w["d_dhT"]) if t == To - 1 else None, H, None, 0,
                    L.ptr(dg[t + 1]) if t + 1 < To else None, L.ptr(dT["whh"]), L.ptr(gates[t]), L.ptr(cs[t]),
                    L.ptr(cs[t - 1]) if t > 0 else None, L.ptr(w["d_dc"]) if t + 1 < To else None, B, H, L.ptr(dg[t]),
