@@ -19,24 +19,36 @@ extern "C" const char* sw_last_error(void) { return g_err; }
 #include <vector>
 #include <map>
 bool g_sw_ktime_on = false;
+#include <mutex>
 namespace {
 struct KtRec { const char* name; hipEvent_t e0, e1; bool ended; };
-std::vector<KtRec> g_kt;
+std::vector<KtRec> g_kt;           // shared by the host threads that launch: every access under g_kt_mu
+std::mutex g_kt_mu;
+thread_local long t_kt_open = -1;  // the record this thread's sw_ktime_begin opened (-1: none - e.g. event creation failed)
 }
 void sw_ktime_begin(const char* name, hipStream_t st) {
+  t_kt_open = -1;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
   KtRec r{name, nullptr, nullptr, false};
-  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) { (void)hipGetLastError(); return; }
+  if (hipEventCreate(&r.e0) != hipSuccess) { (void)hipGetLastError(); return; }
+  if (hipEventCreate(&r.e1) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(r.e0); return; }
   (void)hipEventRecord(r.e0, st);
+  std::lock_guard<std::mutex> lk(g_kt_mu);
   g_kt.push_back(r);
+  t_kt_open = (long)g_kt.size() - 1;
 }
 void sw_ktime_end(hipStream_t st) {
-  if (g_kt.empty() || g_kt.back().ended) return;
-  (void)hipEventRecord(g_kt.back().e1, st);
-  g_kt.back().ended = true;
+  const long i = t_kt_open;
+  t_kt_open = -1;
+  if (i < 0) return;
+  std::lock_guard<std::mutex> lk(g_kt_mu);
+  if (i >= (long)g_kt.size() || g_kt[i].ended) return;      // (the list was reset in between)
+  (void)hipEventRecord(g_kt[i].e1, st);
+  g_kt[i].ended = true;
 }
 extern "C" int sw_kernel_timing(int on) {
+  std::lock_guard<std::mutex> lk(g_kt_mu);
   for (auto& r : g_kt) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   g_kt.clear();
   g_sw_ktime_on = on != 0;
@@ -46,6 +58,7 @@ extern "C" int sw_kernel_timing(int on) {
 extern "C" int sw_kernel_timing_read(char* buf, int cap) {
   if (hipDeviceSynchronize() != hipSuccess) return SW_EHIP;
   std::map<std::string, std::pair<long, double>> agg;
+  std::lock_guard<std::mutex> lk(g_kt_mu);
   for (auto& r : g_kt) {
     if (!r.ended) continue;
     float ms = 0.f;
