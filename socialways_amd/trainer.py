@@ -169,8 +169,7 @@ class SocialWaysTrainer:
             from .wide import WideTrainer
             # widths that are multiples of 32: the wide path (time-step-level kernels, explicit backward, one hipGraph per
             # step); anything else the reference accepts: the layer-by-layer generic path under torch's tape
-            if os.environ.get("SW_WIDE", "1") != "0" and WideTrainer.supports(hidden_size, nl, kw.get("use_variety_loss", False),
-                                                                              kw.get("process_group")):
+            if os.environ.get("SW_WIDE", "1") != "0" and WideTrainer.supports(hidden_size, nl, kw.get("use_variety_loss", False)):
                 return object.__new__(WideTrainer)
             return object.__new__(GenericTrainer)
         return object.__new__(cls)

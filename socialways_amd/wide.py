@@ -80,8 +80,9 @@ class WideTrainer(GenericTrainer):
 
     @staticmethod
     def supports(hidden_size, n_latent_codes=2, use_variety_loss=False, process_group=None):
-        return (int(hidden_size) % 32 == 0 and int(hidden_size) >= 32 and int(n_latent_codes) >= 2 and not use_variety_loss
-                and process_group is None)
+        # use_variety_loss True = train.py:527-536 AS WRITTEN (the L2 of agent 19 of the packed batch); the best-of-K form
+        # ("fixed") exists on the fused 64-unit trainer only
+        return int(hidden_size) % 32 == 0 and int(hidden_size) >= 32 and int(n_latent_codes) >= 2 and use_variety_loss in (False, True)
 
     def __init__(self, n_next, hidden_size=128, lr_g=1e-4, lr_d=1e-3, n_unrolling_steps=1, use_social=True, use_info_loss=True,
                  loss_info_w=0.5, n_latent_codes=2, device="cuda", process_group=None, use_l2_loss=False,
@@ -90,13 +91,14 @@ class WideTrainer(GenericTrainer):
         if unknown:
             raise TypeError("unexpected keyword arguments: %s" % sorted(unknown))
         if not self.supports(hidden_size, n_latent_codes, use_variety_loss, process_group):
-            raise L.SocialWaysHipError("wide path: hidden_size % 32 == 0, n_latent_codes >= 2, single process, no variety loss")
+            raise L.SocialWaysHipError("wide path: hidden_size % 32 == 0, n_latent_codes >= 2, use_variety_loss False / True")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise L.SocialWaysHipError("socialways_amd runs on MI355X only (no CPU fallback)")
         self.n_next, self.noise_len = n_next, hidden_size // 2
         self.n_unrolling_steps, self.use_info_loss, self.loss_info_w = n_unrolling_steps, use_info_loss, loss_info_w
-        self.use_l2_loss, self.use_variety_loss, self.loss_l2_w = use_l2_loss, False, loss_l2_w
+        self.use_l2_loss, self.use_variety_loss, self.loss_l2_w = use_l2_loss, bool(use_variety_loss), loss_l2_w
+        self._row0 = 0
         self.n_latent_codes = n_latent_codes
         self.H = H = int(hidden_size)
         # construction order = train.py:370-385 (RNG -> init mapping, optimizer parameter order)
@@ -106,7 +108,13 @@ class WideTrainer(GenericTrainer):
         self.dp = _Flat(self.D.parameters(), self.device)
         self.predictor_optimizer = PackedAdam(self.gp.flat, self.gp.gflat, self.gp.slices, lr_g)
         self.D_optimizer = PackedAdam(self.dp.flat, self.dp.gflat, self.dp.slices, lr_d)
-        self.pg, self.world, self.rank, self.epoch = None, 1, 0, 0
+        # data parallelism as in the fused trainer: scene-aligned shards, losses normalised by the
+        # GLOBAL batch size, the two packed gradient buffers all-reduced (SUM) in front of their Adam steps - three
+        # all-reduces per training step -, rank 0's replica and RNG streams broadcast (sync_replicas / sync_rng)
+        self.pg, self.epoch = process_group, 0
+        self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
+        self.rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
+        self._force_dist = False
         self.use_graph = True if use_graph is None else bool(use_graph)
         self.last_variety = None
         self._ws = {}            # workspaces per (B, To, P)
@@ -140,6 +148,44 @@ class WideTrainer(GenericTrainer):
         k = np.ones((n_unrolling_steps + 3, 3))
         k[:n_unrolling_steps + 2, 1] = 2.0 / nl
         self._kres = torch.from_numpy(k).to(self.device)
+        if self.world > 1:
+            self.sync_replicas()
+
+    def sync_replicas(self):
+        """Rank 0's weights and optimizer state to every rank (construction, load_checkpoint)."""
+        dist = torch.distributed
+        src = dist.get_global_rank(self.pg, 0)
+        for b in (self.gp.flat, self.dp.flat, self.predictor_optimizer.m, self.predictor_optimizer.v, self.D_optimizer.m,
+                  self.D_optimizer.v):
+            dist.broadcast(b, src, group=self.pg)
+        ts = torch.tensor([float(self.predictor_optimizer.t), float(self.D_optimizer.t), float(self.epoch)],
+                          device=self.device if dist.get_backend(self.pg) == "nccl" else "cpu")
+        dist.broadcast(ts, src, group=self.pg)
+        for o, t in zip((self.predictor_optimizer, self.D_optimizer), ts.tolist()):
+            o.t = int(t)
+            o.step_t.fill_(float(o.t))
+        self.epoch = int(ts[2].item())
+
+    def _allreduce(self, flat):
+        if self.pg is not None and self.world > 1:
+            torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+
+    def _empty_step(self):
+        """A rank without scenes in this packed batch still takes part in the step's three all-reduces and applies the
+        same updates."""
+        U = self.n_unrolling_steps
+        for u in range(U + 1):
+            self.dp.gflat.zero_()
+            self._allreduce(self.dp.gflat)
+            self.D_optimizer.step()
+            if u == 0 and U > 0:
+                self._d_backup.copy_(self.dp.flat)
+        self.gp.gflat.zero_()
+        self._allreduce(self.gp.gflat)
+        self.predictor_optimizer.step()
+        if U > 0:
+            torch.where(self._lin_mask, self._d_backup, self.dp.flat, out=self.dp.flat)
+        return torch.zeros(U + 3, 3, dtype=torch.float64, device=self.device)
 
     def _transpose_table(self, fl, mats):
         tab, views, off, tiles = [], {}, 0, 0
@@ -448,11 +494,13 @@ class WideTrainer(GenericTrainer):
         L.call("sw_sqdiff", _p(a), lda, _p(b), ldb, _p(targets), int(t_idx), R, C, float(gscale), _p(out), _p(da), ldda, L.stream())
 
     # ---- the step ------------------------------------------------------------------------------------------------------------
-    def _step_device(self, w, sc, B, To, ss):
-        """Device-only body of train.py:458-554 on the staged inputs of `w` (capturable)."""
+    def _step_device(self, w, sc, B, To, ss, Bg):
+        """Device-only body of train.py:458-554 on the staged inputs of `w` (capturable), as a GENERATOR: it yields the
+        packed gradient buffer at each of the three points where data-parallel ranks all-reduce before the optimizer step
+        (D, D, G).  Bg = agents of the whole packed batch over all ranks (the loss means run over it)."""
         U, Tp, nl, H = self.n_unrolling_steps, self.n_next, self.n_latent_codes, self.H
         nlp = (nl + 3) // 4 * 4
-        Bg = float(B)
+        Bg = float(Bg)
         wi = self.loss_info_w if self.use_info_loss else 0.0
         sums, z, tg = w["sums"], w["noise"], w["targets"]
         L.call("sw_traj_4d", L.ptr(w["obsv"]), L.ptr(w["pred"]), B, To, Tp, L.ptr(w["o4"]), L.ptr(w["p4"]), L.stream())
@@ -463,6 +511,7 @@ class WideTrainer(GenericTrainer):
             self._sq(_off(w["label"], B), 1, None, 0, tg, 1, B, 1, 2.0 / Bg, _off(sums, 3 * u + 2), _off(w["dlab"], 4 * B), 4)
             self._sq(w["code"], nl, z, H // 2, None, 0, B, nl, wi * 2.0 / (nl * Bg), _off(sums, 3 * u + 1), w["dcod"], nlp)
             self._disc_backward(w, B, To)
+            yield self.dp.gflat
             self.D_optimizer.step()
             if u == 0 and U > 0:
                 self._d_backup.copy_(self.dp.flat)       # deepcopy(D) after the first update (train.py:498-499)
@@ -474,7 +523,12 @@ class WideTrainer(GenericTrainer):
         dpred4 = w["dpx"]
         if self.use_l2_loss:                             # train.py:525-526
             L.call("sw_l2_grad", L.ptr(fake), L.ptr(w["pred"]), B, Tp, 0, B, self.loss_l2_w / (Bg * Tp), L.ptr(dpred4), L.stream())
+        if self.use_variety_loss:                        # train.py:527-536 as written: only the k = 19 term survives - the
+            r = 19 - self._row0                          # L2 of AGENT 19 of the packed batch (its 20 rollouts are identical)
+            if 0 <= r < B:
+                L.call("sw_l2_grad", L.ptr(fake), L.ptr(w["pred"]), B, Tp, r, r + 1, self.loss_l2_w / Tp, L.ptr(dpred4), L.stream())
         self._gen_backward(w, sc, B, To, dpred4)
+        yield self.gp.gflat
         self.predictor_optimizer.step()
         if U > 0:                                        # D.load(backup): Linear layers only (train.py:311-316, 541-542)
             torch.where(self._lin_mask, self._d_backup, self.dp.flat, out=self.dp.flat)
@@ -488,8 +542,10 @@ class WideTrainer(GenericTrainer):
         """One packed batch (train.py:458-554).  Returns the (U+3, 3) float64 sums of SocialWaysTrainer.step()."""
         dev = self.device
         B, To = obsv.shape[0], obsv.shape[1]
-        if global_B is not None and float(global_B) != B:
-            raise L.SocialWaysHipError("wide path: single process only")
+        Bg = float(global_B if global_B is not None else B)
+        self._row0 = int(global_row0)       # first row of this rank's shard in the packed batch (variety term only)
+        if self.use_variety_loss and Bg < 20:
+            raise ValueError("use_variety_loss indexes agent 19 of the packed batch (train.py:531): batch of %d" % Bg)
         sc = _scene_index(sub_batches, B, dev)
         w = self._buffers(B, To, sc.P)
         w["obsv"].copy_(obsv)
@@ -497,23 +553,30 @@ class WideTrainer(GenericTrainer):
         w["noise"].copy_(noise.to(dev, non_blocking=True))
         w["targets"].copy_(torch.tensor([float(zeros_val), float(ones_val)], dtype=torch.float32))
         # the captured step bakes the Adam step indices' ADDRESSES in (PackedAdam.step_t) - their values advance on the host
-        key = (B, To, sc.key, float(ss), self.use_l2_loss, self.use_info_loss, self.n_unrolling_steps)
+        key = (B, To, sc.key, float(ss), Bg, self.use_l2_loss, self.use_info_loss, self.n_unrolling_steps, self.use_variety_loss,
+               self._row0)
         n_seen = self._seen.get(key, 0)
         self._seen[key] = n_seen + 1
         if not self.use_graph or n_seen < 2:           # two eager steps of a layout first (allocations, caches)
-            self._step_device(w, sc, B, To, ss)
+            for buf in self._step_device(w, sc, B, To, ss, Bg):
+                self._allreduce(buf)
         else:
             g = self._graphs.get(key)
             if g is None:
-                g = self._capture(key, w, sc, B, To, ss)
+                g = self._capture(key, w, sc, B, To, ss, Bg)
             self._replay(g)
         self.last_pred_hat = w["pred4"]
         return w["res"].clone()
 
+    def step_many(self, batches, sub_batches, ss=1.0, global_B=None, out=None, global_row0=0):
+        return [self.step(o, p, sub_batches, zv, ov, nz, ss, global_B, out, global_row0) for o, p, zv, ov, nz in batches]
+
     # The optimizers count their updates on the host (PackedAdam.t -> step_t.fill_) - inside a captured graph that fill is
     # replayed with the value of capture time.  A captured step therefore reads the update indices from two device scalars
     # that the host sets before every replay.
-    def _capture(self, key, w, sc, B, To, ss):
+    def _capture(self, key, w, sc, B, To, ss, Bg):
+        """Single process: the whole step as ONE graph.  Data parallel: one graph SEGMENT per stretch between two
+        all-reduce points (4 segments), the collectives run between the segment replays."""
         torch.cuda.synchronize()
         dopt, gopt = self.D_optimizer, self.predictor_optimizer
         steps_d = [torch.zeros((), device=self.device) for _ in range(self.n_unrolling_steps + 1)]
@@ -522,21 +585,35 @@ class WideTrainer(GenericTrainer):
         it = iter(steps_d)
         dopt.step = lambda st=None: real_d(next(it))
         gopt.step = lambda st=None: real_g(step_g)
-        graph = torch.cuda.CUDAGraph()
         t_d, t_g = dopt.t, gopt.t
         for k, s in enumerate(steps_d):
             s.fill_(float(t_d + k + 1))
         step_g.fill_(float(t_g + 1))
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
+        segments, pool = [], None
+        gen = self._step_device(w, sc, B, To, ss, Bg)
         try:
             with torch.cuda.stream(side):
-                with torch.cuda.graph(graph, stream=side):
-                    self._step_device(w, sc, B, To, ss)
+                done = False
+                while not done:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=side, pool=pool):
+                        buf = None
+                        while True:           # a single process runs through the all-reduce points inside ONE capture
+                            try:
+                                buf = next(gen)
+                            except StopIteration:
+                                buf, done = None, True
+                                break
+                            if self.world > 1:
+                                break
+                    pool = graph.pool() if pool is None else pool
+                    segments.append((graph, buf))
         finally:
             dopt.step, gopt.step = real_d, real_g
         torch.cuda.current_stream().wait_stream(side)
-        g = dict(graph=graph, steps_d=steps_d, step_g=step_g, fresh=True)
+        g = dict(segments=segments, steps_d=steps_d, step_g=step_g)
         self._graphs[key] = g
         return g
 
@@ -545,7 +622,10 @@ class WideTrainer(GenericTrainer):
         for k, s in enumerate(g["steps_d"]):
             s.fill_(float(dopt.t + k + 1))
         g["step_g"].fill_(float(gopt.t + 1))
-        g["graph"].replay()
+        for graph, buf in g["segments"]:
+            graph.replay()
+            if buf is not None:
+                self._allreduce(buf)
         dopt.t += len(g["steps_d"])
         gopt.t += 1
         dopt.step_t.fill_(float(dopt.t))
@@ -555,7 +635,7 @@ class WideTrainer(GenericTrainer):
         self._graphs.clear()
 
     def load_checkpoint(self, ck):
-        r = super().load_checkpoint(ck)
+        r = super().load_checkpoint(ck)             # (broadcasts rank 0's replica when there is a process group)
         for fl in (self.gp, self.dp):          # load_state_dict copies in place: the views still alias the packed buffers
             for p in fl.params:
                 assert p.data_ptr() == fl.flat.data_ptr() + 4 * fl.off[id(p)], "parameter left its packed buffer"
