@@ -70,7 +70,7 @@ def alg_flops(B, P, To, Tp):
                 sw_gen_wgrad=2.0 * B * ((To + Tp - 1) * 33024 + Tp * 41680))
 
 
-def kernel_alg_flops(B, P, To, Tp, one_launch_d=False):
+def kernel_alg_flops(B, P, To, Tp, one_launch_d=False, dfuse=None):
     """Algorithmic FLOPs PER STEP of each kernel of the step (all of its launches together), MAC = 2 FLOP, from the
     per-agent / per-pair MAC counts of SURVEY.md §8a (data-gradient passes = forward MACs, weight gradients = forward
     MACs).  U + 1 = 2 discriminator updates + the generator-phase D pass."""
@@ -79,18 +79,26 @@ def kernel_alg_flops(B, P, To, Tp, one_launch_d=False):
     gen_rows = (To + Tp - 1) * lstm + Tp * dec
     soc = B * 4096 + P * 6368
     d_all = To * d_lstm + d_obs + 2 * d_br                 # a whole D pass on both branches (forward = data-gradient MACs)
+    if dfuse is None:     # the generator-phase D pass runs inside the decode BPTT launch (ops.DFUSE, sw_dec_rollout_bwd_dfuse)
+        from socialways_amd import ops as _ops
+        dfuse = _ops.DFUSE
+    g_phase = 2.0 * B * (To * d_lstm + d_obs + 2 * d_br)     # one branch forward + its heads backward
     if one_launch_d:      # sw_disc_update: pass 1 (its LSTM forward rode in the decode launch) + pass 2; disc_fwd = the G phase only
         d_kernels = {"disc_update_kernel": 2.0 * B * ((d_obs + 2 * d_br) + d_all + 2 * d_all),
-                     "disc_fwd_kernel": 2.0 * B * (To * d_lstm + d_obs + 2 * d_br)}     # one branch forward + its heads backward
+                     "disc_fwd_kernel": g_phase}
     else:                 # 3 disc_fwd launches (pass 1 heads only, pass 2, G phase) + 2 disc_bwd launches
         d_kernels = {"disc_fwd_kernel": 2.0 * B * ((d_obs + 2 * d_br) + d_all + d_all),
                      "disc_bwd_kernel": 2.0 * 2 * B * d_all}
+    if dfuse:
+        d_kernels["disc_fwd_kernel"] -= g_phase
+        if d_kernels["disc_fwd_kernel"] <= 0:
+            del d_kernels["disc_fwd_kernel"]
     return {
         **d_kernels,
         "enc_lstm_fwd_kernel": 2.0 * B * To * lstm,
         "enc_lstm_bwd_kernel": 2.0 * B * To * lstm,
         "dec_rollout_fwd_kernel": 2.0 * B * (Tp * dec + (Tp - 1) * lstm) + 2.0 * B * To * d_lstm,   # + D's first obs LSTM (rides here)
-        "dec_rollout_bwd_kernel": 2.0 * B * (Tp * dec + (Tp - 1) * lstm),
+        "dec_rollout_bwd_kernel": 2.0 * B * (Tp * dec + (Tp - 1) * lstm) + (g_phase if dfuse else 0.0),   # + the G-phase D pass
         "social_pool_fwd_kernel": 2.0 * soc,
         "social_pool_bwd_rows_kernel": 2.0 * 2 * soc,     # recomputes the pair MLP + its data gradients
         "social_pool_bwd_kernel": 2.0 * 3 * soc,          # ... + the pair-MLP weight gradients in registers
