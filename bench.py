@@ -86,8 +86,9 @@ def kernel_alg_flops(B, P, To, Tp, one_launch_d=False, dfuse=None):
     if one_launch_d:      # sw_disc_update: pass 1 (its LSTM forward rode in the decode launch) + pass 2; disc_fwd = the G phase only
         d_kernels = {"disc_update_kernel": 2.0 * B * ((d_obs + 2 * d_br) + d_all + 2 * d_all),
                      "disc_fwd_kernel": g_phase}
-    else:                 # 3 disc_fwd launches (pass 1 heads only, pass 2, G phase) + 2 disc_bwd launches
-        d_kernels = {"disc_fwd_kernel": 2.0 * B * ((d_obs + 2 * d_br) + d_all + d_all),
+    else:                 # 3 disc_fwd launches (pass 1, pass 2, G phase) + 2 disc_bwd launches; pass 1's observation LSTM rides in
+        rides = (B + 15) // 16 <= 128     # the decode launch only while that leaves CUs idle (ops.D_OBS_MAX_TILES)
+        d_kernels = {"disc_fwd_kernel": 2.0 * B * (((d_obs + 2 * d_br) if rides else d_all) + d_all) + g_phase,
                      "disc_bwd_kernel": 2.0 * 2 * B * d_all}
     if dfuse:
         d_kernels["disc_fwd_kernel"] -= g_phase
@@ -97,7 +98,8 @@ def kernel_alg_flops(B, P, To, Tp, one_launch_d=False, dfuse=None):
         **d_kernels,
         "enc_lstm_fwd_kernel": 2.0 * B * To * lstm,
         "enc_lstm_bwd_kernel": 2.0 * B * To * lstm,
-        "dec_rollout_fwd_kernel": 2.0 * B * (Tp * dec + (Tp - 1) * lstm) + 2.0 * B * To * d_lstm,   # + D's first obs LSTM (rides here)
+        "dec_rollout_fwd_kernel": 2.0 * B * (Tp * dec + (Tp - 1) * lstm)
+                                  + (2.0 * B * To * d_lstm if (B + 15) // 16 <= 128 else 0.0),   # + D's first obs LSTM (rides here)
         "dec_rollout_bwd_kernel": 2.0 * B * (Tp * dec + (Tp - 1) * lstm) + (g_phase if dfuse else 0.0),   # + the G-phase D pass
         "social_pool_fwd_kernel": 2.0 * soc,
         "social_pool_bwd_rows_kernel": 2.0 * 2 * soc,     # recomputes the pair MLP + its data gradients
