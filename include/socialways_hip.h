@@ -467,6 +467,22 @@ int sw_wide_lstm_seq_fwd(const float* x4, const float* Wx, const float* b1, cons
                          float* gates, float* cs, float* hs, float* h_last2, int h2_ld, void* stream);
 int sw_wide_lstm_seq_bwd(const float* dh_ext, int dhe_ld, const float* dh_ext2, int dhe2_ld, const float* dg_init, const float* dc_init,
                          const float* whhT_img, const float* gates, const float* cs, int B, int H, int T, float* dgates, void* stream);
+/* the decode loop of predict() (train.py:415-432) at 128 hidden units (sw_wide_dec_loop_supported) as ONE launch per 16-agent
+ * tile, streaming the operand images of W1[:, :H], W2, W3 and W_hh per step: replaces Tp x {3 sw_wide_gemm, sw_wide_out_fwd,
+ * sw_wide_lstm_fwd}.  u [B][2.5H] = W1[:, H:] [S; z] + b1; p0 = last observed positions; leaves a1 / a2 / a3 [Tp][B][.],
+ * pred4 [B][Tp][4], x4 rows To.., gates / cs rows To.., hs rows To + 1.., h into cat[i + 1][:, :H] (row stride 2.5H).    */
+int sw_wide_dec_loop_supported(int H);
+int sw_wide_dec_loop_fwd(const float* w1h_img, const float* w2_img, const float* w3_img, const float* whh_img, const float* u,
+                         const float* b2, const float* b3, const float* W4, const float* b4, const float* Wx, const float* bx1,
+                         const float* bx2, const float* p0, int p0_ld, float* a1, float* a2, float* a3, float* pred4, float* x4,
+                         float* gates, float* cs, float* hs, float* cat, int B, int H, int To, int Tp, void* stream);
+/* ... and its backward (data gradients; Tp x {sw_wide_lstm_bwd, sw_wide_out_bwd, 3 sw_wide_gemm} in one launch): images of W_hh^T,
+ * W3^T, W2^T, W1[:, :H]^T and of Wx^T zero-padded to 16 rows; leaves dgates rows To.., dv / dz3 / dz2 / dz1 [Tp][B][.], the gradient
+ * w.r.t. h_{To-1} from decode step 0 (dhcat_out) and w.r.t. c_{To-1} (dc_out), both [B][H].                              */
+int sw_wide_dec_loop_bwd(const float* whhT_img, const float* w3T_img, const float* w2T_img, const float* w1hT_img,
+                         const float* wxT_img, const float* W4, const float* dpred4, const float* a1, const float* a2,
+                         const float* gates, const float* cs, float* dgates, float* dv, float* dz3, float* dz2, float* dz1,
+                         float* dhcat_out, float* dc_out, int B, int H, int To, int Tp, void* stream);
 /* n weight-gradient problems dW[N][K] = delta^T act, db = column sums (desc: n x {delta, ldd, act, lda, R, N, K, dW, ldw, db}
  * as 64-bit host values) through the grouped split-K GEMM; wgrad_ws = sw_workspace_floats(SW_WS_WGRAD, ...) floats       */
 int sw_wide_wgrad(const long long* desc, int n, float* wgrad_ws, void* stream);

@@ -502,7 +502,8 @@ __global__ __launch_bounds__(256) void wide_transpose_kernel(const float* __rest
 // itself or its transpose - the float4 of (row tile t, k-step j, lane l) = Mx[16 t + (l & 15)][16 j + 4 (l >> 4) .. + 3] at
 // dst + ((t K/16 + j) 64 + l) 4, so that a wave loads a tile's operand as 1 KB of consecutive memory.  The LSTM sequence
 // kernels below hold W_hh (forward) / W_hh^T (BPTT) in registers for a whole sequence and load them from these images.
-// table entry (6 ints): src offset, R, K, dst offset, transposed (Mx = M^T, M is [K][R]), -.  One thread per float4.
+// table entry (6 ints): src offset, R, K, dst offset, transposed (Mx = M^T, M is [K][R]), source row stride (0: dense).  One
+// thread per float4.
 __global__ __launch_bounds__(256) void wide_opimage_kernel(const float* __restrict__ src, const int* __restrict__ tab, int ntab,
                                                            float* __restrict__ dst) {
   long long f = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -514,16 +515,17 @@ __global__ __launch_bounds__(256) void wide_opimage_kernel(const float* __restri
   }
   if (m >= ntab) return;
   const int so = tab[6 * m], K = tab[6 * m + 2], dofs = tab[6 * m + 3], tr = tab[6 * m + 4], R = tab[6 * m + 1];
+  const int ld = tab[6 * m + 5] ? tab[6 * m + 5] : (tr ? R : K);      // row stride of the source (a column block of a wider matrix)
   const int KJ = K >> 4;
   const int l = (int)(f & 63);
   const long long tj = f >> 6;
   const int t = (int)(tj / KJ), j = (int)(tj - (long long)t * KJ);
   const int r = 16 * t + (l & 15), k = 16 * j + 4 * (l >> 4);
   f32x4 v;
-  if (!tr) v = ld4(src + so + (size_t)r * K + k);
+  if (!tr) v = ld4(src + so + (size_t)r * ld + k);
   else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = src[so + (size_t)(k + q) * R + r];
+    for (int q = 0; q < 4; ++q) v[q] = src[so + (size_t)(k + q) * ld + r];
   }
   st4(dst + dofs + 4 * f, v);
 }
@@ -727,6 +729,388 @@ __global__ __launch_bounds__(256) void wide_lstm_seq_bwd_kernel(const float* __r
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The DECODE LOOP of predict() at 128 hidden units (train.py:415-432) as ONE persistent launch per 16-agent tile - the wide
+// counterpart of dec_rollout_fwd_kernel.  Nothing is weight-resident: per decode step a workgroup STREAMS the operand
+// images (sw_wide_opimage) of W1[:, :H] (320 x 128), W2 (160 x 320), W3 (80 x 160) and W_hh (512 x 128) - 0.66 MB - from L2
+// straight into MFMA A operands, 8 image loads (1 KB each) in flight per wave, while the activations of the tile move
+// between the layers through LDS tiles (one barrier per layer).  u = W1[:, H:] [S; z] + b1 is constant over the steps
+// (train.py:411, 421) and comes in as the initial accumulators of layer 1.  Per step and wave: 744 matrix instructions
+// (11 us) instead of five launches (36 us).  Leaves exactly the rows the step-level kernels leave (a1 / a2 / a3, the
+// re-fed encoder steps' gates / c / h, x4, the prediction).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct WideDecFwd {
+  const float *w1h_img, *w2_img, *w3_img, *whh_img;     // operand images
+  const float *u /*[B][D1]*/, *b2, *b3, *W4 /*[2][D3]*/, *b4, *Wx /*[4H][4]*/, *bx1, *bx2 /*[4H]*/;
+  const float* p0;                                       // [B][p0_ld]: last observed position
+  int p0_ld;
+  float *a1, *a2, *a3;                                   // [Tp][B][D1 / D2 / D3]
+  float* pred4;                                          // [B][Tp][4]
+  float* x4;                                             // [To + Tp][B][4] time-major: rows To .. To + Tp - 1 written
+  float *gates, *cs, *hs;                                // [Ta][B][4H], [Ta][B][H], [Ta + 1][B][H] (hs[t + 1] = h_t)
+  float* cat;                                            // [Tp][B][D1]: columns 0 .. H-1 of slab i + 1 receive h of step To + i
+  int B, To, Tp;
+};
+// acc[t] += sum_j img(tile[t], j) x b_j for the tiles of one layer: the loads of the linear sequence (j, t) run PD ahead
+template <int NT, int KJ, int PD>
+__device__ __forceinline__ void wide_stream_mm(const float* __restrict__ img, const int (&tile)[NT], const float* brow,
+                                               f32x4 (&acc)[NT], int lane) {
+  constexpr int N = NT * KJ;
+  f32x4 ring[PD];
+  auto addr = [&](int n) {
+    const int nn = n < N ? n : N - 1;
+    return img + (((size_t)tile[nn % NT] * KJ + nn / NT) * 64 + lane) * 4;
+  };
+#pragma unroll
+  for (int n = 0; n < PD; ++n) ring[n] = ld4(addr(n));
+  f32x4 bnext = ld4(brow);
+#pragma unroll
+  for (int j = 0; j < KJ; ++j) {
+    const f32x4 b = bnext;
+    bnext = ld4(brow + 16 * (j + 1 < KJ ? j + 1 : j));      // the next k-step's activation operand (LDS), one step ahead
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = j * NT + t;
+      const f32x4 a = ring[n % PD];
+      ring[n % PD] = ld4(addr(n + PD));
+      asm volatile("" ::: "memory");      // the refill is issued HERE: neither hoisted (the unrolled loop would otherwise
+#pragma unroll                            // request the whole layer at once: 400 registers) nor sunk to its use
+      for (int q = 0; q < 4; ++q) acc[t] = SW_MFMA(a[q], b[q], acc[t]);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void wide_dec_loop_fwd_kernel(WideDecFwd A) {
+  constexpr int H = 128, D1 = 320, D2 = 160, D3 = 80, PD = 16;
+  constexpr int HL = H + 4, L1 = D1 + 4, L2 = D2 + 4, L3 = D3 + 4;
+  __shared__ __attribute__((aligned(16))) float hb[2][16 * HL];
+  __shared__ __attribute__((aligned(16))) float a1b[16 * L1];
+  __shared__ __attribute__((aligned(16))) float a2b[16 * L2];
+  __shared__ __attribute__((aligned(16))) float a3b[16 * L3];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), ln = lane & 15, lg = lane >> 4;
+  const int B = A.B, To = A.To, Tp = A.Tp;
+  const int a0 = blockIdx.x * 16;
+  const int b = min(a0 + ln, B - 1);            // padding lanes of the last tile: replicas of agent B - 1
+  // tiles of this wave per layer (duplicates compute and store the same values)
+  const int t1[5] = {5 * wave, 5 * wave + 1, 5 * wave + 2, 5 * wave + 3, 5 * wave + 4};
+  const int t2[3] = {wave, wave + 4, 8 + (wave & 1)};
+  const int t3[2] = {wave, 4};
+  int tl[8];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    tl[2 * g] = g * 8 + 2 * wave;
+    tl[2 * g + 1] = g * 8 + 2 * wave + 1;
+  }
+  // constants of the tile / wave
+  f32x4 u[5], bias2[3], bias3[2], biasl[8], w4[2][5];
+  float wx[8];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) u[t] = ld4(A.u + (size_t)b * D1 + 16 * t1[t] + 4 * lg);
+#pragma unroll
+  for (int t = 0; t < 3; ++t) bias2[t] = ld4(A.b2 + 16 * t2[t] + 4 * lg);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) bias3[t] = ld4(A.b3 + 16 * t3[t] + 4 * lg);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int row0 = (t >> 1) * H + 16 * (2 * wave + (t & 1));       // gate t / 2, unit tile 2 wave + (t & 1)
+    biasl[t] = ld4(A.bx1 + row0 + 4 * lg) + ld4(A.bx2 + row0 + 4 * lg);
+    wx[t] = A.Wx[(size_t)(row0 + ln) * 4 + lg];
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    w4[0][j] = ld4(A.W4 + 20 * lg + 4 * j);
+    w4[1][j] = ld4(A.W4 + D3 + 20 * lg + 4 * j);
+  }
+  const float b4x = A.b4[0], b4y = A.b4[1];
+  float px = A.p0[(size_t)b * A.p0_ld], py = A.p0[(size_t)b * A.p0_ld + 1];
+  f32x4 c[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int u0 = 16 * (2 * wave + k);
+    c[k] = ld4(A.cs + ((size_t)(To - 1) * B + b) * H + u0 + 4 * lg);
+    st4(&hb[0][ln * HL + u0 + 4 * lg], ld4(A.hs + ((size_t)To * B + b) * H + u0 + 4 * lg));
+  }
+  __syncthreads();
+  for (int i = 0; i < Tp; ++i) {
+    const float* hrow = &hb[i & 1][ln * HL + 4 * lg];
+    // the image bases are made opaque once per step: the ~250 image addresses of a step are the same in every step, and
+    // hoisted out of the loop as loop invariants they alone would take 500 registers
+    const float *w1i = A.w1h_img, *w2i = A.w2_img, *w3i = A.w3_img, *whi = A.whh_img;
+    asm volatile("" : "+s"(w1i), "+s"(w2i), "+s"(w3i), "+s"(whi));
+    // ---- layer 1: a1 = lrelu(W1[:, :H] h + u) ----
+    {
+      f32x4 acc[5];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) acc[t] = u[t];
+      wide_stream_mm<5, H / 16, PD>(w1i, t1, hrow, acc, lane);
+      float* g1 = A.a1 + ((size_t)i * B + b) * D1 + 4 * lg;
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[t][q] = sw_lrelu(acc[t][q]);
+        st4(&a1b[ln * L1 + 16 * t1[t] + 4 * lg], acc[t]);
+        st4(g1 + 16 * t1[t], acc[t]);
+      }
+    }
+    sw_barrier();
+    // ---- layer 2: a2 = lrelu(W2 a1 + b2) ----
+    {
+      f32x4 acc[3] = {bias2[0], bias2[1], bias2[2]};
+      wide_stream_mm<3, D1 / 16, PD>(w2i, t2, &a1b[ln * L1 + 4 * lg], acc, lane);
+      float* g2 = A.a2 + ((size_t)i * B + b) * D2 + 4 * lg;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[t][q] = sw_lrelu(acc[t][q]);
+        st4(&a2b[ln * L2 + 16 * t2[t] + 4 * lg], acc[t]);
+        st4(g2 + 16 * t2[t], acc[t]);
+      }
+    }
+    sw_barrier();
+    // ---- layer 3: a3 = W3 a2 + b3 (no activation, train.py:327-330) ----
+    {
+      f32x4 acc[2] = {bias3[0], bias3[1]};
+      wide_stream_mm<2, D2 / 16, PD>(w3i, t3, &a2b[ln * L2 + 4 * lg], acc, lane);
+      float* g3 = A.a3 + ((size_t)i * B + b) * D3 + 4 * lg;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        st4(&a3b[ln * L3 + 16 * t3[t] + 4 * lg], acc[t]);
+        st4(g3 + 16 * t3[t], acc[t]);
+      }
+    }
+    sw_barrier();
+    // ---- output layer + integration: every wave for itself (each keeps its own copy of the running position) ----
+    float vx = 0.f, vy = 0.f;
+    {
+      const float* ar = &a3b[ln * L3 + 20 * lg];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const f32x4 av = ld4(ar + 4 * j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          vx = fmaf(av[q], w4[0][j][q], vx);
+          vy = fmaf(av[q], w4[1][j][q], vy);
+        }
+      }
+      vx += __shfl_xor(vx, 16);
+      vy += __shfl_xor(vy, 16);
+      vx += __shfl_xor(vx, 32);
+      vy += __shfl_xor(vy, 32);
+      vx += b4x;
+      vy += b4y;
+      px += vx;
+      py += vy;
+      const f32x4 r = {px, py, vx, vy};
+      st4(A.pred4 + ((size_t)b * Tp + i) * 4, r);                   // every lane of agent ln holds the same row: all store it
+      st4(A.x4 + ((size_t)(To + i) * B + b) * 4, r);
+    }
+    if (i + 1 == Tp) break;                                          // the step after the last decode is dead compute (train.py:430)
+    // ---- re-fed encoder step To + i on (p, v) ----
+    {
+      const float xb = lg == 0 ? px : (lg == 1 ? py : (lg == 2 ? vx : vy));
+      f32x4 acc[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = SW_MFMA(wx[t], xb, biasl[t]);
+      wide_stream_mm<8, H / 16, PD>(whi, tl, hrow, acc, lane);
+      const size_t trow = (size_t)(To + i) * B + b;
+      float* gr = A.gates + trow * 4 * H + 4 * lg;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int u0 = 16 * (2 * wave + k);
+        f32x4 gi, gf, gg, go, hn;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          gi[q] = sw_sigmoid(acc[k][q]);
+          gf[q] = sw_sigmoid(acc[2 + k][q]);
+          gg[q] = sw_tanh(acc[4 + k][q]);
+          go[q] = sw_sigmoid(acc[6 + k][q]);
+          c[k][q] = fmaf(gf[q], c[k][q], gi[q] * gg[q]);
+          hn[q] = go[q] * sw_tanh(c[k][q]);
+        }
+        st4(&hb[(i + 1) & 1][ln * HL + u0 + 4 * lg], hn);
+        st4(gr + u0, gi);
+        st4(gr + H + u0, gf);
+        st4(gr + 2 * H + u0, gg);
+        st4(gr + 3 * H + u0, go);
+        st4(A.cs + trow * H + u0 + 4 * lg, c[k]);
+        st4(A.hs + ((size_t)(To + i + 1) * B + b) * H + u0 + 4 * lg, hn);
+        st4(A.cat + ((size_t)(i + 1) * B + b) * D1 + u0 + 4 * lg, hn);
+      }
+    }
+    sw_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Backward of the decode loop at 128 hidden units in ONE persistent launch per 16-agent tile (the wide counterpart of
+// dec_rollout_bwd_kernel): per decode step i = Tp-1 .. 0
+//   [re-fed encoder step To + i, if it exists]  dh = dhcat_{i+1} + W_hh^T dgates_{To+i+1}, cell backward -> dgates_{To+i};
+//                                               dx4 = dgates Wx (K split over the waves)
+//   d p / d v chain (train.py:422-424), dz3 = dv W4, dz2 = (dz3 W3) lrelu'(a2), dz1 = (dz2 W2) lrelu'(a1), dhcat_i = dz1 W1[:, :H]
+// with the operand images of W_hh^T, W3^T, W2^T, W1[:, :H]^T streamed from L2 (wide_stream_mm), delta tiles in LDS, dhcat / dc
+// carried in registers (the wave that produces dhcat's unit tiles is the one whose LSTM cells consume them).  Data gradients
+// only: the rows it leaves (dgates, dv, dz3, dz2, dz1) are what the deferred weight-gradient products contract over.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct WideDecBwd {
+  const float *whhT_img, *w3T_img, *w2T_img, *w1hT_img, *wxT_img;    // [H][4H], [D2][D3], [D1][D2], [H][D1], [16 (4 live)][4H]
+  const float* W4;                                                    // [2][D3]
+  const float* dpred4;                                                // [B][Tp][4]
+  const float *a1, *a2, *gates, *cs;                                  // saved rows (as the forward kernel left them)
+  float *dgates, *dv, *dz3, *dz2, *dz1;                               // [Ta][B][4H], [Tp][B][4], [Tp][B][D3 / D2 / D1]
+  float *dhcat_out, *dc_out;                                          // [B][H]: d h_{To-1} from decode step 0, d c_{To-1}
+  int B, To, Tp;
+};
+__global__ __launch_bounds__(256) void wide_dec_loop_bwd_kernel(WideDecBwd A) {
+  constexpr int H = 128, D1 = 320, D2 = 160, D3 = 80, K4 = 4 * H, PD = 16;
+  constexpr int GL = K4 + 4, L1 = D1 + 4, L2 = D2 + 4, L3 = D3 + 4;
+  __shared__ __attribute__((aligned(16))) float dgt[2][16 * GL];
+  __shared__ __attribute__((aligned(16))) float dz1b[16 * L1];
+  __shared__ __attribute__((aligned(16))) float dz2b[16 * L2];
+  __shared__ __attribute__((aligned(16))) float dz3b[16 * L3];
+  __shared__ __attribute__((aligned(16))) float dxp[4][16 * 4];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), ln = lane & 15, lg = lane >> 4;
+  const int B = A.B, To = A.To, Tp = A.Tp, Ta = To + Tp - 1;
+  const int a0 = blockIdx.x * 16;
+  const int b = min(a0 + ln, B - 1);
+  const int tu[2] = {2 * wave, 2 * wave + 1};                        // unit tiles of this wave (LSTM cells, dhcat)
+  const int t2[3] = {wave, wave + 4, 8 + (wave & 1)};                 // dz2 tiles (duplicates store the same values)
+  const int t1[5] = {5 * wave, 5 * wave + 1, 5 * wave + 2, 5 * wave + 3, 5 * wave + 4};
+  f32x4 w4[2][5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    w4[0][j] = ld4(A.W4 + 20 * lg + 4 * j);
+    w4[1][j] = ld4(A.W4 + D3 + 20 * lg + 4 * j);
+  }
+  f32x4 dh[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  float dpx = 0.f, dpy = 0.f;
+  for (int i = Tp - 1; i >= 0; --i) {
+    const float *whi = A.whhT_img, *w3i = A.w3T_img, *w2i = A.w2T_img, *w1i = A.w1hT_img, *wxi = A.wxT_img;
+    asm volatile("" : "+s"(whi), "+s"(w3i), "+s"(w2i), "+s"(w1i), "+s"(wxi));    // image addresses: per step, not hoisted
+    // the saved activations of this step (for the LeakyReLU derivatives) are requested now
+    f32x4 s2[3], s1[5];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) s2[t] = ld4(A.a2 + ((size_t)i * B + b) * D2 + 16 * t2[t] + 4 * lg);
+#pragma unroll
+    for (int t = 0; t < 5; ++t) s1[t] = ld4(A.a1 + ((size_t)i * B + b) * D1 + 16 * t1[t] + 4 * lg);
+    f32x4 dx4 = {0.f, 0.f, 0.f, 0.f};
+    if (i + 1 < Tp) {
+      // ---- re-fed encoder step t = To + i: its h fed decode step i + 1 (dh holds dhcat_{i+1}) and LSTM step t + 1 ----
+      const int t = To + i;
+      float* cur = dgt[t & 1];
+      if (t + 1 < Ta) {
+        f32x4 acc[2] = {dh[0], dh[1]};
+        wide_stream_mm<2, K4 / 16, PD>(whi, tu, &dgt[(t + 1) & 1][ln * GL + 4 * lg], acc, lane);
+        dh[0] = acc[0];
+        dh[1] = acc[1];
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int u0 = 16 * tu[k];
+        const float* gr = A.gates + ((size_t)t * B + b) * K4 + u0 + 4 * lg;
+        const f32x4 gi = ld4(gr), gf = ld4(gr + H), gg = ld4(gr + 2 * H), go = ld4(gr + 3 * H);
+        const f32x4 ct = ld4(A.cs + ((size_t)t * B + b) * H + u0 + 4 * lg), cp = ld4(A.cs + ((size_t)(t - 1) * B + b) * H + u0 + 4 * lg);
+        f32x4 di, df, dg, dO;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float tc = sw_tanh(ct[q]);
+          const float dct = fmaf(dh[k][q] * go[q], 1.0f - tc * tc, dc[k][q]);
+          di[q] = dct * gg[q] * gi[q] * (1.0f - gi[q]);
+          df[q] = dct * cp[q] * gf[q] * (1.0f - gf[q]);
+          dg[q] = dct * gi[q] * (1.0f - gg[q] * gg[q]);
+          dO[q] = dh[k][q] * tc * go[q] * (1.0f - go[q]);
+          dc[k][q] = dct * gf[q];
+        }
+        float* tr = cur + ln * GL + u0 + 4 * lg;
+        st4(tr, di);
+        st4(tr + H, df);
+        st4(tr + 2 * H, dg);
+        st4(tr + 3 * H, dO);
+      }
+      sw_barrier();
+      // dgates_t rows to memory from the tile (a wave writes 4 agents' rows, consecutive lanes consecutive float4s) ...
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int a = 4 * wave + q, bb = min(a0 + a, B - 1);
+#pragma unroll
+        for (int c4 = 0; c4 < K4 / 4 / 64; ++c4)
+          st4(A.dgates + ((size_t)t * B + bb) * K4 + 4 * (lane + 64 * c4), ld4(cur + a * GL + 4 * (lane + 64 * c4)));
+      }
+      // ... and dx4 = dgates Wx: this wave's quarter of the 4H columns (8 k-steps of the one WxT row tile)
+      {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* drow = cur + ln * GL + 4 * lg + 128 * wave;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const f32x4 a = ld4(wxi + (((size_t)(8 * wave + j)) * 64 + lane) * 4), d = ld4(drow + 16 * j);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = SW_MFMA(a[q], d[q], acc);
+        }
+        if (lg == 0) st4(&dxp[wave][ln * 4], acc);                    // rows 0..3 of the tile = the 4 input components
+      }
+      sw_barrier();
+      dx4 = (ld4(&dxp[0][ln * 4]) + ld4(&dxp[1][ln * 4])) + (ld4(&dxp[2][ln * 4]) + ld4(&dxp[3][ln * 4]));
+    }
+    // ---- position / velocity chain, dz3 = dv W4 (every wave for itself: each keeps its own copy of d p) ----
+    {
+      const f32x4 g = ld4(A.dpred4 + ((size_t)b * Tp + i) * 4) + dx4;
+      dpx += g[0];
+      dpy += g[1];
+      const float dvx = g[2] + dpx, dvy = g[3] + dpy;
+      st4(A.dv + ((size_t)i * B + b) * 4, f32x4{dvx, dvy, 0.f, 0.f});
+      float* zr = A.dz3 + ((size_t)i * B + b) * D3 + 20 * lg;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaf(dvx, w4[0][j][q], dvy * w4[1][j][q]);
+        st4(&dz3b[ln * L3 + 20 * lg + 4 * j], v);
+        st4(zr + 4 * j, v);
+      }
+    }
+    sw_barrier();
+    // ---- dz2 = (dz3 W3) lrelu'(a2) ----
+    {
+      f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      wide_stream_mm<3, D3 / 16, PD>(w3i, t2, &dz3b[ln * L3 + 4 * lg], acc, lane);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[t][q] = sw_lrelu_grad(s2[t][q], acc[t][q]);
+        st4(&dz2b[ln * L2 + 16 * t2[t] + 4 * lg], acc[t]);
+        st4(A.dz2 + ((size_t)i * B + b) * D2 + 16 * t2[t] + 4 * lg, acc[t]);
+      }
+    }
+    sw_barrier();
+    // ---- dz1 = (dz2 W2) lrelu'(a1) ----
+    {
+      f32x4 acc[5];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      wide_stream_mm<5, D2 / 16, PD>(w2i, t1, &dz2b[ln * L2 + 4 * lg], acc, lane);
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[t][q] = sw_lrelu_grad(s1[t][q], acc[t][q]);
+        st4(&dz1b[ln * L1 + 16 * t1[t] + 4 * lg], acc[t]);
+        st4(A.dz1 + ((size_t)i * B + b) * D1 + 16 * t1[t] + 4 * lg, acc[t]);
+      }
+    }
+    sw_barrier();
+    // ---- dhcat_i = dz1 W1[:, :H]: the gradient w.r.t. h of LSTM step To - 1 + i, kept in registers for the next iteration ----
+    {
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      wide_stream_mm<2, D1 / 16, PD>(w1i, tu, &dz1b[ln * L1 + 4 * lg], acc, lane);
+      dh[0] = acc[0];
+      dh[1] = acc[1];
+    }
+    // (the next iteration's first write to dz3b / dgt sits behind its own barriers; dz1b is next written three barriers on)
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    st4(A.dhcat_out + (size_t)b * H + 16 * tu[k] + 4 * lg, dh[k]);
+    st4(A.dc_out + (size_t)b * H + 16 * tu[k] + 4 * lg, dc[k]);
+  }
+}
 }  // namespace
 
 extern "C" int sw_wide_transpose(const float* src, const int* tab /*device, ntab x 4*/, int ntab, int total_tiles, float* dst,
@@ -734,6 +1118,42 @@ extern "C" int sw_wide_transpose(const float* src, const int* tab /*device, ntab
   if (!src || !tab || !dst || ntab < 1 || total_tiles < 1) return SW_EARG;
   SW_LAUNCH(wide_transpose_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, src, (const int4*)tab, ntab, dst);
   SW_CHECK_LAUNCH("wide_transpose_kernel");
+  return SW_OK;
+}
+
+extern "C" int sw_wide_dec_loop_supported(int H) { return H == 128 ? 1 : 0; }
+// The decode loop at 128 hidden units in one launch (see wide_dec_loop_fwd_kernel).  Images: w1h = W1[:, :H] [320][128], w2
+// [160][320], w3 [80][160], whh [512][128] (sw_wide_opimage); u [B][320] = W1[:, H:] [S; z] + b1.
+extern "C" int sw_wide_dec_loop_fwd(const float* w1h_img, const float* w2_img, const float* w3_img, const float* whh_img,
+                                    const float* u, const float* b2, const float* b3, const float* W4, const float* b4,
+                                    const float* Wx, const float* bx1, const float* bx2, const float* p0, int p0_ld, float* a1,
+                                    float* a2, float* a3, float* pred4, float* x4, float* gates, float* cs, float* hs, float* cat,
+                                    int B, int H, int To, int Tp, void* stream) {
+  if (!w1h_img || !w2_img || !w3_img || !whh_img || !u || !b2 || !b3 || !W4 || !b4 || !Wx || !bx1 || !bx2 || !p0 || !a1 || !a2 || !a3 ||
+      !pred4 || !x4 || !gates || !cs || !hs || !cat || B < 1 || To < 1 || Tp < 1 || p0_ld < 2)
+    return SW_EARG;
+  if (!sw_wide_dec_loop_supported(H)) return SW_ESHAPE;
+  WideDecFwd A{w1h_img, w2_img, w3_img, whh_img, u, b2, b3, W4, b4, Wx, bx1, bx2, p0, p0_ld, a1, a2, a3, pred4, x4, gates, cs, hs, cat,
+               B, To, Tp};
+  SW_LAUNCH(wide_dec_loop_fwd_kernel, dim3((B + 15) / 16), dim3(256), 0, (hipStream_t)stream, A);
+  SW_CHECK_LAUNCH("wide_dec_loop_fwd_kernel");
+  return SW_OK;
+}
+
+// Backward of the decode loop at 128 units in one launch (wide_dec_loop_bwd_kernel).  Images: whhT = W_hh^T [128][512], w3T = W3^T
+// [160][80], w2T = W2^T [320][160], w1hT = W1[:, :H]^T [128][320], wxT = Wx^T zero-padded to 16 rows [16][512].
+extern "C" int sw_wide_dec_loop_bwd(const float* whhT_img, const float* w3T_img, const float* w2T_img, const float* w1hT_img,
+                                    const float* wxT_img, const float* W4, const float* dpred4, const float* a1, const float* a2,
+                                    const float* gates, const float* cs, float* dgates, float* dv, float* dz3, float* dz2, float* dz1,
+                                    float* dhcat_out, float* dc_out, int B, int H, int To, int Tp, void* stream) {
+  if (!whhT_img || !w3T_img || !w2T_img || !w1hT_img || !wxT_img || !W4 || !dpred4 || !a1 || !a2 || !gates || !cs || !dgates || !dv ||
+      !dz3 || !dz2 || !dz1 || !dhcat_out || !dc_out || B < 1 || To < 1 || Tp < 1)
+    return SW_EARG;
+  if (!sw_wide_dec_loop_supported(H)) return SW_ESHAPE;
+  WideDecBwd A{whhT_img, w3T_img, w2T_img, w1hT_img, wxT_img, W4, dpred4, a1, a2, gates, cs, dgates, dv, dz3, dz2, dz1, dhcat_out,
+               dc_out, B, To, Tp};
+  SW_LAUNCH(wide_dec_loop_bwd_kernel, dim3((B + 15) / 16), dim3(256), 0, (hipStream_t)stream, A);
+  SW_CHECK_LAUNCH("wide_dec_loop_bwd_kernel");
   return SW_OK;
 }
 

@@ -18,6 +18,7 @@ torch is used for memory (buffers, slicing, broadcast copies of S / z into the d
 Linear-only restore of train.py:541-542); arithmetic runs in the library's kernels.  No CPU fallback.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -142,8 +143,23 @@ class WideTrainer(GenericTrainer):
         # hidden sizes 64 / 128: the observation sequences run as LSTM SEQUENCE kernels (W_hh / W_hh^T register-resident for
         # the whole sequence, loaded from operand-layout images made once per weight update: sw_wide_opimage)
         self.seq = bool(L.load().sw_wide_lstm_seq_supported(H))
-        self.gI, self._gI_args = self._image_table(self.gp, enc.lstm.weight_hh_l0)
-        self.dI, self._dI_args = self._image_table(self.dp, Dm.obsv_encoder_lstm.weight_hh_l0)
+        # 128 units: the decode loop of predict() is ONE persistent launch streaming the decoder's operand images
+        self.decloop = bool(L.load().sw_wide_dec_loop_supported(H)) and os.environ.get("SW_WIDE_DECLOOP", "1") != "0"
+        D1 = 2 * H + H // 2
+        g_entries = [("whh", enc.lstm.weight_hh_l0, 4 * H, H, 0, 0, 0), ("whhT", enc.lstm.weight_hh_l0, H, 4 * H, 0, 1, 0)]
+        if self.decloop:
+            g_entries += [("w1h", dec[0].weight, D1, H, 0, 0, D1), ("w2", dec[2].weight, D1 // 2, D1, 0, 0, 0),
+                          ("w3", dec[4].weight, D1 // 4, D1 // 2, 0, 0, 0),
+                          # ... and of the transposes the backward loop streams (dx = dy W wants W^T rows)
+                          ("w3T", dec[4].weight, D1 // 2, D1 // 4, 0, 1, 0), ("w2T", dec[2].weight, D1, D1 // 2, 0, 1, 0),
+                          ("w1hT", dec[0].weight, H, D1, 0, 1, D1)]
+            # Wx^T (composed per step, not a parameter) zero-padded to one 16-row tile, and its image
+            self._wxT16 = torch.zeros(16, 4 * H, device=self.device)
+            self._wxT_img = torch.zeros(16 * 4 * H, device=self.device)
+            self._wxT_tab = torch.tensor([[0, 16, 4 * H, 0, 0, 0]], dtype=torch.int32).to(self.device)
+        self.gI, self._gI_args = self._image_table(self.gp, g_entries)
+        dwhh = Dm.obsv_encoder_lstm.weight_hh_l0
+        self.dI, self._dI_args = self._image_table(self.dp, [("whh", dwhh, 4 * H, H, 0, 0, 0), ("whhT", dwhh, H, 4 * H, 0, 1, 0)])
         nl = n_latent_codes                     # reported sums: the info term's mean runs over B * nl elements (losses_from)
         k = np.ones((n_unrolling_steps + 3, 3))
         k[:n_unrolling_steps + 2, 1] = 2.0 / nl
@@ -200,14 +216,18 @@ class WideTrainer(GenericTrainer):
         tab_d = torch.tensor(tab, dtype=torch.int32).to(self.device)
         return out, (fl.flat, tab_d, len(tab), tiles, buf)
 
-    def _image_table(self, fl, whh):
-        """Operand images of W_hh [4H][H] (forward) and of its transpose [H][4H] (BPTT)."""
-        n = whh.numel()
-        o = fl.off[id(whh)]
-        R, K = whh.shape
-        tab = torch.tensor([[o, R, K, 0, 0, 0], [o, K, R, n, 1, 0]], dtype=torch.int32).to(self.device)
-        buf = torch.zeros(2 * n, device=self.device)
-        return dict(whh=buf[:n], whhT=buf[n:]), (fl.flat, tab, 2, 2 * n // 4, buf)
+    def _image_table(self, fl, entries):
+        """MFMA operand images (sw_wide_opimage) of matrices of the packed buffer `fl`: entries = (name, parameter, R, K,
+        first column, transposed, source row stride or 0) for the image of Mx [R][K] - a (column block of a) matrix or its
+        transpose."""
+        tab, views, off = [], {}, 0
+        for name, p, R, K, col0, tr, ld in entries:
+            tab.append((fl.off[id(p)] + col0, R, K, off, tr, ld))
+            views[name] = (off, R * K)
+            off += R * K
+        buf = torch.zeros(off, device=self.device)
+        out = {name: buf[o:o + n] for name, (o, n) in views.items()}
+        return out, (fl.flat, torch.tensor(tab, dtype=torch.int32).to(self.device), len(tab), off // 4, buf)
 
     def _images(self, args):
         src, tab, n, n4, dst = args
@@ -238,7 +258,7 @@ class WideTrainer(GenericTrainer):
             x4=z(Ta + 1, B, 4), hs=z(Ta + 1, B, H), cs=z(Ta, B, H), gates=z(Ta, B, 4 * H),
             Wx=z(4 * H, 4), WxT=z(4, 4 * H), bxc=z(4 * H),
             feat=z(max(P, 1), 4), f1=z(max(P, 1), 32), f2=z(max(P, 1), 64), f3=z(max(P, 1), H), wh=z(B, H), attn=z(max(P, 1)),
-            S=z(B, H), cat=z(Tp, B, D1), a1=z(Tp, B, D1), a2=z(Tp, B, D2), a3=z(Tp, B, D3), pcur=z(B, 2),
+            S=z(B, H), u=z(B, D1), cat=z(Tp, B, D1), a1=z(Tp, B, D1), a2=z(Tp, B, D2), a3=z(Tp, B, D3), pcur=z(B, 2),
             # generator backward
             dgates=z(Ta, B, 4 * H), dc=z(B, H), dx4=z(B, 4), dprun=z(B, 2), dv=z(Tp, B, 4), dz3=z(Tp, B, D3), dz2=z(Tp, B, D2),
             dz1=z(Tp, B, D1), dhcat=z(B, H), dsz=z(Tp, B, H), dS=z(B, H), dhT=z(B, H), dsig=z(max(P, 1)),
@@ -280,6 +300,9 @@ class WideTrainer(GenericTrainer):
         gemm(wih, H, enc.embed.bias, 1, None, 4 * H, H, 1, w["bxc"], 1, cin=enc.lstm.bias_ih_l0, cin_ld=1)
         # ... and its transpose [4][4H] (the rows of dx4 = dgates Wx in the backward pass)
         gemm(enc.embed.weight, 1, wih, H, None, 4, H, 4 * H, w["WxT"], 4 * H, x_cs=4)
+        if self.decloop:
+            self._wxT16[:4].copy_(w["WxT"])
+            L.call("sw_wide_opimage", L.ptr(self._wxT16), L.ptr(self._wxT_tab), 1, 16 * 4 * H // 4, L.ptr(self._wxT_img), st)
         x4, hs, cs, gates, cat = w["x4"], w["hs"], w["cs"], w["gates"], w["cat"]
         x4[:To].copy_(w["o4"].transpose(0, 1))
 
@@ -313,6 +336,14 @@ class WideTrainer(GenericTrainer):
             w["S"].zero_()
         cat[:, :, H:2 * H] = w["S"]
         cat[:, :, 2 * H:] = w["noise"]
+        if self.decloop:
+            # u = W1[:, H:] [S; z] + b1: constant over the decode steps (train.py:411, 421), the initial accumulators of layer 1
+            gemm(_off(cat, H), D1, _off(dec[0].weight, H), D1, dec[0].bias, B, D1 - H, D1, w["u"], D1)
+            L.call("sw_wide_dec_loop_fwd", L.ptr(self.gI["w1h"]), L.ptr(self.gI["w2"]), L.ptr(self.gI["w3"]), L.ptr(self.gI["whh"]),
+                   L.ptr(w["u"]), L.ptr(dec[2].bias), L.ptr(dec[4].bias), L.ptr(dec[5].weight), L.ptr(dec[5].bias), L.ptr(w["Wx"]),
+                   L.ptr(w["bxc"]), L.ptr(enc.lstm.bias_hh_l0), _off(w["obsv"], 2 * (To - 1)), 2 * To, L.ptr(w["a1"]), L.ptr(w["a2"]),
+                   L.ptr(w["a3"]), L.ptr(w["pred4"]), L.ptr(x4), L.ptr(gates), L.ptr(cs), L.ptr(hs), L.ptr(cat), B, H, To, Tp, st)
+            return w["pred4"]
         w["pcur"].copy_(w["obsv"][:, -1])
         for i in range(Tp):
             gemm(cat[i], D1, dec[0].weight, D1, dec[0].bias, B, D1, D1, w["a1"][i], D1, EPI_LRELU)
@@ -347,7 +378,13 @@ class WideTrainer(GenericTrainer):
                    L.ptr(w["dc"]) if have_dc else None, B, H, L.ptr(dg[t]), L.ptr(w["dc"]), st)
             have_dc = True
 
-        for i in range(Tp - 1, -1, -1):
+        if self.decloop:
+            gI = self.gI
+            L.call("sw_wide_dec_loop_bwd", L.ptr(gI["whhT"]), L.ptr(gI["w3T"]), L.ptr(gI["w2T"]), L.ptr(gI["w1hT"]), L.ptr(self._wxT_img),
+                   L.ptr(dec[5].weight), L.ptr(dpred4), L.ptr(w["a1"]), L.ptr(w["a2"]), L.ptr(gates), L.ptr(cs), L.ptr(dg), L.ptr(w["dv"]),
+                   L.ptr(w["dz3"]), L.ptr(w["dz2"]), L.ptr(w["dz1"]), L.ptr(w["dhcat"]), L.ptr(w["dc"]), B, H, To, Tp, st)
+            have_dc = Tp > 1
+        for i in range(-1 if self.decloop else Tp - 1, -1, -1):
             t_in = To + i                      # the LSTM step that consumed x4 = (p_i, v_i)
             dgt = None
             if i + 1 < Tp:
