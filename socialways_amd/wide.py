@@ -120,6 +120,7 @@ class WideTrainer(GenericTrainer):
         self.last_variety = None
         self._ws = {}            # workspaces per (B, To, P)
         self._graphs = {}        # captured steps per (B, To, scene layout, switches)
+        self._graph_P = {}       # ... and the pair count of each key's layout (the workspace it replays on)
         self._seen = {}
         # Linear-only mask of D.load() (train.py:311-316): 1 for nn.Linear parameters
         m = torch.zeros_like(self.dp.flat)
@@ -238,11 +239,20 @@ class WideTrainer(GenericTrainer):
         L.call("sw_wide_transpose", L.ptr(src), L.ptr(tab), n, tiles, L.ptr(dst), L.stream())
 
     # ---- buffers -----------------------------------------------------------------------------------------------------------
+    MAX_WORKSPACES = 6      # batch shapes (agents, observed steps, pairs) with live buffers + graphs; ragged datasets produce many
+
     def _buffers(self, B, To, P):
         key = (B, To, P)
         w = self._ws.get(key)
         if w is not None:
+            self._ws[key] = self._ws.pop(key)          # most recently used last
             return w
+        while len(self._ws) >= self.MAX_WORKSPACES:    # a set of buffers is ~0.4 GB at 2 048 agents and 128 units: the least
+            old = next(iter(self._ws))                 # recently used shape goes, with the graphs that have its addresses baked in
+            for gk in [k for k in self._graphs if k[:2] == old[:2] and self._graph_P.get(k) == old[2]]:
+                del self._graphs[gk]
+                self._seen.pop(gk, None)
+            del self._ws[old]
         H, Tp, dev = self.H, self.n_next, self.device
         Z, D1 = H // 2, 2 * H + H // 2
         D2, D3 = D1 // 2, D1 // 4
@@ -594,7 +604,12 @@ class WideTrainer(GenericTrainer):
                self._row0)
         n_seen = self._seen.get(key, 0)
         self._seen[key] = n_seen + 1
-        if not self.use_graph or n_seen < 2:           # two eager steps of a layout first (allocations, caches)
+        self._graph_P[key] = sc.P
+        if len(self._seen) > 4096:                     # ragged datasets: bookkeeping of layouts seen once does not grow forever
+            self._seen = {k: v for k, v in self._seen.items() if k in self._graphs}
+            self._graph_P = {k: v for k, v in self._graph_P.items() if k in self._graphs}
+        if not self.use_graph or n_seen < 2 or (key not in self._graphs and len(self._graphs) >= 4 * self.MAX_WORKSPACES):
+            # two eager steps of a layout first (allocations, caches); beyond the cap on captured layouts: eager
             for buf in self._step_device(w, sc, B, To, ss, Bg):
                 self._allreduce(buf)
         else:

@@ -96,3 +96,24 @@ def test_wide_trainer_l2_and_variety_terms_match_the_oracle():
             w = rec["g_grads"][name + "." + k]
             err = float((p.grad.cpu() - w).abs().max())
             assert err <= 2e-4 * max(float(w.abs().max()), 1e-12) + 1e-9, (name, k, err)
+
+
+def test_wide_trainer_workspace_eviction_keeps_the_trajectory():
+    """Ragged data produces many batch shapes; the wide trainer keeps buffers + captured graphs for a few of them (LRU) and
+    re-creates the rest: the trajectory over alternating shapes must not depend on the cap."""
+    import socialways_amd as sw
+    data = _data()
+    sbs = [(data.the_batches[:k], int(data.the_batches[k - 1][1])) for k in (6, 4, 9)]
+    res = []
+    for cap in (6, 1):
+        torch.manual_seed(7)
+        tr = sw.SocialWaysTrainer(12, hidden_size=H, use_social=True, device="cuda:0")
+        tr.MAX_WORKSPACES = cap
+        gen = torch.Generator().manual_seed(4)
+        outs = []
+        for it in range(12):                       # every shape four times: eager, eager, capture, replay (or rebuilt, cap = 1)
+            sb, B = sbs[it % 3]
+            outs.append(tr.step(data.obsv[:B], data.pred[:B], sb, 0.02, 0.95, torch.rand(B, H // 2, generator=gen), data.ss).cpu())
+        res.append((torch.stack(outs), tr.gp.flat.clone(), tr.dp.flat.clone(), len(tr._ws)))
+    assert res[0][3] == 3 and res[1][3] == 1
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
