@@ -117,3 +117,33 @@ def test_wide_trainer_workspace_eviction_keeps_the_trajectory():
         res.append((torch.stack(outs), tr.gp.flat.clone(), tr.dp.flat.clone(), len(tr._ws)))
     assert res[0][3] == 3 and res[1][3] == 1
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize("use_social,n_next", [(False, 12), (True, 1), (True, 3)])
+def test_wide_trainer_edge_configurations_match_the_generic_path(use_social, n_next):
+    """No social block (train.py:83's default), a one-step horizon (no re-fed encoder step at all) and a short one: the wide
+    engine against the layer-by-layer path under torch's tape on the same modules - sums, rollout, every gradient."""
+    import socialways_amd as sw
+    from socialways_amd.generic import GenericTrainer
+    from socialways_amd.wide import WideTrainer
+    torch.manual_seed(5)
+    a = WideTrainer(n_next, hidden_size=H, use_social=use_social, device="cuda:0", use_graph=False)
+    torch.manual_seed(5)
+    b = GenericTrainer(n_next, hidden_size=H, use_social=use_social, device="cuda:0")
+    t = sw.synth_tracks(6, [5, 1, 9, 16, 3, 2], 8, n_next, seed=5)
+    data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
+    B, sb = 36, data.the_batches[:6]
+    noise = torch.rand(B, H // 2, generator=torch.Generator().manual_seed(2))
+    ra = a.step(data.obsv[:B], data.pred[:B], sb, 0.03, 0.94, noise, data.ss)
+    rb = b.step(data.obsv[:B], data.pred[:B], sb, 0.03, 0.94, noise, data.ss)
+    np.testing.assert_allclose(ra.cpu().numpy(), rb.cpu().numpy(), rtol=3e-6, atol=1e-9)
+    np.testing.assert_allclose(a.last_pred_hat.cpu().numpy(), b.last_pred_hat.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    for (n, p), (_, q) in zip(a.G.named_parameters(), b.G.named_parameters()):     # (the generic trainer drops D's gradients at the end)
+        if q.grad is None:            # torch's tape leaves unused parameters without a gradient; the engine writes zeros
+            assert float(p.grad.abs().max()) == 0.0, n
+            continue
+        err = float((p.grad - q.grad).abs().max())
+        assert err <= 1e-4 * max(float(q.grad.abs().max()), 1e-12) + 1e-10, (n, err)
+    for (n, p), (_, q) in zip(a.D.named_parameters(), b.D.named_parameters()):     # D after its two updates and the Linear-only restore
+        d = (p.detach() - q.detach()).abs()
+        assert float(d.max()) <= 4.4e-3 and float((d <= 1e-4).float().mean()) > 0.98, n
