@@ -278,6 +278,24 @@ __global__ __launch_bounds__(256) void wide_gemm_lds_kernel(const float* __restr
   }
 }
 
+// Products with a contracted width of at most 8 (the heads' K = 1 / 2 / n_latent back-products, the 3-wide pair features,
+// the rank-1 bias terms of the composition): no matrix instruction pays here - one thread per output element, K fused
+// multiply-adds, same operand addressing and epilogue as wide_gemm_kernel.  (The general kernel spent 10 us on each.)
+__global__ __launch_bounds__(256) void wide_smallk_kernel(const float* __restrict__ x, long long x_rs, int x_cs,
+                                                          const float* __restrict__ w, long long w_rs, int w_cs,
+                                                          const float* __restrict__ bias, const float* __restrict__ cin, int cin_ld,
+                                                          const float* __restrict__ aux, int aux_ld, long long R, int K, int N,
+                                                          float* __restrict__ y, int y_ld, int epi) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= R * N) return;
+  const long long r = e / N;
+  const int n = (int)(e - r * N);
+  float v = bias ? bias[n] : 0.f;
+  for (int k = 0; k < K; ++k) v = fmaf(x[r * x_rs + (long long)k * x_cs], w[n * w_rs + (long long)k * w_cs], v);
+  if (cin) v += cin[r * cin_ld + n];
+  y[r * y_ld + n] = epi_apply(v, epi, epi >= EPI_DRELU ? aux[r * aux_ld + n] : 0.f);
+}
+
 // One LSTM step for all agents (nn.LSTM gate order i f g o, train.py:254, 278):
 //   pre = Wx x4 + b1 (+ b2) + Whh h_prev ; c' = f c + i g ; h' = o tanh(c')
 // Wx [4H][4] is the 4-d input's matrix (the encoder's composed W_ih W_embed, the discriminator's W_ih), Whh [4H][H].
@@ -1215,6 +1233,12 @@ extern "C" int sw_wide_gemm(const float* x, long long x_rs, int x_cs, const floa
   const bool ov = (N & 3) == 0 && (y_ld & 3) == 0 && al(y) && (!cin || ((cin_ld & 3) == 0 && al(cin))) &&
                   (!aux || ((aux_ld & 3) == 0 && al(aux)));
   hipStream_t st = (hipStream_t)stream;
+  if (K <= 8 && R * N <= 0x7fffffffLL * 256) {
+    SW_LAUNCH(wide_smallk_kernel, dim3((unsigned)((R * N + 255) / 256)), dim3(256), 0, st, x, x_rs, x_cs, w, w_rs, w_cs, bias, cin, cin_ld,
+              aux, aux_ld, R, K, N, y, y_ld, epi);
+    SW_CHECK_LAUNCH("wide_smallk_kernel");
+    return SW_OK;
+  }
   if (xv && wv && R >= 16) {      // the model's layers: LDS-staged core, 32 x 64 tiles (16 x 64 while those leave CUs idle)
     const long long b2 = ((R + 31) / 32) * ((N + 63) / 64), b1 = ((R + 15) / 16) * ((N + 63) / 64);
     if (b1 > 0x7fffffffLL) return SW_ESHAPE;
