@@ -99,6 +99,9 @@ PROTOTYPES = {
     "sw_wide_dec_loop_supported": (_i, [_i]),
     "sw_wide_dec_loop_fwd": (_i, [_vp] * 13 + [_i] + [_vp] * 9 + [_i, _i, _i, _i, _vp]),
     "sw_wide_dec_loop_bwd": (_i, [_vp] * 18 + [_i, _i, _i, _i, _vp]),
+    "sw_wide_disc_heads_supported": (_i, [_i, _i, _i]),
+    "sw_wide_disc_heads_fwd": (_i, [_vp, _vp]),
+    "sw_wide_disc_heads_bwd": (_i, [_vp, _vp]),
     "sw_wide_opimage": (_i, [_vp, _vp, _i, _ll, _vp, _vp]),
     "sw_wide_lstm_seq_supported": (_i, [_i]),
     "sw_wide_lstm_seq_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),

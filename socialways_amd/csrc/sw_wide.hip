@@ -15,6 +15,7 @@
 #include "../../include/socialways_hip.h"
 #include "sw_common.h"
 #include "sw_wgrad.h"
+#include <cstddef>
 
 namespace {
 enum { EPI_NONE = 0, EPI_RELU = 1, EPI_LRELU = 2, EPI_DRELU = 3, EPI_DLRELU = 4 };
@@ -1129,6 +1130,229 @@ __global__ __launch_bounds__(256) void wide_dec_loop_bwd_kernel(WideDecBwd A) {
     st4(A.dc_out + (size_t)b * H + 16 * tu[k] + 4 * lg, dc[k]);
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The HEADS of the wide discriminator (train.py:280-292, 300-309) for a 16-agent tile and both future branches in ONE launch
+// (forward) / ONE launch (backward) instead of nine / seven product launches of ~5 us each: the observation fc, the
+// prediction encoder, the classifier and the latent-code head are 64-wide layers at 128 hidden units - a handful of matrix
+// instructions per wave between barriers, activations in LDS tiles, weights from their operand images (sw_wide_opimage).
+// Generic in H (H2 = H / 2 a multiple of 16), 4 Tp a multiple of 16, nb = 1 or 2 branches, any latent-code count <= 16.
+// ---------------------------------------------------------------------------------------------------------------------------
+#define WH_MAXH 256
+struct WideHeads {
+  // operand images: forward (of0 [H2][H], of1 [H2][H2], pe0 [H2][K4], pe1 [H2][H2], cl0 [H2][H], la0 [H2][H]) or, for the
+  // backward kernel, of their transposes (of0T [H][H2], of1T, pe0T [K4][H2], pe1T, cl0T [H][H2], la0T)
+  const float *of0, *of1, *pe0, *pe1, *cl0, *la0;
+  const float *b_of0, *b_of1, *b_pe0, *b_pe1, *b_cl0, *b_la0;     // biases (forward)
+  const float *cl1w, *cl1b, *la1w, *la1b;                          // [1][H2], [1], [nl][H2], [nl]
+  const float* hT;                                                 // [B][H]
+  const float* px;                                                 // [nb B][K4]
+  float *o1, *q1, *both, *c1, *l1, *label, *code;                  // [B][H2], [nb B][H2], [nb B][H], .., [nb B], [nb B][nl]
+  // backward
+  const float *dlab, *dcod;                                        // [nb B][4] (col 0), [nb B][nlp]
+  float *dc1, *dl1, *dboth, *dq1, *docode, *do1, *dhT, *dpx;       // deltas (docode / do1 / dhT only with need_obs, dpx with want_dpred)
+  int B, H, K4, nb, nl, nlp, need_obs, want_dpred;
+};
+// acc += W[16 t ..][.] x over K = 16 KJ columns: A operand from the image (tile t), B operand = row `brow` of an LDS tile
+__device__ __forceinline__ f32x4 wh_tile(const float* __restrict__ img, int t, int KJ, const float* brow, f32x4 acc, int lane) {
+  f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+  const float* ip = img + ((size_t)t * KJ * 64 + lane) * 4;
+  for (int j = 0; j < KJ; j += 2) {
+    const f32x4 a0 = ld4(ip + (size_t)j * 256), b0 = ld4(brow + 16 * j);
+    const bool two = j + 1 < KJ;
+    const f32x4 a1 = ld4(ip + (size_t)(two ? j + 1 : j) * 256), b1 = ld4(brow + 16 * (two ? j + 1 : j));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc = SW_MFMA(a0[q], b0[q], acc);
+      if (two) acc1 = SW_MFMA(a1[q], b1[q], acc1);
+    }
+  }
+  return acc + acc1;
+}
+__global__ __launch_bounds__(256) void wide_disc_heads_fwd_kernel(WideHeads A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = A.H, H2 = H >> 1, K4 = A.K4, nb = A.nb, nl = A.nl, B = A.B;
+  const int LH = H + 4, L2 = H2 + 4, LK = K4 + 4;
+  float* hTb = smem;                       // [16][LH]
+  float* o1b = hTb + 16 * LH;              // [16][L2]
+  float* pxb = o1b + 16 * L2;              // [2][16][LK]
+  float* q1b = pxb + 2 * 16 * LK;          // [2][16][L2]
+  float* bob = q1b + 2 * 16 * L2;          // [2][16][LH]   both = obsv_code | pred_code
+  float* c1b = bob + 2 * 16 * LH;          // [2][16][L2]
+  float* l1b = c1b + 2 * 16 * L2;          // [2][16][L2]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), ln = lane & 15, lg = lane >> 4;
+  const int a0 = blockIdx.x * 16;
+  const int b = min(a0 + ln, B - 1);
+  const int NT2 = H2 >> 4;
+  // stage h_T and the prediction rows of the tile (coalesced: 16 threads per row)
+  for (int i = threadIdx.x; i < 16 * (H >> 2); i += 256) {
+    const int a = i / (H >> 2), c4 = i - a * (H >> 2);
+    st4(hTb + a * LH + 4 * c4, ld4(A.hT + (size_t)min(a0 + a, B - 1) * H + 4 * c4));
+  }
+  for (int i = threadIdx.x; i < nb * 16 * (K4 >> 2); i += 256) {
+    const int br = i / (16 * (K4 >> 2)), r = i - br * 16 * (K4 >> 2), a = r / (K4 >> 2), c4 = r - a * (K4 >> 2);
+    st4(pxb + (br * 16 + a) * LK + 4 * c4, ld4(A.px + ((size_t)br * B + min(a0 + a, B - 1)) * K4 + 4 * c4));
+  }
+  __syncthreads();
+  // ---- o1 = lrelu(of0 h_T + b); q1[br] = lrelu(pe0 px[br] + b) (independent of each other: same phase) ----
+  for (int t = wave; t < NT2; t += 4) {
+    f32x4 acc = wh_tile(A.of0, t, H >> 4, hTb + ln * LH + 4 * lg, ld4(A.b_of0 + 16 * t + 4 * lg), lane);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = sw_lrelu(acc[q]);
+    st4(o1b + ln * L2 + 16 * t + 4 * lg, acc);
+    st4(A.o1 + (size_t)b * H2 + 16 * t + 4 * lg, acc);
+    for (int br = 0; br < nb; ++br) {
+      f32x4 aq = wh_tile(A.pe0, t, K4 >> 4, pxb + (br * 16 + ln) * LK + 4 * lg, ld4(A.b_pe0 + 16 * t + 4 * lg), lane);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) aq[q] = sw_lrelu(aq[q]);
+      st4(q1b + (br * 16 + ln) * L2 + 16 * t + 4 * lg, aq);
+      st4(A.q1 + ((size_t)br * B + b) * H2 + 16 * t + 4 * lg, aq);
+    }
+  }
+  __syncthreads();
+  // ---- obsv_code = of1 o1 + b -> both[br][:, :H2]; pred_code[br] = pe1 q1[br] + b -> both[br][:, H2:] ----
+  for (int t = wave; t < NT2; t += 4) {
+    const f32x4 oc = wh_tile(A.of1, t, H2 >> 4, o1b + ln * L2 + 4 * lg, ld4(A.b_of1 + 16 * t + 4 * lg), lane);
+    for (int br = 0; br < nb; ++br) {
+      const f32x4 pc = wh_tile(A.pe1, t, H2 >> 4, q1b + (br * 16 + ln) * L2 + 4 * lg, ld4(A.b_pe1 + 16 * t + 4 * lg), lane);
+      st4(bob + (br * 16 + ln) * LH + 16 * t + 4 * lg, oc);
+      st4(bob + (br * 16 + ln) * LH + H2 + 16 * t + 4 * lg, pc);
+      float* g = A.both + ((size_t)br * B + b) * H + 16 * t + 4 * lg;
+      st4(g, oc);
+      st4(g + H2, pc);
+    }
+  }
+  __syncthreads();
+  // ---- c1 = lrelu(cl0 both + b), l1 = lrelu(la0 both + b) ----
+  for (int t = wave; t < NT2; t += 4)
+    for (int br = 0; br < nb; ++br) {
+      const float* brow = bob + (br * 16 + ln) * LH + 4 * lg;
+      f32x4 ac = wh_tile(A.cl0, t, H >> 4, brow, ld4(A.b_cl0 + 16 * t + 4 * lg), lane);
+      f32x4 al = wh_tile(A.la0, t, H >> 4, brow, ld4(A.b_la0 + 16 * t + 4 * lg), lane);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ac[q] = sw_lrelu(ac[q]);
+        al[q] = sw_lrelu(al[q]);
+      }
+      st4(c1b + (br * 16 + ln) * L2 + 16 * t + 4 * lg, ac);
+      st4(l1b + (br * 16 + ln) * L2 + 16 * t + 4 * lg, al);
+      st4(A.c1 + ((size_t)br * B + b) * H2 + 16 * t + 4 * lg, ac);
+      st4(A.l1 + ((size_t)br * B + b) * H2 + 16 * t + 4 * lg, al);
+    }
+  __syncthreads();
+  // ---- label = cl1 c1 + b (1 output), code = la1 l1 + b (nl outputs): dot products, 16 threads per (branch, agent) ----
+  {
+    const int br = threadIdx.x >> 7 & 1, a = (threadIdx.x >> 3) & 15, l8 = threadIdx.x & 7;   // 2 branches x 16 agents x 8 lanes
+    if (br < nb) {
+      const float* cr = c1b + (br * 16 + a) * L2;
+      const float* lr = l1b + (br * 16 + a) * L2;
+      for (int n = -1; n < nl; ++n) {          // n = -1: the label
+        const float* wr = n < 0 ? A.cl1w : A.la1w + (size_t)n * H2;
+        const float* xr = n < 0 ? cr : lr;
+        float s = 0.f;
+        for (int k = l8; k < H2; k += 8) s = fmaf(xr[k], wr[k], s);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 1);
+        if (l8 == 0 && a0 + a < B) {
+          if (n < 0) A.label[(size_t)br * B + a0 + a] = s + A.cl1b[0];
+          else A.code[((size_t)br * B + a0 + a) * nl + n] = s + A.la1b[n];
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wide_disc_heads_bwd_kernel(WideHeads A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = A.H, H2 = H >> 1, K4 = A.K4, nb = A.nb, nl = A.nl, nlp = A.nlp, B = A.B;
+  const int LH = H + 4, L2 = H2 + 4;
+  float* dc1b = smem;                       // [2][16][L2]
+  float* dl1b = dc1b + 2 * 16 * L2;         // [2][16][L2]
+  float* dbob = dl1b + 2 * 16 * L2;         // [2][16][LH]
+  float* dq1b = dbob + 2 * 16 * LH;         // [2][16][L2]  (docode in slot 0 rows after dq1 is consumed? no: own tile below)
+  float* docb = dq1b + 2 * 16 * L2;         // [16][L2]
+  float* do1b = docb + 16 * L2;             // [16][L2]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), ln = lane & 15, lg = lane >> 4;
+  const int a0 = blockIdx.x * 16;
+  const int b = min(a0 + ln, B - 1);
+  const int NT2 = H2 >> 4, NTH = H >> 4;
+  // ---- dc1 = (dlabel cl1) lrelu'(c1), dl1 = (dcode la1) lrelu'(l1): element-wise (rank 1 / rank nl) ----
+  for (int i = threadIdx.x; i < nb * 16 * (H2 >> 2); i += 256) {
+    const int br = i / (16 * (H2 >> 2)), r = i - br * 16 * (H2 >> 2), a = r / (H2 >> 2), c4 = r - a * (H2 >> 2);
+    const size_t row = (size_t)br * B + min(a0 + a, B - 1);
+    const float dl = A.dlab[row * 4];
+    const f32x4 cw = ld4(A.cl1w + 4 * c4), c1v = ld4(A.c1 + row * H2 + 4 * c4), l1v = ld4(A.l1 + row * H2 + 4 * c4);
+    f32x4 vc, vl = {0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < nl; ++n) {
+      const float dcn = A.dcod[row * nlp + n];
+      const f32x4 lw = ld4(A.la1w + (size_t)n * H2 + 4 * c4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) vl[q] = fmaf(dcn, lw[q], vl[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      vc[q] = sw_lrelu_grad(c1v[q], dl * cw[q]);
+      vl[q] = sw_lrelu_grad(l1v[q], vl[q]);
+    }
+    st4(dc1b + (br * 16 + a) * L2 + 4 * c4, vc);
+    st4(dl1b + (br * 16 + a) * L2 + 4 * c4, vl);
+    if (a0 + a < B) {
+      st4(A.dc1 + row * H2 + 4 * c4, vc);
+      st4(A.dl1 + row * H2 + 4 * c4, vl);
+    }
+  }
+  __syncthreads();
+  // ---- dboth = cl0^T dc1 + la0^T dl1 (H rows) ----
+  for (int t = wave; t < NTH; t += 4)
+    for (int br = 0; br < nb; ++br) {
+      f32x4 acc = wh_tile(A.cl0, t, H2 >> 4, dc1b + (br * 16 + ln) * L2 + 4 * lg, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
+      acc = wh_tile(A.la0, t, H2 >> 4, dl1b + (br * 16 + ln) * L2 + 4 * lg, acc, lane);
+      st4(dbob + (br * 16 + ln) * LH + 16 * t + 4 * lg, acc);
+      st4(A.dboth + ((size_t)br * B + b) * H + 16 * t + 4 * lg, acc);
+    }
+  __syncthreads();
+  // ---- dq1 = (pe1^T dpcode) lrelu'(q1); docode = sum over the branches of dboth[:, :H2] ----
+  for (int t = wave; t < NT2; t += 4) {
+    for (int br = 0; br < nb; ++br) {
+      f32x4 acc = wh_tile(A.pe1, t, H2 >> 4, dbob + (br * 16 + ln) * LH + H2 + 4 * lg, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
+      const f32x4 qv = ld4(A.q1 + ((size_t)br * B + b) * H2 + 16 * t + 4 * lg);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = sw_lrelu_grad(qv[q], acc[q]);
+      st4(dq1b + (br * 16 + ln) * L2 + 16 * t + 4 * lg, acc);
+      st4(A.dq1 + ((size_t)br * B + b) * H2 + 16 * t + 4 * lg, acc);
+    }
+    if (A.need_obs) {
+      f32x4 v = ld4(dbob + ln * LH + 16 * t + 4 * lg);
+      if (nb > 1) v = v + ld4(dbob + (16 + ln) * LH + 16 * t + 4 * lg);
+      st4(docb + ln * L2 + 16 * t + 4 * lg, v);
+      st4(A.docode + (size_t)b * H2 + 16 * t + 4 * lg, v);
+    }
+  }
+  __syncthreads();
+  // ---- do1 = (of1^T docode) lrelu'(o1);  d/d(pred) of branch 0 = pe0^T dq1 (4 Tp rows) ----
+  if (A.need_obs)
+    for (int t = wave; t < NT2; t += 4) {
+      f32x4 acc = wh_tile(A.of1, t, H2 >> 4, docb + ln * L2 + 4 * lg, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
+      const f32x4 ov = ld4(A.o1 + (size_t)b * H2 + 16 * t + 4 * lg);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = sw_lrelu_grad(ov[q], acc[q]);
+      st4(do1b + ln * L2 + 16 * t + 4 * lg, acc);
+      st4(A.do1 + (size_t)b * H2 + 16 * t + 4 * lg, acc);
+    }
+  if (A.want_dpred)
+    for (int t = wave; t < (K4 >> 4); t += 4) {
+      const f32x4 acc = wh_tile(A.pe0, t, H2 >> 4, dq1b + ln * L2 + 4 * lg, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
+      st4(A.dpx + (size_t)b * K4 + 16 * t + 4 * lg, acc);
+    }
+  if (!A.need_obs) return;
+  __syncthreads();
+  // ---- dh_T = of0^T do1 ----
+  for (int t = wave; t < NTH; t += 4) {
+    const f32x4 acc = wh_tile(A.of0, t, H2 >> 4, do1b + ln * L2 + 4 * lg, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
+    st4(A.dhT + (size_t)b * H + 16 * t + 4 * lg, acc);
+  }
+}
 }  // namespace
 
 extern "C" int sw_wide_transpose(const float* src, const int* tab /*device, ntab x 4*/, int ntab, int total_tiles, float* dst,
@@ -1174,6 +1398,42 @@ extern "C" int sw_wide_dec_loop_bwd(const float* whhT_img, const float* w3T_img,
   SW_CHECK_LAUNCH("wide_dec_loop_bwd_kernel");
   return SW_OK;
 }
+
+// The heads of the wide discriminator in one launch per direction (wide_disc_heads_fwd/bwd_kernel).  `p` = 43 host pointers
+// / integers in the order of struct WideHeads (see socialways_amd/wide.py: _heads_args).
+extern "C" int sw_wide_disc_heads_supported(int H, int K4, int nl) {
+  return (H >= 32 && H <= WH_MAXH && (H & 31) == 0 && K4 >= 16 && (K4 & 15) == 0 && nl >= 1 && nl <= 16) ? 1 : 0;
+}
+static int wide_heads_launch(const long long* p, int backward, void* stream) {
+  if (!p) return SW_EARG;
+  WideHeads A;
+  const float** cf = reinterpret_cast<const float**>(&A);
+  // the struct starts with 18 const float* (6 images, 6 biases, 4 small weights, hT, px) + 7 float* + 2 const float* + 8 float*
+  static_assert(offsetof(WideHeads, B) == 35 * sizeof(void*), "WideHeads layout");
+  for (int i = 0; i < 35; ++i) cf[i] = (const float*)(uintptr_t)p[i];
+  A.B = (int)p[35]; A.H = (int)p[36]; A.K4 = (int)p[37]; A.nb = (int)p[38]; A.nl = (int)p[39]; A.nlp = (int)p[40];
+  A.need_obs = (int)p[41]; A.want_dpred = (int)p[42];
+  if (A.B < 1 || A.nb < 1 || A.nb > 2 || !sw_wide_disc_heads_supported(A.H, A.K4, A.nl)) return SW_ESHAPE;
+  const int H = A.H, H2 = H / 2, LH = H + 4, L2 = H2 + 4, LK = A.K4 + 4;
+  const int lds_f = (16 * LH + 16 * L2 + 2 * 16 * LK + 2 * 16 * L2 + 2 * 16 * LH + 4 * 16 * L2) * 4;
+  const int lds_b = (4 * 16 * L2 + 2 * 16 * LH + 2 * 16 * L2 + 2 * 16 * L2) * 4;
+  const int lds = backward ? lds_b : lds_f;
+  static int have_f = 0, have_b = 0;
+  int& have = backward ? have_b : have_f;
+  if (have < lds) {
+    hipError_t e = hipFuncSetAttribute(backward ? (const void*)wide_disc_heads_bwd_kernel : (const void*)wide_disc_heads_fwd_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) { sw_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e); return SW_EHIP; }
+    have = lds;
+  }
+  const dim3 grid((A.B + 15) / 16), block(256);
+  if (backward) SW_LAUNCH(wide_disc_heads_bwd_kernel, grid, block, lds, (hipStream_t)stream, A);
+  else SW_LAUNCH(wide_disc_heads_fwd_kernel, grid, block, lds, (hipStream_t)stream, A);
+  SW_CHECK_LAUNCH("wide_disc_heads_kernel");
+  return SW_OK;
+}
+extern "C" int sw_wide_disc_heads_fwd(const long long* p, void* stream) { return wide_heads_launch(p, 0, stream); }
+extern "C" int sw_wide_disc_heads_bwd(const long long* p, void* stream) { return wide_heads_launch(p, 1, stream); }
 
 extern "C" int sw_wide_opimage(const float* src, const int* tab /*device, ntab x 6*/, int ntab, long long total_float4, float* dst,
                                void* stream) {

@@ -160,7 +160,16 @@ class WideTrainer(GenericTrainer):
             self._wxT_tab = torch.tensor([[0, 16, 4 * H, 0, 0, 0]], dtype=torch.int32).to(self.device)
         self.gI, self._gI_args = self._image_table(self.gp, g_entries)
         dwhh = Dm.obsv_encoder_lstm.weight_hh_l0
-        self.dI, self._dI_args = self._image_table(self.dp, [("whh", dwhh, 4 * H, H, 0, 0, 0), ("whhT", dwhh, H, 4 * H, 0, 1, 0)])
+        d_entries = [("whh", dwhh, 4 * H, H, 0, 0, 0), ("whhT", dwhh, H, 4 * H, 0, 1, 0)] if self.seq else []
+        # D's heads as one launch per direction (sw_wide_disc_heads_*): images of the six 2-D head matrices and their transposes
+        K4, H2 = 4 * n_next, H // 2
+        self.heads = bool(L.load().sw_wide_disc_heads_supported(H, K4, n_latent_codes)) and os.environ.get("SW_WIDE_HEADS", "1") != "0"
+        if self.heads:
+            for nm, m, r, k in (("of0", Dm.obsv_encoder_fc[0], H2, H), ("of1", Dm.obsv_encoder_fc[2], H2, H2),
+                                ("pe0", Dm.pred_encoder[0], H2, K4), ("pe1", Dm.pred_encoder[2], H2, H2),
+                                ("cl0", Dm.classifier[0], H2, H), ("la0", Dm.latent_decoder[0], H2, H)):
+                d_entries += [(nm, m.weight, r, k, 0, 0, 0), (nm + "T", m.weight, k, r, 0, 1, 0)]
+        self.dI, self._dI_args = self._image_table(self.dp, d_entries) if d_entries else ({}, None)
         nl = n_latent_codes                     # reported sums: the info term's mean runs over B * nl elements (losses_from)
         k = np.ones((n_unrolling_steps + 3, 3))
         k[:n_unrolling_steps + 2, 1] = 2.0 / nl
@@ -465,8 +474,9 @@ class WideTrainer(GenericTrainer):
         H2, nl = H // 2, self.n_latent_codes
         lstm = D.obsv_encoder_lstm
         x4, hs, cs, gates = w["x4"], w["d_hs"], w["d_cs"], w["d_gates"]
-        if self.seq:
+        if self._dI_args is not None:
             self._images(self._dI_args)
+        if self.seq:
             L.call("sw_wide_lstm_seq_fwd", L.ptr(x4), L.ptr(lstm.weight_ih_l0), L.ptr(lstm.bias_ih_l0), L.ptr(lstm.bias_hh_l0),
                    L.ptr(self.dI["whh"]), B, H, To, L.ptr(gates), L.ptr(cs), L.ptr(hs), None, 0, st)
         for t in range(0 if self.seq else To):
@@ -475,6 +485,9 @@ class WideTrainer(GenericTrainer):
                    L.ptr(gates[t]), L.ptr(cs[t]), L.ptr(hs[t + 1]), H, None, 0, st)
         of, pe, cl, la = D.obsv_encoder_fc, D.pred_encoder, D.classifier, D.latent_decoder
         R = nb * B
+        if self.heads:
+            L.call("sw_wide_disc_heads_fwd", self._heads_args(w, B, To, nb, False, False, False), st)
+            return
         gemm(hs[To], H, of[0].weight, H, of[0].bias, B, H, H2, w["o1"], H2, EPI_LRELU)
         for k in range(nb):      # obsv_code into the first half of `both`, once per branch
             gemm(w["o1"], H2, of[2].weight, H2, of[2].bias, B, H2, H2, _off(w["both"], k * B * H), H)
@@ -485,12 +498,32 @@ class WideTrainer(GenericTrainer):
         gemm(w["both"], H, la[0].weight, H, la[0].bias, R, H, H2, w["l1"], H2, EPI_LRELU)
         gemm(w["l1"], H2, la[2].weight, H2, la[2].bias, R, H2, nl, w["code"], nl)
 
-    def _disc_heads_backward(self, w, B, nb, want_dpred):
+    def _heads_args(self, w, B, To, nb, backward, need_obs, want_dpred):
+        """struct WideHeads of sw_wide.hip as 43 host values."""
+        D, I = self.D, self.dI
+        of, pe, cl, la = D.obsv_encoder_fc, D.pred_encoder, D.classifier, D.latent_decoder
+        sfx = "T" if backward else ""
+        vals = [I[n + sfx] for n in ("of0", "of1", "pe0", "pe1", "cl0", "la0")]
+        vals += [of[0].bias, of[2].bias, pe[0].bias, pe[2].bias, cl[0].bias, la[0].bias]
+        vals += [cl[2].weight, cl[2].bias, la[2].weight, la[2].bias, w["d_hs"][To], w["px"]]
+        vals += [w[k] for k in ("o1", "q1", "both", "c1", "l1", "label", "code", "dlab", "dcod", "dc1", "dl1", "dboth", "dq1",
+                                "docode", "do1", "d_dhT", "dpx")]
+        nl = self.n_latent_codes
+        ints = [B, self.H, 4 * self.n_next, nb, nl, (nl + 3) // 4 * 4, int(need_obs), int(want_dpred)]
+        arr = (ctypes.c_longlong * 43)(*([v.data_ptr() for v in vals] + ints))
+        return ctypes.cast(arr, ctypes.c_void_p)
+
+    def _disc_heads_backward(self, w, B, nb, want_dpred, need_obs=False):
         """Backward of the heads from dlab / dcod: every delta the weight gradients need, optionally d/d(pred) of branch 0."""
         H, Tp, D = self.H, self.n_next, self.D
         H2, nl, nlp = H // 2, self.n_latent_codes, (self.n_latent_codes + 3) // 4 * 4
         of, pe, cl, la = D.obsv_encoder_fc, D.pred_encoder, D.classifier, D.latent_decoder
         R = nb * B
+        if self.heads:
+            if not self.seq and need_obs:
+                self._transposes(self._dT_args)        # W_hh^T for the per-step LSTM backward
+            L.call("sw_wide_disc_heads_bwd", self._heads_args(w, B, 0, nb, True, need_obs, want_dpred), L.stream())
+            return
         self._transposes(self._dT_args)
         dT = self.dT
         gemm(w["dlab"], 4, dT["cl1"], 1, None, R, 1, H2, w["dc1"], H2, EPI_DLRELU, aux=w["c1"], aux_ld=H2)
@@ -508,11 +541,12 @@ class WideTrainer(GenericTrainer):
         of, pe, cl, la = D.obsv_encoder_fc, D.pred_encoder, D.classifier, D.latent_decoder
         lstm = D.obsv_encoder_lstm
         dT = self.dT
-        self._disc_heads_backward(w, B, 2, False)
-        # obsv_code feeds both branches: its gradient is the sum over the branches
-        L.call("sw_wide_sum_steps", L.ptr(w["dboth"]), B * H, H, 2, B, H2, L.ptr(w["docode"]), H2, st)
-        gemm(w["docode"], H2, dT["of1"], H2, None, B, H2, H2, w["do1"], H2, EPI_DLRELU, aux=w["o1"], aux_ld=H2)
-        gemm(w["do1"], H2, dT["of0"], H2, None, B, H2, H, w["d_dhT"], H)
+        self._disc_heads_backward(w, B, 2, False, need_obs=True)
+        if not self.heads:
+            # obsv_code feeds both branches: its gradient is the sum over the branches
+            L.call("sw_wide_sum_steps", L.ptr(w["dboth"]), B * H, H, 2, B, H2, L.ptr(w["docode"]), H2, st)
+            gemm(w["docode"], H2, dT["of1"], H2, None, B, H2, H2, w["do1"], H2, EPI_DLRELU, aux=w["o1"], aux_ld=H2)
+            gemm(w["do1"], H2, dT["of0"], H2, None, B, H2, H, w["d_dhT"], H)
         hs, cs, gates, dg = w["d_hs"], w["d_cs"], w["d_gates"], w["d_dgates"]
         if self.seq:
             L.call("sw_wide_lstm_seq_bwd", L.ptr(w["d_dhT"]), H, None, 0, None, None, L.ptr(self.dI["whhT"]), L.ptr(gates), L.ptr(cs),
