@@ -1157,15 +1157,23 @@ struct WideHeads {
 __device__ __forceinline__ f32x4 wh_tile(const float* __restrict__ img, int t, int KJ, const float* brow, f32x4 acc, int lane) {
   f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
   const float* ip = img + ((size_t)t * KJ * 64 + lane) * 4;
-  for (int j = 0; j < KJ; j += 2) {
-    const f32x4 a0 = ld4(ip + (size_t)j * 256), b0 = ld4(brow + 16 * j);
-    const bool two = j + 1 < KJ;
-    const f32x4 a1 = ld4(ip + (size_t)(two ? j + 1 : j) * 256), b1 = ld4(brow + 16 * (two ? j + 1 : j));
+  for (int j0 = 0; j0 < KJ; j0 += 8) {            // eight image loads in flight, then their matrix instructions
+    f32x4 a[8], b[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      acc = SW_MFMA(a0[q], b0[q], acc);
-      if (two) acc1 = SW_MFMA(a1[q], b1[q], acc1);
+    for (int u = 0; u < 8; ++u) {
+      const int j = min(j0 + u, KJ - 1);
+      a[u] = ld4(ip + (size_t)j * 256);
+      b[u] = ld4(brow + 16 * j);
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (j0 + u < KJ) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (u & 1) acc1 = SW_MFMA(a[u][q], b[u][q], acc1);
+          else acc = SW_MFMA(a[u][q], b[u][q], acc);
+        }
+      }
   }
   return acc + acc1;
 }
