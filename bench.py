@@ -83,11 +83,11 @@ def kernel_alg_flops(B, P, To, Tp, one_launch_d=False, dfuse=None):
         from socialways_amd import ops as _ops
         dfuse = _ops.DFUSE
     g_phase = 2.0 * B * (To * d_lstm + d_obs + 2 * d_br)     # one branch forward + its heads backward
-    if one_launch_d:      # sw_disc_update: pass 1 (its LSTM forward rode in the decode launch) + pass 2; disc_fwd = the G phase only
-        d_kernels = {"disc_update_kernel": 2.0 * B * ((d_obs + 2 * d_br) + d_all + 2 * d_all),
+    rides = (B + 15) // 16 <= 128     # pass 1's observation LSTM rides in the decode launch while that leaves CUs idle (ops.D_OBS_MAX_TILES)
+    if one_launch_d:      # sw_disc_update: pass 1 + pass 2 (forward + backward each); disc_fwd = the G phase only
+        d_kernels = {"disc_update_kernel": 2.0 * B * (((d_obs + 2 * d_br) if rides else d_all) + d_all + 2 * d_all),
                      "disc_fwd_kernel": g_phase}
-    else:                 # 3 disc_fwd launches (pass 1, pass 2, G phase) + 2 disc_bwd launches; pass 1's observation LSTM rides in
-        rides = (B + 15) // 16 <= 128     # the decode launch only while that leaves CUs idle (ops.D_OBS_MAX_TILES)
+    else:                 # 3 disc_fwd launches (pass 1, pass 2, G phase) + 2 disc_bwd launches
         d_kernels = {"disc_fwd_kernel": 2.0 * B * (((d_obs + 2 * d_br) if rides else d_all) + d_all) + g_phase,
                      "disc_bwd_kernel": 2.0 * 2 * B * d_all}
     if dfuse:
@@ -99,7 +99,7 @@ def kernel_alg_flops(B, P, To, Tp, one_launch_d=False, dfuse=None):
         "enc_lstm_fwd_kernel": 2.0 * B * To * lstm,
         "enc_lstm_bwd_kernel": 2.0 * B * To * lstm,
         "dec_rollout_fwd_kernel": 2.0 * B * (Tp * dec + (Tp - 1) * lstm)
-                                  + (2.0 * B * To * d_lstm if (B + 15) // 16 <= 128 else 0.0),   # + D's first obs LSTM (rides here)
+                                  + (2.0 * B * To * d_lstm if rides else 0.0),   # + D's first obs LSTM (rides here)
         "dec_rollout_bwd_kernel": 2.0 * B * (Tp * dec + (Tp - 1) * lstm) + (g_phase if dfuse else 0.0),   # + the G-phase D pass
         "social_pool_fwd_kernel": 2.0 * soc,
         "social_pool_bwd_rows_kernel": 2.0 * 2 * soc,     # recomputes the pair MLP + its data gradients
@@ -683,7 +683,7 @@ def main():
                          "how": "HIP events around every kernel launch of %d eager steps (sw_kernel_timing), host running ahead "
                                 "of the GPU behind a spin kernel; algorithmic FLOPs of all of the kernel's launches in a step "
                                 "/ their summed time" % n_ev,
-                         "kernels": rows[:6],
+                         "kernels": rows[:int(os.environ.get("SW_BENCH_KERNEL_ROWS", "6"))],
                          # what an event pair adds to a launch (a kernel that does nothing, same queue): subtract from avg_us
                          # for the kernel's own duration; `frac` is computed from the RAW times (conservative)
                          "event_overhead_us": event_overhead_us,

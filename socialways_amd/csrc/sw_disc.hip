@@ -10,6 +10,7 @@
 #include "sw_wgrad.h"
 #include "sw_wgrad_dev.h"
 #include <type_traits>
+#include <cstdlib>
 #ifdef SW_PHASE_STAMPS
 __device__ long long sw_disc_stamps[16];
 #define SW_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); long long _t = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) sw_disc_stamps[k] += _t - _tprev; _tprev = _t; __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -322,9 +323,8 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_bwd_kernel(
 // ---------------------------------------------------------------------------------------------
 // One discriminator UPDATE pass in ONE launch (train.py:476-495): forward of D on the fake and the real branch, the LSGAN /
 // InfoGAN loss gradients (per-agent local: means over the batch, scale known up front) and the whole backward down to the
-// delta rows the weight-gradient GEMM contracts over.  One workgroup per 16-agent tile; used while the tiles leave CUs
-// idle (<= 128 tiles, the metric shape), where the two-launch form costs a launch, a second prologue and the round trip
-// of every head activation through the save buffer.  The two branches share the observation encoding; their heads run
+// delta rows the weight-gradient GEMM contracts over.  One workgroup per 16-agent tile; the two-launch form costs a launch,
+// a second prologue and the round trip of the gates / every head activation through the save buffer.  The two branches share the observation encoding; their heads run
 // SIDE BY SIDE on the two wave pairs (waves 0, 1: fake; 2, 3: real) - a head layer is 2 row tiles, so the pair that used
 // to idle now carries the other branch - forward and backward.  Rows for the weight gradients (saved activations, deltas)
 // are written exactly where sw_disc_fwd / sw_disc_bwd put them.  Needs the registered weight images (sw_disc_images).
@@ -862,10 +862,16 @@ static int disc_bwd_impl(const float* d_w, const float* dsave, const float* cons
   return wg_launch_adam(wb, wgrad_ws, ad, st);
 }
 
-// Can sw_disc_update run this pass (else: sw_disc_fwd + sw_disc_bwd_gan*)?  It is built for the shapes that leave CUs idle.
+// Can sw_disc_update run this pass (else: sw_disc_fwd + sw_disc_bwd_gan*)?  Built in round 3 for the shapes that leave CUs
+// idle (<= 128 tiles); measured in round 4 at 160 .. 2 048 tiles: one workgroup per CU without the round trip of the gates
+// through the save buffer beats the two launches at two workgroups per CU by 1-5 % of the step everywhere.
 extern "C" int sw_disc_update_supported(const float* d_w, int B, int To, int Tp) {
   if (!d_w || B < 1 || To < 1 || Tp < 1 || Tp > 12) return 0;
-  if ((B + SW_TILE - 1) / SW_TILE > 128) return 0;
+  static const int max_tiles = [] {        // SW_DISC_UPDATE_MAX_TILES=128: the round-3 rule (A/B runs)
+    const char* e = getenv("SW_DISC_UPDATE_MAX_TILES");
+    return e ? atoi(e) : 1 << 30;
+  }();
+  if ((B + SW_TILE - 1) / SW_TILE > max_tiles) return 0;
   if (!sw_disc_images_for(d_w, Tp).img) return 0;
   return upd_lds(Tp).total * 4 <= 163840 ? 1 : 0;
 }
