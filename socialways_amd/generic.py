@@ -21,8 +21,8 @@ operations of its own: the sum of the two gate pre-activation products, the posi
 the loss gradients, the loss sum and both Adam steps.  This path is launch-bound (over a thousand small launches per step
 under the tape): 42 steps/s at 128 units on the metric shape.  Widths that are multiples of 32 train on the WIDE path instead
 (wide.py: the same modules, explicit backward over time-step-level kernels, one hipGraph per step - 10 x faster); this file
-remains for every other width the reference accepts, as the module classes of both, and as the cross-check of the wide
-engine (tests).  No CPU fallback: CPU tensors raise.
+remains for every other width the reference accepts (data parallel and with the L2 / variety terms like the other engines),
+as the module classes of both, and as the cross-check of the wide engine (tests).  No CPU fallback: CPU tensors raise.
 """
 import copy
 
@@ -378,7 +378,8 @@ class Generator(nn.Module):
 class GenericTrainer(SocialWaysTrainer):
     """train() / test() / checkpoint (train.py:439-668) for any hidden size / latent-code count on the generic-width
     path.  Same public surface as SocialWaysTrainer (step, step_many, train_epoch, test, checkpoint, load_checkpoint,
-    losses_from); single process."""
+    losses_from), data parallel over a process group like it (scene-aligned shards of every packed batch, losses normalised by
+    the global batch, the gradients of each of the step's three updates all-reduced before their Adam step)."""
 
     def __init__(self, n_next, hidden_size=64, lr_g=1e-4, lr_d=1e-3, n_unrolling_steps=1, use_social=True, use_info_loss=True,
                  loss_info_w=0.5, n_latent_codes=2, device="cuda", process_group=None, use_l2_loss=False,
@@ -388,10 +389,9 @@ class GenericTrainer(SocialWaysTrainer):
         unknown = set(perf_only) - {"variety_k", "use_graph", "fused_adam"}
         if unknown:
             raise TypeError("unexpected keyword arguments: %s" % sorted(unknown))
-        if process_group is not None:
-            raise L.SocialWaysHipError("generic-width path: single process only")
-        if use_variety_loss:
-            raise L.SocialWaysHipError("generic-width path: use_variety_loss is not implemented")
+        if use_variety_loss not in (False, True):
+            raise L.SocialWaysHipError("generic-width path: use_variety_loss=%r (the folded best-of-K form) is not implemented; "
+                                       "True = the reference's term as written" % (use_variety_loss,))
         if int(n_latent_codes) < 2:
             # train.py:486, 516 compare code_hat.squeeze() of shape (B,) with noise[:, :1] of shape (B, 1): nn.MSELoss
             # broadcasts them to (B, B).  That accident is not reproduced here - and not silently replaced by another loss
@@ -402,7 +402,7 @@ class GenericTrainer(SocialWaysTrainer):
             raise L.SocialWaysHipError("socialways_amd runs on MI355X only (no CPU fallback)")
         self.n_next, self.noise_len = n_next, hidden_size // 2
         self.n_unrolling_steps, self.use_info_loss, self.loss_info_w = n_unrolling_steps, use_info_loss, loss_info_w
-        self.use_l2_loss, self.use_variety_loss, self.loss_l2_w = use_l2_loss, False, loss_l2_w
+        self.use_l2_loss, self.use_variety_loss, self.loss_l2_w = use_l2_loss, bool(use_variety_loss), loss_l2_w
         self.n_latent_codes = n_latent_codes
         # construction order = train.py:370-385 (RNG -> init mapping, optimizer parameter order); built on the CPU
         # generator like the reference, then moved
@@ -410,9 +410,13 @@ class GenericTrainer(SocialWaysTrainer):
         self.predictor_optimizer = torch.optim.Adam(self.G.predictor_params(), lr=lr_g, betas=(0.9, 0.999))
         self.D = Discriminator(n_next, hidden_size, n_latent_codes).to(self.device)
         self.D_optimizer = torch.optim.Adam(self.D.parameters(), lr=lr_d, betas=(0.9, 0.999))
-        self.pg, self.world, self.rank, self.epoch = None, 1, 0, 0
+        self.pg, self.world, self.rank, self.epoch = process_group, 1, 0, 0
+        if process_group is not None:      # data parallel like the fused trainer: scene shards, three all-reduces per step
+            self.world, self.rank = torch.distributed.get_world_size(process_group), torch.distributed.get_rank(process_group)
         self.use_graph = False
         self.last_variety = None
+        if self.world > 1:
+            self.sync_replicas()
 
     @property
     def use_social(self):
@@ -425,8 +429,9 @@ class GenericTrainer(SocialWaysTrainer):
         G, D = self.G, self.D
         B = obsv.shape[0]
         Bg = float(global_B if global_B is not None else B)
-        if Bg != B:
-            raise L.SocialWaysHipError("generic-width path: single process only")
+        if self.use_variety_loss and Bg < 20:
+            raise ValueError("use_variety_loss indexes agent 19 of the packed batch (train.py:531): batch of %d" % Bg)
+        k = B / Bg                       # this shard's share of the batch means (1 in a single process)
         obsv, pred = _c(obsv), _c(pred)
         z = _c(noise.to(dev))
         targets = torch.tensor([float(zeros_val), float(ones_val)], dtype=torch.float32).to(dev)
@@ -444,7 +449,8 @@ class GenericTrainer(SocialWaysTrainer):
             l_info, s_info = _Mse.apply(code, z[:, :nl], None, 0)
             rl, _ = D(o4, p4)
             l_real, s_real = _Mse.apply(rl, None, targets, 1)
-            (l_fake + l_real + wi * l_info).backward()
+            (k * (l_fake + l_real + wi * l_info)).backward()
+            self._reduce_grads(self.D_optimizer)
             self.D_optimizer.step()
             res[u, 0], res[u, 1], res[u, 2] = s_fake.double(), s_info.double() * (2.0 / nl), s_real.double()
             if u == 0 and U > 0:
@@ -458,7 +464,14 @@ class GenericTrainer(SocialWaysTrainer):
         if self.use_l2_loss:
             l2, _ = _Mse.apply(pred_hat[:, :, :2].reshape(B, -1), pred.reshape(B, -1), None, 0)
             g_loss = g_loss + self.loss_l2_w * l2
+        g_loss = k * g_loss
+        if self.use_variety_loss:        # train.py:527-536 as written: only the k = 19 term survives - the L2 of AGENT 19
+            r = 19 - int(global_row0)    # of the packed batch (its 20 rollouts are identical); it lives on one rank's shard
+            if 0 <= r < B:
+                lv, _ = _Mse.apply(pred_hat[r:r + 1, :, :2].reshape(1, -1), pred[r:r + 1].reshape(1, -1), None, 0)
+                g_loss = g_loss + self.loss_l2_w * lv
         g_loss.backward()
+        self._reduce_grads(self.predictor_optimizer)
         self.predictor_optimizer.step()
         self.D_optimizer.zero_grad(set_to_none=True)
         if backup is not None:
@@ -477,5 +490,59 @@ class GenericTrainer(SocialWaysTrainer):
     def release_graphs(self):
         pass
 
+    # ---- data parallelism ------------------------------------------------------------------------------------------------
+    def _reduce_grads(self, optim):
+        """SUM over the ranks of every gradient of `optim`'s parameters (the losses are already weighted B_r / B) as ONE
+        flat all-reduce; a parameter without a gradient on this rank (e.g. the social block on a shard of single-agent
+        scenes) contributes zeros - every rank then applies the same update."""
+        if self.pg is None or self.world == 1:
+            return
+        ps = [p for g in optim.param_groups for p in g["params"]]
+        has = torch.tensor([0.0 if p.grad is None else 1.0 for p in ps]).to(self.device)
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ps] + [has])
+        torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        has = flat[-len(ps):].tolist()
+        o = 0
+        for p, h in zip(ps, has):      # a parameter no rank has a gradient for stays without one (Adam skips it, as in one process)
+            p.grad = flat[o:o + p.numel()].view_as(p).clone() if h > 0 else None
+            o += p.numel()
+
+    def _empty_step(self):
+        """A rank without scenes in this packed batch still takes part in the step's three all-reduces and applies the
+        same updates."""
+        U = self.n_unrolling_steps
+        backup = None
+        for u in range(U + 1):
+            self.D_optimizer.zero_grad(set_to_none=True)
+            self._reduce_grads(self.D_optimizer)
+            self.D_optimizer.step()
+            if u == 0 and U > 0:
+                backup = copy.deepcopy(self.D)
+        self.predictor_optimizer.zero_grad(set_to_none=True)
+        self._reduce_grads(self.predictor_optimizer)
+        self.predictor_optimizer.step()
+        if backup is not None:
+            self.D.load(backup)
+        return torch.zeros(U + 3, 3, dtype=torch.float64, device=self.device)
+
     def sync_replicas(self):
-        pass
+        """Rank 0's weights and optimizer state to every rank (construction, load_checkpoint)."""
+        if self.pg is None or self.world == 1:
+            return
+        dist = torch.distributed
+        src = dist.get_global_rank(self.pg, 0)
+        for p in list(self.G.parameters()) + list(self.D.parameters()):
+            dist.broadcast(p.data, src, group=self.pg)
+        for optim in (self.predictor_optimizer, self.D_optimizer):
+            box = [optim.state_dict() if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src, group=self.pg,
+                                       device=self.device if dist.get_backend(self.pg) == "nccl" else None)
+            if self.rank != 0:
+                optim.load_state_dict(box[0])
+        ep = torch.tensor([float(self.epoch)], device=self.device)
+        dist.broadcast(ep, src, group=self.pg)
+        self.epoch = int(ep.item())
+
+    def _allreduce(self, flat):
+        if self.pg is not None and self.world > 1:
+            torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
