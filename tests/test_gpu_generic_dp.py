@@ -98,3 +98,24 @@ def test_generic_trainer_l2_and_variety_terms_match_the_oracle():
             w = rec["g_grads"][name + "." + k]
             err = float((p.grad.cpu() - w).abs().max())
             assert err <= 2e-4 * max(float(w.abs().max()), 1e-12) + 1e-9, (name, k, err)
+
+
+@pytest.mark.parametrize("width", [128, 80])
+def test_wider_trainers_evaluate_like_the_oracle(width):
+    """test() (train.py:563-616) of the wide (128 units) and the generic-width (80) trainer: K = 4 sampled futures per
+    held-out scene from the same generator state as the oracle of that width - min / avg ADE and FDE."""
+    import socialways_amd as sw
+    import sw_oracle as O
+    t = sw.synth_tracks(10, [5, 1, 9, 16, 3, 2, 2, 7, 4, 6], 8, 12, seed=9)
+    data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
+    odata = O.load_and_normalise(t["obsvs"], t["preds"], t["batches"])
+    torch.manual_seed(11)
+    tr = sw.SocialWaysTrainer(12, hidden_size=width, use_social=True, device="cuda:0")
+    torch.manual_seed(11)
+    orc = O.SocialWaysOracle(12, hidden_size=width, use_social=True)
+    assert type(tr).__name__ == ("WideTrainer" if width == 128 else "GenericTrainer")
+    torch.manual_seed(123)
+    got = tr.test(data, n_gen_samples=4)
+    torch.manual_seed(123)
+    want = orc.test(odata, n_gen_samples=4)
+    np.testing.assert_allclose(np.asarray(got), np.asarray(want), rtol=1e-4, atol=1e-6)
