@@ -205,7 +205,7 @@ class SocialWaysTrainer:
         if use_graph is None:          # hipGraph replay of the step (segmented around the all-reduces when world > 1)
             use_graph = self.device.type == "cuda" and fused_adam
         self.use_graph = bool(use_graph)
-        self.max_graphs = 8
+        self.max_graphs = int(os.environ.get("SW_MAX_GRAPHS", "8"))    # captured packed-batch layouts (the rest of the steps run eagerly)
         self._graphs = {}
         self._force_dist = os.environ.get("SW_FORCE_DIST", "") == "1"   # 1-rank group still runs the collectives (tests)
         self._fuse_d_adam = os.environ.get("SW_FUSE_D_ADAM", "1") == "1"  # D's Adam inside the gradient reduction (world 1)
