@@ -248,7 +248,11 @@ class WideTrainer(GenericTrainer):
         L.call("sw_wide_transpose", L.ptr(src), L.ptr(tab), n, tiles, L.ptr(dst), L.stream())
 
     # ---- buffers -----------------------------------------------------------------------------------------------------------
-    MAX_WORKSPACES = 6      # batch shapes (agents, observed steps, pairs) with live buffers + graphs; ragged datasets produce many
+    # batch shapes (agents, observed steps, pairs) with live buffers + graphs: ragged datasets produce one per packed batch,
+    # recurring every epoch - kept up to a count and a byte budget (a set is ~0.4 GB at 2 048 agents and 128 units; 288 GB of HBM)
+    MAX_WORKSPACES = 64
+    MAX_GRAPHS = 96         # captured layouts (a layout beyond the cap runs eagerly)
+    WORKSPACE_BYTES = 24 << 30
 
     def _buffers(self, B, To, P):
         key = (B, To, P)
@@ -256,8 +260,9 @@ class WideTrainer(GenericTrainer):
         if w is not None:
             self._ws[key] = self._ws.pop(key)          # most recently used last
             return w
-        while len(self._ws) >= self.MAX_WORKSPACES:    # a set of buffers is ~0.4 GB at 2 048 agents and 128 units: the least
-            old = next(iter(self._ws))                 # recently used shape goes, with the graphs that have its addresses baked in
+        while self._ws and (len(self._ws) >= self.MAX_WORKSPACES or
+                            sum(v["_bytes"] for v in self._ws.values()) > self.WORKSPACE_BYTES):
+            old = next(iter(self._ws))                 # the least recently used shape goes, with the graphs that have its addresses baked in
             for gk in [k for k in self._graphs if k[:2] == old[:2] and self._graph_P.get(k) == old[2]]:
                 del self._graphs[gk]
                 self._seen.pop(gk, None)
@@ -293,6 +298,7 @@ class WideTrainer(GenericTrainer):
             wgrad=torch.empty(L.workspace_floats(L.WS_WGRAD, 1, 2, 1), device=dev),
             res=torch.zeros(self.n_unrolling_steps + 3, 3, dtype=torch.float64, device=dev),
         )
+        w["_bytes"] = sum(v.numel() * v.element_size() for v in w.values() if torch.is_tensor(v) and v._base is None)
         self._ws[key] = w
         return w
 
@@ -642,7 +648,7 @@ class WideTrainer(GenericTrainer):
         if len(self._seen) > 4096:                     # ragged datasets: bookkeeping of layouts seen once does not grow forever
             self._seen = {k: v for k, v in self._seen.items() if k in self._graphs}
             self._graph_P = {k: v for k, v in self._graph_P.items() if k in self._graphs}
-        if not self.use_graph or n_seen < 2 or (key not in self._graphs and len(self._graphs) >= 4 * self.MAX_WORKSPACES):
+        if not self.use_graph or n_seen < 2 or (key not in self._graphs and len(self._graphs) >= self.MAX_GRAPHS):
             # two eager steps of a layout first (allocations, caches); beyond the cap on captured layouts: eager
             for buf in self._step_device(w, sc, B, To, ss, Bg):
                 self._allreduce(buf)
