@@ -352,6 +352,13 @@ int sw_stage_step_img(const float* slot, int B, int To, int Tp, float* obsv_dst,
                       const float* dec_w, const float* emb_w /*or NULL*/, const float* att_w /*or NULL*/, float* img,
                       /* d_img != NULL: the launch also scatters and registers the discriminator's images (sw_disc_images) */
                       const float* d_w /*or NULL*/, float* d_img /*or NULL*/, const int* d_tab /*or NULL*/, void* stream);
+/*      sw_stage_step_zdev = sw_stage_step_img for a caller whose z (train.py:473) already lives in device memory
+ *      (z_device = 1): slot words [8,9] then hold the device pointer of z (B,32) instead of its values, z_dst is required
+ *      and filled from there - no PCIe read of z inside the step (4 MB at 32 768 agents).                               */
+int sw_stage_step_zdev(const float* slot, int B, int To, int Tp, float* obsv_dst, float* pred_dst, float* pred4_dst,
+                       float* targets_dst, float* z_dst, float* steps_dst, int n_d_updates, const float* enc_w,
+                       const float* dec_w, const float* emb_w, const float* att_w, float* img, const float* d_w, float* d_img,
+                       const int* d_tab, int z_device, void* stream);
 
 /* ---- derived weight images of the DISCRIMINATOR (Discriminator.forward, train.py:294-309, as the kernels consume it):
  *      MFMA A-operand images of lstm.weight_hh and its transpose, and the eight head matrices transposed and zero-padded

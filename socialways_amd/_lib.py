@@ -74,6 +74,7 @@ PROTOTYPES = {
     "sw_gen_image_floats": (_i, []),
     "sw_gen_images": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "sw_stage_step_img": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sw_stage_step_zdev": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sw_disc_image_floats": (_i, [_i]),
     "sw_disc_image_table": (_i, [_i, _vp]),
     "sw_disc_images": (_i, [_vp, _vp, _vp, _i, _vp]),

@@ -17,13 +17,25 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
     const float* __restrict__ c0, int B, int T, float* __restrict__ hT, float* __restrict__ cT,
     float* __restrict__ y, float* __restrict__ act, float* __restrict__ x4s, int t0, const float* __restrict__ aux_src,
     float* __restrict__ aux_dst, long long aux_n, const float* __restrict__ gimg) {
-  // Workgroups beyond the agent tiles only copy aux_src -> aux_dst (the training step pulls z out of its pinned
-  // host slot here: 128 tiles leave half of the CUs idle for the whole latency-bound kernel, the PCIe read is free)
+  // The FIRST workgroups of the grid only copy aux_src -> aux_dst (the training step pulls z out of its pinned host slot
+  // here).  128 tiles leave half of the CUs idle for the whole latency-bound kernel: the PCIe read is free.  With more
+  // tiles than CUs (dense crowds: 4 MB of z) the copy must START with the kernel - workgroups are dispatched in index
+  // order; appended behind the tiles (round 3) they began when the last round of tiles did and the 4 MB then took
+  // longer than that round: 113 -> 173 us - and keep several reads per thread in flight (PCIe round trips).
   const int tiles = (B + SW_TILE - 1) / SW_TILE;
-  if ((int)blockIdx.x >= tiles) {
-    const long long n4 = aux_n >> 2, stride = (long long)(gridDim.x - tiles) * SW_THREADS;
-    for (long long i = (long long)(blockIdx.x - tiles) * SW_THREADS + threadIdx.x; i < n4; i += stride)
-      st4(aux_dst + 4 * i, ld4(aux_src + 4 * i));
+  const int extra = (int)gridDim.x - tiles;
+  if ((int)blockIdx.x < extra) {
+    const long long n4 = aux_n >> 2, stride = (long long)extra * SW_THREADS;
+    long long i = (long long)blockIdx.x * SW_THREADS + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+      const f32x4 v0 = ld4(aux_src + 4 * i), v1 = ld4(aux_src + 4 * (i + stride));
+      const f32x4 v2 = ld4(aux_src + 4 * (i + 2 * stride)), v3 = ld4(aux_src + 4 * (i + 3 * stride));
+      st4(aux_dst + 4 * i, v0);
+      st4(aux_dst + 4 * (i + stride), v1);
+      st4(aux_dst + 4 * (i + 2 * stride), v2);
+      st4(aux_dst + 4 * (i + 3 * stride), v3);
+    }
+    for (; i < n4; i += stride) st4(aux_dst + 4 * i, ld4(aux_src + 4 * i));
     return;
   }
   // h exchange between the waves: with ACT the whole saved row of a step is assembled in LDS (lstm_put_act_tile) and its
@@ -34,7 +46,7 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
   __shared__ __attribute__((aligned(16))) float bx_lds[256];
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
   const int u0 = wave * 16;
-  const int a0 = blockIdx.x * SW_TILE;
+  const int a0 = ((int)blockIdx.x - extra) * SW_TILE;
   const int b = min(a0 + ln, B - 1);
   LstmW W;
   if (gimg) {   // weight images of this step, derived once by the staging launch (swimg, sw_common.h)

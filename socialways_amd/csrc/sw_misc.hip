@@ -817,7 +817,7 @@ extern "C" int sw_gen_images(const float* enc_w, const float* dec_w, const float
 // `slot` is a host-pinned (device-mapped) buffer the host fills before every replay, 4-byte words:
 //   [0,1] device pointer of obsv (B,To,2)   [2,3] device pointer of pred (B,Tp,2)
 //   [4] zeros_val  [5] ones_val (train.py:471-472)   [6] D updates applied so far  [7] G updates applied so far
-//   [8 ..] z (B*32, train.py:473)
+//   [8 ..] z (B*32, train.py:473) - or, z_device = 1, [8,9] = device pointer of a z the caller already holds in HBM
 // The kernel is a node of the captured graph with FIXED arguments; what changes per step travels through
 // the slot.  It copies the tracks into the graph's static buffers, forms the real future as (p, v) rows
 // (get_traj_4d, train.py:135-137) and pulls the scalars + z over PCIe.
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(256) void stage_step_kernel(const float* __restrict
                                                           const float* __restrict__ att_w, float* __restrict__ img,
                                                           int img_blocks, const float* __restrict__ d_w,
                                                           float* __restrict__ d_img, const int* __restrict__ d_tab, int d_n,
-                                                          int dimg_blocks) {
+                                                          int dimg_blocks, int z_device) {
   // the last img_blocks workgroups derive the generator's weight images of this step (sw_gen_images), the dimg_blocks
   // in front of them scatter the discriminator's weights into theirs (sw_disc_images)
   if ((int)blockIdx.x >= (int)gridDim.x - img_blocks) {
@@ -845,8 +845,10 @@ __global__ __launch_bounds__(256) void stage_step_kernel(const float* __restrict
   const float* obsv = reinterpret_cast<const float*>(ptrs[0]);
   const float* pred = reinterpret_cast<const float*>(ptrs[1]);
   const int gid = blockIdx.x * 256 + threadIdx.x, gsz = ((int)gridDim.x - img_blocks - dimg_blocks) * 256;
-  if (z_dst)
-    for (int i = gid; i < B * SW_Z / 4; i += gsz) st4(z_dst + 4 * (size_t)i, ld4(slot + 8 + 4 * (size_t)i));
+  if (z_dst) {
+    const float* zs = z_device ? reinterpret_cast<const float*>(ptrs[4]) : slot + 8;
+    for (int i = gid; i < B * SW_Z / 4; i += gsz) st4(z_dst + 4 * (size_t)i, ld4(zs + 4 * (size_t)i));
+  }
   if (gid < 2) targets_dst[gid] = slot[4 + gid];
   // 1-based Adam step indices of this training step's updates: D update u -> [u], the G update -> [n_d_updates]
   if (steps_dst && gid <= n_d_updates) steps_dst[gid] = gid < n_d_updates ? slot[6] + 1.0f + (float)gid : slot[7] + 1.0f;
@@ -861,10 +863,11 @@ __global__ __launch_bounds__(256) void stage_step_kernel(const float* __restrict
   }
 }
 #define SW_DIMG_BLOCKS 16
-extern "C" int sw_stage_step_img(const float* slot, int B, int To, int Tp, float* obsv_dst, float* pred_dst,
-                                 float* pred4_dst, float* targets_dst, float* z_dst, float* steps_dst, int n_d_updates,
-                                 const float* enc_w, const float* dec_w, const float* emb_w, const float* att_w, float* img,
-                                 const float* d_w, float* d_img, const int* d_tab, void* stream) {
+extern "C" int sw_stage_step_zdev(const float* slot, int B, int To, int Tp, float* obsv_dst, float* pred_dst,
+                                  float* pred4_dst, float* targets_dst, float* z_dst, float* steps_dst, int n_d_updates,
+                                  const float* enc_w, const float* dec_w, const float* emb_w, const float* att_w, float* img,
+                                  const float* d_w, float* d_img, const int* d_tab, int z_device, void* stream) {
+  if (z_device && !z_dst) return SW_EARG;
   if (!slot || !obsv_dst || !pred_dst || !pred4_dst || !targets_dst || B < 1 || To < 2 || Tp < 1 ||
       n_d_updates < 0 || n_d_updates > 254)
     return SW_EARG;
@@ -876,11 +879,18 @@ extern "C" int sw_stage_step_img(const float* slot, int B, int To, int Tp, float
   const int ib = img ? SW_IMG_BLOCKS : 0, db = d_img ? SW_DIMG_BLOCKS : 0;
   SW_LAUNCH(stage_step_kernel, dim3(blocks + ib + db), dim3(256), 0, (hipStream_t)stream, slot, B, To, Tp, obsv_dst,
                      pred_dst, pred4_dst, targets_dst, z_dst, steps_dst, n_d_updates, enc_w, dec_w, emb_w, att_w, img, ib,
-                     d_w, d_img, d_tab, d_img ? swp::disc(Tp).n : 0, db);
+                     d_w, d_img, d_tab, d_img ? swp::disc(Tp).n : 0, db, z_device ? 1 : 0);
   SW_CHECK_LAUNCH("stage_step_kernel");
   if (img) gen_images_register(enc_w, dec_w, emb_w, att_w, img);
   if (d_img) sw_disc_images_register(d_w, d_img, d_tab, Tp);
   return SW_OK;
+}
+extern "C" int sw_stage_step_img(const float* slot, int B, int To, int Tp, float* obsv_dst, float* pred_dst,
+                                 float* pred4_dst, float* targets_dst, float* z_dst, float* steps_dst, int n_d_updates,
+                                 const float* enc_w, const float* dec_w, const float* emb_w, const float* att_w, float* img,
+                                 const float* d_w, float* d_img, const int* d_tab, void* stream) {
+  return sw_stage_step_zdev(slot, B, To, Tp, obsv_dst, pred_dst, pred4_dst, targets_dst, z_dst, steps_dst, n_d_updates, enc_w,
+                            dec_w, emb_w, att_w, img, d_w, d_img, d_tab, 0, stream);
 }
 extern "C" int sw_stage_step(const float* slot, int B, int To, int Tp, float* obsv_dst, float* pred_dst,
                              float* pred4_dst, float* targets_dst, float* z_dst, float* steps_dst, int n_d_updates,

@@ -303,15 +303,24 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_fwd_kernel(
     const float* __restrict__ emb_w, const float* __restrict__ att_w, float* __restrict__ S_out,
     float* __restrict__ attn, int a16, int S, const float* __restrict__ aux_src, float* __restrict__ aux_dst, long long aux_n,
     const float* __restrict__ simg) {
-  // Workgroups beyond the scenes only copy aux_src -> aux_dst (the training step pulls z out of its pinned host slot
-  // here: this launch is light - small scenes use a few KB of LDS each - and the decode launch behind it is the
-  // first consumer of z)
-  if ((int)blockIdx.x >= S) {
-    const long long n4 = aux_n >> 2, stride = (long long)(gridDim.x - S) * SW_THREADS;
-    for (long long i = (long long)(blockIdx.x - S) * SW_THREADS + threadIdx.x; i < n4; i += stride)
-      st4(aux_dst + 4 * i, ld4(aux_src + 4 * i));
+  // The FIRST workgroups of the grid only copy aux_src -> aux_dst (dense crowds: the second half of the step's z comes
+  // out of its pinned host slot here - the decode launch behind is the first consumer; see enc_lstm_fwd_kernel)
+  const int extra = (int)gridDim.x - S;
+  if ((int)blockIdx.x < extra) {
+    const long long n4 = aux_n >> 2, stride = (long long)extra * SW_THREADS;
+    long long i = (long long)blockIdx.x * SW_THREADS + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+      const f32x4 v0 = ld4(aux_src + 4 * i), v1 = ld4(aux_src + 4 * (i + stride));
+      const f32x4 v2 = ld4(aux_src + 4 * (i + 2 * stride)), v3 = ld4(aux_src + 4 * (i + 3 * stride));
+      st4(aux_dst + 4 * i, v0);
+      st4(aux_dst + 4 * (i + stride), v1);
+      st4(aux_dst + 4 * (i + 2 * stride), v2);
+      st4(aux_dst + 4 * (i + 3 * stride), v3);
+    }
+    for (; i < n4; i += stride) st4(aux_dst + 4 * i, ld4(aux_src + 4 * i));
     return;
   }
+  const int scene = (int)blockIdx.x - extra;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SocL Ls = soc_lds(a16);
   const int sa = Ls.sa;
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(SW_THREADS) void social_pool_fwd_kernel(
   float* sig = smem + Ls.sig;
   const float* w0b = smem + Ls.w0b;
   const float* b12 = smem + Ls.b12;
-  const int s0 = scene_off[blockIdx.x], n = scene_off[blockIdx.x + 1] - s0;
+  const int s0 = scene_off[scene], n = scene_off[scene + 1] - s0;
   if (n <= 0 || n > SW_AMAX) return;   // scenes above SW_AMAX agents go through the row-block kernels below
   if (n == 1) {  // train.py:165: single-agent scenes keep S = 0
     if (threadIdx.x < 16) st4(S_out + (size_t)s0 * 64 + 4 * threadIdx.x, f32x4{0.f, 0.f, 0.f, 0.f});

@@ -149,10 +149,13 @@ def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_soc
     x4s_off = (To + n_next - 1) * B * 384
     # z (256 KB over PCIe: ~16 us, request-bound) is first read by the decode launch.  The encoder launch leaves half of
     # the CUs idle for ~20 us at the metric shape: its spare workgroups pull z for free.
-    z_in_enc, z_in_soc = noise_src, None
+    # (Dense crowds: 4 MB of z at c4 are ~170 us of request-bound PCIe reads against 113 us of encoder work.  Splitting the
+    # pull over this launch and the social block's moved the cost, 168 + 148 -> 135 + 185 us: the CUs that host the pulling
+    # workgroups serve their tiles / scenes late.  A caller that wants it gone hands z over in device memory.)
+    z_in_enc, z_in_soc, n_enc = noise_src, None, noise.numel() if noise_src else 0
     L.call("sw_enc_lstm_fwd_aux", L.ptr(obsv), 0, L.ptr(enc_w), None, None, B, To, L.ptr(hT), L.ptr(cT), None,
            L.ptr(gsave), (gsave.data_ptr() + 4 * x4s_off) if save else None, 0,
-           z_in_enc, L.ptr(noise) if z_in_enc else None, noise.numel() if z_in_enc else 0, st)
+           z_in_enc, L.ptr(noise) if z_in_enc else None, n_enc, st)
     attn = wh = ml = None
     if use_social:
         S = torch.empty(B, 64, device=dev)
@@ -162,7 +165,7 @@ def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_soc
             ml = torch.empty(B, 2, device=dev) if save else None
         L.call("sw_social_pool_fwd_aux", L.ptr(obsv), To, L.ptr(hT), L.ptr(scenes.scene_off), scenes.S, B, scenes.amax,
                L.ptr(emb_w), L.ptr(att_w), L.ptr(S), L.ptr(attn), L.ptr(scenes.big_blocks), scenes.NB, L.ptr(wh), L.ptr(ml),
-               z_in_soc, L.ptr(noise) if z_in_soc else None, noise.numel() if z_in_soc else 0, st)
+               z_in_soc, (noise.data_ptr() + 4 * n_enc) if z_in_soc else None, (noise.numel() - n_enc) if z_in_soc else 0, st)
     else:
         S = torch.zeros(B, 64, device=dev)                                   # train.py:413
     L.call("sw_dec_rollout_fwd_aux", L.ptr(obsv), To, L.ptr(noise), L.ptr(S), L.ptr(hT), L.ptr(cT), L.ptr(enc_w),

@@ -529,3 +529,29 @@ def test_five_toy_epochs_track_the_reference():
     print("per-epoch |dADE|, |dFDE|, max |dMSE|:", errs)
     assert all(max(e[:2]) < 1e-4 for e in errs), errs          # north-star tolerance, every epoch (observed <= 2.2e-6)
     assert all(e[2] < 1e-4 for e in errs), errs
+
+
+def test_z_in_device_memory_gives_the_same_steps_as_z_from_the_host():
+    """z (train.py:473) handed over as a device tensor travels by ADDRESS (sw_stage_step_zdev: the staging kernel copies it
+    inside HBM) instead of through the pinned slot: same sums, same weights, bit for bit - eager steps, capture, replays,
+    and K-step launches."""
+    import socialways_amd as sw
+    t = sw.synth_tracks(40, 8, 8, 12, seed=3)
+    data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
+    B, sb = 320, data.the_batches[:40]
+    res = []
+    for on_device in (False, True):
+        torch.manual_seed(5)
+        tr = sw.SocialWaysTrainer(12, use_social=True, device="cuda:0")
+        gen = torch.Generator().manual_seed(9)
+        outs = []
+        for it in range(6):
+            z = torch.rand(B, 32, generator=gen)
+            outs.append(tr.step(data.obsv[:B], data.pred[:B], sb, 0.02, 0.95, z.cuda() if on_device else z, data.ss).cpu())
+        for it in range(3):
+            zs = [torch.rand(B, 32, generator=gen) for _ in range(4)]
+            outs += [o.cpu() for o in tr.step_many([(data.obsv[:B], data.pred[:B], 0.03, 0.93, z.cuda() if on_device else z)
+                                                    for z in zs], sb, data.ss)]
+        torch.cuda.synchronize()
+        res.append((torch.stack(outs), tr.G._flat_all.clone(), tr.D._flat.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
