@@ -646,3 +646,18 @@ def test_encoder_with_stacked_layers_or_wide_units_matches_the_reference_module(
     assert_close(xg.grad.cpu(), xr.grad, 1e-4, 1e-6, "dx")
     for (k, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
         assert_close(p.grad.cpu(), q.grad, 1e-4, 1e-5 * max(float(q.grad.abs().max()), 1e-9), "d" + k)
+
+
+@pytest.mark.timeout(900)
+def test_random_configurations_match_the_oracle():
+    """A fixed-seed slice of the randomised sweep (tools/dbg/fuzz_parity.py: ragged scene sizes up to 90 agents, observation
+    / prediction lengths, unrolling depth 0-2, loss switches incl. L2 / variety, hidden sizes 64 / 32 / 128 / 80 with 2-3
+    latent codes -> fused, wide and generic trainers): two steps each against the CPU oracle - MSE terms, ADE / FDE sums,
+    rollout, every generator gradient."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(root, "tools", "dbg", "fuzz_parity.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.run(14, 2) == 0
