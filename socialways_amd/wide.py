@@ -634,6 +634,8 @@ class WideTrainer(GenericTrainer):
         if self.use_variety_loss and Bg < 20:
             raise ValueError("use_variety_loss indexes agent 19 of the packed batch (train.py:531): batch of %d" % Bg)
         sc = _scene_index(sub_batches, B, dev)
+        if self.G.use_social and sc.NB:       # (checked HERE: a batch whose multi-agent scenes are ALL above the limit has P = 0)
+            raise L.SocialWaysHipError("wide path: scenes above %d agents are not supported" % L.AMAX)
         w = self._buffers(B, To, sc.P)
         w["obsv"].copy_(obsv)
         w["pred"].copy_(pred)

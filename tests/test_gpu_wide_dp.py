@@ -147,3 +147,18 @@ def test_wide_trainer_edge_configurations_match_the_generic_path(use_social, n_n
     for (n, p), (_, q) in zip(a.D.named_parameters(), b.D.named_parameters()):     # D after its two updates and the Linear-only restore
         d = (p.detach() - q.detach()).abs()
         assert float(d.max()) <= 4.4e-3 and float((d <= 1e-4).float().mean()) > 0.98, n
+
+
+def test_wide_trainer_refuses_scenes_above_the_limit_even_when_no_small_scene_has_pairs():
+    """Scenes above 64 agents are not supported on the wide path - also when they are the ONLY multi-agent scenes of the batch
+    (no in-scene pair of a small scene: the pair count the social block is gated on is then 0; found by the randomised sweep:
+    the step ran without social pooling instead of refusing)."""
+    import socialways_amd as sw
+    t = sw.synth_tracks(4, [70, 1, 1, 2], 8, 12, seed=5)
+    data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
+    tr = sw.SocialWaysTrainer(12, hidden_size=H, use_social=True, device="cuda:0")
+    B, sb = 72, data.the_batches[:3]
+    with pytest.raises(sw.SocialWaysHipError, match="above 64 agents"):
+        tr.step(data.obsv[:B], data.pred[:B], sb, 0.03, 0.94, torch.rand(B, H // 2), data.ss)
+    tr2 = sw.SocialWaysTrainer(12, hidden_size=H, use_social=False, device="cuda:0")      # without the social block: fine
+    assert torch.isfinite(tr2.step(data.obsv[:B], data.pred[:B], sb, 0.03, 0.94, torch.rand(B, H // 2), data.ss)).all()

@@ -10,6 +10,13 @@ import socialways_amd as sw
 import sw_oracle as O
 
 
+WIDE_SWEEP = os.environ.get("FUZZ_WIDE", "") == "1"      # rarer shapes: larger scenes, longer horizons, more widths
+AMAX_CHOICES = [1, 3, 8, 8, 20, 64, 90] + ([150, 200] if WIDE_SWEEP else [])
+TO_CHOICES = [2, 3, 5, 8, 8] + ([12, 16] if WIDE_SWEEP else [])
+TP_CHOICES = [1, 2, 5, 8, 12, 12] + ([16, 20] if WIDE_SWEEP else [])
+H_CHOICES = [64, 64, 64, 32, 128, 80] + ([16, 96, 256, 48] if WIDE_SWEEP else [])
+
+
 def run(N=30, seed=0, ONLY=None, VERB=False):
     """N random configurations from `seed`; returns the number of failures (prints one line per configuration).
     A LeakyReLU / ReLU input within rounding of zero may take the other slope on one side: such a kink event shows as a
@@ -18,13 +25,13 @@ def run(N=30, seed=0, ONLY=None, VERB=False):
     rng = np.random.default_rng(seed)
     fails = 0
     for it in range(N):
-        amax = int(rng.choice([1, 3, 8, 8, 20, 64, 90]))
+        amax = int(rng.choice(AMAX_CHOICES))
         budget = int(rng.choice([40, 150, 400, 700]))
         sizes = []
         while sum(sizes) < budget:
             sizes.append(int(rng.integers(1, amax + 1)))
-        To, Tp = int(rng.choice([2, 3, 5, 8, 8])), int(rng.choice([1, 2, 5, 8, 12, 12]))
-        H = int(rng.choice([64, 64, 64, 32, 128, 80]))
+        To, Tp = int(rng.choice(TO_CHOICES)), int(rng.choice(TP_CHOICES))
+        H = int(rng.choice(H_CHOICES))
         nl = 2 if H in (64, 32) else int(rng.choice([2, 3]))
         kw = dict(use_social=bool(rng.random() < 0.8), n_unrolling_steps=int(rng.choice([0, 1, 1, 2])),
                   use_info_loss=bool(rng.random() < 0.8), use_l2_loss=bool(rng.random() < 0.3))
