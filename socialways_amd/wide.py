@@ -277,7 +277,7 @@ class WideTrainer(GenericTrainer):
         # prediction rows into the first, get_traj_4d the real rows into the second; D's pred_encoder reads them in place
         px = z(2 * B, 4 * Tp)
         w = dict(
-            obsv=z(B, To, 2), pred=z(B, Tp, 2), noise=z(B, Z), targets=z(2), o4=z(B, To, 4), px=px,
+            obsv=z(B, To, 2), pred=z(B, Tp, 2), noise=z(B, Z), scal=z(self.n_unrolling_steps + 4), o4=z(B, To, 4), px=px,
             pred4=px[:B].view(B, Tp, 4), p4=px[B:].view(B, Tp, 4),
             x4=z(Ta + 1, B, 4), hs=z(Ta + 1, B, H), cs=z(Ta, B, H), gates=z(Ta, B, 4 * H),
             Wx=z(4 * H, 4), WxT=z(4, 4 * H), bxc=z(4 * H),
@@ -298,6 +298,8 @@ class WideTrainer(GenericTrainer):
             wgrad=torch.empty(L.workspace_floats(L.WS_WGRAD, 1, 2, 1), device=dev),
             res=torch.zeros(self.n_unrolling_steps + 3, 3, dtype=torch.float64, device=dev),
         )
+        # the step's host scalars travel in ONE small copy: [zeros_val, ones_val | Adam step indices of the U + 1 D updates | of G's]
+        w["targets"] = w["scal"][:2]
         w["_bytes"] = sum(v.numel() * v.element_size() for v in w.values() if torch.is_tensor(v) and v._base is None)
         self._ws[key] = w
         return w
@@ -622,7 +624,7 @@ class WideTrainer(GenericTrainer):
         sums[U + 2].zero_()
         L.call("sw_ade_fde", L.ptr(fake), L.ptr(w["pred"]), B, Tp, 1.0 / float(ss), L.ptr(sums[U + 2]), L.ptr(w["ade_scr"]), L.stream())
         # the reported sums (SocialWaysTrainer.step()'s layout): the info term's mean runs over B * nl elements
-        torch.mul(sums.double(), self._kres, out=w["res"])
+        torch.mul(sums, self._kres, out=w["res"])          # (float32 x float64 -> float64 in one launch)
 
     def step(self, obsv, pred, sub_batches, zeros_val, ones_val, noise, ss=1.0, global_B=None, out=None, global_row0=0,
              variety_noise=None):
@@ -639,8 +641,11 @@ class WideTrainer(GenericTrainer):
         w = self._buffers(B, To, sc.P)
         w["obsv"].copy_(obsv)
         w["pred"].copy_(pred)
-        w["noise"].copy_(noise.to(dev, non_blocking=True))
-        w["targets"].copy_(torch.tensor([float(zeros_val), float(ones_val)], dtype=torch.float32))
+        w["noise"].copy_(noise, non_blocking=True)
+        U, dopt, gopt = self.n_unrolling_steps, self.D_optimizer, self.predictor_optimizer
+        # label-noise scalars + the 1-based indices of this step's Adam updates (read by a REPLAYED step; an eager step counts itself)
+        w["scal"].copy_(torch.tensor([float(zeros_val), float(ones_val)] + [float(dopt.t + k + 1) for k in range(U + 1)]
+                                     + [float(gopt.t + 1)], dtype=torch.float32))
         # the captured step bakes the Adam step indices' ADDRESSES in (PackedAdam.step_t) - their values advance on the host
         key = (B, To, sc.key, float(ss), Bg, self.use_l2_loss, self.use_info_loss, self.n_unrolling_steps, self.use_variety_loss,
                self._row0)
@@ -666,23 +671,20 @@ class WideTrainer(GenericTrainer):
         return [self.step(o, p, sub_batches, zv, ov, nz, ss, global_B, out, global_row0) for o, p, zv, ov, nz in batches]
 
     # The optimizers count their updates on the host (PackedAdam.t -> step_t.fill_) - inside a captured graph that fill is
-    # replayed with the value of capture time.  A captured step therefore reads the update indices from two device scalars
-    # that the host sets before every replay.
+    # replayed with the value of capture time.  A captured step therefore reads the update indices from device scalars that
+    # the host sets before every replay (w["scal"], together with the label-noise scalars: one small copy per step).
     def _capture(self, key, w, sc, B, To, ss, Bg):
         """Single process: the whole step as ONE graph.  Data parallel: one graph SEGMENT per stretch between two
         all-reduce points (4 segments), the collectives run between the segment replays."""
         torch.cuda.synchronize()
         dopt, gopt = self.D_optimizer, self.predictor_optimizer
-        steps_d = [torch.zeros((), device=self.device) for _ in range(self.n_unrolling_steps + 1)]
-        step_g = torch.zeros((), device=self.device)
+        U = self.n_unrolling_steps
+        steps_d = [w["scal"][2 + k] for k in range(U + 1)]       # set by step() with the label-noise scalars (one copy)
+        step_g = w["scal"][U + 3]
         real_d, real_g = dopt.step, gopt.step
         it = iter(steps_d)
         dopt.step = lambda st=None: real_d(next(it))
         gopt.step = lambda st=None: real_g(step_g)
-        t_d, t_g = dopt.t, gopt.t
-        for k, s in enumerate(steps_d):
-            s.fill_(float(t_d + k + 1))
-        step_g.fill_(float(t_g + 1))
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
         segments, pool = [], None
@@ -707,23 +709,18 @@ class WideTrainer(GenericTrainer):
         finally:
             dopt.step, gopt.step = real_d, real_g
         torch.cuda.current_stream().wait_stream(side)
-        g = dict(segments=segments, steps_d=steps_d, step_g=step_g)
+        g = dict(segments=segments, n_d=U + 1)
         self._graphs[key] = g
         return g
 
     def _replay(self, g):
         dopt, gopt = self.D_optimizer, self.predictor_optimizer
-        for k, s in enumerate(g["steps_d"]):
-            s.fill_(float(dopt.t + k + 1))
-        g["step_g"].fill_(float(gopt.t + 1))
         for graph, buf in g["segments"]:
             graph.replay()
             if buf is not None:
                 self._allreduce(buf)
-        dopt.t += len(g["steps_d"])
+        dopt.t += g["n_d"]           # (their device counters step_t are refreshed by the next eager update)
         gopt.t += 1
-        dopt.step_t.fill_(float(dopt.t))
-        gopt.step_t.fill_(float(gopt.t))
 
     def release_graphs(self):
         self._graphs.clear()

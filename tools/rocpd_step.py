@@ -1,6 +1,6 @@
 """Dispatch timeline of ONE hipGraph-replayed training step (from one stage_step_kernel to the next) out of a
 rocprofv3 rocpd database of `bench.py`, plus the step period over the timed region.
-    python tools/rocpd_step.py gpurun_out/prof_x/trace_results.db > profiles/rNN_m1_step_timeline.txt"""
+    python tools/rocpd_step.py gpurun_out/prof_x/trace_results.db [first kernel of a step] > profiles/rNN_m1_step_timeline.txt"""
 import sqlite3
 import sys
 
@@ -8,7 +8,8 @@ import numpy as np
 
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end, grid_x, workgroup_x from kernels order by start").fetchall()
-idx = [i for i, r in enumerate(rows) if r[0].startswith("stage_step")]
+first = sys.argv[2] if len(sys.argv) > 2 else "stage_step"      # the kernel a step starts with (wide path: traj4d_kernel)
+idx = [i for i, r in enumerate(rows) if r[0].startswith(first)]
 # graph-mode steps are back to back (period < 1.2 x median); the eager roofline pass at the end is slower
 starts = np.array([rows[i][1] for i in idx], dtype=np.float64)
 per = np.diff(starts) / 1e3
