@@ -491,10 +491,13 @@ int sw_wide_dec_loop_bwd(const float* whhT_img, const float* w3T_img, const floa
                          const float* gates, const float* cs, float* dgates, float* dv, float* dz3, float* dz2, float* dz1,
                          float* dhcat_out, float* dc_out, int B, int H, int To, int Tp, void* stream);
 /* the heads of the discriminator (train.py:280-292, 300-309) for all agents and both future branches in ONE launch per
- * direction (instead of nine / seven sw_wide_gemm launches): p = 43 host values in the order {6 operand images (forward: of0,
+ * direction (instead of nine / seven sw_wide_gemm launches): p = 52 host values in the order {6 operand images (forward: of0,
  * of1, pe0, pe1, cl0, la0; backward: their transposes), 6 biases, cl1 weight, cl1 bias, la1 weight, la1 bias, hT [B][H], px
  * [nb B][4Tp], outputs o1, q1, both, c1, l1, label, code, inputs dlab [nb B][4], dcod [nb B][nlp], deltas dc1, dl1, dboth, dq1,
- * docode, do1, dhT, dpx, then B, H, 4Tp, nb, nl, nlp, need_obs, want_dpred}.                                            */
+ * docode, do1, dhT, dpx, then B, H, 4Tp, nb, nl, nlp, need_obs, want_dpred, then the loss block of the forward launch: loss
+ * (0 / 1), target index of branch 0 / 1, row stride of z, the two gradient scales (as the bit patterns of doubles), targets,
+ * z, part [tiles][3]}: with loss = 1 the forward launch also forms the LSGAN / info-loss gradients dlab / dcod (train.py:484-494,
+ * 512-523) and each tile's sums of squares {branch-0 label, branch-0 code_hat, branch-1 label}.                        */
 int sw_wide_disc_heads_supported(int H, int K4, int nl);
 int sw_wide_disc_heads_fwd(const long long* p, void* stream);
 int sw_wide_disc_heads_bwd(const long long* p, void* stream);

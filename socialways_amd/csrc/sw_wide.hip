@@ -16,6 +16,7 @@
 #include "sw_common.h"
 #include "sw_wgrad.h"
 #include <cstddef>
+#include <cstring>
 
 namespace {
 enum { EPI_NONE = 0, EPI_RELU = 1, EPI_LRELU = 2, EPI_DRELU = 3, EPI_DLRELU = 4 };
@@ -1152,6 +1153,14 @@ struct WideHeads {
   const float *dlab, *dcod;                                        // [nb B][4] (col 0), [nb B][nlp]
   float *dc1, *dl1, *dboth, *dq1, *docode, *do1, *dhT, *dpx;       // deltas (docode / do1 / dhT only with need_obs, dpx with want_dpred)
   int B, H, K4, nb, nl, nlp, need_obs, want_dpred;
+  // forward, loss != 0: the LSGAN / info-loss terms of the pass (train.py:484-494, 512-523) formed where label / code_hat appear:
+  // dlab = gl (label - targets[t_br]), dcod = gc (code_hat - z[:, :nl]) on branch 0 (zero on branch 1), and the tile's sums of
+  // squares {branch-0 label, branch-0 code, branch-1 label} to part[tile][3]
+  int loss, t0, t1, zld;
+  float gl, gc;
+  const float *targets, *z;
+  float* part;
+  float *dlab_w, *dcod_w;      // [nb B][4], [nb B][nlp] (written by the forward kernel with loss != 0)
 };
 // acc += W[16 t ..][.] x over K = 16 KJ columns: A operand from the image (tile t), B operand = row `brow` of an LDS tile
 __device__ __forceinline__ f32x4 wh_tile(const float* __restrict__ img, int t, int KJ, const float* brow, f32x4 acc, int lane) {
@@ -1248,12 +1257,17 @@ __global__ __launch_bounds__(256) void wide_disc_heads_fwd_kernel(WideHeads A) {
       st4(A.l1 + ((size_t)br * B + b) * H2 + 16 * t + 4 * lg, al);
     }
   __syncthreads();
-  // ---- label = cl1 c1 + b (1 output), code = la1 l1 + b (nl outputs): dot products, 16 threads per (branch, agent) ----
+  // ---- label = cl1 c1 + b (1 output), code = la1 l1 + b (nl outputs): dot products, 8 threads per (branch, agent) ----
+  float* lred = hTb;             // (dead since the first layer) [2 branches][16 agents][2]: squared label / code differences
   {
     const int br = threadIdx.x >> 7 & 1, a = (threadIdx.x >> 3) & 15, l8 = threadIdx.x & 7;   // 2 branches x 16 agents x 8 lanes
+    float ql = 0.f, qc = 0.f;
     if (br < nb) {
       const float* cr = c1b + (br * 16 + a) * L2;
       const float* lr = l1b + (br * 16 + a) * L2;
+      const bool live = a0 + a < B;
+      const size_t row = (size_t)br * B + min(a0 + a, B - 1);
+      const float tgt = A.loss ? A.targets[br ? A.t1 : A.t0] : 0.f;
       for (int n = -1; n < nl; ++n) {          // n = -1: the label
         const float* wr = n < 0 ? A.cl1w : A.la1w + (size_t)n * H2;
         const float* xr = n < 0 ? cr : lr;
@@ -1262,11 +1276,40 @@ __global__ __launch_bounds__(256) void wide_disc_heads_fwd_kernel(WideHeads A) {
         s += __shfl_xor(s, 4);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 1);
-        if (l8 == 0 && a0 + a < B) {
-          if (n < 0) A.label[(size_t)br * B + a0 + a] = s + A.cl1b[0];
-          else A.code[((size_t)br * B + a0 + a) * nl + n] = s + A.la1b[n];
+        if (l8 == 0 && live) {
+          if (n < 0) {
+            const float v = s + A.cl1b[0];
+            A.label[row] = v;
+            if (A.loss) {
+              const float d = v - tgt;
+              ql = d * d;
+              A.dlab_w[row * 4] = A.gl * d;
+            }
+          } else {
+            const float v = s + A.la1b[n];
+            A.code[row * nl + n] = v;
+            if (A.loss) {
+              const float d = br == 0 ? v - A.z[(size_t)(a0 + a) * A.zld + n] : 0.f;     // the info term: fake branch only
+              qc = fmaf(d, d, qc);
+              A.dcod_w[row * A.nlp + n] = A.gc * d;
+            }
+          }
         }
       }
+    }
+    if (A.loss && l8 == 0) {
+      lred[((threadIdx.x >> 7 & 1) * 16 + a) * 2] = ql;
+      lred[((threadIdx.x >> 7 & 1) * 16 + a) * 2 + 1] = qc;
+    }
+  }
+  if (A.loss) {
+    __syncthreads();
+    if (threadIdx.x < 3) {       // fixed order: the tile's 16 agents one after the other
+      const int br = threadIdx.x == 2 ? 1 : 0, w = threadIdx.x == 1 ? 1 : 0;
+      float v = 0.f;
+      if (br < nb)
+        for (int a = 0; a < 16; ++a) v += lred[(br * 16 + a) * 2 + w];
+      A.part[(size_t)blockIdx.x * 3 + threadIdx.x] = v;
     }
   }
 }
@@ -1407,7 +1450,7 @@ extern "C" int sw_wide_dec_loop_bwd(const float* whhT_img, const float* w3T_img,
   return SW_OK;
 }
 
-// The heads of the wide discriminator in one launch per direction (wide_disc_heads_fwd/bwd_kernel).  `p` = 43 host pointers
+// The heads of the wide discriminator in one launch per direction (wide_disc_heads_fwd/bwd_kernel).  `p` = 52 host pointers
 // / integers in the order of struct WideHeads (see socialways_amd/wide.py: _heads_args).
 extern "C" int sw_wide_disc_heads_supported(int H, int K4, int nl) {
   return (H >= 32 && H <= WH_MAXH && (H & 31) == 0 && K4 >= 16 && (K4 & 15) == 0 && nl >= 1 && nl <= 16) ? 1 : 0;
@@ -1421,6 +1464,16 @@ static int wide_heads_launch(const long long* p, int backward, void* stream) {
   for (int i = 0; i < 35; ++i) cf[i] = (const float*)(uintptr_t)p[i];
   A.B = (int)p[35]; A.H = (int)p[36]; A.K4 = (int)p[37]; A.nb = (int)p[38]; A.nl = (int)p[39]; A.nlp = (int)p[40];
   A.need_obs = (int)p[41]; A.want_dpred = (int)p[42];
+  A.loss = (int)p[43]; A.t0 = (int)p[44]; A.t1 = (int)p[45]; A.zld = (int)p[46];
+  double gl, gc;
+  memcpy(&gl, &p[47], 8);
+  memcpy(&gc, &p[48], 8);
+  A.gl = (float)gl; A.gc = (float)gc;
+  A.targets = (const float*)(uintptr_t)p[49]; A.z = (const float*)(uintptr_t)p[50]; A.part = (float*)(uintptr_t)p[51];
+  A.dlab_w = (float*)(uintptr_t)p[25];      // the backward kernel's dlab / dcod inputs (struct slots 25, 26): same buffers
+  A.dcod_w = (float*)(uintptr_t)p[26];
+  if (A.loss && !backward && (!A.targets || !A.z || !A.part || !A.dlab_w || !A.dcod_w || A.t0 < 0 || A.t1 < 0 || A.zld < A.nl))
+    return SW_EARG;
   if (A.B < 1 || A.nb < 1 || A.nb > 2 || !sw_wide_disc_heads_supported(A.H, A.K4, A.nl)) return SW_ESHAPE;
   const int H = A.H, H2 = H / 2, LH = H + 4, L2 = H2 + 4, LK = A.K4 + 4;
   const int lds_f = (16 * LH + 16 * L2 + 2 * 16 * LK + 2 * 16 * L2 + 2 * 16 * LH + 4 * 16 * L2) * 4;

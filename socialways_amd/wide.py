@@ -18,6 +18,7 @@ torch is used for memory (buffers, slicing, broadcast copies of S / z into the d
 Linear-only restore of train.py:541-542); arithmetic runs in the library's kernels.  No CPU fallback.
 """
 import ctypes
+import struct
 import os
 
 import numpy as np
@@ -295,6 +296,7 @@ class WideTrainer(GenericTrainer):
             dl1=z(2 * B, H // 2), dboth=z(2 * B, H), dq1=z(2 * B, H // 2), docode=z(B, H // 2), do1=z(B, H // 2),
             d_dhT=z(B, H), d_dgates=z(To, B, 4 * H), d_dc=z(B, H), dpx=z(B, 4 * Tp),
             sums=z(self.n_unrolling_steps + 3, 3), ade_scr=z(3 * L.RED_BLOCKS),
+            lpart=z(self.n_unrolling_steps + 2, (B + 15) // 16, 3),      # per-tile loss sums of the U + 1 D passes and the G phase
             wgrad=torch.empty(L.workspace_floats(L.WS_WGRAD, 1, 2, 1), device=dev),
             res=torch.zeros(self.n_unrolling_steps + 3, 3, dtype=torch.float64, device=dev),
         )
@@ -475,7 +477,7 @@ class WideTrainer(GenericTrainer):
         gemm(wih, 1, w["dbx"], 1, None, H, 4 * H, 1, gp.g(enc.embed.bias), 1, x_cs=H)
         gp.g(enc.lstm.bias_ih_l0).copy_(w["dbx"])
 
-    def _disc_forward(self, w, B, To, nb):
+    def _disc_forward(self, w, B, To, nb, loss=None):
         """Discriminator.forward (train.py:294-309) on nb future branches sharing the observation encoding; rows of branch k
         at [k B, (k + 1) B) of w["px"] (0: the rollout's prediction, 1: the real future)."""
         H, Tp, st, D = self.H, self.n_next, L.stream(), self.D
@@ -494,8 +496,8 @@ class WideTrainer(GenericTrainer):
         of, pe, cl, la = D.obsv_encoder_fc, D.pred_encoder, D.classifier, D.latent_decoder
         R = nb * B
         if self.heads:
-            L.call("sw_wide_disc_heads_fwd", self._heads_args(w, B, To, nb, False, False, False), st)
-            return
+            L.call("sw_wide_disc_heads_fwd", self._heads_args(w, B, To, nb, False, False, False, loss), st)
+            return True
         gemm(hs[To], H, of[0].weight, H, of[0].bias, B, H, H2, w["o1"], H2, EPI_LRELU)
         for k in range(nb):      # obsv_code into the first half of `both`, once per branch
             gemm(w["o1"], H2, of[2].weight, H2, of[2].bias, B, H2, H2, _off(w["both"], k * B * H), H)
@@ -506,8 +508,9 @@ class WideTrainer(GenericTrainer):
         gemm(w["both"], H, la[0].weight, H, la[0].bias, R, H, H2, w["l1"], H2, EPI_LRELU)
         gemm(w["l1"], H2, la[2].weight, H2, la[2].bias, R, H2, nl, w["code"], nl)
 
-    def _heads_args(self, w, B, To, nb, backward, need_obs, want_dpred):
-        """struct WideHeads of sw_wide.hip as 43 host values."""
+    def _heads_args(self, w, B, To, nb, backward, need_obs, want_dpred, loss=None):
+        """struct WideHeads of sw_wide.hip as 52 host values.  loss = (target index of branch 0, of branch 1, label scale, code
+        scale, partial-sum rows [tiles][3]): the forward launch also forms the loss gradients and the tile's sums of squares."""
         D, I = self.D, self.dI
         of, pe, cl, la = D.obsv_encoder_fc, D.pred_encoder, D.classifier, D.latent_decoder
         sfx = "T" if backward else ""
@@ -518,7 +521,14 @@ class WideTrainer(GenericTrainer):
                                 "docode", "do1", "d_dhT", "dpx")]
         nl = self.n_latent_codes
         ints = [B, self.H, 4 * self.n_next, nb, nl, (nl + 3) // 4 * 4, int(need_obs), int(want_dpred)]
-        arr = (ctypes.c_longlong * 43)(*([v.data_ptr() for v in vals] + ints))
+        if loss is None:
+            tail = [0] * 9
+        else:
+            t0, t1, gl, gc, part = loss
+            as_bits = lambda x: struct.unpack("q", struct.pack("d", float(x)))[0]
+            tail = [1, int(t0), int(t1), self.H // 2, as_bits(gl), as_bits(gc), w["targets"].data_ptr(), w["noise"].data_ptr(),
+                    part.data_ptr()]
+        arr = (ctypes.c_longlong * 52)(*([v.data_ptr() for v in vals] + ints + tail))
         return ctypes.cast(arr, ctypes.c_void_p)
 
     def _disc_heads_backward(self, w, B, nb, want_dpred, need_obs=False):
@@ -594,20 +604,23 @@ class WideTrainer(GenericTrainer):
         sums, z, tg = w["sums"], w["noise"], w["targets"]
         L.call("sw_traj_4d", L.ptr(w["obsv"]), L.ptr(w["pred"]), B, To, Tp, L.ptr(w["o4"]), L.ptr(w["p4"]), L.stream())
         fake = self._gen_forward(w, sc, B, To)        # the three predict() calls of a step are identical
+        tiles = (B + 15) // 16
+        gl, gc = 2.0 / Bg, wi * 2.0 / (nl * Bg)
         for u in range(U + 1):                           # train.py:476-499
-            self._disc_forward(w, B, To, 2)
-            self._sq(w["label"], 1, None, 0, tg, 0, B, 1, 2.0 / Bg, _off(sums, 3 * u), w["dlab"], 4)
-            self._sq(_off(w["label"], B), 1, None, 0, tg, 1, B, 1, 2.0 / Bg, _off(sums, 3 * u + 2), _off(w["dlab"], 4 * B), 4)
-            self._sq(w["code"], nl, z, H // 2, None, 0, B, nl, wi * 2.0 / (nl * Bg), _off(sums, 3 * u + 1), w["dcod"], nlp)
+            # (with the fused heads the loss gradients and per-tile sums of squares come out of the forward launch)
+            if not self._disc_forward(w, B, To, 2, loss=(0, 1, gl, gc, w["lpart"][u])):
+                self._sq(w["label"], 1, None, 0, tg, 0, B, 1, gl, _off(sums, 3 * u), w["dlab"], 4)
+                self._sq(_off(w["label"], B), 1, None, 0, tg, 1, B, 1, gl, _off(sums, 3 * u + 2), _off(w["dlab"], 4 * B), 4)
+                self._sq(w["code"], nl, z, H // 2, None, 0, B, nl, gc, _off(sums, 3 * u + 1), w["dcod"], nlp)
             self._disc_backward(w, B, To)
             yield self.dp.gflat
             self.D_optimizer.step()
             if u == 0 and U > 0:
                 self._d_backup.copy_(self.dp.flat)       # deepcopy(D) after the first update (train.py:498-499)
         # ---- generator update (train.py:503-539) ----
-        self._disc_forward(w, B, To, 1)
-        self._sq(w["label"], 1, None, 0, tg, 1, B, 1, 2.0 / Bg, _off(sums, 3 * (U + 1)), w["dlab"], 4)
-        self._sq(w["code"], nl, z, H // 2, None, 0, B, nl, wi * 2.0 / (nl * Bg), _off(sums, 3 * (U + 1) + 1), w["dcod"], nlp)
+        if not self._disc_forward(w, B, To, 1, loss=(1, 1, gl, gc, w["lpart"][U + 1])):
+            self._sq(w["label"], 1, None, 0, tg, 1, B, 1, gl, _off(sums, 3 * (U + 1)), w["dlab"], 4)
+            self._sq(w["code"], nl, z, H // 2, None, 0, B, nl, gc, _off(sums, 3 * (U + 1) + 1), w["dcod"], nlp)
         self._disc_heads_backward(w, B, 1, True)
         dpred4 = w["dpx"]
         if self.use_l2_loss:                             # train.py:525-526
@@ -621,6 +634,8 @@ class WideTrainer(GenericTrainer):
         self.predictor_optimizer.step()
         if U > 0:                                        # D.load(backup): Linear layers only (train.py:311-316, 541-542)
             torch.where(self._lin_mask, self._d_backup, self.dp.flat, out=self.dp.flat)
+        if self.heads:               # the loss rows of all passes: one sum over the tiles
+            torch.sum(w["lpart"], dim=1, out=sums[:U + 2])
         sums[U + 2].zero_()
         L.call("sw_ade_fde", L.ptr(fake), L.ptr(w["pred"]), B, Tp, 1.0 / float(ss), L.ptr(sums[U + 2]), L.ptr(w["ade_scr"]), L.stream())
         # the reported sums (SocialWaysTrainer.step()'s layout): the info term's mean runs over B * nl elements
