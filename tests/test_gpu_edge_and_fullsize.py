@@ -661,3 +661,30 @@ def test_random_configurations_match_the_oracle():
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     assert m.run(14, 2) == 0
+
+
+def _tool(name):
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location(name, os.path.join(root, "tools", "dbg", name + ".py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("hidden,steps", [(64, 70), (128, 40)])
+def test_graph_replay_equals_eager_over_a_random_layout_sequence(hidden, steps):
+    """A fixed-seed run of tools/dbg/fuzz_graph.py: a graph-capturing trainer against the same trainer running eagerly over a
+    random sequence of ragged packed-batch layouts (recurring, growing, shrinking, more than the caches hold, K-step
+    launches) - sums and every weight bit-identical after every step."""
+    assert _tool("fuzz_graph").run(hidden, steps, 1) == 0
+
+
+@pytest.mark.timeout(900)
+def test_random_datasets_epochs_and_evaluation_match_the_oracle():
+    """A fixed-seed slice of tools/dbg/fuzz_epoch.py: train_epoch() (the reference's greedy scene packing, own RNG streams)
+    for two epochs and test() with K sampled futures on random ragged datasets, fused / wide / generic trainers, against the
+    CPU oracle: epoch ADE / FDE, every step's MSE terms, packed-batch sizes, min / avg ADE and FDE."""
+    assert _tool("fuzz_epoch").run(3, 2) == 0
