@@ -294,11 +294,15 @@ class Leg:
         self._zi = 0
 
     def z_resident(self, n=16):
-        """From here on z (train.py:473) is an input that is ALREADY in HBM: a ring of n device tensors drawn once (device
-        generator), handed to the trainer as they are - the staging kernel reads them through their address
-        (sw_stage_step_zdev), no PCIe read of z inside the step.  Only for side legs; the headline leg keeps the host z."""
+        """From here on z (train.py:473) is an input that is ALREADY in HBM when a timed region starts (the bench contract's
+        definition of the inputs): a ring of n device tensors drawn once (device generator), handed to the trainer as they
+        are - the staging kernel reads them through their address (sw_stage_step_zdev), no PCIe read of z inside the step."""
         assert not self.strong
         self._zdev = [torch.rand(self.B, self.tr.noise_len, device=self.data.obsv.device) for _ in range(n)]
+
+    def z_host(self):
+        """Back to z drawn on the host every step and pulled from pinned memory inside the step (the PCIe-inclusive form)."""
+        self._zdev = None
 
     def draw(self, i):
         a = (i % N_BATCHES) * self.stride + self.row0
@@ -317,34 +321,60 @@ class Leg:
         o, p, zv, ov, noise = self.draw(i)
         self.last = self.tr.step(o, p, self.sb, zv, ov, noise, self.data.ss, global_B=self.Bg, out=False)
 
+    def plan(self, n, cold=False):
+        """Launch sizes for n consecutive steps (identical work in any split: SocialWaysTrainer.step_many).  `cold`: the GPU
+        is idle (right behind a fence) - ONE single-step launch gets it going after one step's host preparation, the rest
+        follows in launches of up to KG steps that the host prepares while the GPU works (a launch boundary costs ~13 us, the
+        fence at the end of a hipGraph; [1, 19] for the driver's 20-step region: 0.3700 ms per step where [1, 1, 2, 4, 4, 4, 4]
+        gave 0.3728)."""
+        if not self.tr.use_graph or self.KG <= 1:
+            return [1] * n
+        if not getattr(self, "_zdev", None):
+            # z drawn on the host per step (train.py:473): preparing a step costs ~0.15 ms (4 MB of z at c4: ~2 ms), so the
+            # launches stay small - 1, 1, 2 behind a fence, then 4 steps each
+            out = [1, 1, 2] if cold and n >= 8 else []
+            n -= sum(out)
+            out += [4] * (n // 4) + [1] * (n % 4)
+            return out
+        if os.environ.get("SW_BENCH_RAMP") and cold:          # experiments: explicit first launches
+            out = [int(x) for x in os.environ["SW_BENCH_RAMP"].split(",")]
+            n -= sum(out)
+        else:
+            out = [1] if cold and n > 1 else []
+            n -= len(out)
+        while n >= self.KG:
+            out.append(self.KG)
+            n -= self.KG
+        if n > 0:
+            out.append(n)
+        return out
+
     def run_steps(self, i0, n, cold=False):
-        """n training steps, KG per graph launch where possible (identical work: see SocialWaysTrainer.step_many).
-        `cold`: the GPU is idle (right behind a fence).  The host needs ~0.15 ms per step to draw z and fill the slot, so
-        a KG-step launch reaches an idle GPU ~0.6 ms late; starting with single-step launches gets the GPU going after
-        one step's preparation and the later, larger launches are prepared while it works."""
-        i, KG, tr = i0, self.KG, self.tr
-        ramp = [1, 1, 2] if cold and KG >= 4 and n >= 8 else []
-        while i < i0 + n:
-            k = ramp.pop(0) if ramp else KG
-            if k > 1 and tr.use_graph and i + k <= i0 + n:
+        i, tr = i0, self.tr
+        for k in self.plan(n, cold):
+            if k > 1:
                 self.last = tr.step_many([self.draw(i + j) for j in range(k)], self.sb, self.data.ss, global_B=self.Bg,
                                          out=False)[-1]
-                i += k
             else:
                 self.one_step(i)
-                i += 1
+            i += k
 
-    def prime(self):
-        """Untimed: the first 3 calls of a launch shape run eagerly / capture the graphs - every shape (KG steps per
-        launch, the 2-step and single-step launches of the ramp) is primed so that no capture falls into a timed region,
-        and called twice more so that BOTH alternating executables of a shape have been launched once (the first launch of
-        an executable costs ~2 ms on this runtime: the first timed region used to carry two of them)."""
+    def prime(self, counts=()):
+        """Untimed: the first 3 calls of a launch shape run eagerly / capture the graphs - every launch size the regions of
+        `counts` steps will use is primed so that no capture falls into a timed region, and called twice more so that BOTH
+        alternating executables of a shape have been launched once (the first launch of an executable costs ~2 ms on this
+        runtime: the first timed region used to carry two of them)."""
+        shapes = {1, self.KG}
+        for j, n in enumerate(counts):      # counts = (steps of a timed region, untimed warmup steps in front of it)
+            shapes |= set(self.plan(n, cold=(j == 0)))
+        shapes = sorted(shapes, reverse=True)
         for rep in range(5):
-            if self.KG > 1:
-                self.run_steps(0, self.KG)
-                self.last = self.tr.step_many([self.draw(j) for j in range(2)], self.sb, self.data.ss, global_B=self.Bg,
-                                              out=False)[-1]     # the 2-step launch of the ramp-up
-            self.one_step(rep)
+            for k in shapes:
+                if k > 1:
+                    self.last = self.tr.step_many([self.draw(j) for j in range(k)], self.sb, self.data.ss, global_B=self.Bg,
+                                                  out=False)[-1]
+                else:
+                    self.one_step(rep)
 
     def timed(self, fence, i0, steps):
         fence()
@@ -397,7 +427,8 @@ def main():
         pg = torch.distributed.group.WORLD
 
     from socialways_amd import _lib as L
-    KG = int(os.environ.get("SW_BENCH_STEPS_PER_LAUNCH", "4"))   # steps per graph launch (step_many)
+    KG = int(os.environ.get("SW_BENCH_STEPS_PER_LAUNCH", "32"))   # most steps per graph launch (step_many; Leg.plan)
+    os.environ.setdefault("SW_MAX_GRAPHS", "16")                  # launch sizes x input modes of one layout
 
     def fence():
         if world > 1:
@@ -413,7 +444,11 @@ def main():
 
     import gc
     leg = Leg(args.workload, dev, pg, world, rank, args.scaling, args.global_scenes, KG)
-    if os.environ.get("SW_BENCH_Z_RESIDENT", "") == "1":      # experiments: the headline leg with z already in HBM
+    # Inputs resident in HBM when a timed region starts (tracks AND z: the contract's definition); --scaling strong draws z for
+    # the global batch on the host and slices it (the reference's stream), SW_BENCH_HOST_Z=1 forces the host form everywhere
+    HOST_Z = os.environ.get("SW_BENCH_HOST_Z", "") == "1" or args.scaling == "strong"
+    RESIDENT = "resident in HBM when the timed region starts (tracks; z: a ring of 16 device tensors drawn beforehand)"
+    if not HOST_Z:
         leg.z_resident()
     tr, To, Tp, A = leg.tr, leg.To, leg.Tp, leg.A
     # host-side noise sources of a 20-step window: the collector (a gen-2 pass over torch's module graph is ~10 ms) is off
@@ -421,22 +456,42 @@ def main():
     # priming and warmup steps: tens of idle milliseconds right in front of the timed region cost its first launches ~0.4 ms
     gc.collect()
     gc.disable()
-    leg.prime()
+    leg.prime((args.steps, args.warmup))
     # The runtime's one-time stalls (16-55 ms host blocks seen in the FIRST timed region of a young process in ~1 of 10 runs,
     # never in 180 later regions: tools/scratch/hiccup.py) are let happen in untimed steps: ~0.4 s of the same graph launches
     # in front of the W warmup steps.  Reported as config.settle_steps.
     SETTLE = int(os.environ.get("SW_BENCH_SETTLE_STEPS", "1000")) // KG * KG
     leg.run_steps(0, SETTLE)
     leg.run_steps(0, args.warmup)
+    # ... and two untimed REHEARSALS of the region itself (same launch sizes behind a fence): a graph executable that has not
+    # been launched for ~0.4 s (the settle steps use other launch sizes) replays ~70 us slower the first time - 3.6 us per step
+    # of a 20-step region (measured: first region 0.3750, the following five 0.3701 .. 0.3711)
+    REHEARSALS = 2
+    for r in range(REHEARSALS):
+        leg.timed(fence, args.warmup, args.steps)
     dt = max_over_ranks(leg.timed(fence, args.warmup, args.steps))          # THE timed region: exactly K steps
     reps = [max_over_ranks(leg.timed(fence, args.warmup + (r + 1) * args.steps, args.steps)) for r in range(REPEATS)]
+    if os.environ.get("SW_BENCH_VERBOSE"):
+        print("regions (ms per step): first %.4f, then %s" % (1e3 * dt / args.steps, ["%.4f" % (1e3 * r / args.steps) for r in reps]),
+              file=sys.stderr)
     # a sustained leg (>= ~2 s of back-to-back steps): long enough for an external GPU-busy sampler to see the device
     sustained = None
     if not args.no_sustained:
-        n_sus = max(args.steps, int(2.2 / max(dt / args.steps, 1e-5)) // KG * KG)
+        n_sus = 1 + max(args.steps, int(2.2 / max(dt / args.steps, 1e-5))) // KG * KG      # [1, KG, KG, ...]: no new launch size
         d_sus = max_over_ranks(leg.timed(fence, 0, n_sus))
         sustained = {"steps": n_sus, "seconds": d_sus, "steps_s": n_sus * (world if args.scaling == "weak" else 1) / d_sus,
                      "ms_per_step": 1e3 * d_sus / n_sus}
+    # the PCIe-inclusive form of the same K steps: z drawn on the host every step (train.py:473), copied into the pinned slot and
+    # pulled inside the step (small launches: the host needs ~0.15 ms per step to prepare)
+    pcie = None
+    if not HOST_Z:
+        leg.z_host()
+        leg.prime((args.steps, args.warmup))
+        leg.run_steps(0, args.warmup)
+        d_pc = min(max_over_ranks(leg.timed(fence, args.warmup + r * args.steps, args.steps)) for r in range(3))
+        pcie = {"steps_s": args.steps * (world if args.scaling == "weak" else 1) / d_pc, "ms_per_step": 1e3 * d_pc / args.steps,
+                "what": "z drawn on the host per step (train.py:473) and pulled from pinned memory inside the step; fastest of 3 regions"}
+        leg.z_resident()
     gc.enable()
     # Roofline leg: the timed region replays hipGraphs, where no per-kernel event can be placed, so EVERY kernel launch
     # of a few EAGER steps of the same workload is bracketed by HIP events on its launch stream (sw_kernel_timing); a
@@ -492,7 +547,7 @@ def main():
         """A side leg: n steps timed three times, the fastest region reported.  (Regions of 40-80 ms are exposed to the
         sporadic 3-50 ms host stalls of this runtime - tools/scratch/hiccup.py - which are not a property of the leg;
         THE timed region of the headline workload is never treated this way.)"""
-        lg.prime()
+        lg.prime((n, w))
         lg.run_steps(0, w)
         gc.collect()
         gc.disable()
@@ -511,6 +566,8 @@ def main():
                 continue
             torch.cuda.empty_cache()
             lg = Leg(name, dev, None, 1, 0, "weak", 0, KG)
+            if not HOST_Z:
+                lg.z_resident()
             n, w = OTHER_STEPS[name]
             d = short_leg(lg, n, w)
             fl_o = alg_flops(lg.B, lg.P, lg.To, lg.Tp)
@@ -527,21 +584,15 @@ def main():
             # matrix FLOP the kernels really issued per step (SQ counter pass of these sources) / this leg's time
             other[name]["step_executed_mfma_gflop"] = ex / 1e9 if ex else None
             other[name]["step_frac_executed"] = ex / (d / n) / (PEAK_FP32_TFLOPS * 1e12) if ex else None
-            if name == "c4":
-                # 4 MB of z per step are ~170 us of request-bound PCIe reads that 113 us of encoder work cannot hide: the same
-                # leg with z handed over in HBM (inputs resident, the contract's definition) next to the PCIe-inclusive one
-                lg.z_resident()
+            other[name]["inputs"] = "z drawn on the host every step" if HOST_Z else RESIDENT
+            if name == "c4" and not HOST_Z:
+                # 4 MB of z per step are ~170 us of request-bound PCIe reads that 113 us of encoder work cannot hide (and ~2 ms
+                # of host work per step): the PCIe-inclusive figure next to the one with resident inputs
+                lg.z_host()
                 d2 = short_leg(lg, n, w)
-                # `steps_s` follows the contract's definition (inputs resident in HBM when the timed region starts); the
-                # PCIe-inclusive figure - z drawn on the host every step and pulled from pinned memory inside the step, as
-                # the headline leg does - stays next to it
-                other[name]["pcie_inclusive"] = {"steps_s": other[name]["steps_s"], "ms_per_step": other[name]["ms_per_step"],
+                other[name]["pcie_inclusive"] = {"steps_s": n / d2, "ms_per_step": 1e3 * d2 / n,
                                                  "what": "z drawn on the host per step (train.py:473) and pulled from pinned memory "
                                                          "inside the step: 4 MB = ~170 us of request-bound PCIe reads"}
-                other[name].update({"steps_s": n / d2, "ms_per_step": 1e3 * d2 / n,
-                                    "step_frac_of_fp32_peak": fl_o["step"] / (d2 / n) / (PEAK_FP32_TFLOPS * 1e12),
-                                    "step_frac_executed": ex / (d2 / n) / (PEAK_FP32_TFLOPS * 1e12) if ex else None,
-                                    "inputs": "resident in HBM (z: a ring of 16 device tensors drawn before the timed region)"})
             del lg
         # The data-parallel step structure at N = 1 - the only scaling evidence a 1-GPU box can give: the same workload on a
         # 1-rank RCCL group (SW_FORCE_DIST: all three all-reduces are issued, the Adam updates run behind them as kernels
@@ -555,6 +606,8 @@ def main():
             try:
                 torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
                 lg = Leg("m1", dev, torch.distributed.group.WORLD, 1, 0, "weak", 0, KG)
+                if not HOST_Z:
+                    lg.z_resident()
                 n, w = OTHER_STEPS["m1"]
                 d = short_leg(lg, n, w)
                 other["dp1_rccl"] = {"workload": "m1 on a 1-rank RCCL process group (3 all-reduces per step issued, Adam behind them)",
@@ -575,6 +628,8 @@ def main():
             # throughput stress of the generator path; eager steps (the folded step is not graph-captured)
             torch.cuda.empty_cache()
             lg = Leg("m1", dev, None, 1, 0, "weak", 0, 1, use_variety_loss="fixed", variety_k=20, use_l2_loss=True)
+            if not HOST_Z:
+                lg.z_resident()
             n, w = 40, 6
             d = short_leg(lg, n, w)
             other["m1_variety_k20"] = {"workload": "m1 + best-of-20 variety loss (use_variety_loss='fixed'): decode loop on 40 960 agent copies, encoder and social block once on the 2 048 agents",
@@ -690,7 +745,7 @@ def main():
                                    ("%s-strong: ONE packed batch of %d scenes x %d agents (reference --batch-size %d) sharded "
                                     "scene-aligned over %d ranks; use_social=True, n_unrolling_steps=1, info loss on"
                                     % (args.workload, leg.S_global, A, leg.Bg, world)),
-                       "global_batch_scenes": leg.S_global, "parallelism": "dp%d" % world, "steps_per_graph_launch": KG, "settle_steps": SETTLE,
+                       "global_batch_scenes": leg.S_global, "parallelism": "dp%d" % world, "steps_per_graph_launch": KG, "settle_steps": SETTLE, "rehearsal_regions": REHEARSALS,
                        "collectives": collectives, "rccl_ranks": (world if pg is not None else None),
                        "backend": backend,       # "nccl" = RCCL; "gloo" = ranks sharing devices, a rehearsal, not a measurement
                        "allreduces_per_step": (3 if pg is not None else 0),
@@ -702,6 +757,8 @@ def main():
                        "repeats": {"n": len(rep_ms), "steps_each": args.steps, "ms_per_step_min": rep_ms[0],
                                    "ms_per_step_median": rep_ms[len(rep_ms) // 2], "ms_per_step_max": rep_ms[-1]},
                        "sustained": sustained,
+                       "inputs": "z drawn on the host every step" if HOST_Z else RESIDENT,
+                       "pcie_inclusive": pcie,
                        "other_workloads": other},
             "roofline": {"bound": "mfma", "kernel": top["name"], "achieved": achieved,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
