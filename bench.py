@@ -180,7 +180,8 @@ def cpu_baseline(tracks, S, A, To, Tp, budget_s=10.0):
     res = {"value": variants[best][0], "unit": "steps/s", "cores": best, "kind": "port",
            "sample": "%d steps of one %dx%d-agent packed batch (To=%d, Tp=%d), torch CPU fp32, block-diagonal social "
                      "block, reference call structure; fastest of the sampled thread counts" % (variants[best][1], S, A, To, Tp),
-           "by_threads": {str(k): {"value": v[0], "steps": v[1]} for k, v in variants.items()}, "host_threads": threads}
+           "by_threads": {str(k): {"value": v[0], "steps": v[1]} for k, v in variants.items()}, "host_threads": threads,
+           "host_cores": os.cpu_count()}
     Sf = min(S, 512 // A) if A <= 512 else 1
     Bf = Sf * A
     orf = O.SocialWaysOracle(Tp, use_social=True, social="faithful")
@@ -444,9 +445,11 @@ def main():
 
     import gc
     leg = Leg(args.workload, dev, pg, world, rank, args.scaling, args.global_scenes, KG)
-    # Inputs resident in HBM when a timed region starts (tracks AND z: the contract's definition); --scaling strong draws z for
-    # the global batch on the host and slices it (the reference's stream), SW_BENCH_HOST_Z=1 forces the host form everywhere
-    HOST_Z = os.environ.get("SW_BENCH_HOST_Z", "") == "1" or args.scaling == "strong"
+    # The headline step is the reference's: z = torch.rand(bs, noise_len) drawn on the HOST every step and copied
+    # to the device inside the step (train.py:473); the tracks are resident in HBM.  SW_BENCH_HOST_Z=0 makes the all-resident
+    # form (z a ring of device tensors drawn beforehand) the headline instead; by default it is the secondary figure
+    # config.inputs_resident.  --scaling strong always draws z for the global batch on the host and slices it.
+    HOST_Z = os.environ.get("SW_BENCH_HOST_Z", "1") != "0" or args.scaling == "strong"
     RESIDENT = "resident in HBM when the timed region starts (tracks; z: a ring of 16 device tensors drawn beforehand)"
     if not HOST_Z:
         leg.z_resident()
@@ -456,6 +459,7 @@ def main():
     # priming and warmup steps: tens of idle milliseconds right in front of the timed region cost its first launches ~0.4 ms
     gc.collect()
     gc.disable()
+    UNTIMED_BEFORE = 5 * sum({1, KG} | set(leg.plan(args.steps, cold=True)) | set(leg.plan(args.warmup)))
     leg.prime((args.steps, args.warmup))
     # The runtime's one-time stalls (16-55 ms host blocks seen in the FIRST timed region of a young process in ~1 of 10 runs,
     # never in 180 later regions: tools/scratch/hiccup.py) are let happen in untimed steps: ~0.4 s of the same graph launches
@@ -467,6 +471,7 @@ def main():
     # been launched for ~0.4 s (the settle steps use other launch sizes) replays ~70 us slower the first time - 3.6 us per step
     # of a 20-step region (measured: first region 0.3750, the following five 0.3701 .. 0.3711)
     REHEARSALS = 2
+    UNTIMED_BEFORE += SETTLE + args.warmup + REHEARSALS * args.steps
     for r in range(REHEARSALS):
         leg.timed(fence, args.warmup, args.steps)
     dt = max_over_ranks(leg.timed(fence, args.warmup, args.steps))          # THE timed region: exactly K steps
@@ -492,6 +497,17 @@ def main():
         pcie = {"steps_s": args.steps * (world if args.scaling == "weak" else 1) / d_pc, "ms_per_step": 1e3 * d_pc / args.steps,
                 "what": "z drawn on the host per step (train.py:473) and pulled from pinned memory inside the step; fastest of 3 regions"}
         leg.z_resident()
+    # ... and, when the headline is the reference's host-drawn z, the all-resident form of the same K steps as the secondary figure
+    resident = None
+    if HOST_Z and args.scaling == "weak":
+        leg.z_resident()
+        leg.prime((args.steps, args.warmup))
+        leg.run_steps(0, args.warmup)
+        d_rs = min(max_over_ranks(leg.timed(fence, args.warmup + r * args.steps, args.steps)) for r in range(3))
+        resident = {"steps_s": args.steps * world / d_rs, "ms_per_step": 1e3 * d_rs / args.steps,
+                    "what": "z too resident in HBM (a ring of 16 device tensors drawn beforehand, read by address: no draw, no "
+                            "PCIe read inside the step); fastest of 3 regions"}
+        leg.z_host()
     gc.enable()
     # Roofline leg: the timed region replays hipGraphs, where no per-kernel event can be placed, so EVERY kernel launch
     # of a few EAGER steps of the same workload is bracketed by HIP events on its launch stream (sw_kernel_timing); a
@@ -593,6 +609,11 @@ def main():
                 other[name]["pcie_inclusive"] = {"steps_s": n / d2, "ms_per_step": 1e3 * d2 / n,
                                                  "what": "z drawn on the host per step (train.py:473) and pulled from pinned memory "
                                                          "inside the step: 4 MB = ~170 us of request-bound PCIe reads"}
+            if name == "c4" and HOST_Z:
+                lg.z_resident()     # the all-resident form next to the reference's host-drawn z (4 MB per step at this shape)
+                d2 = short_leg(lg, n, w)
+                other[name]["inputs_resident"] = {"steps_s": n / d2, "ms_per_step": 1e3 * d2 / n,
+                                                  "what": "z too resident in HBM (device tensors read by address)"}
             del lg
         # The data-parallel step structure at N = 1 - the only scaling evidence a 1-GPU box can give: the same workload on a
         # 1-rank RCCL group (SW_FORCE_DIST: all three all-reduces are issued, the Adam updates run behind them as kernels
@@ -746,6 +767,9 @@ def main():
                                     "scene-aligned over %d ranks; use_social=True, n_unrolling_steps=1, info loss on"
                                     % (args.workload, leg.S_global, A, leg.Bg, world)),
                        "global_batch_scenes": leg.S_global, "parallelism": "dp%d" % world, "steps_per_graph_launch": KG, "settle_steps": SETTLE, "rehearsal_regions": REHEARSALS,
+                       # everything that ran untimed in front of THE region: priming (5 passes over every launch size), settle steps,
+                       # the W warmup steps and the rehearsals of the region ("warmup" above is only W)
+                       "untimed_steps_before_region": UNTIMED_BEFORE,
                        "collectives": collectives, "rccl_ranks": (world if pg is not None else None),
                        "backend": backend,       # "nccl" = RCCL; "gloo" = ranks sharing devices, a rehearsal, not a measurement
                        "allreduces_per_step": (3 if pg is not None else 0),
@@ -759,6 +783,7 @@ def main():
                        "sustained": sustained,
                        "inputs": "z drawn on the host every step" if HOST_Z else RESIDENT,
                        "pcie_inclusive": pcie,
+                       "inputs_resident": resident,
                        "other_workloads": other},
             "roofline": {"bound": "mfma", "kernel": top["name"], "achieved": achieved,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,

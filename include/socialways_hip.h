@@ -427,7 +427,7 @@ int sw_dec_rollout_bwd_dfuse(const float* obsv, const float* pred4, const float*
                              const float* dec_w, const float* gsave, int B, int To, int Tp, float* gdelta, float* dhT, float* dcT,
                              float* dS_pool, void* stream);
 
-/* ---- WIDE path (socialways_amd/wide.py, csrc/sw_wide.hip): the model at hidden sizes H > 64, H % 16 == 0 (train.py:42-44,
+/* ---- WIDE path (socialways_amd/wide.py, csrc/sw_wide.hip): the model at hidden sizes H > 64, H % 32 == 0 (WideTrainer.supports; train.py:42-44,
  *      76-81) as one launch per LSTM step and per decoder / head layer over all agents, explicit backward, deferred
  *      weight gradients.  Replaces, per call, the stock-PyTorch ops behind nn.Linear / nn.LSTM / nn.LeakyReLU / nn.ReLU of
  *      train.py:153-335 (forward and autograd backward).  All buffers row-major fp32, row strides in floats.            */

@@ -187,3 +187,12 @@ def workspace_floats(ws_id, B, To, Tp, nb=1, P=0):
 def require_gpu(t):
     if not t.is_cuda:
         raise SocialWaysHipError("socialways_amd runs on MI355X only: got a %s tensor (no CPU fallback)" % t.device)
+
+
+def indexed_device(device):
+    """torch.device with its index resolved ("cuda" -> cuda:<current>): tensors report indexed devices, and a trainer that
+    compares `tensor.device == self.device` (is z already in HBM?) must not be told apart from them by a missing index."""
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None and torch.cuda.is_available():
+        d = torch.device("cuda", torch.cuda.current_device())
+    return d

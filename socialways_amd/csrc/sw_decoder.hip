@@ -665,7 +665,11 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
       R.a1[q] = ld4(a1_b + (size_t)i * B * 160 + 32 * wave + 16 * q);
       R.a1s[q] = ld4(a1_b + (size_t)i * B * 160 + 128 + 16 * q);
     }
-    R.g4 = ld4(dpred4 + ((size_t)b * Tp + i) * 4);  // every wave keeps its own copy of the p/v gradient state
+    // every wave keeps its own copy of the p/v gradient state.  DFUSE: the rows were written by THIS workgroup through df.dpred
+    // (disc_fwd_tile above) - they are read back through the same unqualified pointer, never through the __restrict__
+    // const parameter that aliases it (the compiler may treat such loads as invariant across the barrier)
+    if constexpr (DFUSE) R.g4 = ld4(df.dpred + ((size_t)b * Tp + i) * 4);
+    else R.g4 = ld4(dpred4 + ((size_t)b * Tp + i) * 4);
   };
   Rows R;
   load_rows(Tp - 1, R, F_{});

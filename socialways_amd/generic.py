@@ -397,7 +397,7 @@ class GenericTrainer(SocialWaysTrainer):
             # broadcasts them to (B, B).  That accident is not reproduced here - and not silently replaced by another loss
             raise L.SocialWaysHipError("n_latent_codes = 1: the reference's info loss broadcasts (B,) against (B, 1) into a "
                                        "(B, B) mean (train.py:486, 516); not supported - use >= 2 latent codes")
-        self.device = torch.device(device)
+        self.device = L.indexed_device(device)
         if self.device.type != "cuda":
             raise L.SocialWaysHipError("socialways_amd runs on MI355X only (no CPU fallback)")
         self.n_next, self.noise_len = n_next, hidden_size // 2

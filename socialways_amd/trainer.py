@@ -180,7 +180,7 @@ class SocialWaysTrainer:
     def __init__(self, n_next, hidden_size=64, lr_g=1e-4, lr_d=1e-3, n_unrolling_steps=1, use_social=True,
                  use_info_loss=True, loss_info_w=0.5, n_latent_codes=2, device="cuda", process_group=None,
                  fused_adam=True, use_graph=None, use_l2_loss=False, use_variety_loss=False, loss_l2_w=0.5, variety_k=20):
-        self.device = torch.device(device)
+        self.device = L.indexed_device(device)
         self.n_next = n_next
         self.noise_len = hidden_size // 2
         self.n_unrolling_steps = n_unrolling_steps

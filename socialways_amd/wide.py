@@ -94,7 +94,7 @@ class WideTrainer(GenericTrainer):
             raise TypeError("unexpected keyword arguments: %s" % sorted(unknown))
         if not self.supports(hidden_size, n_latent_codes, use_variety_loss, process_group):
             raise L.SocialWaysHipError("wide path: hidden_size % 32 == 0, n_latent_codes >= 2, use_variety_loss False / True")
-        self.device = torch.device(device)
+        self.device = L.indexed_device(device)
         if self.device.type != "cuda":
             raise L.SocialWaysHipError("socialways_amd runs on MI355X only (no CPU fallback)")
         self.n_next, self.noise_len = n_next, hidden_size // 2
@@ -662,8 +662,13 @@ class WideTrainer(GenericTrainer):
         w["scal"].copy_(torch.tensor([float(zeros_val), float(ones_val)] + [float(dopt.t + k + 1) for k in range(U + 1)]
                                      + [float(gopt.t + 1)], dtype=torch.float32))
         # the captured step bakes the Adam step indices' ADDRESSES in (PackedAdam.step_t) - their values advance on the host
+        # ... and, as host scalars of the recorded launches, both optimizers' hyper-parameters and the loss weights: they are part
+        # of the key (as in SocialWaysTrainer._graph_key), so a checkpoint loaded with another lr never replays the old one
+        og, od = gopt.param_groups[0], dopt.param_groups[0]
         key = (B, To, sc.key, float(ss), Bg, self.use_l2_loss, self.use_info_loss, self.n_unrolling_steps, self.use_variety_loss,
-               self._row0)
+               self._row0, self.loss_info_w, self.loss_l2_w,
+               og["lr"], tuple(og["betas"]), og["eps"], og.get("weight_decay", 0),
+               od["lr"], tuple(od["betas"]), od["eps"], od.get("weight_decay", 0))
         n_seen = self._seen.get(key, 0)
         self._seen[key] = n_seen + 1
         self._graph_P[key] = sc.P
@@ -742,6 +747,9 @@ class WideTrainer(GenericTrainer):
 
     def load_checkpoint(self, ck):
         r = super().load_checkpoint(ck)             # (broadcasts rank 0's replica when there is a process group)
+        self.release_graphs()                       # captured steps bake the optimizers' host scalars in: re-capture
+        self._seen.clear()
+        self._graph_P.clear()
         for fl in (self.gp, self.dp):          # load_state_dict copies in place: the views still alias the packed buffers
             for p in fl.params:
                 assert p.data_ptr() == fl.flat.data_ptr() + 4 * fl.off[id(p)], "parameter left its packed buffer"

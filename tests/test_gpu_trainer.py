@@ -555,3 +555,37 @@ def test_z_in_device_memory_gives_the_same_steps_as_z_from_the_host():
         torch.cuda.synchronize()
         res.append((torch.stack(outs), tr.G._flat_all.clone(), tr.D._flat.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+@pytest.mark.gpu
+def test_generator_phase_d_pass_inside_the_decode_bptt_launch_equals_the_two_launches(monkeypatch):
+    """sw_dec_rollout_bwd_dfuse (D's generator-phase pass in front of the tile's decode BPTT, one launch) against
+    sw_disc_dpred + sw_dec_rollout_bwd (ops.DFUSE off): the same sums and the same weights after six steps, bit for bit -
+    the fused kernel reads the d/d(pred) rows its own workgroup wrote (through the unqualified pointer)."""
+    import socialways_amd as sw
+    from socialways_amd import ops
+    t = sw.synth_tracks(40, 8, 8, 12, seed=11)
+    data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
+    B, sb = 320, data.the_batches[:40]
+    res = []
+    for fuse in (True, False):
+        monkeypatch.setattr(ops, "DFUSE", fuse)
+        torch.manual_seed(5)
+        tr = sw.SocialWaysTrainer(12, use_social=True, device="cuda:0")
+        gen = torch.Generator().manual_seed(9)
+        outs = [tr.step(data.obsv[:B], data.pred[:B], sb, 0.02, 0.95, torch.rand(B, 32, generator=gen), data.ss).cpu()
+                for it in range(6)]
+        torch.cuda.synchronize()
+        res.append((torch.stack(outs), tr.G._flat_all.clone(), tr.D._flat.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+@pytest.mark.gpu
+def test_default_device_trainer_reads_device_z_by_address():
+    """A trainer built with device="cuda" (no index) must recognise a z that already lives on the current device (ADVICE r4:
+    torch.device('cuda') != tensor.device == cuda:0 sent every step through noise.cpu() and the PCIe pull)."""
+    import socialways_amd as sw
+    tr = sw.SocialWaysTrainer(12, use_social=True, device="cuda")
+    assert tr.device.index == torch.cuda.current_device()
+    z = torch.rand(64, 32, device="cuda")
+    assert tr._z_resident([(torch.zeros(64, 8, 2, device="cuda"), None, 0.0, 1.0, z)])

@@ -119,6 +119,36 @@ def test_wide_trainer_workspace_eviction_keeps_the_trajectory():
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
 
 
+def test_wide_trainer_checkpoint_with_another_lr_is_not_replayed_from_old_graphs():
+    """A captured wide step bakes the optimizers' host scalars (lr, betas, eps) in.  Loading a checkpoint whose Adam dicts
+    carry another lr after a layout was captured must re-capture: the graph-replaying trainer against an eager one
+    through the same sequence - capture at lr0, load a checkpoint with 3 x lr, four more steps - bit for bit."""
+    import copy
+    import socialways_amd as sw
+    data = _data()
+    sb, B = data.the_batches[:6], int(data.the_batches[5][1])
+    res = []
+    for use_graph in (True, False):
+        torch.manual_seed(7)
+        tr = sw.SocialWaysTrainer(12, hidden_size=H, use_social=True, device="cuda:0", use_graph=use_graph)
+        gen = torch.Generator().manual_seed(4)
+        outs = []
+
+        def run(n):
+            for it in range(n):
+                outs.append(tr.step(data.obsv[:B], data.pred[:B], sb, 0.02, 0.95, torch.rand(B, H // 2, generator=gen), data.ss).cpu())
+        run(4)                                             # eager, eager, capture, replay
+        ck = copy.deepcopy(tr.checkpoint(1))
+        for key in ("pred_optimizer", "D_optimizer"):
+            for g in ck[key]["param_groups"]:
+                g["lr"] = 3.0 * g["lr"]
+        tr.load_checkpoint(ck)
+        assert tr.D_optimizer.param_groups[0]["lr"] == pytest.approx(3e-3)
+        run(4)
+        res.append((torch.stack(outs), tr.gp.flat.clone(), tr.dp.flat.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
 @pytest.mark.parametrize("use_social,n_next", [(False, 12), (True, 1), (True, 3)])
 def test_wide_trainer_edge_configurations_match_the_generic_path(use_social, n_next):
     """No social block (train.py:83's default), a one-step horizon (no re-fed encoder step at all) and a short one: the wide
