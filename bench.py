@@ -462,7 +462,7 @@ def main():
     UNTIMED_BEFORE = 5 * sum({1, KG} | set(leg.plan(args.steps, cold=True)) | set(leg.plan(args.warmup)))
     leg.prime((args.steps, args.warmup))
     # The runtime's one-time stalls (16-55 ms host blocks seen in the FIRST timed region of a young process in ~1 of 10 runs,
-    # never in 180 later regions: tools/scratch/hiccup.py) are let happen in untimed steps: ~0.4 s of the same graph launches
+    # never in 180 later regions: round-3 per-launch host / GPU time stamps) are let happen in untimed steps: ~0.4 s of the same graph launches
     # in front of the W warmup steps.  Reported as config.settle_steps.
     SETTLE = int(os.environ.get("SW_BENCH_SETTLE_STEPS", "1000")) // KG * KG
     leg.run_steps(0, SETTLE)
@@ -561,7 +561,7 @@ def main():
 
     def short_leg(lg, n, w):
         """A side leg: n steps timed three times, the fastest region reported.  (Regions of 40-80 ms are exposed to the
-        sporadic 3-50 ms host stalls of this runtime - tools/scratch/hiccup.py - which are not a property of the leg;
+        sporadic 3-50 ms host stalls of this runtime - round-3 per-launch host / GPU time stamps - which are not a property of the leg;
         THE timed region of the headline workload is never treated this way.)"""
         lg.prime((n, w))
         lg.run_steps(0, w)

@@ -336,7 +336,11 @@ constexpr int OP_E2 = OP_E1 + 2048;      // embedder fc.4.weight [64][64]:   4 t
 constexpr int OP_E1T = OP_E2 + 4096;     // fc.2.weight^T [32][64]:          2 tiles, KJ 4
 constexpr int OP_E2T = OP_E1T + 2048;    // fc.4.weight^T [64][64]:          4 tiles, KJ 4
 constexpr int OP_ATT_T = OP_E2T + 4096;  // attention weight^T [64][64]:     4 tiles, KJ 4
-constexpr int N = OP_ATT_T + 4096;
+// W_hh once more for the 8-WAVE encoder pilot (enc_lstm_fwd8_kernel, round 5): wave w owns units 8w .. 8w+7 of all four
+// gates as TWO row tiles whose row m = 4 g + r is gate 2 tile + (r >> 1) of unit 8 w + 2 g + (r & 1), so that a lane's result
+// registers hold i, f (tile 0) and g, o (tile 1) of the same two units: [wave 8][tile 2][j 4][lane 64] float4
+constexpr int OP_WHH8 = OP_ATT_T + 4096;
+constexpr int N = OP_WHH8 + 16384;
 }  // namespace swimg
 // the images registered for (enc_w, dec_w) by the current step, or null (sw_gen_images)
 const float* sw_gen_images_for(const float* enc_w, const float* dec_w);

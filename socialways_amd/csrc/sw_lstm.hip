@@ -4,6 +4,7 @@
 #include "../../include/socialways_hip.h"
 #include "sw_lstm_dev.h"
 #include <type_traits>
+#include <cstdlib>
 
 // XMODE 0: x = positions [B][T][2] (4-d state formed on the fly); 1: x = [B][T][4].  ACT / Y / X4S: which per-step
 // rows are stored.  All of them are template parameters so that the step loop has NO conditional memory operation:
@@ -96,6 +97,104 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_fwd_kernel(
   }
   st4(hT + (size_t)b * 64 + u0 + 4 * lg, h);
   st4(cT + (size_t)b * 64 + u0 + 4 * lg, c);
+}
+
+// ---- round-5 pilot: the same kernel on EIGHT waves (two per SIMD), weights split 8 ways -----------------------------
+// The r4 verdict's lever for the register-resident serial kernels.  Wave w owns hidden units 8w .. 8w+7 of all four gates
+// as two row tiles (swimg::OP_WHH8: a lane's result registers hold i, f | g, o of the same two units, so the cell update
+// stays lane-local): 34 instead of 68 matrix instructions per wave and step, 32 instead of 64 weight registers, the saved
+// row assembled in the same LDS tile.  Training-step instance only (positions in, saved rows + inputs out, weight images
+// registered); selected by SW_ENC8=1.  Measured against the 4-wave kernel in DESIGN section 9 (round 5).
+__global__ __launch_bounds__(512) void enc_lstm_fwd8_kernel(
+    const float* __restrict__ x, const float* __restrict__ h0, const float* __restrict__ c0, int B, int T,
+    float* __restrict__ hT, float* __restrict__ cT, float* __restrict__ act, float* __restrict__ x4s, int t0,
+    const float* __restrict__ aux_src, float* __restrict__ aux_dst, long long aux_n, const float* __restrict__ gimg) {
+  const int tiles = (B + SW_TILE - 1) / SW_TILE;
+  const int extra = (int)gridDim.x - tiles;
+  if ((int)blockIdx.x < extra) {      // z's pull out of the pinned slot, as in enc_lstm_fwd_kernel
+    const long long n4 = aux_n >> 2, stride = (long long)extra * 512;
+    long long i = (long long)blockIdx.x * 512 + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+      const f32x4 v0 = ld4(aux_src + 4 * i), v1 = ld4(aux_src + 4 * (i + stride));
+      st4(aux_dst + 4 * i, v0);
+      st4(aux_dst + 4 * (i + stride), v1);
+    }
+    for (; i < n4; i += stride) st4(aux_dst + 4 * i, ld4(aux_src + 4 * i));
+    return;
+  }
+  __shared__ __attribute__((aligned(16))) float hbuf[2][SW_TILE * SW_ALD];
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  const int ub = 8 * wave + 2 * lg;                 // this lane's two units (result rows 4 lg + r: gate r >> 1, unit ub + (r & 1))
+  const int a0 = ((int)blockIdx.x - extra) * SW_TILE;
+  const int b = min(a0 + ln, B - 1);
+  f32x4 whh[2][4], bias[2];
+  float wx[2];
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) whh[tl][j] = ld4(gimg + swimg::OP_WHH8 + ((((size_t)wave * 2 + tl) * 4 + j) * 64 + lane) * 4);
+    const int rowA = (2 * tl + ((ln & 3) >> 1)) * 64 + 8 * wave + 2 * (ln >> 2) + (ln & 1);   // A row of lane ln
+    wx[tl] = gimg[swimg::WX + rowA * 4 + lg];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[tl][r] = gimg[swimg::BX + (2 * tl + (r >> 1)) * 64 + ub + (r & 1)];
+  }
+  float2 c = {0.f, 0.f}, h = {0.f, 0.f};
+  if (h0) h = *reinterpret_cast<const float2*>(h0 + (size_t)b * 64 + ub);
+  if (c0) c = *reinterpret_cast<const float2*>(c0 + (size_t)b * 64 + ub);
+  *reinterpret_cast<float2*>(&hbuf[0][ln * SW_ALD + 320 + ub]) = h;
+  sw_barrier();
+  float xa, xq = 0.f;
+  obs_x4_load(x, b, 0, T, lg, xa, xq);
+  asm volatile("" : "+v"(xa), "+v"(xq));
+  float* xrow = x4s + ((size_t)t0 * B + b) * 4 + lg;
+  for (int t = 0; t < T; ++t) {
+    const float xb = xa - (lg >= 2 ? xq : 0.f);
+    obs_x4_load(x, b, min(t + 1, T - 1), T, lg, xa, xq);
+    const float* hrow = &hbuf[t & 1][ln * SW_ALD + 320 + 4 * lg];
+    f32x4 bq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bq[j] = ld4(hrow + 16 * j);
+    f32x4 acc0 = SW_MFMA(wx[0], xb, bias[0]), acc1 = SW_MFMA(wx[1], xb, bias[1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc0 = SW_MFMA(whh[0][j][r], bq[j][r], acc0);
+        acc1 = SW_MFMA(whh[1][j][r], bq[j][r], acc1);
+      }
+    float2 gi, gf, gg, go;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float i_ = sw_sigmoid(acc0[e]), f_ = sw_sigmoid(acc0[2 + e]), g_ = sw_tanh(acc1[e]), o_ = sw_sigmoid(acc1[2 + e]);
+      const float cp = e ? c.y : c.x;
+      const float cn = fmaf(f_, cp, i_ * g_);
+      const float hn = o_ * sw_tanh(cn);
+      if (e) { gi.y = i_; gf.y = f_; gg.y = g_; go.y = o_; c.y = cn; h.y = hn; }
+      else   { gi.x = i_; gf.x = f_; gg.x = g_; go.x = o_; c.x = cn; h.x = hn; }
+    }
+    float* row = &hbuf[(t + 1) & 1][ln * SW_ALD + ub];
+    *reinterpret_cast<float2*>(row) = gi;
+    *reinterpret_cast<float2*>(row + 64) = gf;
+    *reinterpret_cast<float2*>(row + 128) = gg;
+    *reinterpret_cast<float2*>(row + 192) = go;
+    *reinterpret_cast<float2*>(row + 256) = c;
+    *reinterpret_cast<float2*>(row + 320) = h;
+    *xrow = xb;
+    xrow += (size_t)B * 4;
+    sw_barrier();
+    {   // the saved rows of the step: 16 agents x 96 float4, three per thread, 1 KB of consecutive memory per wave instruction
+      float* rows_t = act + (size_t)(t0 + t) * B * 384;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int f = k * 512 + (int)threadIdx.x, a = f / 96, c4 = f - a * 96;
+        const f32x4 v = ld4(&hbuf[(t + 1) & 1][a * SW_ALD + 4 * c4]);
+        st4g(rows_t + (size_t)min(a0 + a, B - 1) * 384 + 4 * c4, v);
+      }
+    }
+    asm volatile("" : "+v"(xa), "+v"(xq));
+  }
+  *reinterpret_cast<float2*>(hT + (size_t)b * 64 + ub) = h;
+  *reinterpret_cast<float2*>(cT + (size_t)b * 64 + ub) = c;
 }
 
 // BPTT.  Per step: elementwise gate gradients (lane-local) -> dgates row to HBM (for the
@@ -235,6 +334,16 @@ extern "C" int sw_enc_lstm_fwd_aux(const float* x, int x_mode, const float* enc_
   const int tiles = (B + SW_TILE - 1) / SW_TILE;
   int extra = aux_n > 0 ? (int)((aux_n / 4 + SW_THREADS - 1) / SW_THREADS) : 0;
   if (extra > 64) extra = 64;
+  // the 8-wave kernel (bit-identical results): per step -7.5 % when every tile has a CU to itself (m1: 1.67 -> 1.54 us per
+  // step), +3.5 % once tiles queue for CUs (c4) - used up to one tile per CU; SW_ENC8=0 / 1 forces either kernel
+  static const int enc8_env = getenv("SW_ENC8") ? atoi(getenv("SW_ENC8")) : -1;
+  const bool enc8 = enc8_env >= 0 ? enc8_env != 0 : tiles <= 256;
+  if (enc8 && gimg && x_mode == 0 && act && x4s && !y) {
+    SW_LAUNCH(enc_lstm_fwd8_kernel, dim3(tiles + extra), dim3(512), 0, (hipStream_t)stream, x, h0, c0, B, T, hT, cT, act, x4s, t0,
+              aux_src, aux_dst, aux_n, gimg);
+    SW_CHECK_LAUNCH("enc_lstm_fwd8_kernel");
+    return SW_OK;
+  }
 #define SW_ENC_FWD(XM, A, Y_, X4)                                                                                   \
   SW_LAUNCH((enc_lstm_fwd_kernel<XM, A, Y_, X4>), dim3(tiles + extra), dim3(SW_THREADS), 0, (hipStream_t)stream,    \
             x, enc_w, h0, c0, B, T, hT, cT, y, act, x4s, t0, aux_src, aux_dst, aux_n, gimg)

@@ -772,6 +772,11 @@ __device__ __forceinline__ void gen_images_block(const float* __restrict__ enc_w
   op_image_T(swimg::OP_WHHT, enc_w + ENC_WHH, 64, 16, 4);
   op_image_T(swimg::OP_W2T, dec_w + DEC_W2, 160, 5, 10);
   op_image_T(swimg::OP_W1HT, dec_w + DEC_W1, 160, 10, 4);
+  for (int f = tid; f < 8 * 2 * 4 * 64; f += nth) {      // OP_WHH8 (sw_common.h): the 8-wave row assignment of W_hh
+    const int l = f & 63, j = (f >> 6) & 3, tile = (f >> 8) & 1, w = f >> 9, m = l & 15;
+    const int row = (2 * tile + ((m & 3) >> 1)) * 64 + 8 * w + 2 * (m >> 2) + (m & 1);
+    st4(img + swimg::OP_WHH8 + 4 * (size_t)f, ld4(enc_w + ENC_WHH + (size_t)row * 64 + 16 * j + 4 * (l >> 4)));
+  }
   if (emb_w) {
     op_image(swimg::OP_E1, emb_w + EMB_W1, 32, 0, 2, 4);
     op_image(swimg::OP_E2, emb_w + EMB_W2, 64, 0, 4, 4);

@@ -232,7 +232,7 @@ int wg_add_pre(WgBatch& b, int N, int K, float* dW, int ldw, float* db, int nsli
 // Cost of a problem in wave-cycles: per 4-row group a wave issues NI x KT MFMAs (32 cycles each), the tail / ones columns
 // on the VALU (4 cycles per instruction) and SW_WG_GROUP_C0 cycles of loads, masks and address arithmetic; a problem has
 // ceil(N/64) output blocks.  C0 and the VALU term are fitted on per-workgroup start / end stamps of the launches at the
-// metric shape (-DSW_WG_STAMP, tools/scratch/wg_stamps.py): the LSTM problem measures 848 cycles per group and wave = 512 +
+// metric shape (-DSW_WG_STAMP): the LSTM problem measures 848 cycles per group and wave = 512 +
 // 80 + 256.  With C0 = 0 the narrow problems (K = 32 blocks, the 2048-row S / z blocks of fc1.0) were undersplit and their
 // jobs ended the generator's launch 8 us after the average job.
 #ifndef SW_WG_GROUP_C0
@@ -247,7 +247,7 @@ static double wg_cost(const WgProblem& P) {
     int ni = (P.N - n0 + 15) / 16;
     if (ni > 4) ni = 4;
     double per_group = ni * P.nbk * 32.0 + ni * (P.K2 + P.ones) * 4.0 + SW_WG_GROUP_C0;   // MFMAs, tail / ones columns (VALU),   // + loads / masks / address arithmetic of a group (fitted on
-    if (per_group < 192.0) per_group = 192.0;                // per-job stamps of the generator pass, tools/scratch/wg_stamps.py)
+    if (per_group < 192.0) per_group = 192.0;                // per-job stamps of the generator pass)
     c += per_group;
   }
   return c * (P.R / 4.0 + 8.0);
