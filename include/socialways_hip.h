@@ -505,6 +505,26 @@ int sw_wide_disc_heads_bwd(const long long* p, void* stream);
  * as 64-bit host values) through the grouped split-K GEMM; wgrad_ws = sw_workspace_floats(SW_WS_WGRAD, ...) floats       */
 int sw_wide_wgrad(const long long* desc, int n, float* wgrad_ws, void* stream);
 
+/* ---- A two-hop gradient all-reduce over peer-mapped exchange buffers (csrc/sw_comm.hip) - the data-parallel step's
+ *      alternative to `torch.distributed.all_reduce` on RCCL (3 flat buckets of 112 / 112 / 344 KB per step; the
+ *      reference itself is single-process, train.py has no counterpart).  Every rank allocates ONE exchange buffer
+ *      (sw_comm_alloc, sw_comm_bytes(world, max_floats) bytes, zero-filled device memory), exports it (sw_comm_ipc_export:
+ *      a 64-byte hipIpc handle the host passes to the peers by any means), imports the peers' (sw_comm_ipc_import) and then
+ *      calls sw_allreduce_direct with the `world` buffer addresses as mapped in ITS process (its own at [rank]): grad[0..n)
+ *      becomes the element-wise sum over the ranks, every element summed in rank order by one rank (replicas receive
+ *      identical bits).  Collective: every rank must issue the same sequence of calls (same n); asynchronous on `stream`,
+ *      capturable in a hipGraph.  A peer that never arrives is given up after ~4 s: sw_comm_status then reports 1 (the
+ *      gradient is garbage) instead of a hung device.  world <= 16.                                                     */
+long long sw_comm_bytes(int world, long long max_floats);
+int sw_comm_alloc(long long bytes, void** ptr);
+int sw_comm_free(void* ptr);
+int sw_comm_ipc_export(void* ptr, void* handle64 /* 64 bytes out */);
+int sw_comm_ipc_import(const void* handle64, void** ptr);
+int sw_comm_ipc_close(void* ptr);
+int sw_comm_status(const void* own_buf, int* status /* 0 ok, 1 a wait timed out */);
+int sw_allreduce_direct(void* const* peer_bufs /* [world] */, int rank, int world, long long max_floats, float* grad,
+                        long long n, void* stream);
+
 /* ---- measurement aids.  sw_kernel_timing(1): every kernel launch of the library is bracketed by two HIP events on its
  *      own stream (never inside a graph capture) until sw_kernel_timing(0); sw_kernel_timing_read(buf, cap) waits for
  *      the device and writes one line "kernel calls total_us" per kernel, returning the bytes needed.  sw_debug_spin

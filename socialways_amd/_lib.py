@@ -107,6 +107,14 @@ PROTOTYPES = {
     "sw_wide_lstm_seq_supported": (_i, [_i]),
     "sw_wide_lstm_seq_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "sw_wide_lstm_seq_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "sw_comm_bytes": (_ll, [_i, _ll]),
+    "sw_comm_alloc": (_i, [_ll, _vp]),
+    "sw_comm_free": (_i, [_vp]),
+    "sw_comm_ipc_export": (_i, [_vp, _vp]),
+    "sw_comm_ipc_import": (_i, [_vp, _vp]),
+    "sw_comm_ipc_close": (_i, [_vp]),
+    "sw_comm_status": (_i, [_vp, _vp]),
+    "sw_allreduce_direct": (_i, [_vp, _i, _i, _ll, _vp, _ll, _vp]),
     "sw_kernel_timing": (_i, [_i]),
     "sw_kernel_timing_read": (_i, [ctypes.c_char_p, _i]),
     "sw_debug_spin": (_i, [ctypes.c_double, _vp]),

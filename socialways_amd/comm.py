@@ -1,0 +1,75 @@
+"""Two-hop gradient all-reduce over peer-mapped exchange buffers (csrc/sw_comm.hip, include/socialways_hip.h) - the
+data-parallel step's alternative to RCCL's ring for its three small flat buckets.
+
+`DirectAllReduce(process_group, device, max_floats)` is built once per trainer: every rank allocates an exchange buffer,
+the 64-byte hipIpc handles travel through the process group (`all_gather_object`: any backend), every rank maps its peers'
+buffers.  `ar(flat)` then all-reduces a flat fp32 device tensor in place on the current stream (a plain kernel launch:
+capturable in the step's hipGraph).  Selected by `SW_ALLREDUCE=direct` (SocialWaysTrainer); the default stays RCCL until a
+multi-GPU node has measured both.
+"""
+import ctypes
+import socket
+
+import torch
+
+from . import _lib as L
+
+
+class DirectAllReduce:
+    def __init__(self, process_group, device, max_floats):
+        dist = torch.distributed
+        self.pg, self.device = process_group, L.indexed_device(device)
+        self.rank, self.world = dist.get_rank(process_group), dist.get_world_size(process_group)
+        self.max_floats = int(max_floats)
+        lib = L.load()
+        nbytes = lib.sw_comm_bytes(self.world, self.max_floats)
+        if nbytes <= 0:
+            raise L.SocialWaysHipError("sw_comm_bytes(%d, %d) = %d" % (self.world, self.max_floats, nbytes))
+        with torch.cuda.device(self.device):
+            own = ctypes.c_void_p()
+            L.call("sw_comm_alloc", nbytes, ctypes.byref(own))
+            self._own = own.value
+            handle = ctypes.create_string_buffer(64)
+            L.call("sw_comm_ipc_export", self._own, handle)
+            # (host name + pid: a handle must be opened by ANOTHER process of the same host)
+            mine = (socket.gethostname(), int(torch.multiprocessing.current_process().pid), bytes(handle.raw))
+            everyone = [None] * self.world
+            dist.all_gather_object(everyone, mine, group=process_group)
+            if any(h[0] != mine[0] for h in everyone):
+                raise L.SocialWaysHipError("SW_ALLREDUCE=direct needs all ranks on one node (hipIpc)")
+            self._peers, self._opened = [], []
+            for r, (_, pid, raw) in enumerate(everyone):
+                if r == self.rank:
+                    self._peers.append(self._own)
+                    continue
+                p = ctypes.c_void_p()
+                L.call("sw_comm_ipc_import", ctypes.create_string_buffer(raw, 64), ctypes.byref(p))
+                self._peers.append(p.value)
+                self._opened.append(p.value)
+            self._arr = (ctypes.c_void_p * self.world)(*self._peers)
+        dist.barrier(group=process_group)      # nobody launches before every rank has mapped every buffer
+
+    def __call__(self, flat):
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous() and flat.numel() <= self.max_floats
+        L.call("sw_allreduce_direct", ctypes.cast(self._arr, ctypes.c_void_p), self.rank, self.world, self.max_floats,
+               L.ptr(flat), flat.numel(), L.stream())
+        return flat
+
+    def status(self):
+        """0, or 1 after a wait on a peer has timed out (synchronises the device)."""
+        st = ctypes.c_int(0)
+        L.call("sw_comm_status", self._own, ctypes.byref(st))
+        return st.value
+
+    def close(self):
+        if getattr(self, "_own", None) is None:
+            return
+        torch.cuda.synchronize(self.device)
+        try:
+            torch.distributed.barrier(group=self.pg)     # peers have stopped storing into this buffer
+        except Exception:      # noqa: BLE001 - the group may be gone at interpreter exit
+            pass
+        for p in self._opened:
+            L.call("sw_comm_ipc_close", p)
+        L.call("sw_comm_free", self._own)
+        self._own, self._opened = None, []

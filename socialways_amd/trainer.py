@@ -235,6 +235,16 @@ class SocialWaysTrainer:
         self.epoch = 0
         if self.pg is not None and self.world > 1:
             self.sync_replicas()
+        # SW_ALLREDUCE=direct: the three gradient buckets of a step go through the library's own two-hop all-reduce over
+        # hipIpc-mapped exchange buffers (csrc/sw_comm.hip) instead of RCCL's ring; everything else (epoch sums, broadcasts)
+        # stays on the process group.  The kernel is an ordinary graph node: the step is captured as ONE graph.
+        self._direct = None
+        if (self.pg is not None and (self.world > 1 or self._force_dist) and self.device.type == "cuda"
+                and os.environ.get("SW_ALLREDUCE", "") == "direct"):
+            from .comm import DirectAllReduce
+            self._direct = DirectAllReduce(self.pg, self.device, max(self.G._gflat_all.numel(), self.D._gflat.numel()))
+            if self._graph_collectives is None:
+                self._graph_collectives = bool(self.use_graph)
         self.ws = ops.Workspaces(self.device)
         self._ws_version = 0
         # derived images of the generator's weights (composed input matrix, fc4 . fc3, transposed decoder matrices):
@@ -300,7 +310,12 @@ class SocialWaysTrainer:
 
     def _allreduce(self, flat):
         if self.pg is not None and (self.world > 1 or self._force_dist):
-            torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            d = self._direct
+            if (d is not None and flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+                    and 1024 <= flat.numel() <= d.max_floats):
+                d(flat)        # SW_ALLREDUCE=direct: the two-hop exchange over peer-mapped buffers (comm.py), a plain kernel
+            else:
+                torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
     def _probe_graph_collectives(self):
         """Can this process group's all-reduce be recorded in a hipGraph and replayed?  Only RCCL ("nccl") is

@@ -1,0 +1,130 @@
+"""The library's own gradient all-reduce (csrc/sw_comm.hip, socialways_amd/comm.py): W processes that share the
+test box's ONE GPU map each other's exchange buffers through hipIpc and all-reduce flat fp32 buffers of the step's bucket
+sizes - against the sum taken in rank order on the host, bit for bit, eagerly and replayed from a hipGraph; then the
+data-parallel training step with SW_ALLREDUCE=direct against the same step on the process group's own all-reduce."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+SIZES = (27939, 86122, 4096, 1031)        # D's and G's packed gradients (train.py:379-385), a round size, an odd one
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ar_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from socialways_amd.comm import DirectAllReduce
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ar = DirectAllReduce(dist.group.WORLD, "cuda:0", max(SIZES))
+    ok, worst = True, 0.0
+    gen = torch.Generator().manual_seed(100 + rank)
+    for it in range(6):
+        for n in SIZES:
+            x = torch.randn(n, generator=gen) * (10.0 ** (it - 3))
+            parts = [torch.empty(n) for _ in range(world)]
+            dist.all_gather(parts, x)
+            want = parts[0].clone()
+            for p in parts[1:]:
+                want += p                       # the kernel's order: rank 0, 1, 2, ...
+            g = x.cuda()
+            ar(g)
+            got = g.cpu()
+            ok = ok and torch.equal(got, want)
+            worst = max(worst, float((got - want).abs().max()))
+    # the three buckets of a training step, recorded in ONE hipGraph and replayed (arguments fixed, epochs advance on the device)
+    bufs = [torch.zeros(n, device="cuda") for n in (27939, 27939, 86122)]
+    srcs = [torch.randn(n, generator=gen).cuda() for n in (27939, 27939, 86122)]
+    wants = []
+    for s_ in srcs:
+        parts = [torch.empty(s_.numel()) for _ in range(world)]
+        dist.all_gather(parts, s_.cpu())
+        w = parts[0].clone()
+        for p in parts[1:]:
+            w += p
+        wants.append(w)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for b_, s_ in zip(bufs, srcs):
+                b_.copy_(s_)
+                ar(b_)
+    graph_ok = True
+    for rep in range(5):
+        g.replay()
+        torch.cuda.synchronize()
+        graph_ok = graph_ok and all(torch.equal(b_.cpu(), w) for b_, w in zip(bufs, wants))
+    ret[rank] = (ok, worst, graph_ok, ar.status())
+    ar.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4])
+def test_direct_allreduce_equals_the_sum_in_rank_order(world):
+    import torch.multiprocessing as mp
+    ret = mp.Manager().dict()
+    mp.spawn(_ar_worker, args=(world, _port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        ok, worst, graph_ok, status = ret[r]
+        assert status == 0, "rank %d: a wait on a peer timed out" % r
+        assert ok, "rank %d: eager all-reduce differs from the rank-order sum (max |diff| %.3g)" % (r, worst)
+        assert graph_ok, "rank %d: replayed all-reduces differ" % r
+
+
+def _dp_worker(rank, world, port, ret, mode):
+    import torch.distributed as dist
+    import socialways_amd as sw
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if mode == "direct":
+        os.environ["SW_ALLREDUCE"] = "direct"
+    else:
+        os.environ.pop("SW_ALLREDUCE", None)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = sw.synth_tracks(24, [5, 1, 9, 16, 3, 2, 2, 2, 7, 8, 4, 6] * 2, 8, 12, seed=5)
+    data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
+    torch.manual_seed(3)
+    tr = sw.SocialWaysTrainer(12, use_social=True, device="cuda:0", process_group=dist.group.WORLD)
+    gen = torch.Generator().manual_seed(8)
+    out = []
+    for e in range(6):              # eager steps, capture, replays (direct: ONE graph with the three exchange kernels in it)
+        z = torch.rand(data.n_train_samples, 32, generator=gen)
+        ade, fde, losses, sizes = tr.train_epoch(data, data.n_train_samples, draw=lambda bs: (0.01 * (e + 1), 0.95, z))
+        out.append((ade, fde, np.asarray(losses[0]).tolist()))
+    ret[(mode, rank)] = (out, tr.G._flat_all.cpu().clone(), tr.D._flat.cpu().clone(), tr._graph_collectives,
+                         tr._direct.status() if tr._direct is not None else 0)
+    tr.release_graphs()
+    if tr._direct is not None:
+        tr._direct.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_data_parallel_step_on_the_direct_allreduce_equals_the_process_groups():
+    """2 ranks, scene-sharded ragged batches: with two ranks a sum has one order, so the trajectory on the direct all-reduce
+    (recorded inside the step graph) must equal the one on the group's own all-reduce (graph segments) bit for bit."""
+    import torch.multiprocessing as mp
+    ret = mp.Manager().dict()
+    for mode in ("group", "direct"):
+        mp.spawn(_dp_worker, args=(2, _port(), ret, mode), nprocs=2, join=True)
+    for r in (0, 1):
+        assert ret[("direct", r)][4] == 0 and ret[("direct", r)][3] is True and ret[("group", r)][3] is False
+        assert ret[("direct", r)][0] == ret[("group", r)][0], "losses / ADE / FDE differ on rank %d" % r
+        assert torch.equal(ret[("direct", r)][1], ret[("group", r)][1]) and torch.equal(ret[("direct", r)][2], ret[("group", r)][2])
+    assert torch.equal(ret[("direct", 0)][1], ret[("direct", 1)][1]) and torch.equal(ret[("direct", 0)][2], ret[("direct", 1)][2])
