@@ -559,6 +559,53 @@ def main():
     if pg is not None:
         tr.release_graphs()                     # recorded collectives go before their communicator
 
+    def dp_exchange_report():
+        """N > 1: what one gradient all-reduce of each of the step's three buckets costs on this group (HIP events around 50
+        back-to-back calls; D = 27 939 floats twice, G = 86 122 floats) on the process group's own all-reduce (RCCL) and on the
+        library's two-hop exchange (SW_ALLREDUCE=direct, csrc/sw_comm.hip), then the whole step on the direct form as a secondary
+        leg - so that a scaling run explains itself."""
+        from socialways_amd.comm import DirectAllReduce
+        rep = {"buckets_floats": [int(tr.D._gflat.numel()), int(tr.D._gflat.numel()), int(tr.G._gflat_all.numel())]}
+        bufs = [torch.zeros(n, device=dev) for n in rep["buckets_floats"]]
+
+        def time_calls(fn):
+            out = []
+            for b in bufs:
+                for _ in range(5):
+                    fn(b)
+                fence()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(50):
+                    fn(b)
+                e1.record()
+                torch.cuda.synchronize()
+                out.append(max_over_ranks(e0.elapsed_time(e1) * 1e3 / 50))
+            return out
+        rep["group_us"] = time_calls(lambda b: torch.distributed.all_reduce(b, group=pg))
+        rep["group_backend"] = backend
+        try:
+            ar = DirectAllReduce(pg, dev, max(rep["buckets_floats"]))
+            rep["direct_us"] = time_calls(ar)
+            rep["direct_status"] = ar.status()
+            ar.close()
+            os.environ["SW_ALLREDUCE"] = "direct"
+            lg = Leg(args.workload, dev, pg, world, rank, args.scaling, args.global_scenes, KG)
+            n, w = OTHER_STEPS["m1"]
+            d = max_over_ranks(short_leg(lg, n, w))
+            rep["direct_step"] = {"steps": n, "steps_s": n * (world if args.scaling == "weak" else 1) / d, "ms_per_step": 1e3 * d / n,
+                                  "collectives": "in-graph" if lg.tr._graph_collectives else "between graph segments",
+                                  "status": lg.tr._direct.status() if lg.tr._direct is not None else None}
+            lg.tr.release_graphs()
+            if lg.tr._direct is not None:
+                lg.tr._direct.close()
+            del lg
+        except Exception as e:      # noqa: BLE001 - the report must not lose the bench line
+            rep["direct_error"] = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
+        finally:
+            os.environ.pop("SW_ALLREDUCE", None)
+        return rep
+
     def short_leg(lg, n, w):
         """A side leg: n steps timed three times, the fastest region reported.  (Regions of 40-80 ms are exposed to the
         sporadic 3-50 ms host stalls of this runtime - round-3 per-launch host / GPU time stamps - which are not a property of the leg;
@@ -572,6 +619,9 @@ def main():
         assert torch.isfinite(lg.last).all(), "non-finite losses (%s)" % lg.name
         return d
 
+    exchange = None
+    if pg is not None and world > 1 and os.environ.get("SW_ALLREDUCE", "") != "direct" and not args.no_other_workloads:
+        exchange = dp_exchange_report()
     other = None
     if world == 1 and pg is None and not args.no_other_workloads:
         other = {}
@@ -773,6 +823,8 @@ def main():
                        "collectives": collectives, "rccl_ranks": (world if pg is not None else None),
                        "backend": backend,       # "nccl" = RCCL; "gloo" = ranks sharing devices, a rehearsal, not a measurement
                        "allreduces_per_step": (3 if pg is not None else 0),
+                       "allreduce": ("direct (csrc/sw_comm.hip)" if os.environ.get("SW_ALLREDUCE", "") == "direct" else "process group") if pg is not None else None,
+                       "exchange": exchange,      # N > 1: us per all-reduce of each bucket on both forms + the step on the direct form
                        "replicas_identical": replicas_identical,
                        "step_alg_gflop": fl["step"] / 1e9,
                        "step_frac_of_fp32_peak": fl["step"] / per_step / (PEAK_FP32_TFLOPS * 1e12),

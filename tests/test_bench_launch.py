@@ -57,3 +57,22 @@ def test_two_rank_bench_line_on_one_box():
     assert cfg["rccl_ranks"] == 2 and cfg["allreduces_per_step"] == 3 and cfg["replicas_identical"] is True
     assert cfg["backend"] == backend
     assert rec["value"] > 0 and abs(rec["value"] - 2 * 1e3 / rec["ms_per_step"]) < 1e-6 * rec["value"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_two_rank_bench_line_reports_both_gradient_exchanges():
+    """N > 1 without --no-other-workloads: the line carries config.exchange - microseconds per all-reduce of the step's three
+    buckets on the process group and on the library's direct exchange (SW_ALLREDUCE=direct), and the step on the direct
+    form - so that a scaling run explains itself (2 ranks sharing cuda:0 here: a rehearsal of the plumbing)."""
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    p, lines = _run(["--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-sustained"],
+                    {"SW_BENCH_BACKEND": backend, "SW_BENCH_SETTLE_STEPS": "8"}, 850)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = json.loads(lines[-1])
+    ex = rec["config"]["exchange"]
+    assert ex is not None and "direct_error" not in ex, ex
+    assert ex["buckets_floats"] == [27939, 27939, 86122]
+    assert len(ex["group_us"]) == 3 and len(ex["direct_us"]) == 3 and min(ex["direct_us"]) > 0 and ex["direct_status"] == 0
+    assert ex["direct_step"]["steps_s"] > 0 and ex["direct_step"]["collectives"] == "in-graph" and ex["direct_step"]["status"] == 0
