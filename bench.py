@@ -561,7 +561,7 @@ def main():
 
     def dp_exchange_report():
         """N > 1: what one gradient all-reduce of each of the step's three buckets costs on this group (HIP events around 50
-        back-to-back calls; D = 27 939 floats twice, G = 86 122 floats) on the process group's own all-reduce (RCCL) and on the
+        back-to-back calls; D = 27 942 floats twice, G = 86 124: the packed buffers) on the process group's own all-reduce (RCCL) and on the
         library's two-hop exchange (SW_ALLREDUCE=direct, csrc/sw_comm.hip), then the whole step on the direct form as a secondary
         leg - so that a scaling run explains itself."""
         from socialways_amd.comm import DirectAllReduce

@@ -73,6 +73,6 @@ def test_two_rank_bench_line_reports_both_gradient_exchanges():
     rec = json.loads(lines[-1])
     ex = rec["config"]["exchange"]
     assert ex is not None and "direct_error" not in ex, ex
-    assert ex["buckets_floats"] == [27939, 27939, 86122]
+    assert ex["buckets_floats"] == [27942, 27942, 86124]      # packed D, D, G gradient buffers (tensors on 4-float boundaries)
     assert len(ex["group_us"]) == 3 and len(ex["direct_us"]) == 3 and min(ex["direct_us"]) > 0 and ex["direct_status"] == 0
     assert ex["direct_step"]["steps_s"] > 0 and ex["direct_step"]["collectives"] == "in-graph" and ex["direct_step"]["status"] == 0
