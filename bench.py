@@ -97,6 +97,7 @@ def kernel_alg_flops(B, P, To, Tp, one_launch_d=False, dfuse=None):
     return {
         **d_kernels,
         "enc_lstm_fwd_kernel": 2.0 * B * To * lstm,
+        "enc_lstm_fwd8_kernel": 2.0 * B * To * lstm,      # the same launch on eight waves (up to one tile per CU)
         "enc_lstm_bwd_kernel": 2.0 * B * To * lstm,
         "dec_rollout_fwd_kernel": 2.0 * B * (Tp * dec + (Tp - 1) * lstm)
                                   + (2.0 * B * To * d_lstm if rides else 0.0),   # + D's first obs LSTM (rides here)
