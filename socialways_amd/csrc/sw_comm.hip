@@ -18,6 +18,7 @@
 #include "../../include/socialways_hip.h"
 #include "sw_common.h"
 #include <cstring>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #define SW_COMM_MAXW 16          // ranks
@@ -156,7 +157,9 @@ extern "C" long long sw_comm_bytes(int world, long long max_floats) {
 extern "C" int sw_comm_alloc(long long bytes, void** ptr) {
   if (bytes < 1 || !ptr) return SW_EARG;
   void* p = nullptr;
-  hipError_t e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached);
+  // SW_COMM_CACHED=1 (tests): ordinary cached device memory - the exchange then relies on the release / acquire fences alone
+  static const bool cached = getenv("SW_COMM_CACHED") && atoi(getenv("SW_COMM_CACHED")) != 0;
+  hipError_t e = cached ? hipErrorNotSupported : hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     e = hipMalloc(&p, (size_t)bytes);

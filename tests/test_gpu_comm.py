@@ -73,10 +73,13 @@ def _ar_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("world", [2, 4])
-def test_direct_allreduce_equals_the_sum_in_rank_order(world):
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,cached", [(2, False), (4, False), (8, False), (4, True)])
+def test_direct_allreduce_equals_the_sum_in_rank_order(world, cached, monkeypatch):
+    """cached: the exchange buffers in ordinary cached device memory (SW_COMM_CACHED=1) instead of uncached - the hand-off
+    then rests on the kernel's release / acquire fences alone (workgroups of the processes sit on different XCDs)."""
     import torch.multiprocessing as mp
+    monkeypatch.setenv("SW_COMM_CACHED", "1" if cached else "0")
     ret = mp.Manager().dict()
     mp.spawn(_ar_worker, args=(world, _port(), ret), nprocs=world, join=True)
     for r in range(world):
