@@ -691,6 +691,26 @@ def main():
                                      "plain_over_dp1_time_ratio": (dt / args.steps) / (d / n)}
                 lg.tr.release_graphs()
                 del lg
+                # ... and the same on the library's direct exchange (SW_ALLREDUCE=direct: per bucket ONE launch that exchanges
+                # the gradient and applies Adam; with one rank the exchange moves nothing): its structure cost
+                os.environ["SW_ALLREDUCE"] = "direct"
+                try:
+                    lg = Leg("m1", dev, torch.distributed.group.WORLD, 1, 0, "weak", 0, KG)
+                    if not HOST_Z:
+                        lg.z_resident()
+                    d = short_leg(lg, n, w)
+                    other["dp1_direct"] = {"workload": "m1 on a 1-rank group with SW_ALLREDUCE=direct (3 exchange + Adam launches per step)",
+                                           "steps": n, "steps_s": n / d, "ms_per_step": 1e3 * d / n,
+                                           "delta_us_per_step": 1e3 * (1e3 * d / n - 1e3 * dt / args.steps),
+                                           "collectives": "in-graph" if lg.tr._graph_collectives else "between graph segments",
+                                           "status": lg.tr._direct.status()}
+                    lg.tr.release_graphs()
+                    lg.tr._direct.close()
+                    del lg
+                except Exception as e:      # noqa: BLE001
+                    other["dp1_direct"] = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")}
+                finally:
+                    os.environ.pop("SW_ALLREDUCE", None)
                 torch.distributed.destroy_process_group()
             except Exception as e:      # noqa: BLE001 - a box without a working RCCL must not lose the bench line
                 other["dp1_rccl"] = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")}

@@ -524,6 +524,13 @@ int sw_comm_ipc_close(void* ptr);
 int sw_comm_status(const void* own_buf, int* status /* 0 ok, 1 a wait timed out */);
 int sw_allreduce_direct(void* const* peer_bufs /* [world] */, int rank, int world, long long max_floats, float* grad,
                         long long n, void* stream);
+/* ... and with the optimizer step behind it in the same launch: every rank applies Adam (sw_adam_packed's arithmetic, same
+ * arguments; disc_Tp > 0: the packed weights are a Discriminator's and its registered images follow) to its replica from
+ * the reduced gradient while it copies it out.  Interoperates with sw_allreduce_direct on other ranks (a rank without rows
+ * in a batch exchanges zeros and updates separately). */
+int sw_allreduce_direct_adam(void* const* peer_bufs, int rank, int world, long long max_floats, float* grad, long long n,
+                             float* w, float* m, float* v, const float* step, double lr, double beta1, double beta2,
+                             double eps, int disc_Tp, void* stream);
 
 /* ---- measurement aids.  sw_kernel_timing(1): every kernel launch of the library is bracketed by two HIP events on its
  *      own stream (never inside a graph capture) until sw_kernel_timing(0); sw_kernel_timing_read(buf, cap) waits for

@@ -115,6 +115,8 @@ PROTOTYPES = {
     "sw_comm_ipc_close": (_i, [_vp]),
     "sw_comm_status": (_i, [_vp, _vp]),
     "sw_allreduce_direct": (_i, [_vp, _i, _i, _ll, _vp, _ll, _vp]),
+    "sw_allreduce_direct_adam": (_i, [_vp, _i, _i, _ll, _vp, _ll, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double,
+                                      ctypes.c_double, ctypes.c_double, _i, _vp]),
     "sw_kernel_timing": (_i, [_i]),
     "sw_kernel_timing_read": (_i, [ctypes.c_char_p, _i]),
     "sw_debug_spin": (_i, [ctypes.c_double, _vp]),

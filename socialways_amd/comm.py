@@ -55,6 +55,14 @@ class DirectAllReduce:
                L.ptr(flat), flat.numel(), L.stream())
         return flat
 
+    def adam(self, flat_grad, opt, step_tensor=None):
+        """All-reduce `flat_grad` AND apply `opt` (a PackedAdam over the packed weights that gradient belongs to) in the same
+        launch; `step_tensor` = device scalar with the 1-based index of this update (None: the optimizer counts itself)."""
+        m, v, st, lr, b1, b2, eps = opt.fused_args(step_tensor)
+        L.call("sw_allreduce_direct_adam", ctypes.cast(self._arr, ctypes.c_void_p), self.rank, self.world, self.max_floats,
+               L.ptr(flat_grad), flat_grad.numel(), L.ptr(opt.flat), L.ptr(m), L.ptr(v), L.ptr(st), float(lr), float(b1),
+               float(b2), float(eps), int(opt.disc_tp), L.stream())
+
     def status(self):
         """0, or 1 after a wait on a peer has timed out (synchronises the device)."""
         st = ctypes.c_int(0)

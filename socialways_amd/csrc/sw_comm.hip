@@ -3,33 +3,37 @@
 // hops for them.  Here every rank holds an EXCHANGE BUFFER that all its peers have mapped (hipIpc), and one kernel per bucket
 // runs a two-hop exchange over the direct xGMI links:
 //
-//   hop 1 (reduce-scatter)  rank r STORES slice p of its gradient into peer p's buffer (slot r), for every p, then raises
-//                           flag[hop 1][r] at p;  p waits for all W flags and sums the W slots of its slice IN RANK ORDER
-//                           (every element is reduced by exactly one rank in a fixed order: replicas get identical bits);
-//   hop 2 (all-gather)      p stores its reduced slice into every peer's `out` region (slice p) and raises flag[hop 2][p];
-//                           every rank waits for all W flags and copies `out` over its gradient buffer.
+//   hop 1 (reduce-scatter)  rank r STORES slice p of its gradient into peer p's buffer (slot r), for every p;  p sums the W
+//                           slots of its slice IN RANK ORDER (every element is reduced by exactly one rank in a fixed order:
+//                           replicas get identical bits);
+//   hop 2 (all-gather)      p stores its reduced slice into every peer's `out` region (slice p); every rank copies `out` over
+//                           its gradient buffer - and, in the _adam form, applies its optimizer step from it.
 //
-// Remote traffic is stores only (a load over the fabric costs a round trip).  A launch is NBLK workgroups; workgroup b owns
-// chunk b of every slice on every rank and synchronises only with the workgroups b of the peers (flags per workgroup), so
-// there is no grid-wide barrier.  Flags carry a monotonically rising epoch (kept in the buffer, advanced by the kernel:
-// a launch recorded in a hipGraph needs no changing argument).  Payload stores are released and flags raised / polled at
-// SYSTEM scope (peers are other devices, or other processes on this device).  A wait gives up after ~4 s of the constant
-// 100 MHz clock and leaves an error code in the buffer (sw_comm_status) instead of hanging the GPU.
+// Remote traffic is stores only (a load over the fabric costs a round trip).  The hand-off is DATA-TAGGED: the payload
+// travels as 8-byte granules {value, epoch}, two per 16-byte system-scope (sc0 sc1, write-through) store; the consumer polls
+// the granules themselves with L2-bypassing system-scope loads until both tags carry this call's epoch.  No flag, no
+// s_waitcnt drain in front of a flag, no fence (a system-scope release / acquire writes back / invalidates the XCD's whole L2,
+// full of the backward pass's saved rows: 9 us per call measured), no workgroup barrier: a hop costs one store becoming
+// visible plus one load (MI355X_MICROARCH.md, hand-off price list: granules for latency; 8-byte granules observed untorn).
+// The epoch is kept in the buffer and advanced by the kernel - a launch recorded in a hipGraph needs no changing argument;
+// buffers start zeroed and epochs at 1.  A launch is NBLK workgroups, every thread owning the same pairs of floats of every
+// slice on every rank.  A poll gives up after ~4 s of the constant 100 MHz clock and leaves an error code in the buffer
+// (sw_comm_status) instead of hanging the GPU.
 #include "../../include/socialways_hip.h"
 #include "sw_common.h"
+#include "sw_wgrad.h"
 #include <cstring>
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #define SW_COMM_MAXW 16          // ranks
-#define SW_COMM_MAXBLK 32        // workgroups per launch
-#define SW_COMM_FLAG_STRIDE 16   // uint32 per flag (one 64-byte line each)
+#define SW_COMM_MAXBLK 128       // workgroups per launch
 #define SW_COMM_TIMEOUT_TICKS 400000000ULL   // 4 s of wall_clock64() (100 MHz)
 
 namespace {
-// layout of an exchange buffer (bytes): header | flags | recv [W][Ls] | out [W][Ls], Ls = slice capacity in floats
+// layout of an exchange buffer (bytes): header | recv [W][Ls] granules | out [W][Ls] granules, Ls = slice capacity in floats
 struct CommLayout {
-  size_t flags, recv, out, total;
+  size_t recv, out, total;
   long long ls_cap;
 };
 __host__ __device__ inline long long comm_slice_floats(long long n, int W, int nblk) {   // multiple of 4 * nblk
@@ -39,112 +43,126 @@ __host__ __device__ inline long long comm_slice_floats(long long n, int W, int n
 __host__ __device__ inline CommLayout comm_layout(int W, long long max_floats) {
   CommLayout L;
   L.ls_cap = comm_slice_floats(max_floats, W, SW_COMM_MAXBLK);
-  L.flags = 256;      // header: [0] status, [16 + b] epoch of workgroup b
-  L.recv = L.flags + (size_t)2 * SW_COMM_MAXW * SW_COMM_MAXBLK * SW_COMM_FLAG_STRIDE * 4;
-  L.out = L.recv + (size_t)W * L.ls_cap * 4;
-  L.total = L.out + (size_t)W * L.ls_cap * 4;
+  L.recv = 1024;      // header: [0] status, [16] epoch of the last call, [17] workgroups of the running call that have finished
+  L.out = L.recv + (size_t)W * L.ls_cap * 8;
+  L.total = L.out + (size_t)W * L.ls_cap * 8;
   return L;
 }
 struct CommArgs {
   char* peer[SW_COMM_MAXW];   // every rank's exchange buffer as mapped HERE (own buffer at [rank])
   int rank, W, nblk;
   long long n, ls, ls_cap;
-  size_t flags, recv, out;
+  size_t recv, out;
 };
-__device__ __forceinline__ unsigned* comm_flag(char* buf, size_t flags, int hop, int src, int blk) {
-  return reinterpret_cast<unsigned*>(buf + flags) + ((size_t)(hop * SW_COMM_MAXW + src) * SW_COMM_MAXBLK + blk) * SW_COMM_FLAG_STRIDE;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// system-scope 16-byte accesses to exchange buffers (own or a peer's): two granules {value bits, epoch}
+__device__ __forceinline__ void st_gran(char* p, float a, float b, unsigned e) {
+  const u32x4 v = {__float_as_uint(a), e, __float_as_uint(b), e};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
 }
-// all threads: their payload stores are complete and visible system-wide before thread 0 raises the flags
-__device__ __forceinline__ void comm_publish(const CommArgs& A, int hop, int blk, unsigned e) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's stores have been acknowledged (memory / the peer)
-  __syncthreads();
-  if (threadIdx.x < 64) {                               // ONE wave releases (a cached buffer: the write-back of this CU's L2)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    if ((int)threadIdx.x < A.W)
-      __hip_atomic_store(comm_flag(A.peer[threadIdx.x], A.flags, hop, A.rank, blk), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+__device__ __forceinline__ void ld_gran_issue(u32x4& v, const char* p) {        // no wait: ld_gran_wait() in front of the first use
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
 }
-// thread s < W polls the flag rank s raises here; returns false (for every thread) on a time-out
-__device__ __forceinline__ bool comm_wait(const CommArgs& A, int hop, int blk, unsigned e, int* ok_lds) {
-  if (threadIdx.x == 0) *ok_lds = 1;
-  __syncthreads();
-  if ((int)threadIdx.x < A.W) {
-    unsigned* f = comm_flag(A.peer[A.rank], A.flags, hop, threadIdx.x, blk);
-    const unsigned long long t0 = wall_clock64();
-    // (epochs are compared as a signed distance: the counter may wrap)
-    while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
-      __builtin_amdgcn_s_sleep(2);
-      if (wall_clock64() - t0 > SW_COMM_TIMEOUT_TICKS) {
-        *ok_lds = 0;
-        break;
+__device__ __forceinline__ void ld_gran_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// the W granule pairs at base + k * stride (k < W), polled until every tag is e; false on a time-out
+__device__ __forceinline__ bool poll_grans(u32x4 (&v)[SW_COMM_MAXW], const char* base, size_t stride, int W, unsigned e) {
+  unsigned long long t0 = 0;
+  for (;;) {
+#pragma unroll
+    for (int k = 0; k < SW_COMM_MAXW; ++k)
+      if (k < W) ld_gran_issue(v[k], base + (size_t)k * stride);        // W loads in flight, one wait
+    ld_gran_wait();
+    bool all = true;
+#pragma unroll
+    for (int k = 0; k < SW_COMM_MAXW; ++k)
+      if (k < W) {
+        asm volatile("" : "+v"(v[k]));                                  // uses stay behind the wait
+        all = all && v[k][1] == e && v[k][3] == e;
       }
-    }
+    if (all) return true;
+    if (t0 == 0) t0 = wall_clock64();
+    else if (wall_clock64() - t0 > SW_COMM_TIMEOUT_TICKS) return false;
+    __builtin_amdgcn_s_sleep(1);
   }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  return *ok_lds != 0;
 }
 }  // namespace
 
-__global__ __launch_bounds__(256) void allreduce_direct_kernel(CommArgs A, float* __restrict__ grad) {
-  __shared__ int ok_lds;
-  const int b = blockIdx.x, W = A.W, r = A.rank;
+// ADAM: the rank also applies the optimizer step to its replica while it copies the reduced gradient out (the arithmetic of
+// sw_adam_packed / the in-reduction updates, sw_wgrad.h; a Discriminator's registered weight images follow the update): one
+// launch per bucket instead of exchange + update.  The bias corrections (two double-precision pow) are computed by one lane
+// under hop 1.
+template <bool ADAM>
+__global__ __launch_bounds__(256) void allreduce_direct_kernel(CommArgs A, float* __restrict__ grad, WgAdam ad) {
+  __shared__ float bcs[2];
+  if (ADAM && threadIdx.x == 64) wg_adam_bc_compute(ad.step, ad.beta1, ad.beta2, bcs[0], bcs[1]);
+  const int b = blockIdx.x, W = A.W, r = A.rank;   // (b: this workgroup's chunk of every slice)
   char* mine = A.peer[r];
   unsigned* hdr = reinterpret_cast<unsigned*>(mine);
-  const unsigned e = hdr[16 + b] + 1u;
+  // ONE epoch per call for the whole buffer (a per-workgroup epoch could collide: the chunking depends on n, so a granule is
+  // written by different workgroup indices in different calls).  It advances when the LAST workgroup of the launch finishes -
+  // by then every workgroup has read it.
+  const unsigned e = __hip_atomic_load(&hdr[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
   const long long chunk = A.ls / A.nblk, c0 = (long long)b * chunk;      // floats; multiple of 4
-  const int nq = (int)(chunk >> 2);
+  const int np = (int)(chunk >> 1);                                       // pairs of floats in this workgroup's chunk
+  bool ok = true;
   // ---- hop 1: slice p of this rank's gradient -> slot r of rank p's recv region -------------------------------------
   for (int pp = 0; pp < W; ++pp) {
     const int p = (r + 1 + pp) % W;                                        // own slice last; peers start on different links
     const long long g0 = (long long)p * A.ls + c0;
-    float* dst = reinterpret_cast<float*>(A.peer[p] + A.recv) + (size_t)r * A.ls_cap + c0;
-    for (int q = threadIdx.x; q < nq; q += 256) {
-      const long long g = g0 + 4LL * q;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (g + 3 < A.n) v = ld4(grad + g);
-      else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (g + k < A.n) v[k] = grad[g + k];
-      }
-      st4(dst + 4 * q, v);
+    char* dst = A.peer[p] + A.recv + ((size_t)r * A.ls_cap + c0) * 8;
+    for (int i = threadIdx.x; i < np; i += 256) {
+      const long long g = g0 + 2LL * i;
+      const float a = g < A.n ? grad[g] : 0.f, bb = g + 1 < A.n ? grad[g + 1] : 0.f;
+      st_gran(dst + (size_t)i * 16, a, bb, e);
     }
   }
-  comm_publish(A, 0, b, e);
-  bool ok = comm_wait(A, 0, b, e, &ok_lds);
-  // ---- reduce this rank's slice in rank order, hop 2: the sum -> slice r of every rank's out region ------------------
+  // ---- this rank's slice summed in rank order as the slots arrive, hop 2: the sum -> slice r of every rank's out region
   {
-    const float* rv = reinterpret_cast<const float*>(mine + A.recv) + c0;
-    for (int q = threadIdx.x; q < nq; q += 256) {
-      f32x4 s = ld4(rv + 4 * q);
-      for (int src = 1; src < W; ++src) s += ld4(rv + (size_t)src * A.ls_cap + 4 * q);
+    const char* rv = mine + A.recv + (size_t)c0 * 8;
+    for (int i = threadIdx.x; i < np; i += 256) {
+      u32x4 v[SW_COMM_MAXW];
+      ok = poll_grans(v, rv + (size_t)i * 16, (size_t)A.ls_cap * 8, W, e) && ok;
+      float s0 = __uint_as_float(v[0][0]), s1 = __uint_as_float(v[0][2]);
+#pragma unroll
+      for (int src = 1; src < SW_COMM_MAXW; ++src)
+        if (src < W) {
+          s0 += __uint_as_float(v[src][0]);
+          s1 += __uint_as_float(v[src][2]);
+        }
       for (int pp = 0; pp < W; ++pp) {
         const int p = (r + 1 + pp) % W;
-        st4(reinterpret_cast<float*>(A.peer[p] + A.out) + (size_t)r * A.ls_cap + c0 + 4 * q, s);
+        st_gran(A.peer[p] + A.out + ((size_t)r * A.ls_cap + c0) * 8 + (size_t)i * 16, s0, s1, e);
       }
     }
   }
-  comm_publish(A, 1, b, e);
-  ok = comm_wait(A, 1, b, e, &ok_lds) && ok;
-  // ---- the all-reduced gradient back over the rank's buffer ----------------------------------------------------------
+  if constexpr (ADAM) __syncthreads();      // bcs
+  // ---- the all-reduced gradient back over the rank's buffer (and the optimizer step) ----------------------------------
   {
-    const float* ov = reinterpret_cast<const float*>(mine + A.out) + c0;
-    for (int p = 0; p < W; ++p) {
-      const long long g0 = (long long)p * A.ls + c0;
-      for (int q = threadIdx.x; q < nq; q += 256) {
-        const long long g = g0 + 4LL * q;
-        const f32x4 v = ld4(ov + (size_t)p * A.ls_cap + 4 * q);
-        if (g + 3 < A.n) st4(grad + g, v);
-        else {
+    const char* ov = mine + A.out + (size_t)c0 * 8;
+    for (int i = threadIdx.x; i < np; i += 256) {
+      u32x4 vs[SW_COMM_MAXW];
+      ok = poll_grans(vs, ov + (size_t)i * 16, (size_t)A.ls_cap * 8, W, e) && ok;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) if (g + k < A.n) grad[g + k] = v[k];
+      for (int p = 0; p < SW_COMM_MAXW; ++p) {
+        if (p >= W) continue;
+        const long long g = (long long)p * A.ls + c0 + 2LL * i;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          if (g + k >= A.n) continue;
+          const float val = __uint_as_float(vs[p][2 * k]);
+          grad[g + k] = val;
+          if constexpr (ADAM) wg_adam_fin(ad, wg_adam_pre(ad, grad + g + k), bcs[0], bcs[1], val);
         }
       }
     }
   }
+  if (!ok) hdr[0] = 1u;          // a peer never arrived: the result is garbage, say so (sw_comm_status)
+  __syncthreads();
   if (threadIdx.x == 0) {
-    hdr[16 + b] = e;
-    if (!ok) hdr[0] = 1u;      // a peer never arrived: the result is garbage, say so (sw_comm_status)
+    if (__hip_atomic_fetch_add(&hdr[17], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)A.nblk - 1u) {
+      __hip_atomic_store(&hdr[17], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&hdr[16], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -206,8 +224,8 @@ extern "C" int sw_comm_status(const void* own_buf, int* status) {
   *status = (int)v;
   return SW_OK;
 }
-extern "C" int sw_allreduce_direct(void* const* peer_bufs, int rank, int world, long long max_floats, float* grad, long long n,
-                                   void* stream) {
+static int allreduce_direct_launch(void* const* peer_bufs, int rank, int world, long long max_floats, float* grad, long long n,
+                                   const WgAdam* adam, void* stream) {
   if (!peer_bufs || !grad || world < 1 || world > SW_COMM_MAXW || rank < 0 || rank >= world || n < 0 || n > max_floats)
     return SW_EARG;
   if (n == 0) return SW_OK;
@@ -218,15 +236,35 @@ extern "C" int sw_allreduce_direct(void* const* peer_bufs, int rank, int world, 
     A.peer[p] = static_cast<char*>(peer_bufs[p]);
   }
   A.rank = rank; A.W = world;
-  // ~4 KB of every slice per workgroup, 4 .. SW_COMM_MAXBLK workgroups: the same on every rank (a function of n and W)
-  long long nb = (n * 4 / world + 4095) / 4096;
+  // ~2 KB of every slice per workgroup (one pair of floats = one 16-byte granule pair per thread and slice: every poll of
+  // a phase is ONE round trip), 4 .. SW_COMM_MAXBLK workgroups: the same on every rank (a function of n and W)
+  long long nb = (n * 4 / world + 2047) / 2048;
   A.nblk = (int)(nb < 4 ? 4 : nb > SW_COMM_MAXBLK ? SW_COMM_MAXBLK : nb);
   A.n = n;
   A.ls = comm_slice_floats(n, world, A.nblk);
   A.ls_cap = L.ls_cap;
   if (A.ls > A.ls_cap) return SW_ESHAPE;
-  A.flags = L.flags; A.recv = L.recv; A.out = L.out;
-  SW_LAUNCH(allreduce_direct_kernel, dim3(A.nblk), dim3(256), 0, (hipStream_t)stream, A, grad);
+  A.recv = L.recv; A.out = L.out;
+  if (adam) SW_LAUNCH(allreduce_direct_kernel<true>, dim3(A.nblk), dim3(256), 0, (hipStream_t)stream, A, grad, *adam);
+  else SW_LAUNCH(allreduce_direct_kernel<false>, dim3(A.nblk), dim3(256), 0, (hipStream_t)stream, A, grad, WgAdam());
   SW_CHECK_LAUNCH("allreduce_direct_kernel");
   return SW_OK;
+}
+extern "C" int sw_allreduce_direct(void* const* peer_bufs, int rank, int world, long long max_floats, float* grad, long long n,
+                                   void* stream) {
+  return allreduce_direct_launch(peer_bufs, rank, world, max_floats, grad, n, nullptr, stream);
+}
+extern "C" int sw_allreduce_direct_adam(void* const* peer_bufs, int rank, int world, long long max_floats, float* grad, long long n,
+                                        float* w, float* m, float* v, const float* step, double lr, double beta1, double beta2,
+                                        double eps, int disc_Tp, void* stream) {
+  if (!w || !m || !v || !step || n < 1) return SW_EARG;
+  WgAdam ad;
+  ad.w = w; ad.m = m; ad.v = v; ad.g0 = grad; ad.step = step; ad.n = (size_t)n;
+  ad.lr = lr; ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps;
+  if (disc_Tp > 0) {
+    const DiscImages di = sw_disc_images_for(w, disc_Tp);
+    ad.img = const_cast<float*>(di.img);
+    ad.tab = di.tab;
+  }
+  return allreduce_direct_launch(peer_bufs, rank, world, max_floats, grad, n, &ad, stream);
 }

@@ -317,6 +317,12 @@ class SocialWaysTrainer:
             else:
                 torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
+    def _exchange_adam(self, opt, flat):
+        """Does the direct exchange also apply this optimizer's update (sw_allreduce_direct_adam)?  A data-parallel step on
+        SW_ALLREDUCE=direct with a packed, decay-free Adam; SW_EXCHANGE_ADAM=0 keeps exchange and update apart."""
+        return (self._direct is not None and (self.world > 1 or self._force_dist) and isinstance(opt, PackedAdam) and opt.native
+                and opt.fusable and flat.numel() >= 1024 and os.environ.get("SW_EXCHANGE_ADAM", "1") != "0")
+
     def _probe_graph_collectives(self):
         """Can this process group's all-reduce be recorded in a hipGraph and replayed?  Only RCCL ("nccl") is
         tried: a 4 KB SUM all-reduce is captured, replayed twice and compared with the known answer; every rank
@@ -684,6 +690,10 @@ class SocialWaysTrainer:
                                                        w_snapshot=backup if u == 1 else None)
                 ops.disc_backward_gan(D._flat, dctx, labels, codes, targets, (0, 1), noise, g_label, g_code, d_gflat, (), ws=ws,
                                       loss_part=out[u], adam=adam)
+            if self._exchange_adam(self.D_optimizer, d_gflat):
+                # SW_ALLREDUCE=direct: gradient exchange + D's Adam update in ONE launch (no all-reduce point to hand back)
+                self._direct.adam(d_gflat, self.D_optimizer, None if steps is None else steps[u])
+                continue
             yield d_gflat
             if not fuse:
                 self.D_optimizer.step() if steps is None else self.D_optimizer.step(steps[u])
@@ -734,9 +744,12 @@ class SocialWaysTrainer:
         else:
             ops.gen_backward(enc._flat, emb._flat, att._flat, dec._flat, gctx, dpred, enc._gflat, emb._gflat, att._gflat,
                              dec._gflat, ws=ws, aux=restore, tag="g", adam=adam, dfuse=dfuse)
-        yield G._gflat_all
-        if not fuse:
-            self.predictor_optimizer.step() if steps is None else self.predictor_optimizer.step(steps[U + 1])
+        if self._exchange_adam(self.predictor_optimizer, G._gflat_all):
+            self._direct.adam(G._gflat_all, self.predictor_optimizer, None if steps is None else steps[U + 1])
+        else:
+            yield G._gflat_all
+            if not fuse:
+                self.predictor_optimizer.step() if steps is None else self.predictor_optimizer.step(steps[U + 1])
         self.last_pred_hat = pred_hat
         self.last_pred_hat_k = pred_hat_k if KV > 1 else None
 

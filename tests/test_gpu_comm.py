@@ -10,7 +10,8 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-SIZES = (27939, 86122, 4096, 1031)        # D's and G's packed gradients (train.py:379-385), a round size, an odd one
+SIZES = (27942, 86124, 4096, 1031, 86124, 2048, 27942)   # D's and G's packed gradients (train.py:379-385), round and odd sizes;
+                                                        # alternating sizes change the chunking between consecutive calls
 
 
 def _port():
