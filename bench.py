@@ -119,7 +119,8 @@ def kernel_src_sha16():
     """Identity of the kernel sources a PMC pass was taken with (profiles/*_pmc_*.json carries the same)."""
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "socialways_amd", "csrc", "*.h*"))):
-        if os.path.basename(f) != "sw_wide.hip":       # the wide path's kernels (hidden sizes > 64) are in no measured step
+        # the wide path's kernels (hidden sizes > 64) and the data-parallel exchange are in no measured single-process step
+        if os.path.basename(f) not in ("sw_wide.hip", "sw_comm.hip"):
             h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 

@@ -65,7 +65,7 @@ if mfma:
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 h = hashlib.sha256()
 for f in sorted(glob.glob(os.path.join(root, "socialways_amd", "csrc", "*.h*"))):
-    if os.path.basename(f) != "sw_wide.hip":       # as bench.kernel_src_sha16: the wide path is in no measured step
+    if os.path.basename(f) not in ("sw_wide.hip", "sw_comm.hip"):       # as bench.kernel_src_sha16: in no measured step
         h.update(open(f, "rb").read())
 commit = os.environ.get("SW_COMMIT")          # the GPU box has no .git: tools/collect_profiles.sh is given the commit
 if not commit:
