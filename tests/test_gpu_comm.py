@@ -132,3 +132,60 @@ def test_data_parallel_step_on_the_direct_allreduce_equals_the_process_groups():
         assert ret[("direct", r)][0] == ret[("group", r)][0], "losses / ADE / FDE differ on rank %d" % r
         assert torch.equal(ret[("direct", r)][1], ret[("group", r)][1]) and torch.equal(ret[("direct", r)][2], ret[("group", r)][2])
     assert torch.equal(ret[("direct", 0)][1], ret[("direct", 1)][1]) and torch.equal(ret[("direct", 0)][2], ret[("direct", 1)][2])
+
+
+def _dp4_worker(rank, world, port, ret, mode):
+    import torch.distributed as dist
+    import socialways_amd as sw
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if mode == "direct":
+        os.environ["SW_ALLREDUCE"] = "direct"
+    else:
+        os.environ.pop("SW_ALLREDUCE", None)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # packed batches of 3 .. 5 scenes over 4 ranks: in most steps at least one rank has NO scene and takes part in the three
+    # exchanges through _empty_step (plain exchange + separate update) while its peers run the fused exchange + Adam launch
+    t = sw.synth_tracks(15, [9, 2, 7, 12, 3, 5, 8, 1, 6, 4, 10, 2, 7, 3, 5], 8, 12, seed=21)
+    data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
+    torch.manual_seed(3)
+    tr = sw.SocialWaysTrainer(12, use_social=True, device="cuda:0", process_group=dist.group.WORLD)
+    gen = torch.Generator().manual_seed(8)
+    out, empties = [], 0
+    for e in range(3):
+        draws = []
+        ade, fde, losses, sizes = tr.train_epoch(data, 24, draw=lambda bs: (0.01 * (e + 1), 0.95, torch.rand(bs, 32, generator=gen)))
+        out.append((ade, fde, np.asarray(losses).tolist()))
+    ret[(mode, rank)] = (out, tr.G._flat_all.cpu().clone(), tr.D._flat.cpu().clone(),
+                         tr._direct.status() if tr._direct is not None else 0)
+    tr.release_graphs()
+    if tr._direct is not None:
+        tr._direct.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_four_ranks_with_idle_ranks_direct_exchange_follows_the_process_groups():
+    """4 ranks and packed batches of a few scenes: ranks without a scene join the exchanges through _empty_step (the plain
+    sw_allreduce_direct + a separate update) while their peers run sw_allreduce_direct_adam - the two forms must interoperate.
+    Replicas stay bit-identical in each mode; the direct trajectory (rank-order sums) follows the process group's (gloo's
+    order) within fp32 summation noise."""
+    import torch.multiprocessing as mp
+    from socialways_amd import data as D
+    sb = np.asarray([[0, 9], [9, 11], [11, 18]])
+    assert any(hi <= lo for lo, hi in D.shard_scenes(sb, 4)), "the test needs a rank without scenes"
+    ret = mp.Manager().dict()
+    for mode in ("group", "direct"):
+        mp.spawn(_dp4_worker, args=(4, _port(), ret, mode), nprocs=4, join=True)
+    for mode in ("group", "direct"):
+        for r in range(1, 4):
+            assert torch.equal(ret[(mode, r)][1], ret[(mode, 0)][1]) and torch.equal(ret[(mode, r)][2], ret[(mode, 0)][2]), \
+                "%s: replicas diverged (rank %d)" % (mode, r)
+            assert ret[(mode, r)][3] == 0
+    a, b = ret[("direct", 0)], ret[("group", 0)]
+    for e in range(3):
+        np.testing.assert_allclose(a[0][e][2], b[0][e][2], rtol=2e-4, atol=1e-6)
+        assert abs(a[0][e][0] - b[0][e][0]) < 1e-5 and abs(a[0][e][1] - b[0][e][1]) < 1e-5
+    lr = 1e-3
+    assert float((a[2] - b[2]).abs().max()) <= 2.2 * lr * 3 * 8 and float((a[1] - b[1]).abs().max()) <= 2.2 * 1e-4 * 3 * 8
