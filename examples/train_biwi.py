@@ -11,6 +11,8 @@
   prediction npz files visualize.py / calc_statistics.py read, checkpoint in the reference's format
 * data parallel: `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 examples/train_biwi.py ...`
   (one rank per GPU over RCCL; every packed batch is sharded scene-aligned, rank 0 evaluates and saves)
+  `SW_ALLREDUCE=direct` exchanges the gradients through the library's own two-hop kernel over hipIpc-mapped peer buffers
+  (one launch per optimizer step: exchange + Adam, inside the step's hipGraph) instead of RCCL's ring
 """
 import argparse
 import os
