@@ -845,8 +845,10 @@ def main():
                        "collectives": collectives, "rccl_ranks": (world if pg is not None else None),
                        "backend": backend,       # "nccl" = RCCL; "gloo" = ranks sharing devices, a rehearsal, not a measurement
                        "allreduces_per_step": (3 if pg is not None else 0),
-                       "allreduce": ("direct (csrc/sw_comm.hip)" if os.environ.get("SW_ALLREDUCE", "") == "direct" else "process group") if pg is not None else None,
+                       "allreduce": ("direct (csrc/sw_comm.hip)" if (leg.tr is not None and getattr(leg.tr, "_direct", None) is not None)
+                                     else "process group") if pg is not None else None,
                        "exchange": exchange,      # N > 1: us per all-reduce of each bucket on both forms + the step on the direct form
+                       "exchange_probe": getattr(leg.tr, "exchange_probe", None) if leg.tr is not None else None,      # SW_ALLREDUCE=auto: what the probe measured / chose
                        "replicas_identical": replicas_identical,
                        "step_alg_gflop": fl["step"] / 1e9,
                        "step_frac_of_fp32_peak": fl["step"] / per_step / (PEAK_FP32_TFLOPS * 1e12),

@@ -81,3 +81,75 @@ class DirectAllReduce:
             L.call("sw_comm_ipc_close", p)
         L.call("sw_comm_free", self._own)
         self._own, self._opened = None, []
+
+
+def probe(process_group, device, bucket_floats, rounds=3, reps=30):
+    """SW_ALLREDUCE=auto: build the direct exchange, check it against the process group's all-reduce on this node and time
+    both on the step's bucket sizes; every rank runs this at the same point (it is collective).  Returns (DirectAllReduce or
+    None, report): the direct form is chosen only if EVERY rank built it, every check agreed (to fp32 summation order: the
+    group's reduction order is its own) and its summed time over the buckets is the smaller one (max over ranks)."""
+    dist = torch.distributed
+    dev = L.indexed_device(device)
+    cpu_pg = dist.get_backend(process_group) != "nccl"
+    rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+
+    def agree(ok):          # logical AND over the ranks
+        t = torch.tensor([1.0 if ok else 0.0], device="cpu" if cpu_pg else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=process_group)
+        return bool(t.item() > 0.5)
+
+    def slowest(x):
+        t = torch.tensor([float(x)], device="cpu" if cpu_pg else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=process_group)
+        return float(t.item())
+    rep = {"buckets_floats": [int(n) for n in bucket_floats], "chosen": "group"}
+    ar, err = None, None
+    try:
+        ar = DirectAllReduce(process_group, dev, max(bucket_floats))
+    except Exception as e:      # noqa: BLE001 - any failure means "use the process group"
+        err = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
+    if not agree(ar is not None):
+        rep["reason"] = err or "a peer could not build the exchange"
+        if ar is not None:
+            ar.close()
+        return None, rep
+    gen = torch.Generator().manual_seed(1234 + rank)
+    ok = True
+    for _ in range(rounds):
+        for n in bucket_floats:
+            x = torch.randn(n, generator=gen).to(dev)
+            want = x.clone()
+            dist.all_reduce(want, group=process_group)
+            got = ar(x.clone())
+            torch.cuda.synchronize(dev)
+            ok = ok and bool(torch.allclose(got, want, rtol=1e-5, atol=1e-6 * world))
+    ok = ok and ar.status() == 0
+    if not agree(ok):
+        rep["reason"] = "the direct exchange disagreed with the group's all-reduce (or a wait timed out)"
+        ar.close()
+        return None, rep
+
+    def time_calls(fn):
+        out = []
+        for n in bucket_floats:
+            b = torch.zeros(n, device=dev)
+            for _ in range(5):
+                fn(b)
+            dist.barrier(group=process_group)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn(b)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            out.append(slowest(e0.elapsed_time(e1) * 1e3 / reps))
+        return out
+    rep["group_us"] = time_calls(lambda b: dist.all_reduce(b, group=process_group))
+    rep["direct_us"] = time_calls(ar)
+    if sum(rep["direct_us"]) < sum(rep["group_us"]):
+        rep["chosen"] = "direct"
+        return ar, rep
+    rep["reason"] = "the process group's all-reduce is faster here"
+    ar.close()
+    return None, rep

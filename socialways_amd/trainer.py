@@ -238,12 +238,19 @@ class SocialWaysTrainer:
         # SW_ALLREDUCE=direct: the three gradient buckets of a step go through the library's own two-hop all-reduce over
         # hipIpc-mapped exchange buffers (csrc/sw_comm.hip) instead of RCCL's ring; everything else (epoch sums, broadcasts)
         # stays on the process group.  The kernel is an ordinary graph node: the step is captured as ONE graph.
-        self._direct = None
+        # SW_ALLREDUCE=auto: build it, check it against the group's all-reduce and time both on this node's links; use it if
+        # every rank agrees that it is correct and faster (comm.probe; the verdict is kept in self.exchange_probe).
+        self._direct, self.exchange_probe = None, None
+        mode = os.environ.get("SW_ALLREDUCE", "")
         if (self.pg is not None and (self.world > 1 or self._force_dist) and self.device.type == "cuda"
-                and os.environ.get("SW_ALLREDUCE", "") == "direct"):
-            from .comm import DirectAllReduce
-            self._direct = DirectAllReduce(self.pg, self.device, max(self.G._gflat_all.numel(), self.D._gflat.numel()))
-            if self._graph_collectives is None:
+                and mode in ("direct", "auto")):
+            from . import comm
+            buckets = [self.D._gflat.numel(), self.G._gflat_all.numel()]
+            if mode == "direct":
+                self._direct = comm.DirectAllReduce(self.pg, self.device, max(buckets))
+            else:
+                self._direct, self.exchange_probe = comm.probe(self.pg, self.device, buckets)
+            if self._direct is not None and self._graph_collectives is None:
                 self._graph_collectives = bool(self.use_graph)
         self.ws = ops.Workspaces(self.device)
         self._ws_version = 0
@@ -819,6 +826,9 @@ class SocialWaysTrainer:
         flush()
         allo = torch.stack(outs)
         self._allreduce(allo)
+        if self._direct is not None and self._direct.status() != 0:
+            raise L.SocialWaysHipError("the direct gradient exchange timed out waiting for a peer during this epoch "
+                                       "(sw_comm_status): gradients of at least one step are invalid")
         o = allo.double().cpu().numpy()
         ade = float(o[:, -1, 0].sum() / data.n_train_samples)
         fde = float(o[:, -1, 1].sum() / data.n_train_samples)

@@ -95,8 +95,8 @@ def _dp_worker(rank, world, port, ret, mode):
     import socialways_amd as sw
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if mode == "direct":
-        os.environ["SW_ALLREDUCE"] = "direct"
+    if mode in ("direct", "auto"):
+        os.environ["SW_ALLREDUCE"] = mode
     else:
         os.environ.pop("SW_ALLREDUCE", None)
     torch.cuda.set_device(0)
@@ -112,11 +112,28 @@ def _dp_worker(rank, world, port, ret, mode):
         ade, fde, losses, sizes = tr.train_epoch(data, data.n_train_samples, draw=lambda bs: (0.01 * (e + 1), 0.95, z))
         out.append((ade, fde, np.asarray(losses[0]).tolist()))
     ret[(mode, rank)] = (out, tr.G._flat_all.cpu().clone(), tr.D._flat.cpu().clone(), tr._graph_collectives,
-                         tr._direct.status() if tr._direct is not None else 0)
+                         tr._direct.status() if tr._direct is not None else 0, tr.exchange_probe)
     tr.release_graphs()
     if tr._direct is not None:
         tr._direct.close()
     dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_auto_mode_probes_both_exchanges_and_trains_like_the_chosen_one():
+    """SW_ALLREDUCE=auto: every rank builds the direct exchange, checks it against the group's all-reduce and times both;
+    the choice is collective.  Here (gloo stages CUDA tensors through the host) the direct form must win, and the trajectory
+    must equal the SW_ALLREDUCE=direct run bit for bit."""
+    import torch.multiprocessing as mp
+    ret = mp.Manager().dict()
+    for mode in ("auto", "direct"):
+        mp.spawn(_dp_worker, args=(2, _port(), ret, mode), nprocs=2, join=True)
+    for r in (0, 1):
+        pr = ret[("auto", r)][5]
+        assert pr["chosen"] == "direct" and len(pr["group_us"]) == 2 and sum(pr["direct_us"]) < sum(pr["group_us"]), pr
+        assert ret[("auto", r)][0] == ret[("direct", r)][0]
+        assert torch.equal(ret[("auto", r)][1], ret[("direct", r)][1]) and torch.equal(ret[("auto", r)][2], ret[("direct", r)][2])
+    assert ret[("auto", 0)][5]["direct_us"] == ret[("auto", 1)][5]["direct_us"]        # the ranks decided on the same numbers
 
 
 @pytest.mark.timeout(900)
