@@ -1,4 +1,4 @@
-"""Run the generator forward (save + ADE) a few times at m1 size in the tile mode given by SW_TILE_MODE (for rocprofv3)."""
+"""Run the generator forward (save + ADE) a few times at m1 size (for rocprofv3)."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
