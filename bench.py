@@ -586,6 +586,7 @@ def main():
             return out
         rep["group_us"] = time_calls(lambda b: torch.distributed.all_reduce(b, group=pg))
         rep["group_backend"] = backend
+        prev_mode = os.environ.get("SW_ALLREDUCE")
         try:
             ar = DirectAllReduce(pg, dev, max(rep["buckets_floats"]))
             rep["direct_us"] = time_calls(ar)
@@ -605,7 +606,10 @@ def main():
         except Exception as e:      # noqa: BLE001 - the report must not lose the bench line
             rep["direct_error"] = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
         finally:
-            os.environ.pop("SW_ALLREDUCE", None)
+            if prev_mode is None:
+                os.environ.pop("SW_ALLREDUCE", None)
+            else:
+                os.environ["SW_ALLREDUCE"] = prev_mode
         return rep
 
     def short_leg(lg, n, w):
