@@ -523,3 +523,50 @@ def test_rows_gemm_on_the_matrix_cores_any_shape_and_stride(R, K, N):
     want = dx0[:, :K].double() + dy[:, :N].double() @ W.double()
     assert_close(dx[:, :K].cpu(), want.float(), 2e-5, 2e-6 * max(float(want.abs().max()), 1.0), "dx += dy W")
     assert torch.equal(dx[:, K:].cpu(), dx0[:, K:])
+
+
+_ENC8_SNIPPET = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+import socialways_amd as sw
+from socialways_amd import _lib as L
+torch.manual_seed(0)
+G = sw.Generator(use_social=True, device="cuda:0")
+G.unify()
+enc, dec, emb, att = G.encoder._flat, G.decoder._flat, G.feature_embedder._flat, G.attention._flat
+lib = L.load()
+img = torch.empty(lib.sw_gen_image_floats(), device="cuda")
+L.call("sw_gen_images", L.ptr(enc), L.ptr(dec), L.ptr(emb), L.ptr(att), L.ptr(img), L.stream())
+out = {}
+for B, T in ((2048, 8), (37, 5), (16, 2)):          # the metric shape, a ragged last tile, the shortest sequence
+    x = (torch.rand(B, T, 2, device="cuda", generator=torch.Generator(device="cuda").manual_seed(B)).cumsum(1) * 0.1).contiguous()
+    h0, c0 = torch.randn(B, 64, device="cuda") * 0.1, torch.randn(B, 64, device="cuda") * 0.1
+    hT, cT = torch.empty(B, 64, device="cuda"), torch.empty(B, 64, device="cuda")
+    act, x4s = torch.zeros(T * B * 384, device="cuda"), torch.zeros(T * B * 4, device="cuda")
+    L.call("sw_enc_lstm_fwd", L.ptr(x), 0, L.ptr(enc), L.ptr(h0), L.ptr(c0), B, T, L.ptr(hT), L.ptr(cT), None, L.ptr(act), L.ptr(x4s), 0, L.stream())
+    torch.cuda.synchronize()
+    out[(B, T)] = [t.cpu() for t in (hT, cT, act, x4s)]
+torch.save(out, sys.argv[2])
+'''
+
+
+@pytest.mark.gpu
+def test_encoder_forward_on_eight_waves_equals_the_four_wave_kernel(tmp_path):
+    """enc_lstm_fwd8_kernel (two waves per SIMD, W_hh split 8 ways, rows permuted so that the cell update stays lane-local;
+    used up to one tile per CU) against enc_lstm_fwd_kernel: final state, saved rows and saved inputs bit for bit - with an
+    initial state, a ragged last tile and a two-step sequence.  The switch is read once per process: two subprocesses."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for v in ("0", "1"):
+        f = str(tmp_path / ("enc8_%s.pt" % v))
+        p = subprocess.run([sys.executable, "-c", _ENC8_SNIPPET, root, f], env=dict(os.environ, SW_ENC8=v), capture_output=True,
+                           text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[v] = torch.load(f)
+    for key in res["0"]:
+        for a, b, what in zip(res["0"][key], res["1"][key], ("hT", "cT", "act", "x4s")):
+            assert torch.equal(a, b), "B, T = %s: %s differs (max |diff| %.3g)" % (key, what, float((a - b).abs().max()))
+    assert float(res["0"][(2048, 8)][0].abs().max()) > 0.0
