@@ -159,6 +159,8 @@ class PackedAdam:
 class SocialWaysTrainer:
     STEPS_PER_LAUNCH = 4    # train_epoch: consecutive packed batches of one scene layout per graph launch (step_many)
     Z_COLS = 32             # noise columns of the kernels (hidden size 64: train.py:81); smaller models are zero-padded
+    _direct = None          # the direct gradient exchange (SW_ALLREDUCE=direct / auto; the fused trainer only) and what the
+    exchange_probe = None   # auto mode's probe measured - class-level defaults: the wider trainers have their own __init__
 
     def __new__(cls, n_next=None, hidden_size=64, *args, **kw):
         """Widths above the fused kernels' 64 units and latent-code counts other than 2 (train.py:42-44, 65) train on
