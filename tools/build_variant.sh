@@ -5,7 +5,7 @@ set -e
 cd $(dirname $0)/..
 N=$1; X=$2
 mkdir -p variants/obj_$N
-for f in sw_lstm sw_decoder sw_social sw_disc sw_wgrad sw_misc sw_modules sw_generic; do
+for f in sw_lstm sw_decoder sw_social sw_disc sw_wgrad sw_misc sw_modules sw_generic sw_wide sw_comm; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -fno-gpu-rdc -fno-slp-vectorize $X -c socialways_amd/csrc/$f.hip -o variants/obj_$N/$f.o &
 done
 wait
