@@ -77,7 +77,7 @@ def main(argv=None):
             print("Avg ADE,FDE = (%.3f, %.3f) | Min(%d) ADE,FDE = (%.3f, %.3f)" % (m[0], m[1], args.k, m[2], m[3]))
             tr.save(os.path.join(args.out, "socialWays-crowd.pt"), epoch=epoch)
     if world > 1:
-        tr.release_graphs()
+        tr.close()              # captured collectives and the direct exchange's buffers go before their process group
         torch.distributed.destroy_process_group()
     return tr
 

@@ -513,8 +513,11 @@ int sw_wide_wgrad(const long long* desc, int n, float* wgrad_ws, void* stream);
  *      calls sw_allreduce_direct with the `world` buffer addresses as mapped in ITS process (its own at [rank]): grad[0..n)
  *      becomes the element-wise sum over the ranks, every element summed in rank order by one rank (replicas receive
  *      identical bits).  Collective: every rank must issue the same sequence of calls (same n); asynchronous on `stream`,
- *      capturable in a hipGraph.  A peer that never arrives is given up after ~4 s: sw_comm_status then reports 1 (the
- *      gradient is garbage) instead of a hung device.  world <= 16.                                                     */
+ *      capturable in a hipGraph.  A peer that never arrives is given up after SW_COMM_TIMEOUT_S seconds (environment,
+ *      default 30) instead of hanging the device: the rank whose wait timed out publishes nothing from it (its peers time
+ *      out in turn), writes neither the gradient nor - in the _adam form - the weights for those elements, every later call
+ *      on its buffer returns at once, and sw_comm_status (which synchronises the device) reports 1.  The caller makes the
+ *      status collective before it trusts the results (trainer.train_epoch).  world <= 16.                                 */
 long long sw_comm_bytes(int world, long long max_floats);
 int sw_comm_alloc(long long bytes, void** ptr);
 int sw_comm_free(void* ptr);

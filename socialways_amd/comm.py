@@ -17,37 +17,77 @@ from . import _lib as L
 
 class DirectAllReduce:
     def __init__(self, process_group, device, max_floats):
+        """Collective over `process_group`, and FAILURE-SYMMETRIC: every rank takes part in the same sequence of group
+        operations whatever fails locally (allocation, export, a peer mapping), the ranks agree on the outcome, and either
+        all of them hold a working exchange or all of them raise (buffers freed, mappings closed) - a caller may catch the
+        exception on every rank and fall back to the process group (comm.probe, bench.py's exchange report)."""
         dist = torch.distributed
         self.pg, self.device = process_group, L.indexed_device(device)
         self.rank, self.world = dist.get_rank(process_group), dist.get_world_size(process_group)
         self.max_floats = int(max_floats)
-        lib = L.load()
-        nbytes = lib.sw_comm_bytes(self.world, self.max_floats)
-        if nbytes <= 0:
-            raise L.SocialWaysHipError("sw_comm_bytes(%d, %d) = %d" % (self.world, self.max_floats, nbytes))
+        self._own, self._opened, self._peers = None, [], []
+        host, pid = socket.gethostname(), int(torch.multiprocessing.current_process().pid)
+
+        def first_line(e):
+            return "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
         with torch.cuda.device(self.device):
-            own = ctypes.c_void_p()
-            L.call("sw_comm_alloc", nbytes, ctypes.byref(own))
-            self._own = own.value
-            handle = ctypes.create_string_buffer(64)
-            L.call("sw_comm_ipc_export", self._own, handle)
-            # (host name + pid: a handle must be opened by ANOTHER process of the same host)
-            mine = (socket.gethostname(), int(torch.multiprocessing.current_process().pid), bytes(handle.raw))
+            raw, err = None, None
+            try:
+                lib = L.load()
+                nbytes = lib.sw_comm_bytes(self.world, self.max_floats)
+                if nbytes <= 0:
+                    raise L.SocialWaysHipError("sw_comm_bytes(%d, %d) = %d" % (self.world, self.max_floats, nbytes))
+                own = ctypes.c_void_p()
+                L.call("sw_comm_alloc", nbytes, ctypes.byref(own))
+                self._own = own.value
+                handle = ctypes.create_string_buffer(64)
+                L.call("sw_comm_ipc_export", self._own, handle)
+                raw = bytes(handle.raw)
+            except Exception as e:      # noqa: BLE001 - reported to the peers below: they must not wait for this rank
+                err = first_line(e)
+            # (host name + pid: a handle must be opened by ANOTHER process of the same host); a rank that failed sends None
             everyone = [None] * self.world
-            dist.all_gather_object(everyone, mine, group=process_group)
-            if any(h[0] != mine[0] for h in everyone):
-                raise L.SocialWaysHipError("SW_ALLREDUCE=direct needs all ranks on one node (hipIpc)")
-            self._peers, self._opened = [], []
-            for r, (_, pid, raw) in enumerate(everyone):
-                if r == self.rank:
-                    self._peers.append(self._own)
-                    continue
-                p = ctypes.c_void_p()
-                L.call("sw_comm_ipc_import", ctypes.create_string_buffer(raw, 64), ctypes.byref(p))
-                self._peers.append(p.value)
-                self._opened.append(p.value)
+            dist.all_gather_object(everyone, (host, pid, raw, err), group=process_group)
+            if err is None:
+                bad = [(r, h[3]) for r, h in enumerate(everyone) if h[2] is None]
+                if bad:
+                    err = "rank %d could not build its exchange buffer (%s)" % bad[0]
+                elif any(h[0] != host for h in everyone):
+                    err = "SW_ALLREDUCE=direct needs all ranks on one node (hipIpc)"
+            if err is None:
+                try:
+                    for r, (_, _, peer_raw, _) in enumerate(everyone):
+                        if r == self.rank:
+                            self._peers.append(self._own)
+                            continue
+                        p = ctypes.c_void_p()
+                        L.call("sw_comm_ipc_import", ctypes.create_string_buffer(peer_raw, 64), ctypes.byref(p))
+                        self._peers.append(p.value)
+                        self._opened.append(p.value)
+                except Exception as e:      # noqa: BLE001
+                    err = first_line(e)
+            # nobody launches before every rank has mapped every buffer - and nobody keeps a half-built exchange
+            verdicts = [None] * self.world
+            dist.all_gather_object(verdicts, err, group=process_group)
+            failed = [(r, v) for r, v in enumerate(verdicts) if v is not None]
+            if failed:
+                self._release()
+                raise L.SocialWaysHipError("direct exchange not built: rank %d: %s" % failed[0])
             self._arr = (ctypes.c_void_p * self.world)(*self._peers)
-        dist.barrier(group=process_group)      # nobody launches before every rank has mapped every buffer
+
+    def _release(self):
+        """Close the peer mappings and free the own buffer (local, no collective)."""
+        for p in self._opened:
+            try:
+                L.call("sw_comm_ipc_close", p)
+            except Exception:      # noqa: BLE001 - best effort on a failure path / at exit
+                pass
+        if self._own is not None:
+            try:
+                L.call("sw_comm_free", self._own)
+            except Exception:      # noqa: BLE001
+                pass
+        self._own, self._opened, self._peers = None, [], []
 
     def __call__(self, flat):
         assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous() and flat.numel() <= self.max_floats
@@ -64,10 +104,39 @@ class DirectAllReduce:
                float(b2), float(eps), int(opt.disc_tp), L.stream())
 
     def status(self):
-        """0, or 1 after a wait on a peer has timed out (synchronises the device)."""
+        """0, or 1 after a wait on a peer has timed out (synchronises the whole device)."""
         st = ctypes.c_int(0)
         L.call("sw_comm_status", self._own, ctypes.byref(st))
         return st.value
+
+    def status_all(self):
+        """The status of the WHOLE group (collective: max over the ranks) - what a caller checks before it trusts the
+        gradients of an epoch: a rank whose wait timed out publishes nothing, so its peers time out in turn."""
+        dist = torch.distributed
+        cpu_pg = dist.get_backend(self.pg) != "nccl"
+        t = torch.tensor([float(self.status())], device="cpu" if cpu_pg else self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
+        return int(t.item())
+
+    def check(self, bucket_floats, rounds=2):
+        """Collective: does the exchange agree with the process group's own all-reduce on buffers of these sizes (to fp32
+        summation order) on THIS node's links?  True / False, the same on every rank."""
+        dist = torch.distributed
+        cpu_pg = dist.get_backend(self.pg) != "nccl"
+        gen = torch.Generator().manual_seed(1234 + self.rank)
+        ok = True
+        for _ in range(rounds):
+            for n in bucket_floats:
+                x = torch.randn(n, generator=gen).to(self.device)
+                want = x.clone()
+                dist.all_reduce(want, group=self.pg)
+                got = self(x.clone())
+                torch.cuda.synchronize(self.device)
+                ok = ok and bool(torch.allclose(got, want, rtol=1e-5, atol=1e-6 * self.world))
+        ok = ok and self.status() == 0
+        t = torch.tensor([1.0 if ok else 0.0], device="cpu" if cpu_pg else self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.pg)
+        return bool(t.item() > 0.5)
 
     def close(self):
         if getattr(self, "_own", None) is None:
@@ -77,10 +146,7 @@ class DirectAllReduce:
             torch.distributed.barrier(group=self.pg)     # peers have stopped storing into this buffer
         except Exception:      # noqa: BLE001 - the group may be gone at interpreter exit
             pass
-        for p in self._opened:
-            L.call("sw_comm_ipc_close", p)
-        L.call("sw_comm_free", self._own)
-        self._own, self._opened = None, []
+        self._release()
 
 
 def probe(process_group, device, bucket_floats, rounds=3, reps=30):
@@ -103,28 +169,12 @@ def probe(process_group, device, bucket_floats, rounds=3, reps=30):
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=process_group)
         return float(t.item())
     rep = {"buckets_floats": [int(n) for n in bucket_floats], "chosen": "group"}
-    ar, err = None, None
-    try:
+    try:        # the constructor is failure-symmetric: it raises on every rank or on none
         ar = DirectAllReduce(process_group, dev, max(bucket_floats))
     except Exception as e:      # noqa: BLE001 - any failure means "use the process group"
-        err = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
-    if not agree(ar is not None):
-        rep["reason"] = err or "a peer could not build the exchange"
-        if ar is not None:
-            ar.close()
+        rep["reason"] = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
         return None, rep
-    gen = torch.Generator().manual_seed(1234 + rank)
-    ok = True
-    for _ in range(rounds):
-        for n in bucket_floats:
-            x = torch.randn(n, generator=gen).to(dev)
-            want = x.clone()
-            dist.all_reduce(want, group=process_group)
-            got = ar(x.clone())
-            torch.cuda.synchronize(dev)
-            ok = ok and bool(torch.allclose(got, want, rtol=1e-5, atol=1e-6 * world))
-    ok = ok and ar.status() == 0
-    if not agree(ok):
+    if not ar.check(bucket_floats, rounds):      # collective; the verdict is the same on every rank
         rep["reason"] = "the direct exchange disagreed with the group's all-reduce (or a wait timed out)"
         ar.close()
         return None, rep

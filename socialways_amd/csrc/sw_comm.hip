@@ -17,18 +17,22 @@
 // visible plus one load (MI355X_MICROARCH.md, hand-off price list: granules for latency; 8-byte granules observed untorn).
 // The epoch is kept in the buffer and advanced by the kernel - a launch recorded in a hipGraph needs no changing argument;
 // buffers start zeroed and epochs at 1.  A launch is NBLK workgroups, every thread owning the same pairs of floats of every
-// slice on every rank.  A poll gives up after ~4 s of the constant 100 MHz clock and leaves an error code in the buffer
-// (sw_comm_status) instead of hanging the GPU.
+// slice on every rank.  A poll gives up after SW_COMM_TIMEOUT_S seconds (default 30) of the constant 100 MHz clock instead of
+// hanging the GPU; a rank whose wait timed out publishes NOTHING from that wait (no hop-2 stores with a valid tag, no
+// gradient write, no optimizer step), leaves an error code in its buffer (sw_comm_status) and every later call on that
+// buffer returns at once - its peers then time out in turn.  The host makes the status collective before it trusts an
+// epoch (trainer.train_epoch).
 #include "../../include/socialways_hip.h"
 #include "sw_common.h"
 #include "sw_wgrad.h"
+#include <cstdio>
 #include <cstring>
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #define SW_COMM_MAXW 16          // ranks
 #define SW_COMM_MAXBLK 128       // workgroups per launch
-#define SW_COMM_TIMEOUT_TICKS 400000000ULL   // 4 s of wall_clock64() (100 MHz)
+#define SW_COMM_TICKS_PER_S 100000000ULL       // wall_clock64(): constant 100 MHz
 
 namespace {
 // layout of an exchange buffer (bytes): header | recv [W][Ls] granules | out [W][Ls] granules, Ls = slice capacity in floats
@@ -53,6 +57,7 @@ struct CommArgs {
   int rank, W, nblk;
   long long n, ls, ls_cap;
   size_t recv, out;
+  unsigned long long timeout_ticks;
 };
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // system-scope 16-byte accesses to exchange buffers (own or a peer's): two granules {value bits, epoch}
@@ -60,28 +65,33 @@ __device__ __forceinline__ void st_gran(char* p, float a, float b, unsigned e) {
   const u32x4 v = {__float_as_uint(a), e, __float_as_uint(b), e};
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
 }
-__device__ __forceinline__ void ld_gran_issue(u32x4& v, const char* p) {        // no wait: ld_gran_wait() in front of the first use
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+// One granule = one naturally aligned 8-byte {value bits, epoch}: read as ONE relaxed system-scope atomic load
+// (global_load_dwordx2 sc0 sc1: served from memory, not from this XCD's L2 or the CU's L1); the compiler places the waits.
+struct Gran2 { unsigned long long a, b; };      // the two granules of a 16-byte pair
+__device__ __forceinline__ Gran2 ld_gran(const char* p) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  Gran2 g;
+  g.a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  g.b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return g;
 }
-__device__ __forceinline__ void ld_gran_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ float gran_val(unsigned long long g) { return __uint_as_float((unsigned)g); }
+__device__ __forceinline__ unsigned gran_tag(unsigned long long g) { return (unsigned)(g >> 32); }
 // the W granule pairs at base + k * stride (k < W), polled until every tag is e; false on a time-out
-__device__ __forceinline__ bool poll_grans(u32x4 (&v)[SW_COMM_MAXW], const char* base, size_t stride, int W, unsigned e) {
+__device__ __forceinline__ bool poll_grans(Gran2 (&v)[SW_COMM_MAXW], const char* base, size_t stride, int W, unsigned e,
+                                           unsigned long long timeout_ticks) {
   unsigned long long t0 = 0;
   for (;;) {
 #pragma unroll
     for (int k = 0; k < SW_COMM_MAXW; ++k)
-      if (k < W) ld_gran_issue(v[k], base + (size_t)k * stride);        // W loads in flight, one wait
-    ld_gran_wait();
+      if (k < W) v[k] = ld_gran(base + (size_t)k * stride);             // 2 W loads in flight
     bool all = true;
 #pragma unroll
     for (int k = 0; k < SW_COMM_MAXW; ++k)
-      if (k < W) {
-        asm volatile("" : "+v"(v[k]));                                  // uses stay behind the wait
-        all = all && v[k][1] == e && v[k][3] == e;
-      }
+      if (k < W) all = all && gran_tag(v[k].a) == e && gran_tag(v[k].b) == e;
     if (all) return true;
     if (t0 == 0) t0 = wall_clock64();
-    else if (wall_clock64() - t0 > SW_COMM_TIMEOUT_TICKS) return false;
+    else if (wall_clock64() - t0 > timeout_ticks) return false;
     __builtin_amdgcn_s_sleep(1);
   }
 }
@@ -94,10 +104,16 @@ __device__ __forceinline__ bool poll_grans(u32x4 (&v)[SW_COMM_MAXW], const char*
 template <bool ADAM>
 __global__ __launch_bounds__(256) void allreduce_direct_kernel(CommArgs A, float* __restrict__ grad, WgAdam ad) {
   __shared__ float bcs[2];
+  __shared__ unsigned dead;
   if (ADAM && threadIdx.x == 64) wg_adam_bc_compute(ad.step, ad.beta1, ad.beta2, bcs[0], bcs[1]);
   const int b = blockIdx.x, W = A.W, r = A.rank;   // (b: this workgroup's chunk of every slice)
   char* mine = A.peer[r];
   unsigned* hdr = reinterpret_cast<unsigned*>(mine);
+  // a wait of an EARLIER call on this buffer timed out: the exchange is dead (sw_comm_status says so to the host); nothing is
+  // sent, nothing is written, nobody is waited for - one time-out costs one time-out, not one per remaining call of the epoch
+  if (threadIdx.x == 0) dead = __hip_atomic_load(&hdr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (dead != 0u) return;
   // ONE epoch per call for the whole buffer (a per-workgroup epoch could collide: the chunking depends on n, so a granule is
   // written by different workgroup indices in different calls).  It advances when the LAST workgroup of the launch finishes -
   // by then every workgroup has read it.
@@ -120,14 +136,17 @@ __global__ __launch_bounds__(256) void allreduce_direct_kernel(CommArgs A, float
   {
     const char* rv = mine + A.recv + (size_t)c0 * 8;
     for (int i = threadIdx.x; i < np; i += 256) {
-      u32x4 v[SW_COMM_MAXW];
-      ok = poll_grans(v, rv + (size_t)i * 16, (size_t)A.ls_cap * 8, W, e) && ok;
-      float s0 = __uint_as_float(v[0][0]), s1 = __uint_as_float(v[0][2]);
+      Gran2 v[SW_COMM_MAXW];
+      if (!poll_grans(v, rv + (size_t)i * 16, (size_t)A.ls_cap * 8, W, e, A.timeout_ticks)) {
+        ok = false;          // a peer never arrived: this pair is NOT published (its readers time out in turn)
+        continue;
+      }
+      float s0 = gran_val(v[0].a), s1 = gran_val(v[0].b);
 #pragma unroll
       for (int src = 1; src < SW_COMM_MAXW; ++src)
         if (src < W) {
-          s0 += __uint_as_float(v[src][0]);
-          s1 += __uint_as_float(v[src][2]);
+          s0 += gran_val(v[src].a);
+          s1 += gran_val(v[src].b);
         }
       for (int pp = 0; pp < W; ++pp) {
         const int p = (r + 1 + pp) % W;
@@ -135,13 +154,16 @@ __global__ __launch_bounds__(256) void allreduce_direct_kernel(CommArgs A, float
       }
     }
   }
-  if constexpr (ADAM) __syncthreads();      // bcs
   // ---- the all-reduced gradient back over the rank's buffer (and the optimizer step) ----------------------------------
   {
     const char* ov = mine + A.out + (size_t)c0 * 8;
     for (int i = threadIdx.x; i < np; i += 256) {
-      u32x4 vs[SW_COMM_MAXW];
-      ok = poll_grans(vs, ov + (size_t)i * 16, (size_t)A.ls_cap * 8, W, e) && ok;
+      Gran2 vs[SW_COMM_MAXW];
+      // (a thread that has already given up on a peer does not wait a second time: the call has failed)
+      if (!ok || !poll_grans(vs, ov + (size_t)i * 16, (size_t)A.ls_cap * 8, W, e, A.timeout_ticks)) {
+        ok = false;          // no valid sum for these elements: neither the gradient nor the weights are touched
+        continue;
+      }
 #pragma unroll
       for (int p = 0; p < SW_COMM_MAXW; ++p) {
         if (p >= W) continue;
@@ -149,14 +171,14 @@ __global__ __launch_bounds__(256) void allreduce_direct_kernel(CommArgs A, float
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           if (g + k >= A.n) continue;
-          const float val = __uint_as_float(vs[p][2 * k]);
+          const float val = gran_val(k ? vs[p].b : vs[p].a);
           grad[g + k] = val;
           if constexpr (ADAM) wg_adam_fin(ad, wg_adam_pre(ad, grad + g + k), bcs[0], bcs[1], val);
         }
       }
     }
   }
-  if (!ok) hdr[0] = 1u;          // a peer never arrived: the result is garbage, say so (sw_comm_status)
+  if (!ok) __hip_atomic_store(&hdr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // a peer never arrived (sw_comm_status)
   __syncthreads();
   if (threadIdx.x == 0) {
     if (__hip_atomic_fetch_add(&hdr[17], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)A.nblk - 1u) {
@@ -175,11 +197,16 @@ extern "C" long long sw_comm_bytes(int world, long long max_floats) {
 extern "C" int sw_comm_alloc(long long bytes, void** ptr) {
   if (bytes < 1 || !ptr) return SW_EARG;
   void* p = nullptr;
-  // SW_COMM_CACHED=1 (tests): ordinary cached device memory - the exchange then relies on the release / acquire fences alone
+  // SW_COMM_CACHED=1 (tests): ordinary cached device memory.  The kernel has no fences: visibility then rests on its
+  // system-scope (sc0 sc1) write-through stores and L2-bypassing loads alone, which is what every access to the buffer is.
+  // Uncached memory is the intended form; if the runtime refuses it the fallback is SAID, never silent.
   static const bool cached = getenv("SW_COMM_CACHED") && atoi(getenv("SW_COMM_CACHED")) != 0;
   hipError_t e = cached ? hipErrorNotSupported : hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached);
   if (e != hipSuccess) {
     (void)hipGetLastError();
+    if (!cached)
+      fprintf(stderr, "socialways_hip: sw_comm_alloc: uncached device memory unavailable (%s); the exchange buffer is ordinary "
+                      "cached memory accessed with system-scope stores / loads only\n", hipGetErrorString(e));
     e = hipMalloc(&p, (size_t)bytes);
   }
   if (e != hipSuccess) { sw_set_error("sw_comm_alloc", e); return SW_EHIP; }
@@ -204,6 +231,13 @@ extern "C" int sw_comm_ipc_export(void* ptr, void* handle64) {
 }
 extern "C" int sw_comm_ipc_import(const void* handle64, void** ptr) {
   if (!handle64 || !ptr) return SW_EARG;
+  // SW_COMM_FAULT_INJECT=1 (tests of the harness around this path - bench.py's exchange report runs it in a child job):
+  // the process dies here, the way a GPU fault inside the never-hardware-tested peer mapping would take it down
+  if (getenv("SW_COMM_FAULT_INJECT") && atoi(getenv("SW_COMM_FAULT_INJECT")) == 1) abort();
+  if (getenv("SW_COMM_FAULT_INJECT") && atoi(getenv("SW_COMM_FAULT_INJECT")) == 2) {      // ... or the mapping is refused
+    sw_set_error("hipIpcOpenMemHandle (SW_COMM_FAULT_INJECT)", hipErrorInvalidValue);
+    return SW_EHIP;
+  }
   hipIpcMemHandle_t h;
   std::memcpy(&h, handle64, 64);
   hipError_t e = hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess);
@@ -219,7 +253,9 @@ extern "C" int sw_comm_ipc_close(void* ptr) {
 extern "C" int sw_comm_status(const void* own_buf, int* status) {
   if (!own_buf || !status) return SW_EARG;
   unsigned v = 0;
-  hipError_t e = hipMemcpy(&v, own_buf, 4, hipMemcpyDeviceToHost);
+  // the whole device, not the null stream: exchange kernels run on the caller's (non-blocking) streams
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(&v, own_buf, 4, hipMemcpyDeviceToHost);
   if (e != hipSuccess) { sw_set_error("sw_comm_status", e); return SW_EHIP; }
   *status = (int)v;
   return SW_OK;
@@ -245,6 +281,9 @@ static int allreduce_direct_launch(void* const* peer_bufs, int rank, int world, 
   A.ls_cap = L.ls_cap;
   if (A.ls > A.ls_cap) return SW_ESHAPE;
   A.recv = L.recv; A.out = L.out;
+  // how long a poll waits for a peer (rank skew: a rank that evaluates / saves / captures while the others step)
+  static const double timeout_s = getenv("SW_COMM_TIMEOUT_S") && atof(getenv("SW_COMM_TIMEOUT_S")) > 0.0 ? atof(getenv("SW_COMM_TIMEOUT_S")) : 30.0;
+  A.timeout_ticks = (unsigned long long)(timeout_s * (double)SW_COMM_TICKS_PER_S);
   if (adam) SW_LAUNCH(allreduce_direct_kernel<true>, dim3(A.nblk), dim3(256), 0, (hipStream_t)stream, A, grad, *adam);
   else SW_LAUNCH(allreduce_direct_kernel<false>, dim3(A.nblk), dim3(256), 0, (hipStream_t)stream, A, grad, WgAdam());
   SW_CHECK_LAUNCH("allreduce_direct_kernel");

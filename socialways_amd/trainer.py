@@ -250,6 +250,13 @@ class SocialWaysTrainer:
             buckets = [self.D._gflat.numel(), self.G._gflat_all.numel()]
             if mode == "direct":
                 self._direct = comm.DirectAllReduce(self.pg, self.device, max(buckets))
+                # no timing, but never unchecked: the exchange must reproduce the group's all-reduce on this node's links
+                # before a weight depends on it (collective; SW_ALLREDUCE_CHECK=0 skips it)
+                if os.environ.get("SW_ALLREDUCE_CHECK", "1") != "0" and not self._direct.check(buckets):
+                    self._direct.close()
+                    self._direct = None
+                    raise L.SocialWaysHipError("SW_ALLREDUCE=direct: the exchange disagrees with the process group's all-reduce "
+                                               "on this node (or a wait timed out); use SW_ALLREDUCE=auto or unset it")
             else:
                 self._direct, self.exchange_probe = comm.probe(self.pg, self.device, buckets)
             if self._direct is not None and self._graph_collectives is None:
@@ -398,6 +405,14 @@ class SocialWaysTrainer:
         self._graphs.clear()
         self.ws.release_retired()
         self._ws_version = self.ws.version
+
+    def close(self):
+        """End of this trainer's life: captured graphs dropped, the direct exchange's buffers freed and its peer mappings
+        closed (collective when a direct exchange exists: every rank calls it).  Idempotent."""
+        self.release_graphs()
+        d, self._direct = self._direct, None
+        if d is not None:
+            d.close()
 
     def _z_resident(self, batches):
         """Is the z of every step of this launch a contiguous fp32 device tensor of the kernels' width?  Then the
@@ -785,6 +800,10 @@ class SocialWaysTrainer:
         pend, pend_key = [], None        # consecutive packed batches of one layout share a graph launch
         if self.world > 1 and draw is None:
             self.sync_rng()
+        if self._direct is not None and self.world > 1:
+            # the exchange kernels WAIT for their peers on the device (bounded: SW_COMM_TIMEOUT_S): ranks enter an epoch
+            # together, whatever one of them did alone in between (test(), save(), a capture)
+            torch.distributed.barrier(group=self.pg)
 
         def flush():
             nonlocal pend, pend_key
@@ -828,9 +847,11 @@ class SocialWaysTrainer:
         flush()
         allo = torch.stack(outs)
         self._allreduce(allo)
-        if self._direct is not None and self._direct.status() != 0:
-            raise L.SocialWaysHipError("the direct gradient exchange timed out waiting for a peer during this epoch "
-                                       "(sw_comm_status): gradients of at least one step are invalid")
+        if self._direct is not None and self._direct.status_all() != 0:      # collective: every rank raises, none hangs
+            raise L.SocialWaysHipError("the direct gradient exchange timed out waiting for a peer during this epoch on at "
+                                       "least one rank (sw_comm_status): a rank whose wait times out publishes nothing and "
+                                       "applies no update from it, so the replicas are no longer identical - restart from "
+                                       "the last checkpoint (SW_COMM_TIMEOUT_S sets the wait, default 30 s)")
         o = allo.double().cpu().numpy()
         ade = float(o[:, -1, 0].sum() / data.n_train_samples)
         fde = float(o[:, -1, 1].sum() / data.n_train_samples)

@@ -206,3 +206,93 @@ def test_four_ranks_with_idle_ranks_direct_exchange_follows_the_process_groups()
         assert abs(a[0][e][0] - b[0][e][0]) < 1e-5 and abs(a[0][e][1] - b[0][e][1]) < 1e-5
     lr = 1e-3
     assert float((a[2] - b[2]).abs().max()) <= 2.2 * lr * 3 * 8 and float((a[1] - b[1]).abs().max()) <= 2.2 * 1e-4 * 3 * 8
+
+
+def _timeout_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from socialways_amd.comm import DirectAllReduce
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["SW_COMM_TIMEOUT_S"] = "0.5"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ar = DirectAllReduce(dist.group.WORLD, "cuda:0", 27942)
+    g = torch.full((27942,), float(rank + 1), device="cuda")
+    ar(g)
+    torch.cuda.synchronize()
+    first_ok = bool((g == 3.0).all()) and ar.status() == 0
+    dist.barrier()
+    untouched = later_untouched = True
+    if rank == 0:                     # rank 1 never joins this call: the wait gives up after 0.5 s
+        g2 = torch.full((27942,), 7.0, device="cuda")
+        ar(g2)
+        torch.cuda.synchronize()
+        untouched = bool((g2 == 7.0).all())          # no stale / partial sum was written over the gradient
+        st = ar.status()
+        g3 = torch.full((27942,), 9.0, device="cuda")
+        t0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0[0].record()
+        ar(g3)                                        # the exchange is dead: returns at once, writes nothing
+        t0[1].record()
+        torch.cuda.synchronize()
+        later_untouched = bool((g3 == 9.0).all()) and t0[0].elapsed_time(t0[1]) < 100.0
+    else:
+        st = ar.status()
+    dist.barrier()
+    ret[rank] = (first_ok, untouched, later_untouched, st, ar.status_all())
+    ar.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_a_timed_out_wait_publishes_nothing_and_the_status_is_collective():
+    """rank skew beyond the time-out.  The rank whose wait gives up must not write a partly stale sum over its
+    gradient (nor publish it to its peers with a valid tag), later calls on the dead exchange return at once, and
+    status_all() tells EVERY rank (the healthy one too) that the epoch is invalid."""
+    import torch.multiprocessing as mp
+    ret = mp.Manager().dict()
+    mp.spawn(_timeout_worker, args=(2, _port(), ret), nprocs=2, join=True)
+    assert ret[0][0] and ret[1][0], "the first (complete) call must work"
+    assert ret[0][1], "rank 0: the timed-out call wrote into the gradient buffer"
+    assert ret[0][2], "rank 0: a call on the dead exchange wrote / waited"
+    assert ret[0][3] == 1 and ret[1][3] == 0
+    assert ret[0][4] == 1 and ret[1][4] == 1, "status_all must report the time-out on every rank"
+
+
+def _asym_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from socialways_amd import _lib as L
+    from socialways_amd.comm import DirectAllReduce, probe
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if rank == 1:
+        os.environ["SW_COMM_FAULT_INJECT"] = "2"        # this rank cannot map its peer's buffer
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    raised = None
+    try:
+        DirectAllReduce(dist.group.WORLD, "cuda:0", 27942)
+    except L.SocialWaysHipError as e:
+        raised = str(e)
+    # the group's collectives still line up after the failure (nobody is left in a barrier / all_gather)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    ar, rep = probe(dist.group.WORLD, "cuda:0", [27942, 86124])
+    t2 = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t2)
+    ret[rank] = (raised, float(t.item()), ar is None, rep.get("chosen"), rep.get("reason"), float(t2.item()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_construction_failure_on_one_rank_raises_on_every_rank():
+    """DirectAllReduce.__init__ is collective; a rank that fails locally (here: rank 1's peer mapping is refused)
+    must not leave its peers in a barrier - every rank raises, and comm.probe falls back to the group on every rank."""
+    import torch.multiprocessing as mp
+    ret = mp.Manager().dict()
+    mp.spawn(_asym_worker, args=(2, _port(), ret), nprocs=2, join=True)
+    for r in (0, 1):
+        raised, s1, none, chosen, reason, s2 = ret[r]
+        assert raised is not None and "rank 1" in raised, (r, raised)
+        assert s1 == 3.0 and s2 == 3.0
+        assert none and chosen == "group" and reason and "rank 1" in reason
