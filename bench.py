@@ -50,8 +50,13 @@ WORKLOADS = {   # name -> (scenes per GPU step, agents per scene, To, Tp)
     # BASELINE config 3's SHAPE (ETH-hotel: <= 8 agents per scene; the recordings themselves are not in the image): one
     # packed batch of 2048 agents in scenes of 1..8 agents (data.ragged_scene_sizes), A = None marks the ragged layout
     "c3_ragged": (None, None, 8, 12),
+    # the natural per-GPU shard of an 8 192-scene global batch (train.py:446-456 packs --batch-size agents): 8 192 agents =
+    # 512 sixteen-agent tiles, two per CU - a shape on which the step's three gradient exchanges amortise
+    "m4": (1024, 8, 8, 12),
 }
-OTHER_STEPS = {"m1": (100, 12), "c2": (100, 12), "c4": (24, 8), "c3_ragged": (100, 12)}     # (steps, warm-up) of a short leg
+OTHER_STEPS = {"m1": (100, 12), "c2": (100, 12), "c4": (24, 8), "c3_ragged": (100, 12), "m4": (60, 10)}     # (steps, warm-up) of a short leg
+RESIDENT = "resident in HBM when the timed region starts (tracks; z: a ring of 16 device tensors drawn beforehand)"
+SIDE_GROUPS = ("shapes", "dp1", "extra")     # side legs of the N = 1 line, one child process per group (run_side_children)
 PEAK_HBM_BPS = 8.0e12          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_FP32_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / VALU fp32 peak
 N_BATCHES = 8                  # distinct packed batches cycled through
@@ -246,6 +251,67 @@ def launch_check(world, rank, args):
     return 0
 
 
+
+def _err(e):
+    return {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")}
+
+
+def _write_json(path, obj):
+    """Atomic (a reader never sees half a file): side legs rewrite their record after every leg, so whatever finished before a
+    crash or a time-out of the child survives it."""
+    tmp = "%s.tmp%d" % (path, os.getpid())
+    with open(tmp, "w") as f:
+        json.dump(obj, f)
+    os.replace(tmp, path)
+
+
+def _read_json(path):
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+_CHILD = {"proc": None}     # the side-leg child that is running (the SIGTERM handler of the parent ends it)
+LAUNCHER_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_NAME",
+                "ROLE_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SW_FORCE_DIST", "SW_ALLREDUCE")
+
+
+def run_child(cmd, timeout_s, env_extra=None):
+    """A side leg as a process (group) of its own: whatever happens in it - an exception, a GPU memory fault that aborts the
+    process, a wait that never ends - costs that leg, never the ranks that hold the headline measurement.  Returns
+    (return code or None after a time-out, last lines of its stderr)."""
+    import signal
+    import subprocess
+    import tempfile
+    env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_ENV and not k.startswith("TORCHELASTIC_")}
+    env["SW_BENCH_CHILD"] = "1"
+    env.update(env_extra or {})
+    with tempfile.TemporaryFile(mode="w+") as errf:
+        proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=errf, start_new_session=True)
+        _CHILD["proc"] = proc
+        try:
+            rc = proc.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            rc = None
+        finally:
+            _CHILD["proc"] = None
+        if rc is None or rc != 0:            # its own process group (start_new_session): the launcher's workers go with it
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            proc.wait()
+        errf.seek(0)
+        tail = errf.read()[-1500:]
+    return rc, tail
+
+
+def child_timeout(default_s):
+    return float(os.environ.get("SW_BENCH_CHILD_TIMEOUT_S", default_s))
+
+
 class Leg:
     """One workload on this rank: trainer, resident synthetic batches and the stepping closures."""
 
@@ -387,6 +453,321 @@ class Leg:
         return time.perf_counter() - t0
 
 
+def short_leg(lg, n, w, fence):
+    """A side leg: n steps timed three times, the fastest region reported.  (Regions of 40-80 ms are exposed to the
+    sporadic 3-50 ms host stalls of this runtime - round-3 per-launch host / GPU time stamps - which are not a property of the leg;
+    THE timed region of the headline workload is never treated this way.)"""
+    import gc
+    lg.prime((n, w))
+    lg.run_steps(0, w)
+    gc.collect()
+    gc.disable()
+    d = min(lg.timed(fence, w + r * n, n) for r in range(3))
+    gc.enable()
+    assert torch.isfinite(lg.last).all(), "non-finite losses (%s)" % lg.name
+    return d
+
+
+def init_group(backend, dev, world=None, rank=None):
+    kw = {} if world is None else {"world_size": world, "rank": rank}
+    if backend == "nccl":
+        torch.distributed.init_process_group("nccl", device_id=dev, **kw)
+    else:
+        torch.distributed.init_process_group(backend, **kw)
+    return torch.distributed.group.WORLD
+
+
+def side_legs_main(args, dev, KG, HOST_Z):
+    """`bench.py --side-legs GROUP --side-out FILE` - a CHILD of the N = 1 bench (run_side_children): the side legs of one
+    group, each under its own guard ({"error": ...} in its place), the record rewritten after every leg."""
+    import socialways_amd as sw
+    out = {}
+    ref_ms = args.ref_ms                      # the parent's headline ms per step (dp1 legs report their distance to it)
+
+    def fence():
+        torch.cuda.synchronize()
+
+    def put(key, fn):
+        try:
+            out[key] = fn()
+        except Exception as e:      # noqa: BLE001 - a leg that fails is reported in its place; the others still run
+            out[key] = _err(e)
+            torch.cuda.synchronize()
+        _write_json(args.side_out, out)
+        torch.cuda.empty_cache()
+
+    def shape_leg(name):
+        lg = Leg(name, dev, None, 1, 0, "weak", 0, KG)
+        if not HOST_Z:
+            lg.z_resident()
+        n, w = OTHER_STEPS[name]
+        d = short_leg(lg, n, w, fence)
+        fl_o = alg_flops(lg.B, lg.P, lg.To, lg.Tp)
+        S_o, A_o = WORKLOADS[name][:2]
+        wl = ("%d scenes x %d agents x %d+%d" % (S_o, A_o, lg.To, lg.Tp)) if A_o is not None else \
+             ("%d scenes of 1..8 agents (%d agents, %d in-scene pairs, %d single-agent scenes) x %d+%d: the SHAPE of a real "
+              "ETH/UCY packed batch, synthetic tracks" % (lg.S_local, lg.B, lg.P, sum(a == 1 for a in lg.sizes), lg.To, lg.Tp))
+        rec = {"workload": wl, "steps": n, "warmup": w, "agents": lg.B,
+               "steps_s": n / d, "ms_per_step": 1e3 * d / n, "agent_steps_s": lg.B * n / d, "step_alg_gflop": fl_o["step"] / 1e9,
+               # reference-formulation FLOPs (SURVEY 8d) / time: CREDITS work the kernels eliminate algebraically
+               "step_frac_of_fp32_peak": fl_o["step"] / (d / n) / (PEAK_FP32_TFLOPS * 1e12)}
+        rec_o = pmc_record(name)
+        ex = rec_o and rec_o.get("_step", {}).get("mfma_flop_per_step")
+        # matrix FLOP the kernels really issued per step (SQ counter pass of these sources) / this leg's time
+        rec["step_executed_mfma_gflop"] = ex / 1e9 if ex else None
+        rec["step_frac_executed"] = ex / (d / n) / (PEAK_FP32_TFLOPS * 1e12) if ex else None
+        rec["inputs"] = "z drawn on the host every step" if HOST_Z else RESIDENT
+        if name in ("c4", "m4"):
+            # z in the other form next to it (c4: 4 MB of z per step, m4: 1 MB)
+            if HOST_Z:
+                lg.z_resident()
+            else:
+                lg.z_host()
+            d2 = short_leg(lg, n, w, fence)
+            rec["inputs_resident" if HOST_Z else "pcie_inclusive"] = {
+                "steps_s": n / d2, "ms_per_step": 1e3 * d2 / n,
+                "what": "z too resident in HBM (device tensors read by address)" if HOST_Z else
+                        "z drawn on the host per step (train.py:473) and pulled from pinned memory inside the step"}
+        lg.tr.close()
+        return rec
+
+    def dp1_leg(direct):
+        """The data-parallel step STRUCTURE at N = 1 - the only scaling evidence a 1-GPU box can give: the same workload on a
+        1-rank RCCL group (SW_FORCE_DIST: all three all-reduces are issued, the Adam updates run behind them as kernels of
+        their own instead of inside the gradient reductions); `direct`: the same on the library's exchange (per bucket ONE
+        launch that exchanges the gradient and applies Adam; with one rank the exchange moves nothing).  `delta_us_per_step`
+        = what the structure costs per step before any wire time - it says nothing about N > 1."""
+        os.environ["SW_FORCE_DIST"] = "1"
+        if direct:
+            os.environ["SW_ALLREDUCE"] = "direct"
+        else:
+            os.environ.pop("SW_ALLREDUCE", None)
+        try:
+            lg = Leg("m1", dev, torch.distributed.group.WORLD, 1, 0, "weak", 0, KG)
+            if not HOST_Z:
+                lg.z_resident()
+            n, w = OTHER_STEPS["m1"]
+            d = short_leg(lg, n, w, fence)
+            rec = {"workload": ("m1 on a 1-rank group with SW_ALLREDUCE=direct (3 exchange + Adam launches per step)" if direct else
+                                "m1 on a 1-rank RCCL process group (3 all-reduces per step issued, Adam behind them)"),
+                   "steps": n, "steps_s": n / d, "ms_per_step": 1e3 * d / n,
+                   "delta_us_per_step": (1e3 * (1e3 * d / n - ref_ms)) if ref_ms else None,
+                   "collectives": "in-graph" if lg.tr._graph_collectives else "between graph segments"}
+            if direct:
+                rec["status"] = lg.tr._direct.status()
+            elif ref_ms:
+                rec["plain_over_dp1_time_ratio"] = ref_ms / (1e3 * d / n)
+            lg.tr.close()
+            return rec
+        finally:
+            os.environ.pop("SW_FORCE_DIST", None)
+            os.environ.pop("SW_ALLREDUCE", None)
+
+    def variety_leg():
+        # SURVEY 8f-4: the best-of-K variety term (K = 20 rollouts folded into one batch of 20 x 2048 agents) as a
+        # throughput stress of the generator path; eager steps (the folded step is not graph-captured)
+        lg = Leg("m1", dev, None, 1, 0, "weak", 0, 1, use_variety_loss="fixed", variety_k=20, use_l2_loss=True)
+        if not HOST_Z:
+            lg.z_resident()
+        n, w = 40, 6
+        d = short_leg(lg, n, w, fence)
+        return {"workload": "m1 + best-of-20 variety loss (use_variety_loss='fixed'): decode loop on 40 960 agent copies, encoder and social block once on the 2 048 agents",
+                "steps": n, "steps_s": n / d, "ms_per_step": 1e3 * d / n}
+
+    def wide_leg(Hw):
+        # `--hidden-size 128` (train.py:42-44): the WIDE path (wide.py: time-step-level kernels, explicit backward, one
+        # hipGraph per step) on the metric shape; the generic path's layer-by-layer form ran 42 steps/s here in round 3
+        S_w, A_w, To, Tp = WORKLOADS["m1"]
+        torch.manual_seed(0)
+        np.random.seed(0)
+        tr_w = sw.SocialWaysTrainer(Tp, hidden_size=Hw, use_social=True, device=dev)
+        tk = sw.synth_tracks(S_w * 2, A_w, To, Tp, seed=99)
+        dw = sw.SceneDataset(tk["obsvs"], tk["preds"], tk["batches"], device=dev)
+        Bw, sbw = S_w * A_w, np.stack([np.arange(S_w) * A_w, (np.arange(S_w) + 1) * A_w], axis=1).astype(np.int64)
+        zb = torch.empty(Bw, Hw // 2).pin_memory()
+
+        def wstep(i):
+            a = (i % 2) * Bw
+            torch.rand(zb.shape, out=zb)
+            return tr_w.step(dw.obsv[a:a + Bw], dw.pred[a:a + Bw], sbw, np.random.uniform(0, 0.1), np.random.uniform(0.9, 1.0),
+                             zb, dw.ss)
+        for i in range(6):
+            last_w = wstep(i)
+        n_w, t_best = 60, float("inf")
+        for rep in range(3):
+            fence()
+            t0 = time.perf_counter()
+            for i in range(n_w):
+                last_w = wstep(i)
+            fence()
+            t_best = min(t_best, time.perf_counter() - t0)
+        assert torch.isfinite(last_w).all(), "non-finite losses (hidden size %d)" % Hw
+        rec = {"workload": "m1 at --hidden-size %d (decoder %d-%d-%d-%d-2, noise %d): %s" % (
+                   Hw, 5 * Hw // 2, 5 * Hw // 2, 5 * Hw // 4, 5 * Hw // 8, Hw // 2, type(tr_w).__name__),
+               "steps": n_w, "steps_s": n_w / t_best, "ms_per_step": 1e3 * t_best / n_w}
+        tr_w.release_graphs()
+        return rec
+
+    def test_leg():
+        # SURVEY 8f-1: the evaluation pass test() exists for - K = 20 sampled futures per held-out scene, min / avg ADE
+        # and FDE (train.py:563-616) - on the m1-shaped recording's held-out fifth (scenes folded into rollout launches)
+        To, Tp = WORKLOADS["m1"][2:]
+        torch.manual_seed(0)
+        tr_e = sw.SocialWaysTrainer(Tp, use_social=True, device=dev)
+        tk = sw.synth_tracks(1280, 8, To, Tp, seed=4321)
+        data_e = sw.SceneDataset(tk["obsvs"], tk["preds"], tk["batches"], device=dev)
+        tr_e.test(data_e, 20)
+        fence()
+        t_best = float("inf")
+        for _ in range(3):
+            t0 = time.perf_counter()
+            res_e = tr_e.test(data_e, 20)
+            fence()
+            t_best = min(t_best, time.perf_counter() - t0)
+        n_sc = len(data_e.test_batches)
+        return {"workload": "test(): K = 20 sampled futures for each of %d held-out scenes x 8 agents (%d agents), "
+                            "min / avg ADE and FDE; scenes folded into launches of <= %d agent copies"
+                            % (n_sc, data_e.n_test_samples, tr_e.TEST_CHUNK),
+                "seconds": t_best, "scenes_s": n_sc / t_best, "rollouts_s": 20 * data_e.n_test_samples / t_best,
+                "ade_avg_min": [res_e[0], res_e[2]], "fde_avg_min": [res_e[1], res_e[3]]}
+
+    if args.side_legs == "shapes":
+        for name in sorted(WORKLOADS):
+            if name != args.workload:
+                put(name, lambda name=name: shape_leg(name))
+    elif args.side_legs == "dp1":
+        import socket
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(sk.getsockname()[1])
+        sk.close()
+        try:
+            init_group("nccl", dev, world=1, rank=0)
+        except Exception as e:      # noqa: BLE001 - a box without a working RCCL
+            out["dp1_rccl"] = _err(e)
+            _write_json(args.side_out, out)
+            return 0
+        put("dp1_rccl", lambda: dp1_leg(False))
+        put("dp1_direct", lambda: dp1_leg(True))
+        torch.distributed.destroy_process_group()
+    elif args.side_legs == "extra":
+        put("m1_variety_k20", variety_leg)
+        for Hw in (128, 96):
+            put("m1_hidden%d" % Hw, lambda Hw=Hw: wide_leg(Hw))
+        put("test_k20", test_leg)
+    _write_json(args.side_out, out)
+    return 0
+
+
+def run_side_children(args, ref_ms, tmpdir):
+    """The N = 1 line's side legs (config.other_workloads), one child process per group: the line cannot be lost to them."""
+    other = {}
+    base = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--ref-ms", "%.6f" % ref_ms]
+    for group, t_s in zip(SIDE_GROUPS, (360.0, 240.0, 360.0)):
+        path = os.path.join(tmpdir, "side_%s.json" % group)
+        t0 = time.perf_counter()
+        rc, tail = run_child(base + ["--side-legs", group, "--side-out", path], child_timeout(t_s))
+        got = _read_json(path) or {}
+        other.update(got)
+        if rc != 0:      # whatever the child finished before it died is kept; the rest of its group is reported missing
+            other["_%s_child" % group] = {"error": ("timed out after %.0f s" % (time.perf_counter() - t0)) if rc is None else "exit code %d" % rc,
+                                          "legs_finished": sorted(got), "stderr_tail": tail[-600:]}
+    return other
+
+
+def exchange_child_main(args, world, rank, dev, pg, backend, KG):
+    """`bench.py --gpus N --exchange-only --side-out FILE` under the launcher - a CHILD JOB of the N > 1 bench
+    (run_exchange_child): what one gradient all-reduce of each of the step's three buckets costs on this node (HIP events
+    around 50 back-to-back calls; D twice, G once: the packed buffers) on the process group's own all-reduce (RCCL) and on the
+    library's two-hop exchange (SW_ALLREDUCE=direct, csrc/sw_comm.hip), then the whole step on the direct form.  Rank 0
+    rewrites the record after every stage: what was measured before a fault survives it."""
+    import socialways_amd as sw
+    from socialways_amd.comm import DirectAllReduce
+    rep = {}
+
+    def fence():
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def save():
+        if rank == 0:
+            _write_json(args.side_out, rep)
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item())
+    Tp = WORKLOADS[args.workload][3]
+    probe_tr = sw.SocialWaysTrainer(Tp, use_social=True, device=dev)       # (no group: only for the bucket sizes)
+    rep["buckets_floats"] = [int(probe_tr.D._gflat.numel()), int(probe_tr.D._gflat.numel()), int(probe_tr.G._gflat_all.numel())]
+    del probe_tr
+    bufs = [torch.zeros(n, device=dev) for n in rep["buckets_floats"]]
+
+    def time_calls(fn):
+        out = []
+        for b in bufs:
+            for _ in range(5):
+                fn(b)
+            fence()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                fn(b)
+            e1.record()
+            torch.cuda.synchronize()
+            out.append(max_over_ranks(e0.elapsed_time(e1) * 1e3 / 50))
+        return out
+    rep["group_backend"] = backend
+    rep["group_us"] = time_calls(lambda b: torch.distributed.all_reduce(b, group=pg))
+    save()
+    try:
+        ar = DirectAllReduce(pg, dev, max(rep["buckets_floats"]))          # failure-symmetric: raises on every rank or none
+        rep["direct_agrees_with_group"] = ar.check(rep["buckets_floats"][1:])
+        rep["direct_us"] = time_calls(ar)
+        rep["direct_status"] = ar.status_all()
+        ar.close()
+        save()
+        os.environ["SW_ALLREDUCE"] = "direct"
+        lg = Leg(args.workload, dev, pg, world, rank, args.scaling, args.global_scenes, KG)
+        n, w = OTHER_STEPS[args.workload]
+        d = max_over_ranks(short_leg(lg, n, w, fence))
+        rep["direct_step"] = {"steps": n, "steps_s": n * (world if args.scaling == "weak" else 1) / d, "ms_per_step": 1e3 * d / n,
+                              "collectives": "in-graph" if lg.tr._graph_collectives else "between graph segments",
+                              "status": lg.tr._direct.status_all() if lg.tr._direct is not None else None}
+        lg.tr.close()
+    except Exception as e:      # noqa: BLE001
+        rep["direct_error"] = _err(e)["error"]
+    save()
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+    return 0
+
+
+def run_exchange_child(args, world, tmpdir):
+    """Rank 0 of the N > 1 bench: the exchange report as a second job on the same GPUs (the parent's ranks idle on the host
+    meanwhile).  The library's direct exchange has never crossed an xGMI link on hardware this build has seen: a GPU fault, a
+    failed peer mapping or a wait that never ends there ends the CHILD; the line keeps config.exchange.error."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    path = os.path.join(tmpdir, "exchange.json")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(world), "--exchange-only", "--side-out", path, "--workload", args.workload,
+           "--scaling", args.scaling, "--global-scenes", str(args.global_scenes)]
+    t0 = time.perf_counter()
+    rc, tail = run_child(cmd, child_timeout(300.0), {"OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS", "8")})
+    rep = _read_json(path) or {}
+    if rc != 0:
+        rep["error"] = ("the exchange child job timed out after %.0f s" % (time.perf_counter() - t0)) if rc is None else \
+                       "the exchange child job exited with code %d" % rc
+        rep["stderr_tail"] = tail[-600:]
+    rep["how"] = "a child job of %d ranks on the same GPUs (bench.py --exchange-only), the parent's ranks idle" % world
+    return rep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -400,6 +781,11 @@ def main():
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained leg")
     ap.add_argument("--launch-check", action="store_true",
                     help="only launch / rendezvous / reduce over the N ranks (no GPU needed), print a JSON line with value null")
+    # children of this file (run_side_children / run_exchange_child): the side legs run where they cannot take the line down
+    ap.add_argument("--side-legs", choices=SIDE_GROUPS, help=argparse.SUPPRESS)
+    ap.add_argument("--side-out", help=argparse.SUPPRESS)
+    ap.add_argument("--ref-ms", type=float, default=0.0, help=argparse.SUPPRESS)
+    ap.add_argument("--exchange-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -423,11 +809,7 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("SW_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
-        if backend == "nccl":
-            torch.distributed.init_process_group("nccl", device_id=dev)
-        else:
-            torch.distributed.init_process_group(backend)
-        pg = torch.distributed.group.WORLD
+        pg = init_group(backend, dev)
 
     from socialways_amd import _lib as L
     KG = int(os.environ.get("SW_BENCH_STEPS_PER_LAUNCH", "32"))   # most steps per graph launch (step_many; Leg.plan)
@@ -445,14 +827,17 @@ def main():
             return float(t.item())
         return x
 
+    HOST_Z = os.environ.get("SW_BENCH_HOST_Z", "1") != "0" or args.scaling == "strong"
+    if args.side_legs:
+        return side_legs_main(args, dev, KG, HOST_Z)
+    if args.exchange_only:
+        return exchange_child_main(args, world, rank, dev, pg, backend, KG)
     import gc
     leg = Leg(args.workload, dev, pg, world, rank, args.scaling, args.global_scenes, KG)
     # The headline step is the reference's: z = torch.rand(bs, noise_len) drawn on the HOST every step and copied
     # to the device inside the step (train.py:473); the tracks are resident in HBM.  SW_BENCH_HOST_Z=0 makes the all-resident
     # form (z a ring of device tensors drawn beforehand) the headline instead; by default it is the secondary figure
     # config.inputs_resident.  --scaling strong always draws z for the global batch on the host and slices it.
-    HOST_Z = os.environ.get("SW_BENCH_HOST_Z", "1") != "0" or args.scaling == "strong"
-    RESIDENT = "resident in HBM when the timed region starts (tracks; z: a ring of 16 device tensors drawn beforehand)"
     if not HOST_Z:
         leg.z_resident()
     tr, To, Tp, A = leg.tr, leg.To, leg.Tp, leg.A
@@ -516,39 +901,44 @@ def main():
     # spin kernel queued in front lets the host run ahead, so the launches reach the GPU back to back and the event
     # intervals hold no host gaps.  profiles/ holds the rocprofv3 trace of the graph-replayed run for comparison.
     n_ev = max(4, min(args.steps, 20))
-    tr.use_graph = False
-    for i in range(2):
-        leg.one_step(i)
-    # inputs of the timed eager steps are placed on the device beforehand: a host-to-device copy inside the pass would
-    # make the host wait for the stream and the launches behind it would reach an idle GPU one by one
-    from socialways_amd import ops as sw_ops
-    scenes = sw_ops.SceneIndex.get(leg.sb, leg.B, dev)
-    ins = []
-    for i in range(n_ev):
-        o, p_, zv, ov, nz = leg.draw(i)
-        ins.append((o.contiguous(), p_.contiguous(), torch.tensor([zv, ov], dtype=torch.float32).to(dev),
-                    tr._pad_z(nz.to(dev)).contiguous()))
-    part = torch.zeros(tr.n_unrolling_steps + 3, (leg.B + 15) // 16, 3, device=dev)
-    tr._row0, tr._vnoise = 0, None
-    fence()
-    lib = L.load()
-    lib.sw_kernel_timing(1)
-    lib.sw_debug_spin(float(os.environ.get("SW_BENCH_SPIN_US", 2500.0 * n_ev)), L.stream())
-    for o, p_, tg, nz in ins:
-        leg.last = tr._step_impl(o, p_, None, scenes, tg, nz, float(leg.data.ss), float(leg.Bg), part)
-    for _ in range(32):
-        lib.sw_debug_spin(0.0, L.stream())       # calibration: the event interval of a kernel that does nothing
-    fence()
-    buf = ctypes.create_string_buffer(1 << 16)
-    lib.sw_kernel_timing_read(buf, len(buf))
-    lib.sw_kernel_timing(0)
-    ktimes, event_overhead_us = {}, None
-    for line in buf.value.decode().splitlines():
-        name, calls, total_us = line.split()
-        if name == "nop_kernel":
-            event_overhead_us = float(total_us) / int(calls)
-        elif name != "spin_kernel":
-            ktimes[name] = (int(calls), float(total_us))
+    ktimes, event_overhead_us, roofline_error = {}, None, None
+    try:
+        tr.use_graph = False
+        for i in range(2):
+            leg.one_step(i)
+        # inputs of the timed eager steps are placed on the device beforehand: a host-to-device copy inside the pass would
+        # make the host wait for the stream and the launches behind it would reach an idle GPU one by one
+        from socialways_amd import ops as sw_ops
+        scenes = sw_ops.SceneIndex.get(leg.sb, leg.B, dev)
+        ins = []
+        for i in range(n_ev):
+            o, p_, zv, ov, nz = leg.draw(i)
+            ins.append((o.contiguous(), p_.contiguous(), torch.tensor([zv, ov], dtype=torch.float32).to(dev),
+                        tr._pad_z(nz.to(dev)).contiguous()))
+        part = torch.zeros(tr.n_unrolling_steps + 3, (leg.B + 15) // 16, 3, device=dev)
+        tr._row0, tr._vnoise = 0, None
+        fence()
+        lib = L.load()
+        lib.sw_kernel_timing(1)
+        lib.sw_debug_spin(float(os.environ.get("SW_BENCH_SPIN_US", 2500.0 * n_ev)), L.stream())
+        for o, p_, tg, nz in ins:
+            leg.last = tr._step_impl(o, p_, None, scenes, tg, nz, float(leg.data.ss), float(leg.Bg), part)
+        for _ in range(32):
+            lib.sw_debug_spin(0.0, L.stream())       # calibration: the event interval of a kernel that does nothing
+        fence()
+        buf = ctypes.create_string_buffer(1 << 16)
+        lib.sw_kernel_timing_read(buf, len(buf))
+        lib.sw_kernel_timing(0)
+        for line in buf.value.decode().splitlines():
+            name, calls, total_us = line.split()
+            if name == "nop_kernel":
+                event_overhead_us = float(total_us) / int(calls)
+            elif name != "spin_kernel":
+                ktimes[name] = (int(calls), float(total_us))
+    except Exception as e:      # noqa: BLE001 - the per-kernel view is lost, the timed region is not
+        if world > 1:
+            raise               # (collectives inside the eager steps: a one-sided failure cannot be survived in place)
+        roofline_error, ktimes = _err(e)["error"], {}
     assert torch.isfinite(leg.last).all(), "non-finite losses"
     replicas_identical = None
     if world > 1:      # data-parallel replicas must hold bit-identical weights after the same all-reduced updates
@@ -560,238 +950,12 @@ def main():
     collectives = None if pg is None else "in-graph" if tr._graph_collectives else "between graph segments"
     if pg is not None:
         tr.release_graphs()                     # recorded collectives go before their communicator
-
-    def dp_exchange_report():
-        """N > 1: what one gradient all-reduce of each of the step's three buckets costs on this group (HIP events around 50
-        back-to-back calls; D = 27 942 floats twice, G = 86 124: the packed buffers) on the process group's own all-reduce (RCCL) and on the
-        library's two-hop exchange (SW_ALLREDUCE=direct, csrc/sw_comm.hip), then the whole step on the direct form as a secondary
-        leg - so that a scaling run explains itself."""
-        from socialways_amd.comm import DirectAllReduce
-        rep = {"buckets_floats": [int(tr.D._gflat.numel()), int(tr.D._gflat.numel()), int(tr.G._gflat_all.numel())]}
-        bufs = [torch.zeros(n, device=dev) for n in rep["buckets_floats"]]
-
-        def time_calls(fn):
-            out = []
-            for b in bufs:
-                for _ in range(5):
-                    fn(b)
-                fence()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(50):
-                    fn(b)
-                e1.record()
-                torch.cuda.synchronize()
-                out.append(max_over_ranks(e0.elapsed_time(e1) * 1e3 / 50))
-            return out
-        rep["group_us"] = time_calls(lambda b: torch.distributed.all_reduce(b, group=pg))
-        rep["group_backend"] = backend
-        prev_mode = os.environ.get("SW_ALLREDUCE")
-        try:
-            ar = DirectAllReduce(pg, dev, max(rep["buckets_floats"]))
-            rep["direct_us"] = time_calls(ar)
-            rep["direct_status"] = ar.status()
-            ar.close()
-            os.environ["SW_ALLREDUCE"] = "direct"
-            lg = Leg(args.workload, dev, pg, world, rank, args.scaling, args.global_scenes, KG)
-            n, w = OTHER_STEPS["m1"]
-            d = max_over_ranks(short_leg(lg, n, w))
-            rep["direct_step"] = {"steps": n, "steps_s": n * (world if args.scaling == "weak" else 1) / d, "ms_per_step": 1e3 * d / n,
-                                  "collectives": "in-graph" if lg.tr._graph_collectives else "between graph segments",
-                                  "status": lg.tr._direct.status() if lg.tr._direct is not None else None}
-            lg.tr.release_graphs()
-            if lg.tr._direct is not None:
-                lg.tr._direct.close()
-            del lg
-        except Exception as e:      # noqa: BLE001 - the report must not lose the bench line
-            rep["direct_error"] = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
-        finally:
-            if prev_mode is None:
-                os.environ.pop("SW_ALLREDUCE", None)
-            else:
-                os.environ["SW_ALLREDUCE"] = prev_mode
-        return rep
-
-    def short_leg(lg, n, w):
-        """A side leg: n steps timed three times, the fastest region reported.  (Regions of 40-80 ms are exposed to the
-        sporadic 3-50 ms host stalls of this runtime - round-3 per-launch host / GPU time stamps - which are not a property of the leg;
-        THE timed region of the headline workload is never treated this way.)"""
-        lg.prime((n, w))
-        lg.run_steps(0, w)
-        gc.collect()
-        gc.disable()
-        d = min(lg.timed(fence, w + r * n, n) for r in range(3))
-        gc.enable()
-        assert torch.isfinite(lg.last).all(), "non-finite losses (%s)" % lg.name
-        return d
-
-    exchange = None
-    if pg is not None and world > 1 and os.environ.get("SW_ALLREDUCE", "") != "direct" and not args.no_other_workloads:
-        exchange = dp_exchange_report()
-    other = None
-    if world == 1 and pg is None and not args.no_other_workloads:
-        other = {}
-        del tr
-        leg.tr = None
-        for name in sorted(WORKLOADS):
-            if name == args.workload:
-                continue
-            torch.cuda.empty_cache()
-            lg = Leg(name, dev, None, 1, 0, "weak", 0, KG)
-            if not HOST_Z:
-                lg.z_resident()
-            n, w = OTHER_STEPS[name]
-            d = short_leg(lg, n, w)
-            fl_o = alg_flops(lg.B, lg.P, lg.To, lg.Tp)
-            S_o, A_o = WORKLOADS[name][:2]
-            wl = ("%d scenes x %d agents x %d+%d" % (S_o, A_o, lg.To, lg.Tp)) if A_o is not None else \
-                 ("%d scenes of 1..8 agents (%d agents, %d in-scene pairs, %d single-agent scenes) x %d+%d: the SHAPE of a real "
-                  "ETH/UCY packed batch, synthetic tracks" % (lg.S_local, lg.B, lg.P, sum(a == 1 for a in lg.sizes), lg.To, lg.Tp))
-            other[name] = {"workload": wl, "steps": n, "warmup": w,
-                           "steps_s": n / d, "ms_per_step": 1e3 * d / n, "step_alg_gflop": fl_o["step"] / 1e9,
-                           # reference-formulation FLOPs (SURVEY 8d) / time: CREDITS work the kernels eliminate algebraically
-                           "step_frac_of_fp32_peak": fl_o["step"] / (d / n) / (PEAK_FP32_TFLOPS * 1e12)}
-            rec_o = pmc_record(name)
-            ex = rec_o and rec_o.get("_step", {}).get("mfma_flop_per_step")
-            # matrix FLOP the kernels really issued per step (SQ counter pass of these sources) / this leg's time
-            other[name]["step_executed_mfma_gflop"] = ex / 1e9 if ex else None
-            other[name]["step_frac_executed"] = ex / (d / n) / (PEAK_FP32_TFLOPS * 1e12) if ex else None
-            other[name]["inputs"] = "z drawn on the host every step" if HOST_Z else RESIDENT
-            if name == "c4" and not HOST_Z:
-                # 4 MB of z per step are ~170 us of request-bound PCIe reads that 113 us of encoder work cannot hide (and ~2 ms
-                # of host work per step): the PCIe-inclusive figure next to the one with resident inputs
-                lg.z_host()
-                d2 = short_leg(lg, n, w)
-                other[name]["pcie_inclusive"] = {"steps_s": n / d2, "ms_per_step": 1e3 * d2 / n,
-                                                 "what": "z drawn on the host per step (train.py:473) and pulled from pinned memory "
-                                                         "inside the step: 4 MB = ~170 us of request-bound PCIe reads"}
-            if name == "c4" and HOST_Z:
-                lg.z_resident()     # the all-resident form next to the reference's host-drawn z (4 MB per step at this shape)
-                d2 = short_leg(lg, n, w)
-                other[name]["inputs_resident"] = {"steps_s": n / d2, "ms_per_step": 1e3 * d2 / n,
-                                                  "what": "z too resident in HBM (device tensors read by address)"}
-            del lg
-        # The data-parallel step structure at N = 1 - the only scaling evidence a 1-GPU box can give: the same workload on a
-        # 1-rank RCCL group (SW_FORCE_DIST: all three all-reduces are issued, the Adam updates run behind them as kernels
-        # of their own instead of inside the gradient reductions).  `delta_us_per_step` = what the DP structure costs
-        # per step before any wire time; weak-scaling efficiency at N ranks <= t_plain / (t_dp1 + 3 x all-reduce latency).
-        if args.workload == "m1":
-            torch.cuda.empty_cache()
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29537")
-            os.environ["SW_FORCE_DIST"] = "1"
-            try:
-                torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-                lg = Leg("m1", dev, torch.distributed.group.WORLD, 1, 0, "weak", 0, KG)
-                if not HOST_Z:
-                    lg.z_resident()
-                n, w = OTHER_STEPS["m1"]
-                d = short_leg(lg, n, w)
-                other["dp1_rccl"] = {"workload": "m1 on a 1-rank RCCL process group (3 all-reduces per step issued, Adam behind them)",
-                                     "steps": n, "steps_s": n / d, "ms_per_step": 1e3 * d / n,
-                                     "delta_us_per_step": 1e3 * (1e3 * d / n - 1e3 * dt / args.steps),
-                                     "collectives": "in-graph" if lg.tr._graph_collectives else "between graph segments",
-                                     # plain-path time / 1-rank-group time: what the DP step STRUCTURE costs with no peer
-                                     # on the wire - says nothing about N > 1 (no wire latency is in it)
-                                     "plain_over_dp1_time_ratio": (dt / args.steps) / (d / n)}
-                lg.tr.release_graphs()
-                del lg
-                # ... and the same on the library's direct exchange (SW_ALLREDUCE=direct: per bucket ONE launch that exchanges
-                # the gradient and applies Adam; with one rank the exchange moves nothing): its structure cost
-                os.environ["SW_ALLREDUCE"] = "direct"
-                try:
-                    lg = Leg("m1", dev, torch.distributed.group.WORLD, 1, 0, "weak", 0, KG)
-                    if not HOST_Z:
-                        lg.z_resident()
-                    d = short_leg(lg, n, w)
-                    other["dp1_direct"] = {"workload": "m1 on a 1-rank group with SW_ALLREDUCE=direct (3 exchange + Adam launches per step)",
-                                           "steps": n, "steps_s": n / d, "ms_per_step": 1e3 * d / n,
-                                           "delta_us_per_step": 1e3 * (1e3 * d / n - 1e3 * dt / args.steps),
-                                           "collectives": "in-graph" if lg.tr._graph_collectives else "between graph segments",
-                                           "status": lg.tr._direct.status()}
-                    lg.tr.release_graphs()
-                    lg.tr._direct.close()
-                    del lg
-                except Exception as e:      # noqa: BLE001
-                    other["dp1_direct"] = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")}
-                finally:
-                    os.environ.pop("SW_ALLREDUCE", None)
-                torch.distributed.destroy_process_group()
-            except Exception as e:      # noqa: BLE001 - a box without a working RCCL must not lose the bench line
-                other["dp1_rccl"] = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")}
-            finally:
-                os.environ.pop("SW_FORCE_DIST", None)
-            # SURVEY 8f-4: the best-of-K variety term (K = 20 rollouts folded into one batch of 20 x 2048 agents) as a
-            # throughput stress of the generator path; eager steps (the folded step is not graph-captured)
-            torch.cuda.empty_cache()
-            lg = Leg("m1", dev, None, 1, 0, "weak", 0, 1, use_variety_loss="fixed", variety_k=20, use_l2_loss=True)
-            if not HOST_Z:
-                lg.z_resident()
-            n, w = 40, 6
-            d = short_leg(lg, n, w)
-            other["m1_variety_k20"] = {"workload": "m1 + best-of-20 variety loss (use_variety_loss='fixed'): decode loop on 40 960 agent copies, encoder and social block once on the 2 048 agents",
-                                       "steps": n, "steps_s": n / d, "ms_per_step": 1e3 * d / n}
-            del lg
-            # `--hidden-size 128` (train.py:42-44): the WIDE path (wide.py: time-step-level kernels, explicit backward, one
-            # hipGraph per step) on the metric shape; the generic path's layer-by-layer form ran 42 steps/s here in round 3
-            for Hw in (128, 96):
-                torch.cuda.empty_cache()
-                import socialways_amd as sw
-                torch.manual_seed(0)
-                np.random.seed(0)
-                tr_w = sw.SocialWaysTrainer(Tp, hidden_size=Hw, use_social=True, device=dev)
-                S_w, A_w = WORKLOADS["m1"][:2]
-                tk = sw.synth_tracks(S_w * 2, A_w, To, Tp, seed=99)
-                dw = sw.SceneDataset(tk["obsvs"], tk["preds"], tk["batches"], device=dev)
-                Bw, sbw = S_w * A_w, np.stack([np.arange(S_w) * A_w, (np.arange(S_w) + 1) * A_w], axis=1).astype(np.int64)
-                zb = torch.empty(Bw, Hw // 2).pin_memory()
-
-                def wstep(i):
-                    a = (i % 2) * Bw
-                    torch.rand(zb.shape, out=zb)
-                    return tr_w.step(dw.obsv[a:a + Bw], dw.pred[a:a + Bw], sbw, np.random.uniform(0, 0.1), np.random.uniform(0.9, 1.0),
-                                     zb, dw.ss)
-                for i in range(6):
-                    last_w = wstep(i)
-                n_w, t_best = 60, float("inf")
-                for rep in range(3):
-                    fence()
-                    t0 = time.perf_counter()
-                    for i in range(n_w):
-                        last_w = wstep(i)
-                    fence()
-                    t_best = min(t_best, time.perf_counter() - t0)
-                assert torch.isfinite(last_w).all(), "non-finite losses (hidden size %d)" % Hw
-                other["m1_hidden%d" % Hw] = {
-                    "workload": "m1 at --hidden-size %d (decoder %d-%d-%d-%d-2, noise %d): %s" % (
-                        Hw, 5 * Hw // 2, 5 * Hw // 2, 5 * Hw // 4, 5 * Hw // 8, Hw // 2, type(tr_w).__name__),
-                    "steps": n_w, "steps_s": n_w / t_best, "ms_per_step": 1e3 * t_best / n_w}
-                tr_w.release_graphs()
-                del tr_w, dw
-            # SURVEY 8f-1: the evaluation pass test() exists for - K = 20 sampled futures per held-out scene, min / avg ADE
-            # and FDE (train.py:563-616) - on the m1-shaped recording's held-out fifth (scenes folded into rollout launches)
-            torch.cuda.empty_cache()
-            import socialways_amd as sw
-            torch.manual_seed(0)
-            tr_e = sw.SocialWaysTrainer(Tp, use_social=True, device=dev)
-            tk = sw.synth_tracks(1280, 8, To, Tp, seed=4321)
-            data_e = sw.SceneDataset(tk["obsvs"], tk["preds"], tk["batches"], device=dev)
-            tr_e.test(data_e, 20)
-            fence()
-            t_best = float("inf")
-            for _ in range(3):
-                t0 = time.perf_counter()
-                res_e = tr_e.test(data_e, 20)
-                fence()
-                t_best = min(t_best, time.perf_counter() - t0)
-            n_sc = len(data_e.test_batches)
-            other["test_k20"] = {"workload": "test(): K = 20 sampled futures for each of %d held-out scenes x 8 agents (%d agents), "
-                                             "min / avg ADE and FDE; scenes folded into launches of <= %d agent copies"
-                                             % (n_sc, data_e.n_test_samples, tr_e.TEST_CHUNK),
-                                 "seconds": t_best, "scenes_s": n_sc / t_best, "rollouts_s": 20 * data_e.n_test_samples / t_best,
-                                 "ade_avg_min": [res_e[0], res_e[2]], "fde_avg_min": [res_e[1], res_e[3]]}
-            del tr_e, data_e
-
+    # ---- the line exists from here on: the headline region, its repeats and the per-kernel pass are measured.  Everything
+    # below decorates it and runs where it cannot take it down (side legs: child processes; the N > 1 exchange report: a child job)
+    res = None
+    allreduce_form = (("direct (csrc/sw_comm.hip)" if getattr(tr, "_direct", None) is not None else "process group")
+                      if pg is not None else None)
+    exchange_probe = getattr(tr, "exchange_probe", None)
     if rank == 0:
         S = leg.S_local
         B, P = leg.B, leg.P
@@ -807,6 +971,9 @@ def main():
                          "alg_gflop_per_step": (gf / 1e9) if gf else None,
                          "frac": (gf / (us_step * 1e-6) / (PEAK_FP32_TFLOPS * 1e12)) if gf else None})
         rows.sort(key=lambda r: -r["us_per_step"])
+        if not rows:        # the per-kernel pass failed (roofline.error says why): the roofline object keeps its keys, valued null
+            rows = [{"name": None, "launches_per_step": 0.0, "avg_us": float("nan"), "us_per_step": float("nan"),
+                     "alg_gflop_per_step": None, "frac": None}]
         top = rows[0]
         kern_s = top["avg_us"] * 1e-6
         achieved = (top["alg_gflop_per_step"] or float("nan")) * 1e9 / (top["us_per_step"] * 1e-6) / 1e12
@@ -849,10 +1016,10 @@ def main():
                        "collectives": collectives, "rccl_ranks": (world if pg is not None else None),
                        "backend": backend,       # "nccl" = RCCL; "gloo" = ranks sharing devices, a rehearsal, not a measurement
                        "allreduces_per_step": (3 if pg is not None else 0),
-                       "allreduce": ("direct (csrc/sw_comm.hip)" if (leg.tr is not None and getattr(leg.tr, "_direct", None) is not None)
-                                     else "process group") if pg is not None else None,
-                       "exchange": exchange,      # N > 1: us per all-reduce of each bucket on both forms + the step on the direct form
-                       "exchange_probe": getattr(leg.tr, "exchange_probe", None) if leg.tr is not None else None,      # SW_ALLREDUCE=auto: what the probe measured / chose
+                       "allreduce": allreduce_form,
+                       "exchange": None,          # N > 1: us per all-reduce of each bucket on both forms + the step on the direct form (below)
+                       "exchange_probe": exchange_probe,      # SW_ALLREDUCE=auto: what the probe measured / chose
+                       "agent_steps_s": value * B if args.scaling == "weak" else value * leg.Bg,      # agents stepped per second, whole job
                        "replicas_identical": replicas_identical,
                        "step_alg_gflop": fl["step"] / 1e9,
                        "step_frac_of_fp32_peak": fl["step"] / per_step / (PEAK_FP32_TFLOPS * 1e12),
@@ -864,8 +1031,8 @@ def main():
                        "inputs": "z drawn on the host every step" if HOST_Z else RESIDENT,
                        "pcie_inclusive": pcie,
                        "inputs_resident": resident,
-                       "other_workloads": other},
-            "roofline": {"bound": "mfma", "kernel": top["name"], "achieved": achieved,
+                       "other_workloads": None},
+            "roofline": {"bound": "mfma", "kernel": top["name"], "achieved": achieved, "error": roofline_error,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
                          "avg_launch_ms": kern_s * 1e3, "launches": int(round(top["launches_per_step"] * n_ev)),
                          "launches_per_step": top["launches_per_step"],
@@ -893,13 +1060,73 @@ def main():
                          "step_hbm_GBps": (step_traffic / per_step / 1e9) if step_traffic else None,
                          "step_hbm_frac": (step_traffic / per_step / PEAK_HBM_BPS) if step_traffic else None},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(leg.tracks, S if args.workload != "c4" else 16, A, To, Tp)
+
+    import shutil
+    import signal
+    import tempfile
+
+    def emit():
         ctypes.CDLL(None).fflush(None)          # RCCL's version banner sits in the C stdio buffer: keep the JSON line last
         print(json.dumps(res), flush=True)
+
+    if rank == 0:
+        def on_term(signum, frame):             # told to stop while a side leg runs: the line goes out as it stands
+            res["config"]["terminated"] = "signal %d during the side legs: the line as it stood" % signum
+            ch = _CHILD["proc"]
+            if ch is not None:
+                try:
+                    os.killpg(ch.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+            emit()
+            os._exit(0)
+        signal.signal(signal.SIGTERM, on_term)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(leg.tracks, S if args.workload != "c4" else 16, A, To, Tp)
+            except Exception as e:      # noqa: BLE001
+                res["cpu_baseline"] = dict(_err(e), value=None, unit="steps/s", cores=None, kind="port", sample=None)
+    tmpdir = None
+    if world == 1 and pg is None and not args.no_other_workloads:
+        tr.close()
+        del tr
+        leg.tr = None
+        torch.cuda.empty_cache()
+        tmpdir = tempfile.mkdtemp(prefix="sw_bench_")
+        try:
+            res["config"]["other_workloads"] = run_side_children(args, 1e3 * dt / args.steps, tmpdir)
+        except Exception as e:      # noqa: BLE001
+            res["config"]["other_workloads"] = _err(e)
+    if pg is not None and world > 1 and os.environ.get("SW_ALLREDUCE", "") != "direct" and not args.no_other_workloads:
+        # N > 1: the exchange report is a CHILD JOB of rank 0 on the same GPUs; the other ranks wait on the host (a file, no
+        # collective: a barrier's kernels would spin on the GPUs the child measures on)
+        obj = [tempfile.mkdtemp(prefix="sw_bench_")] if rank == 0 else [None]
+        torch.distributed.broadcast_object_list(obj, src=0, device=dev if backend == "nccl" else None)
+        tmpdir = obj[0]
+        done = os.path.join(tmpdir, "exchange.done")
+        if rank == 0:
+            try:
+                res["config"]["exchange"] = run_exchange_child(args, world, tmpdir)
+            except Exception as e:      # noqa: BLE001
+                res["config"]["exchange"] = _err(e)
+            open(done, "w").close()
+        else:
+            deadline = time.monotonic() + child_timeout(300.0) + 120.0
+            while not os.path.exists(done) and time.monotonic() < deadline:
+                time.sleep(0.2)
+    if rank == 0:
+        emit()
     if pg is not None:
-        torch.distributed.destroy_process_group()
+        try:
+            tr.close()                          # (a direct exchange of the headline run: buffers and peer mappings)
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        except Exception:      # noqa: BLE001 - the line is out
+            pass
+    if tmpdir is not None and rank == 0:
+        shutil.rmtree(tmpdir, ignore_errors=True)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -104,20 +104,19 @@ __device__ __forceinline__ bool poll_grans(Gran2 (&v)[SW_COMM_MAXW], const char*
 template <bool ADAM>
 __global__ __launch_bounds__(256) void allreduce_direct_kernel(CommArgs A, float* __restrict__ grad, WgAdam ad) {
   __shared__ float bcs[2];
-  __shared__ unsigned dead;
   if (ADAM && threadIdx.x == 64) wg_adam_bc_compute(ad.step, ad.beta1, ad.beta2, bcs[0], bcs[1]);
   const int b = blockIdx.x, W = A.W, r = A.rank;   // (b: this workgroup's chunk of every slice)
   char* mine = A.peer[r];
   unsigned* hdr = reinterpret_cast<unsigned*>(mine);
   // a wait of an EARLIER call on this buffer timed out: the exchange is dead (sw_comm_status says so to the host); nothing is
   // sent, nothing is written, nobody is waited for - one time-out costs one time-out, not one per remaining call of the epoch
-  if (threadIdx.x == 0) dead = __hip_atomic_load(&hdr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (dead != 0u) return;
+  // (read next to the epoch, one round trip; lanes that leave early are simply gone - a barrier does not wait for them)
+  const unsigned dead = __hip_atomic_load(&hdr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // ONE epoch per call for the whole buffer (a per-workgroup epoch could collide: the chunking depends on n, so a granule is
   // written by different workgroup indices in different calls).  It advances when the LAST workgroup of the launch finishes -
   // by then every workgroup has read it.
   const unsigned e = __hip_atomic_load(&hdr[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  if (dead != 0u) return;
   const long long chunk = A.ls / A.nblk, c0 = (long long)b * chunk;      // floats; multiple of 4
   const int np = (int)(chunk >> 1);                                       // pairs of floats in this workgroup's chunk
   bool ok = true;
@@ -154,6 +153,7 @@ __global__ __launch_bounds__(256) void allreduce_direct_kernel(CommArgs A, float
       }
     }
   }
+  if constexpr (ADAM) __syncthreads();      // bcs
   // ---- the all-reduced gradient back over the rank's buffer (and the optimizer step) ----------------------------------
   {
     const char* ov = mine + A.out + (size_t)c0 * 8;

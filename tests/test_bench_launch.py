@@ -76,3 +76,38 @@ def test_two_rank_bench_line_reports_both_gradient_exchanges():
     assert ex["buckets_floats"] == [27942, 27942, 86124]      # packed D, D, G gradient buffers (tensors on 4-float boundaries)
     assert len(ex["group_us"]) == 3 and len(ex["direct_us"]) == 3 and min(ex["direct_us"]) > 0 and ex["direct_status"] == 0
     assert ex["direct_step"]["steps_s"] > 0 and ex["direct_step"]["collectives"] == "in-graph" and ex["direct_step"]["status"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_a_crash_in_the_exchange_report_cannot_lose_the_line():
+    """r5 verdict item 1: the exchange report (the library's direct exchange has never crossed an xGMI link) runs in a CHILD
+    JOB.  SW_COMM_FAULT_INJECT=1 makes sw_comm_ipc_import abort() the process - what a GPU fault in the peer mapping would
+    do: the child job dies, the parent's ranks do not; the line comes out valid, with config.exchange.error set and the
+    group's own all-reduce times (measured before the fault) kept."""
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    p, lines = _run(["--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-sustained"],
+                    {"SW_BENCH_BACKEND": backend, "SW_BENCH_SETTLE_STEPS": "8", "SW_COMM_FAULT_INJECT": "1"}, 850)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["replicas_identical"] is True
+    ex = rec["config"]["exchange"]
+    assert ex is not None and "error" in ex, ex
+    assert len(ex["group_us"]) == 3 and "direct_us" not in ex
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_a_dead_side_leg_child_cannot_lose_the_single_gpu_line():
+    """The N = 1 line's side legs run in child processes: a child that cannot even start its legs (here: its time limit is
+    too short for the first one) leaves {"error": ...} records, the headline, roofline and cpu_baseline are untouched."""
+    p, lines = _run(["--steps", "4", "--warmup", "2", "--no-sustained"],
+                    {"SW_BENCH_SETTLE_STEPS": "8", "SW_BENCH_CHILD_TIMEOUT_S": "1"}, 850)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["roofline"]["frac"] > 0 and rec["cpu_baseline"]["value"] > 0
+    ow = rec["config"]["other_workloads"]
+    assert all("error" in ow["_%s_child" % g] for g in ("shapes", "dp1", "extra")), ow
