@@ -505,13 +505,6 @@ int sw_wide_disc_heads_bwd(const long long* p, void* stream);
  * as 64-bit host values) through the grouped split-K GEMM; wgrad_ws = sw_workspace_floats(SW_WS_WGRAD, ...) floats       */
 int sw_wide_wgrad(const long long* desc, int n, float* wgrad_ws, void* stream);
 
-/* Weight-gradient launches fold their second stage (the fixed-order sum of the split-K partials + the optimizer step) into
- * the tail of the GEMM grid: finisher workgroups wait - bounded, ~2 s - for the partials they need.  sw_wgrad_status
- * synchronises the current device and reports how many such waits have been given up since the library was loaded (0 in a
- * healthy process; anything else: the gradients of some step were incomplete).  SW_WG_FOLD=0 (environment) selects the
- * two-launch form. */
-int sw_wgrad_status(int* errors);
-
 /* ---- A two-hop gradient all-reduce over peer-mapped exchange buffers (csrc/sw_comm.hip) - the data-parallel step's
  *      alternative to `torch.distributed.all_reduce` on RCCL (3 flat buckets of 112 / 112 / 344 KB per step; the
  *      reference itself is single-process, train.py has no counterpart).  Every rank allocates ONE exchange buffer

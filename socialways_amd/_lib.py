@@ -107,7 +107,6 @@ PROTOTYPES = {
     "sw_wide_lstm_seq_supported": (_i, [_i]),
     "sw_wide_lstm_seq_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "sw_wide_lstm_seq_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
-    "sw_wgrad_status": (_i, [_vp]),
     "sw_comm_bytes": (_ll, [_i, _ll]),
     "sw_comm_alloc": (_i, [_ll, _vp]),
     "sw_comm_free": (_i, [_vp]),

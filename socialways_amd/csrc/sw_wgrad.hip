@@ -18,7 +18,6 @@
 #include "sw_wgrad.h"
 #include "sw_wgrad_dev.h"
 #include <stdlib.h>
-#include <mutex>
 
 // One wave = one job: a 64 x 64 output block (4 x 4 MFMA tiles, 16 accumulators) of one column block
 // of one problem over one row slice.  Operands come straight from global memory in MFMA layout
@@ -38,47 +37,15 @@ extern "C" int sw_debug_wg_stamps(unsigned long long* host, int n) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -1;
 }
 #endif
-// FOLDED REDUCTION (round 6): the second stage used to be a launch of its own (wgrad_reduce_kernel: 6.4 us + a kernel
-// boundary, three times per training step, no matrix work).  Now it is the TAIL of this grid: workgroups behind the jobs are
-// FINISHERS - each owns the output elements one workgroup of wgrad_reduce_kernel owned and runs the same code (same fixed
-// summation order, same Adam arithmetic: bit-identical), after waiting until every partial its elements need has been
-// published (per output block a ticket counter the publishing workgroups increment, wg_job).  They are dispatched behind the
-// jobs (a grid is dispatched in block order; every job workgroup is resident or done before the first finisher gets a slot,
-// and jobs wait for nothing: no deadlock, also with several processes on one device), start while the last jobs still
-// stream, and compute Adam's bias corrections while they wait.  Partials travel write-through (sc0 sc1 stores, sc0 sc1 loads):
-// no fence, no L2 write-back.  A wait is bounded (~2 s): it then counts an error (sw_wgrad_status) instead of hanging.
-template <bool FOLD>
-__device__ __forceinline__ void wg_reduce_body(const WgBatch& batch, const float* __restrict__ ws, const WgAdam& ad, int gid,
-                                               unsigned* __restrict__ tix);
-
-__global__ __launch_bounds__(SW_THREADS, 2) void wgrad_partial_kernel(WgBatch batch, float* __restrict__ ws, WgAdam ad,
-                                                                      unsigned* __restrict__ tix, float* __restrict__ bc_out) {
+__global__ __launch_bounds__(SW_THREADS, 2) void wgrad_partial_kernel(WgBatch batch, float* __restrict__ ws,
+                                                                      const float* __restrict__ adam_step, double beta1,
+                                                                      double beta2, float* __restrict__ bc_out) {
   __shared__ __attribute__((aligned(16))) float red[SW_WG_RED_FLOATS];   // per-wave 64 x <=69 blocks, summed before the store
-  const int njobs = wg_grid_jobs(batch.total_jobs);
-  if ((int)blockIdx.x >= njobs) {
-    if (tix) {            // a finisher of the folded reduction
-      const int f = (int)blockIdx.x - njobs;
-      if (f == 0 && threadIdx.x == 0 && bc_out) {      // kernels behind this launch (the composition back-propagation) reuse them
-        float bc1, bc2s;
-        wg_adam_bc_compute(ad.step, ad.beta1, ad.beta2, bc1, bc2s);
-        bc_out[0] = bc1;
-        bc_out[1] = bc2s;
-      }
-      wg_reduce_body<true>(batch, ws, ad, f * SW_THREADS + (int)threadIdx.x, tix);
-      // the LAST finisher clears the tickets for the next launch on this slot (nobody reads them any more)
-      sw_barrier();
-      if (threadIdx.x == 0) {
-        const unsigned nfin = gridDim.x - (unsigned)njobs;
-        if (__hip_atomic_fetch_add(&tix[SW_WG_TIX_FIN], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nfin - 1u) {
-          for (int i = 0; i <= SW_WG_TIX_FIN; ++i) __hip_atomic_store(&tix[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      return;
-    }
-    // two-launch form: Adam's bias corrections for the reduction that follows, by one extra workgroup, no job delayed
+  // Adam's bias corrections for the reduction that follows (it applies the update): one extra workgroup, no job delayed
+  if ((int)blockIdx.x >= wg_grid_jobs(batch.total_jobs)) {
     if (threadIdx.x == 0) {
       float bc1, bc2s;
-      wg_adam_bc_compute(ad.step, ad.beta1, ad.beta2, bc1, bc2s);
+      wg_adam_bc_compute(adam_step, beta1, beta2, bc1, bc2s);
       bc_out[0] = bc1;
       bc_out[1] = bc2s;
     }
@@ -94,7 +61,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void wgrad_partial_kernel(WgBatch ba
 #ifdef SW_WG_STAMP
   const unsigned long long t0 = wall_clock64();
 #endif
-  wg_job(batch, ws, job, red, tix);
+  wg_job(batch, ws, job, red);
 #ifdef SW_WG_STAMP
   if (threadIdx.x == 0 && blockIdx.x < 2048) {      // launches below 400 jobs (discriminator passes at m1): second half
     int p = 0;
@@ -126,49 +93,6 @@ static float* wg_bc_slot() {
   return base[dev] + 2 * (next++ % 64);
 }
 
-// ... and the ticket counters of a folded launch: zero at module load, cleared by the launch's last finisher.  A slot
-// belongs to a partial WORKSPACE: launches that share a workspace are ordered by their caller anyway (they share the
-// partials), launches on different workspaces (other streams, other trainers) get different slots.  Beyond SW_WG_TIX_SLOTS
-// distinct workspaces per process the launch takes the two-launch form.
-#define SW_WG_TIX_SLOTS 256
-__device__ unsigned g_wg_tix[SW_WG_TIX_WORDS * SW_WG_TIX_SLOTS];
-static unsigned* wg_tix_slot(const float* ws) {
-  static std::mutex mu;
-  static unsigned* base[32] = {};
-  static const float* owner[32][SW_WG_TIX_SLOTS] = {};
-  static int used[32] = {};
-  int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  if (!base[dev]) {
-    void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wg_tix)) != hipSuccess) {
-      (void)hipGetLastError();
-      return nullptr;
-    }
-    base[dev] = (unsigned*)p;
-  }
-  int i = 0;
-  while (i < used[dev] && owner[dev][i] != ws) ++i;
-  if (i == used[dev]) {
-    if (used[dev] == SW_WG_TIX_SLOTS) return nullptr;
-    owner[dev][used[dev]++] = ws;
-  }
-  return base[dev] + SW_WG_TIX_WORDS * i;
-}
-// waits the finishers of folded launches have given up so far on the current device (0 in a healthy process); synchronises
-extern "C" int sw_wgrad_status(int* errors) {
-  if (!errors) return SW_EARG;
-  static unsigned host[SW_WG_TIX_WORDS * SW_WG_TIX_SLOTS];
-  hipError_t e = hipDeviceSynchronize();
-  if (e == hipSuccess) e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg_tix), sizeof(host));
-  if (e != hipSuccess) { sw_set_error("sw_wgrad_status", e); return SW_EHIP; }
-  unsigned n = 0;
-  for (int i = 0; i < SW_WG_TIX_SLOTS; ++i) n += host[i * SW_WG_TIX_WORDS + SW_WG_TIX_ERR];
-  *errors = (int)n;
-  return SW_OK;
-}
-
 // out element e of problem p = sum over slices.  A wave owns SW_WG_REL consecutive elements (lanes el = lane %
 // REL: one coalesced segment per slice) and splits the slices SW_WG_RSUB ways (sub = lane / REL handles slices
 // q = sub, sub + RSUB, ..), 4 independent loads in flight per lane; the sub-sums meet in a fixed shuffle tree.
@@ -176,9 +100,8 @@ extern "C" int sw_wgrad_status(int* errors) {
 #define SW_WG_RSUB 4
 #endif
 #define SW_WG_REL (64 / SW_WG_RSUB)
-template <bool FOLD>
-__device__ __forceinline__ void wg_reduce_body(const WgBatch& batch, const float* __restrict__ ws, const WgAdam& ad, int gid,
-                                               unsigned* __restrict__ tix) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgBatch batch, const float* __restrict__ ws, WgAdam ad) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
   const int lane = gid & 63, el = lane % SW_WG_REL, sub = lane / SW_WG_REL;
   const int i = (gid >> 6) * SW_WG_REL + el;
   bool live = i < batch.total_out;
@@ -205,48 +128,21 @@ __device__ __forceinline__ void wg_reduce_body(const WgBatch& batch, const float
     old1 = *dst;
     if (dst2) old2 = *dst2;
   }
-  float bc1 = 1.f, bc2s = 1.f;
-  if constexpr (FOLD) {
-    // bias corrections first (two double-precision pow: free while the jobs still run), then the wait for the partials of
-    // this element's output block: every lane polls its own block's ticket (a wave's 16 elements may straddle two blocks)
-    if (ad.w) wg_adam_bc_compute(ad.step, ad.beta1, ad.beta2, bc1, bc2s);
-    if (!P.pre) {         // (precomputed partials were written by an earlier launch)
-      const unsigned need = (unsigned)P.nsplit;
-      const unsigned* t = tix + p * 4 + (n >> 6);
-      unsigned long long t0 = 0;
-      while (__hip_atomic_load(t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-        if (t0 == 0) t0 = wall_clock64();
-        else if (wall_clock64() - t0 > 200000000ULL) {          // 2 s of the 100 MHz clock: give up, say so
-          __hip_atomic_fetch_add(tix + SW_WG_TIX_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(2);
-      }
-    }
-  }
-  auto ld = [&](size_t q) -> float {
-    if constexpr (FOLD)      // published write-through by another workgroup of this launch: read past L1 / L2
-      return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(src + q * stride), __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_SYSTEM));
-    else
-      return src[q * stride];
-  };
   float s = 0.f;
   float s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int q = sub;
   for (; q + 3 * SW_WG_RSUB < P.nsplit; q += 4 * SW_WG_RSUB) {  // fixed combination order
-    s += ld(q);
-    s1 += ld(q + SW_WG_RSUB);
-    s2 += ld(q + 2 * SW_WG_RSUB);
-    s3 += ld(q + 3 * SW_WG_RSUB);
+    s += src[(size_t)q * stride];
+    s1 += src[(size_t)(q + SW_WG_RSUB) * stride];
+    s2 += src[(size_t)(q + 2 * SW_WG_RSUB) * stride];
+    s3 += src[(size_t)(q + 3 * SW_WG_RSUB) * stride];
   }
-  for (; q < P.nsplit; q += SW_WG_RSUB) s += ld(q);
+  for (; q < P.nsplit; q += SW_WG_RSUB) s += src[(size_t)q * stride];
   s = (s + s1) + (s2 + s3);
 #pragma unroll
   for (int o = SW_WG_REL; o < 64; o <<= 1) s += __shfl_xor(s, o);
-  if constexpr (!FOLD) {
-    if (ad.w) wg_adam_bc(ad, bc1, bc2s);   // wave-uniform; computed here so that graph and eager steps share the code
-  }
+  float bc1 = 1.f, bc2s = 1.f;
+  if (ad.w) wg_adam_bc(ad, bc1, bc2s);   // wave-uniform; computed here so that graph and eager steps share the code
   if (!live || sub != 0) return;
   const float g = P.accumulate ? old1 + s : s;
   *dst = g;
@@ -256,9 +152,6 @@ __device__ __forceinline__ void wg_reduce_body(const WgBatch& batch, const float
     *dst2 = g2;
     if (ad.w) wg_adam_fin(ad, a2, bc1, bc2s, g2);
   }
-}
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgBatch batch, const float* __restrict__ ws, WgAdam ad) {
-  wg_reduce_body<false>(batch, ws, ad, blockIdx.x * 256 + threadIdx.x, nullptr);
 }
 
 // host side -------------------------------------------------------------------------------------
@@ -427,7 +320,6 @@ size_t wg_finalize(WgBatch& b) {
       const int Kc = P.K + P.K2 + P.ones;
       out += P.N * Kc;
       if (!P.pre) {
-        ws = (ws + 3) & ~(size_t)3;      // 16-byte aligned partial blocks (the folded reduction publishes them in 16-byte stores)
         P.ws_off = ws;
         ws += (size_t)ns * P.N * Kc;
       }
@@ -466,12 +358,6 @@ int wg_reduce_launch_adam(WgBatch& b, float* ws, const WgAdam& ad, hipStream_t s
   return SW_OK;
 }
 int wg_reduce_launch(WgBatch& b, float* ws, hipStream_t stream) { return wg_reduce_launch_adam(b, ws, WgAdam(), stream); }
-
-// SW_WG_FOLD=0: the two-launch form (GEMM, then wgrad_reduce_kernel) - the A/B partner of the folded reduction
-static bool wg_fold_on() {      // (read per launch: a test compares both forms in one process; a captured launch keeps its form)
-  const char* e = getenv("SW_WG_FOLD");
-  return !(e && atoi(e) == 0);
-}
 int wg_launch_adam(WgBatch& b, float* ws, WgAdam& ad, hipStream_t stream) {
   if (b.np == 0) return SW_OK;
   size_t need = wg_finalize(b);
@@ -480,16 +366,8 @@ int wg_launch_adam(WgBatch& b, float* ws, WgAdam& ad, hipStream_t stream) {
   ad.bc = nullptr;
   if (b.total_jobs > 0) {
     float* bc = ad.w ? wg_bc_slot() : nullptr;
-    unsigned* tix = wg_fold_on() ? wg_tix_slot(ws) : nullptr;
-    if (tix) {      // ONE launch: jobs, then the finishers (the workgroups of wgrad_reduce_kernel) in the same grid
-      const int nfin = (b.total_out * SW_WG_RSUB + SW_THREADS - 1) / SW_THREADS;
-      SW_LAUNCH(wgrad_partial_kernel, dim3(wg_grid_jobs(b.total_jobs) + nfin), dim3(SW_THREADS), 0, stream, b, ws, ad, tix, bc);
-      SW_CHECK_LAUNCH("wgrad_partial_kernel");
-      ad.bc = bc;
-      return SW_OK;
-    }
-    SW_LAUNCH(wgrad_partial_kernel, dim3(wg_grid_jobs(b.total_jobs) + (bc ? 1 : 0)), dim3(SW_THREADS), 0, stream, b, ws, ad,
-              (unsigned*)nullptr, bc);
+    SW_LAUNCH(wgrad_partial_kernel, dim3(wg_grid_jobs(b.total_jobs) + (bc ? 1 : 0)), dim3(SW_THREADS), 0, stream, b, ws, ad.step,
+                       ad.beta1, ad.beta2, bc);
     SW_CHECK_LAUNCH("wgrad_partial_kernel");
     ad.bc = bc;
   }
@@ -499,12 +377,9 @@ int wg_launch_adam(WgBatch& b, float* ws, WgAdam& ad, hipStream_t stream) {
 int wg_launch_finalized(WgBatch& b, float* ws, hipStream_t stream) {
   if (b.total_out == 0) return SW_OK;
   if (b.total_jobs > 0) {
-    unsigned* tix = wg_fold_on() ? wg_tix_slot(ws) : nullptr;
-    const int nfin = tix ? (b.total_out * SW_WG_RSUB + SW_THREADS - 1) / SW_THREADS : 0;
-    SW_LAUNCH(wgrad_partial_kernel, dim3(wg_grid_jobs(b.total_jobs) + nfin), dim3(SW_THREADS), 0, stream, b, ws, WgAdam(), tix,
-              (float*)nullptr);
+    SW_LAUNCH(wgrad_partial_kernel, dim3(wg_grid_jobs(b.total_jobs)), dim3(SW_THREADS), 0, stream, b, ws, (const float*)nullptr,
+                       0.0, 0.0, (float*)nullptr);
     SW_CHECK_LAUNCH("wgrad_partial_kernel");
-    if (tix) return SW_OK;
   }
   return wg_reduce_launch(b, ws, stream);
 }

@@ -181,27 +181,8 @@ __device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const fl
 // One workgroup-job = 4 waves = 4 consecutive row slices of one output block (summed through LDS at the end); every
 // wave streams independently (no LDS, no barriers in the loop).  `red` = 4 x 64 x SW_WG_RLD floats of LDS.
 #define SW_WG_RED_FLOATS (4 * 64 * SW_WG_RLD)
-// Write-through 16-byte / 4-byte stores (system scope: the line leaves this XCD's L2 at once) for partials that another
-// workgroup of the SAME launch reads back (the folded reduction, sw_wgrad.hip): MI355X_MICROARCH.md, hand-off price list,
-// "publish-large" - tens of KB per workgroup are published 2.7 x faster write-through than by plain stores + a release fence.
-typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void wg_st4_wt(float* p, float a, float b, float c, float d) {
-  const wg_u32x4 v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void wg_st1_wt(float* p, float a) {
-  asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(a) : "memory");
-}
-
-// Ticket counters of one launch (the folded reduction): [p * 4 + nb] = workgroups that have published their partial of output
-// block nb of problem p; [SW_WG_TIX_FIN] = finisher workgroups done; [SW_WG_TIX_ERR] = waits given up (sticky).
-#define SW_WG_TIX_FIN (SW_WG_MAXP * 4)
-#define SW_WG_TIX_ERR (SW_WG_MAXP * 4 + 1)
-#define SW_WG_TIX_WORDS (SW_WG_MAXP * 4 + 2)
-
 template <int DSCALE = 1>
-__device__ __forceinline__ void wg_job(const WgBatch& batch, float* __restrict__ ws, int job, float* red,
-                                       unsigned* __restrict__ tix = nullptr) {
+__device__ __forceinline__ void wg_job(const WgBatch& batch, float* __restrict__ ws, int job, float* red) {
   const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
   int p = 0;
 #pragma unroll 1
@@ -244,33 +225,10 @@ __device__ __forceinline__ void wg_job(const WgBatch& batch, float* __restrict__
   // one partial per workgroup (4 row slices summed): ws[ws_off + (sg*N + n)*Kc + k]
   float* out = ws + P.ws_off + (size_t)sg * N * Kc;
   const int rows = min(64, N - n0), cols = min(SW_WG_RLD, Kc);
-  const float* r0 = red, *r1 = red + 64 * SW_WG_RLD, *r2 = red + 2 * 64 * SW_WG_RLD, *r3 = red + 3 * 64 * SW_WG_RLD;
-  if (tix) {
-    // Folded reduction: the partial is PUBLISHED to the finisher workgroups of this launch.  The block's rows are
-    // contiguous in the workspace (rows x cols floats from `blk`): 16-byte write-through stores where the block starts on a
-    // 16-byte boundary (every problem but the 2-row one behind fc3 / fc4), then every wave drains its stores and ONE lane
-    // takes the block's ticket (hand-off price list: "sc1 payload -> vmcnt(0) -> sc1 flag").  Same values as below.
-    float* blk = out + (size_t)n0 * Kc;
-    const int total = rows * cols;
-    auto val = [&](int e) {
-      const int rr = e / cols, cc = e - rr * cols, o = rr * SW_WG_RLD + cc;
-      return (r0[o] + r1[o]) + (r2[o] + r3[o]);
-    };
-    if ((reinterpret_cast<size_t>(blk) & 15) == 0) {
-      const int t4 = total & ~3;
-      for (int e = 4 * threadIdx.x; e < t4; e += 4 * SW_THREADS) wg_st4_wt(blk + e, val(e), val(e + 1), val(e + 2), val(e + 3));
-      for (int e = t4 + threadIdx.x; e < total; e += SW_THREADS) wg_st1_wt(blk + e, val(e));
-    } else {
-      for (int e = threadIdx.x; e < total; e += SW_THREADS) wg_st1_wt(blk + e, val(e));
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    sw_barrier();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(&tix[p * 4 + nb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
-  }
   // element e = rr * cols + cc walks the block row-major; (rr, cc) advance incrementally (one division per thread)
   const int dq = SW_THREADS / cols, dr = SW_THREADS - dq * cols;
   int rr = threadIdx.x / cols, cc = threadIdx.x - rr * cols;
+  const float* r0 = red, *r1 = red + 64 * SW_WG_RLD, *r2 = red + 2 * 64 * SW_WG_RLD, *r3 = red + 3 * 64 * SW_WG_RLD;
   for (int e = threadIdx.x; e < rows * cols; e += SW_THREADS) {
     const int o = rr * SW_WG_RLD + cc;
     const float v = (r0[o] + r1[o]) + (r2[o] + r3[o]);

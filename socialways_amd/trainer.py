@@ -853,14 +853,6 @@ class SocialWaysTrainer:
                                        "applies no update from it, so the replicas are no longer identical - restart from "
                                        "the last checkpoint (SW_COMM_TIMEOUT_S sets the wait, default 30 s)")
         o = allo.double().cpu().numpy()
-        if self.device.type == "cuda":        # finisher waits of the folded weight-gradient reductions given up (never, in a healthy run)
-            import ctypes
-            err = ctypes.c_int(0)
-            L.call("sw_wgrad_status", ctypes.byref(err))
-            if err.value:
-                raise L.SocialWaysHipError("%d waits of the folded gradient reduction were given up (sw_wgrad_status): the "
-                                           "gradients of at least one step were incomplete; SW_WG_FOLD=0 selects the "
-                                           "two-launch form" % err.value)
         ade = float(o[:, -1, 0].sum() / data.n_train_samples)
         fde = float(o[:, -1, 1].sum() / data.n_train_samples)
         losses = self.losses_from(allo, [s[0] for s in sizes], data.n_next, data.ss)

@@ -590,44 +590,3 @@ def test_default_device_trainer_reads_device_z_by_address():
     z = torch.rand(64, 32, device="cuda")
     assert tr._z_resident([(torch.zeros(64, 8, 2, device="cuda"), None, 0.0, 1.0, z)])
 
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("shape", ["m", "ragged", "dense"])
-def test_folded_gradient_reduction_equals_the_two_launch_form(shape, monkeypatch):
-    """r5 verdict item 2: the second stage of every weight-gradient launch (fixed-order sum of the split-K partials + Adam +
-    D's image updates) runs as FINISHER workgroups in the tail of the GEMM grid (partials published write-through, per-block
-    tickets) instead of as wgrad_reduce_kernel.  Same code, same summation order: the sums, the weights and both optimizers'
-    moments after eager steps, a capture and replays must equal the two-launch form (SW_WG_FOLD=0) bit for bit - on uniform
-    small scenes, on ragged scenes incl. single-agent ones, and on dense scenes (in-register pair-MLP partials: `pre`
-    problems without tickets).  No finisher wait may have been given up."""
-    import ctypes
-    import socialways_amd as sw
-    from socialways_amd import _lib as L
-    sizes = {"m": 8, "ragged": [5, 1, 9, 16, 3, 2, 2, 2, 7, 8, 4, 6, 1, 13] * 3, "dense": [64, 48, 64, 33]}[shape]
-    n_sc = 40 if shape == "m" else len(sizes)
-    t = sw.synth_tracks(n_sc, sizes, 8, 12, seed=3)
-    data = sw.SceneDataset(t["obsvs"], t["preds"], t["batches"], device="cuda:0")
-    sb = data.the_batches[:n_sc]
-    B = int(sb[-1][1])
-    res = []
-    for fold in ("1", "0"):
-        monkeypatch.setenv("SW_WG_FOLD", fold)
-        torch.manual_seed(5)
-        tr = sw.SocialWaysTrainer(12, use_social=True, device="cuda:0")
-        gen = torch.Generator().manual_seed(9)
-        outs = []
-        for it in range(6):           # eager, eager, capture, replays
-            outs.append(tr.step(data.obsv[:B], data.pred[:B], sb, 0.02, 0.95, torch.rand(B, 32, generator=gen), data.ss).cpu())
-        zs = [torch.rand(B, 32, generator=gen) for _ in range(4)]
-        for rep in range(3):
-            outs += [o.cpu() for o in tr.step_many([(data.obsv[:B], data.pred[:B], 0.03, 0.93, z) for z in zs], sb, data.ss)]
-        torch.cuda.synchronize()
-        res.append((torch.stack(outs), tr.G._flat_all.clone(), tr.D._flat.clone(), tr.predictor_optimizer.m.clone(),
-                    tr.predictor_optimizer.v.clone(), tr.D_optimizer.m.clone(), tr.D_optimizer.v.clone()))
-        tr.close()
-    for a, b in zip(*res):
-        assert torch.equal(a, b)
-    assert torch.isfinite(res[0][0]).all()
-    err = ctypes.c_int(-1)
-    L.call("sw_wgrad_status", ctypes.byref(err))
-    assert err.value == 0, "%d finisher waits were given up" % err.value
