@@ -535,19 +535,20 @@ int sw_allreduce_direct_adam(void* const* peer_bufs, int rank, int world, long l
                              float* w, float* m, float* v, const float* step, double lr, double beta1, double beta2,
                              double eps, int disc_Tp, void* stream);
 
-/* ---- measurement aids.  sw_kernel_timing(1): every kernel launch of the library is bracketed by two HIP events on its
- *      own stream (never inside a graph capture) until sw_kernel_timing(0); sw_kernel_timing_read(buf, cap) waits for
- *      the device and writes one line "kernel calls total_us" per kernel, returning the bytes needed.  sw_debug_spin
- *      queues a kernel that occupies the stream for ~us microseconds (queued in front of a timed sequence it lets the
- *      host run ahead, so the event intervals hold no launch gaps).                                                */
-int sw_kernel_timing(int on);
-int sw_kernel_timing_read(char* buf, int cap);
-int sw_debug_spin(double us, void* stream);
-
 /* ---- ADE/FDE partial sums of train.py:546-551:
  *      out[3] = { sum_{b,t} err / Tp, sum_b err[:, -1], sum_{b,t} err^2 },  err = |(p_hat - p) / ss|   */
 int sw_ade_fde(const float* pred4 /*[B,Tp,4]*/, const float* gt /*[B,Tp,2]*/, int B, int Tp, float inv_ss,
                float* out /*[3]*/, float* scratch /*[3*SW_RED_BLOCKS] or NULL*/, void* stream);
+
+/* ==== MEASUREMENT SECTION - not part of the product surface (the drop-in boundary ends above this line; tests/test_abi.py
+ *      checks the two lists separately).  sw_kernel_timing(1): every kernel launch of the library is bracketed by two HIP
+ *      events on its own stream (never inside a graph capture) until sw_kernel_timing(0); sw_kernel_timing_read(buf, cap)
+ *      waits for the device and writes one line "kernel calls total_us" per kernel, returning the bytes needed.
+ *      sw_debug_spin queues a kernel that occupies the stream for ~us microseconds (queued in front of a timed sequence it
+ *      lets the host run ahead, so the event intervals hold no launch gaps).  bench.py's roofline pass is their only caller. */
+int sw_kernel_timing(int on);
+int sw_kernel_timing_read(char* buf, int cap);
+int sw_debug_spin(double us, void* stream);
 
 #ifdef __cplusplus
 }

@@ -117,11 +117,14 @@ PROTOTYPES = {
     "sw_allreduce_direct": (_i, [_vp, _i, _i, _ll, _vp, _ll, _vp]),
     "sw_allreduce_direct_adam": (_i, [_vp, _i, _i, _ll, _vp, _ll, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double,
                                       ctypes.c_double, ctypes.c_double, _i, _vp]),
+}
+
+# the header's MEASUREMENT section (include/socialways_hip.h, behind the product surface): bench.py's per-kernel event pass
+DEBUG_PROTOTYPES = {
     "sw_kernel_timing": (_i, [_i]),
     "sw_kernel_timing_read": (_i, [ctypes.c_char_p, _i]),
     "sw_debug_spin": (_i, [ctypes.c_double, _vp]),
 }
-
 _lib = None
 
 
@@ -140,7 +143,7 @@ def load():
             "%s not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
             "`make -C socialways_amd/csrc`; socialways_amd has no CPU fallback" % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in PROTOTYPES.items():
+    for name, (res, args) in list(PROTOTYPES.items()) + list(DEBUG_PROTOTYPES.items()):
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args

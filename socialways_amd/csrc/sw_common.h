@@ -54,12 +54,8 @@ __device__ __forceinline__ float sw_lrelu_grad(float a, float g) { return a > 0.
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-// the saved-row / delta-row stores of the time loops; -DSW_EXP_NOSTORE (timing experiments, wrong results) drops them
-#ifdef SW_EXP_NOSTORE
-__device__ __forceinline__ void st4g(float* p, f32x4 v) { asm volatile("" ::"v"(v), "v"(p)); }
-#else
+// the saved-row / delta-row stores of the time loops (a name of their own: tools/patches/timing_experiments.patch drops them)
 __device__ __forceinline__ void st4g(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-#endif
 
 // acc += W[row][16j+4lg+r] * X[agent][16j+4lg+r], j < KJ.  `wrow` / `xrow` already point at
 // column 4*lg of the lane's weight row / activation row.  Works for LDS and global pointers

@@ -867,11 +867,6 @@ static int disc_bwd_impl(const float* d_w, const float* dsave, const float* cons
 // through the save buffer beats the two launches at two workgroups per CU by 1-5 % of the step everywhere.
 extern "C" int sw_disc_update_supported(const float* d_w, int B, int To, int Tp) {
   if (!d_w || B < 1 || To < 1 || Tp < 1 || Tp > 12) return 0;
-  static const int max_tiles = [] {        // SW_DISC_UPDATE_MAX_TILES=128: the round-3 rule (A/B runs)
-    const char* e = getenv("SW_DISC_UPDATE_MAX_TILES");
-    return e ? atoi(e) : 1 << 30;
-  }();
-  if ((B + SW_TILE - 1) / SW_TILE > max_tiles) return 0;
   if (!sw_disc_images_for(d_w, Tp).img) return 0;
   return upd_lds(Tp).total * 4 <= 163840 ? 1 : 0;
 }

@@ -112,10 +112,6 @@ __device__ __forceinline__ void lstm_cell(const LstmW& W, float xb, const float*
       for (int g = 0; g < 4; ++g) acc[g] = SW_MFMA(W.whh[g][j][r], b[j][r], acc[g]);
     }
   }
-#ifdef SW_EXP_NOVALU   // timing experiment (wrong results): no gate non-linearities
-  gate[0] = acc[0]; gate[1] = acc[1]; gate[2] = acc[2]; gate[3] = acc[3]; c = c + acc[0]; h = acc[3] + acc[2];
-  return;
-#endif
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     float i = sw_sigmoid(acc[0][r]);
@@ -137,10 +133,6 @@ __device__ __forceinline__ void lstm_cell(const LstmW& W, float xb, const float*
 // gradient w.r.t. c_{t-1}.
 __device__ __forceinline__ void lstm_cell_bwd(const f32x4 gate[4], f32x4 ct, f32x4 cprev, f32x4 dh,
                                               f32x4& dc, f32x4 dgate[4]) {
-#ifdef SW_EXP_NOVALU   // timing experiment (wrong results): no elementwise work
-  dgate[0] = dh + gate[0]; dgate[1] = dh + gate[1]; dgate[2] = ct + gate[2]; dgate[3] = cprev + gate[3]; dc = dc + dh;
-  return;
-#endif
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     float i = gate[0][r], f = gate[1][r], g = gate[2][r], o = gate[3][r];

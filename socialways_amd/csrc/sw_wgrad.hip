@@ -172,11 +172,7 @@ int wg_add(WgBatch& b, const float* delta, int ldd, const float* act, int lda, i
   // of a problem gets the same number of row slices, and the narrow block's jobs - a quarter of the matrix work over the
   // same rows - finished at two thirds of the launch (and, the blocks alternating with the workgroup index, all on the
   // even XCDs).  With its own split it gets fewer, longer slices.
-#ifdef SW_WG_NOSPLIT     // timing experiment
-  const int Nfull = N;
-#else
   const int Nfull = N > 64 && (N & 63) && (N & 63) <= 32 && b.np + 2 * ((K + 63) / 64) <= SW_WG_MAXP ? (N & ~63) : N;
-#endif
   for (int n0 = 0; n0 < N; n0 = (n0 == 0 ? Nfull : N)) {
     const int Nseg = n0 == 0 ? Nfull : N - Nfull;
     for (int c0 = 0; c0 < K; c0 += 64) {
@@ -275,21 +271,20 @@ size_t wg_finalize(WgBatch& b) {
   const double total = wg_total_work(b) + 1.0;
   // workgroups per launch: every wave should carry >= ~16K cycles of work (fixed per-workgroup costs -
   // pipeline fill, LDS reduction, partial store - are ~8 us), at most 1024 (two rounds of residency)
-  static const double grain = getenv("SW_WG_GRAIN") ? atof(getenv("SW_WG_GRAIN")) : 8192.0 * (1.0 + SW_WG_GROUP_C0 / 512.0);   // tuning knob (cycles of work per wave)
+  static const double grain = 8192.0 * (1.0 + SW_WG_GROUP_C0 / 512.0);   // cycles of work per wave (swept in round 3)
   double target = total / grain / 4.0;
   if (target < 64.0) target = 64.0;
   // ... at most ONE round of residency (2 workgroups x 256 CUs) - a sharp optimum once every workgroup streams with a
   // full pipeline (swept: 512 -> 63 us, 448 -> 72, 576 -> 78, 1024 -> 69 for the generator pass at m1) - unless the
   // batch is so large that a second round still leaves each wave several grains of work (dense crowds: better balance)
-  static const double maxwg_env = getenv("SW_WG_MAXWG") ? atof(getenv("SW_WG_MAXWG")) : 0.0;
-  const double maxwg = maxwg_env > 0.0 ? maxwg_env : (target >= 4096.0 ? 1024.0 : 512.0);
+  const double maxwg = target >= 4096.0 ? 1024.0 : 512.0;
   if (target > maxwg) target = maxwg;
   // A batch whose natural size lies between one workgroup per CU and one resident round (a discriminator pass at the
   // metric shape: ~300) runs best with AT MOST one workgroup on every CU: beyond 256 some CUs get two and the launch
   // lasts as long as those (swept in round 3: 224 / 240 / 256 / 264 / 288 workgroups -> 0.4056 / 0.4057 / 0.4025 /
-  // 0.4095 / 0.4090 ms per training step).  SW_WG_SMALL overrides the count.
-  static const double small_env = getenv("SW_WG_SMALL") ? atof(getenv("SW_WG_SMALL")) : 256.0;
-  const bool one_per_cu = target > 256.0 && target < 448.0 && small_env > 0.0;
+  // 0.4095 / 0.4090 ms per training step).
+  const double small_env = 256.0;
+  const bool one_per_cu = target > 256.0 && target < 448.0;
   if (one_per_cu) target = small_env;
   auto assign = [&](double tgt) {
     size_t ws = 0;

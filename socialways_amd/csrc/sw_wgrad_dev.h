@@ -85,11 +85,7 @@ __device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const fl
   float a[DEPTH][NA], b[DEPTH][KT];
   f32x4 xq[DEPTH];
   auto load = [&](int r0, float (&av)[NA], float (&bv)[KT], f32x4& xv) {
-#ifdef SW_WG_EXP_NOMEM      // timing experiment: every group re-reads the slice's first rows (L1 hits)
-    const int rc = min(rbeg + lg + 0 * r0, rmax);
-#else
     const int rc = min(r0 + lg, rmax);
-#endif
     // 32-bit element offsets (the host rejects a problem whose rows x stride reach 2^31): one multiply-add per load
     // instead of a 64-bit multiply-add + shift-add
     wg_ldv<NA>(av, dbase + (unsigned)(rc * ldd + acol));
@@ -134,11 +130,7 @@ __device__ __forceinline__ void wg_run(const float* __restrict__ dbase, const fl
       for (int i = 0; i < NA; ++i) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-#ifdef SW_WG_EXP_NOMFMA     // timing experiment: one VALU op instead of the MFMA
-          acc[i][kt][0] = fmaf(av[i], bv[kt], acc[i][kt][0]);
-#else
           acc[i][kt] = SW_MFMA(av[i], bv[kt], acc[i][kt]);
-#endif
         }
       }
 #pragma unroll

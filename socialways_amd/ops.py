@@ -181,7 +181,7 @@ def gen_forward(enc_w, emb_w, att_w, dec_w, obsv, noise, scenes, n_next, use_soc
     return pred4, ctx
 
 
-DFUSE = os.environ.get("SW_DFUSE", "1") != "0"     # A/B switch: generator-phase D pass inside the decode BPTT launch
+DFUSE = True     # generator-phase D pass inside the decode BPTT launch (a test compares it with the two launches)
 
 
 def gen_backward(enc_w, emb_w, att_w, dec_w, ctx, dpred4, d_enc, d_emb, d_att, d_dec, ws=None, tag="g", aux=None, adam=None,

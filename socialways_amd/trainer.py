@@ -210,9 +210,8 @@ class SocialWaysTrainer:
         self.max_graphs = int(os.environ.get("SW_MAX_GRAPHS", "8"))    # captured packed-batch layouts (the rest of the steps run eagerly)
         self._graphs = {}
         self._force_dist = os.environ.get("SW_FORCE_DIST", "") == "1"   # 1-rank group still runs the collectives (tests)
-        self._fuse_d_adam = os.environ.get("SW_FUSE_D_ADAM", "1") == "1"  # D's Adam inside the gradient reduction (world 1)
-        self._fuse_g_adam = os.environ.get("SW_FUSE_G_ADAM", "1") == "1"  # ... and the generator's (needs the weight images)
-        self._one_launch_d = os.environ.get("SW_DISC_UPDATE", "1") == "1"   # a D update pass as one launch where it pays (sw_disc_update)
+        self._fuse_d_adam = True      # D's Adam inside the gradient reduction (single process; tests switch it off to compare)
+        self._fuse_g_adam = True      # ... and the generator's (needs the weight images)
         # Data parallel: are the RCCL all-reduces recorded INSIDE the step graph (one launch for K steps) or run
         # eagerly between graph segments (3 segment boundaries per step)?  SW_GRAPH_COLLECTIVES=1 / 0 decides;
         # unset = probe once (a small captured all-reduce replayed twice and checked on every rank) and use the
@@ -265,13 +264,12 @@ class SocialWaysTrainer:
         self._ws_version = 0
         # derived images of the generator's weights (composed input matrix, fc4 . fc3, transposed decoder matrices):
         # computed once per step by the staging launch instead of by every workgroup of four launches (sw_gen_images)
-        self._gimg = (torch.empty(L.load().sw_gen_image_floats(), device=self.device)
-                      if self.device.type == "cuda" and os.environ.get("SW_GEN_IMAGES", "1") == "1" else None)
+        self._gimg = torch.empty(L.load().sw_gen_image_floats(), device=self.device) if self.device.type == "cuda" else None
         # ... and of the discriminator's (A-operand images of weight_hh / its transpose, the transposed head matrices in the
         # backward kernels' LDS layout): scattered by the staging launch, kept current by the kernels that apply D's Adam
         # update (sw_disc_images; include/socialways_hip.h)
         self._dimg = self._dtab = None
-        if self.device.type == "cuda" and os.environ.get("SW_DISC_IMAGES", "1") == "1":
+        if self.device.type == "cuda":
             lib = L.load()
             tab = np.empty((self.D._flat.numel(), 2), dtype=np.int32)
             if lib.sw_disc_image_table(n_next, tab.ctypes.data) != 0:
@@ -335,9 +333,9 @@ class SocialWaysTrainer:
 
     def _exchange_adam(self, opt, flat):
         """Does the direct exchange also apply this optimizer's update (sw_allreduce_direct_adam)?  A data-parallel step on
-        SW_ALLREDUCE=direct with a packed, decay-free Adam; SW_EXCHANGE_ADAM=0 keeps exchange and update apart."""
+        SW_ALLREDUCE=direct with a packed, decay-free Adam."""
         return (self._direct is not None and (self.world > 1 or self._force_dist) and isinstance(opt, PackedAdam) and opt.native
-                and opt.fusable and flat.numel() >= 1024 and os.environ.get("SW_EXCHANGE_ADAM", "1") != "0")
+                and opt.fusable and flat.numel() >= 1024)
 
     def _probe_graph_collectives(self):
         """Can this process group's all-reduce be recorded in a hipGraph and replayed?  Only RCCL ("nccl") is
@@ -703,7 +701,7 @@ class SocialWaysTrainer:
             fuse = (self._fuse_d_adam and isinstance(self.D_optimizer, PackedAdam) and self.D_optimizer.fusable
                     and not (self.world > 1 or self._force_dist))
             adam = self.D_optimizer.fused_args(None if steps is None else steps[u]) if fuse else None
-            if self._one_launch_d and obsv.shape[2] == 2 and ops.disc_update_supported(D._flat, B, obsv.shape[1], Tp):
+            if obsv.shape[2] == 2 and ops.disc_update_supported(D._flat, B, obsv.shape[1], Tp):
                 # shapes that leave CUs idle: forward + loss gradients + backward of the pass in ONE launch (sw_disc_update)
                 ops.disc_update(D._flat, obsv, [pred_hat, pred4], targets, (0, 1), noise, g_label, g_code, d_gflat, ws,
                                 obs_pre=(u == 0 and d_pre is not None), w_snapshot=backup if u == 1 else None,

@@ -146,7 +146,7 @@ class WideTrainer(GenericTrainer):
         # the whole sequence, loaded from operand-layout images made once per weight update: sw_wide_opimage)
         self.seq = bool(L.load().sw_wide_lstm_seq_supported(H))
         # 128 units: the decode loop of predict() is ONE persistent launch streaming the decoder's operand images
-        self.decloop = bool(L.load().sw_wide_dec_loop_supported(H)) and os.environ.get("SW_WIDE_DECLOOP", "1") != "0"
+        self.decloop = bool(L.load().sw_wide_dec_loop_supported(H))
         D1 = 2 * H + H // 2
         g_entries = [("whh", enc.lstm.weight_hh_l0, 4 * H, H, 0, 0, 0), ("whhT", enc.lstm.weight_hh_l0, H, 4 * H, 0, 1, 0)]
         if self.decloop:
@@ -164,7 +164,7 @@ class WideTrainer(GenericTrainer):
         d_entries = [("whh", dwhh, 4 * H, H, 0, 0, 0), ("whhT", dwhh, H, 4 * H, 0, 1, 0)] if self.seq else []
         # D's heads as one launch per direction (sw_wide_disc_heads_*): images of the six 2-D head matrices and their transposes
         K4, H2 = 4 * n_next, H // 2
-        self.heads = bool(L.load().sw_wide_disc_heads_supported(H, K4, n_latent_codes)) and os.environ.get("SW_WIDE_HEADS", "1") != "0"
+        self.heads = bool(L.load().sw_wide_disc_heads_supported(H, K4, n_latent_codes))
         if self.heads:
             for nm, m, r, k in (("of0", Dm.obsv_encoder_fc[0], H2, H), ("of1", Dm.obsv_encoder_fc[2], H2, H2),
                                 ("pe0", Dm.pred_encoder[0], H2, K4), ("pe1", Dm.pred_encoder[2], H2, H2),

@@ -11,9 +11,12 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
+def header_symbols(section="product"):
+    """Entry points the header declares: the product surface, or the measurement section behind it."""
     src = open(os.path.join(ROOT, "include", "socialways_hip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    product, marker, measurement = src.partition("/* ==== MEASUREMENT SECTION")
+    assert marker, "include/socialways_hip.h lost its measurement-section marker"
+    src = re.sub(r"/\*.*?\*/", "", product if section == "product" else "/*" + measurement, flags=re.S)
     return sorted(set(re.findall(r"\b(sw_[a-z0-9_]+)\s*\(", src)))
 
 
@@ -25,6 +28,9 @@ def test_library_exports_every_header_symbol():
     for name in syms:
         assert hasattr(lib, name), "include/socialways_hip.h declares %s but the library does not export it" % name
     assert sorted(L.PROTOTYPES) == syms, "socialways_amd/_lib.py binds exactly the header's entry points"
+    dbg = header_symbols("measurement")
+    assert dbg == sorted(L.DEBUG_PROTOTYPES) == ["sw_debug_spin", "sw_kernel_timing", "sw_kernel_timing_read"]
+    assert not set(dbg) & set(syms) and all(hasattr(lib, n) for n in dbg)
     assert lib.sw_version() >= 1
     assert isinstance(lib.sw_last_error(), bytes)
 
