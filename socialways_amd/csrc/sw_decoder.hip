@@ -14,6 +14,7 @@
 #include "sw_lstm_dev.h"
 #include "sw_disc_dev.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {     // (LD64 = sw_ld(64) = 68 comes with sw_disc_dev.h)
 constexpr int LD160 = sw_ld(160);  // 164
@@ -462,6 +463,387 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same kernel for TWO 16-agent column blocks per workgroup (round 6): for batches with more tiles than CUs (dense
+// crowds, large shards).  At 394 registers the kernel above runs one workgroup per CU, so with eight tiles queued per CU
+// nothing fills a tile's barrier / LDS turn-arounds (4 per decode step, ~0.9 K cycles each of a 10.9 K-cycle step).  Here
+// every register-resident A operand (weight) is issued against two B operands - the blocks' activation tiles - so the
+// four turn-arounds, the prologue and the weight loads are paid once per 32 agents, and each wave carries two independent
+// chains.  Every agent's arithmetic is the 16-agent kernel's, operation for operation (same accumulator order): results
+// are bit-identical.  Workgroup v owns the tiles 2v, 2v + 1; a second block beyond the batch is a replica of agent B - 1
+// (every load is clamped) and stores the same values to the same rows.  No observation-LSTM riders (only launched when
+// CUs are idle).
+template <bool SAVE, bool ADE>
+__global__ __launch_bounds__(SW_THREADS) void dec_rollout_fwd2_kernel(
+    const float* __restrict__ obsv, int To, const float* __restrict__ z, const float* __restrict__ S_pool,
+    const float* __restrict__ hT, const float* __restrict__ cT, const float* __restrict__ enc_w,
+    const float* __restrict__ dec_w, int B, int Tp, float* __restrict__ pred4, float* __restrict__ h_end,
+    float* __restrict__ c_end, float* __restrict__ gsave, const float* __restrict__ gt, float inv_ss,
+    float* __restrict__ ade_part, const float* __restrict__ gimg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int LD128 = FwdLds::LD128, LD32 = FwdLds::LD32, LD16 = FwdLds::LD16;
+  constexpr int NB = 2;
+  float *hbuf[NB], *a1buf[NB], *p1[NB], *a2buf[NB], *q2[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    float* base = smem + k * FwdLds::total;
+    hbuf[k] = base + FwdLds::hbuf;
+    a1buf[k] = base + FwdLds::a1buf;
+    p1[k] = base + FwdLds::p1;
+    a2buf[k] = base + FwdLds::a2buf;
+    q2[k] = base + FwdLds::q2;
+  }
+  const int lane = sw_lane(), wave = sw_wave(), ln = lane & 15, lg = lane >> 4;
+  const int u0 = wave * 16;
+  const int tiles16 = (B + SW_TILE - 1) / SW_TILE;
+  int a0[NB], b[NB];
+  bool live[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    a0[k] = (2 * (int)blockIdx.x + k) * SW_TILE;
+    b[k] = min(a0[k] + ln, B - 1);
+    live[k] = (a0[k] + ln) < B;
+  }
+  const GSave gs = gsave_layout(B, To, Tp);
+  const int m1a = 32 * wave, m1b = m1a + 16;
+  const int hf = wave & 1, t1p = wave >> 1;
+  const int m2 = 16 * wave;
+  const int J0 = wave < 2 ? 3 * wave : 2 + 2 * wave;
+  const int m1p = 128 + 16 * t1p;
+
+  // ---- prologue: the weights once (operand-layout images of the step: this kernel is only launched with them) ----
+  LstmW W;
+  f32x4 w1a[4], w1b[4], w1p[2], w2f[10], w2p[3];
+  f32x4 wu[3][6];
+  f32x4 ua[NB], ub[NB], up[NB];
+  auto op = [&](int base, int KJ, int tile, int j) { return ld4(gimg + base + (((size_t)tile * KJ + j) * 64 + lane) * 4); };
+  lstm_load_img(W, gimg, wave, lane);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    w1a[j] = op(swimg::OP_W1H, 4, 2 * wave, j);
+    w1b[j] = op(swimg::OP_W1H, 4, 2 * wave + 1, j);
+  }
+  w1p[0] = op(swimg::OP_W1H, 4, 8 + t1p, 2 * hf);
+  w1p[1] = op(swimg::OP_W1H, 4, 8 + t1p, 2 * hf + 1);
+#pragma unroll
+  for (int j = 0; j < 10; ++j) w2f[j] = op(swimg::OP_W2, 10, wave, j);
+  w2p[0] = op(swimg::OP_W2, 10, 4, J0);
+  w2p[1] = op(swimg::OP_W2, 10, 4, J0 + 1);
+  w2p[2] = op(swimg::OP_W2, 10, 4, J0 + (wave < 2 ? 2 : 1));
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    wu[0][j] = op(swimg::OP_W1SZ, 6, 2 * wave, j);
+    wu[1][j] = op(swimg::OP_W1SZ, 6, 2 * wave + 1, j);
+    wu[2][j] = op(swimg::OP_W1SZ, 6, 8 + t1p, j);
+  }
+  const f32x4 ua0 = ld4(dec_w + swp::DEC_B1 + m1a + 4 * lg);
+  const f32x4 ub0 = ld4(dec_w + swp::DEC_B1 + m1b + 4 * lg);
+  const f32x4 up0 = ld4(dec_w + swp::DEC_B1 + m1p + 4 * lg);
+  const f32x4 b2f = ld4(dec_w + swp::DEC_B2 + m2 + 4 * lg), b2p = ld4(dec_w + swp::DEC_B2 + 64 + 4 * lg);
+  f32x4 c[NB], h[NB];
+  float px[NB], py[NB];
+  float szs[NB][6], szz[NB][6];
+  {
+    const float* sp = S_pool ? S_pool : z;
+    const int sld = S_pool ? 64 : 32;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      c[k] = ld4(cT + (size_t)b[k] * 64 + u0 + 4 * lg);
+      h[k] = ld4(hT + (size_t)b[k] * 64 + u0 + 4 * lg);
+      px[k] = obsv[((size_t)b[k] * To + To - 1) * 2 + 0];
+      py[k] = obsv[((size_t)b[k] * To + To - 1) * 2 + 1];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int i = threadIdx.x + q * SW_THREADS, a = i / 96, cc = i - a * 96;
+        const int bb = min(a0[k] + a, B - 1);
+        szs[k][q] = sp[(size_t)bb * sld + min(cc, sld - 1)];
+        szz[k][q] = z[(size_t)bb * 32 + max(cc - 64, 0)];
+      }
+    }
+  }
+  f32x4 w43[2][5];
+  float b43i[2];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    w43[0][j] = ld4(gimg + swimg::W43 + 16 * j + 4 * lg);
+    w43[1][j] = ld4(gimg + swimg::W43 + 80 + 16 * j + 4 * lg);
+  }
+  b43i[0] = gimg[swimg::W43 + 160];
+  b43i[1] = gimg[swimg::W43 + 161];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    float* szbuf = a1buf[k];      // prologue alias [16][100]
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int i = threadIdx.x + q * SW_THREADS, a = i / 96, cc = i - a * 96;
+      szbuf[a * LD96 + cc] = cc < 64 ? (S_pool ? szs[k][q] : 0.f) : szz[k][q];
+    }
+    st4(&hbuf[k][ln * SW_ALD + 320 + u0 + 4 * lg], h[k]);
+  }
+  sw_barrier();
+  // u = W1[:, 64:160] [S; z] + b1: the initial accumulators of this wave's layer-1 tiles, per block
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    f32x4 bz[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) bz[j] = ld4(&a1buf[k][ln * LD96 + 16 * j + 4 * lg]);
+    ua[k] = ua0;
+    ub[k] = ub0;
+    up[k] = up0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ua[k] = SW_MFMA(wu[0][j][r], bz[j][r], ua[k]);
+        ub[k] = SW_MFMA(wu[1][j][r], bz[j][r], ub[k]);
+        up[k] = SW_MFMA(wu[2][j][r], bz[j][r], up[k]);
+      }
+    if (hf != 0) up[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  sw_barrier();  // the prologue aliases are dead from here on
+
+  float e_sum[NB] = {0.f, 0.f}, e_last[NB] = {0.f, 0.f}, e_sq[NB] = {0.f, 0.f};
+  int cur = 0;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) asm volatile("" : "+v"(w43[0][j]), "+v"(w43[1][j]));
+  asm volatile("" : "+v"(b43i[0]), "+v"(b43i[1]));
+#pragma unroll
+  for (int k = 0; k < NB; ++k) asm volatile("" : "+v"(px[k]), "+v"(py[k]), "+v"(c[k]), "+v"(h[k]));
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  auto step = [&](int i, auto last_) {
+    constexpr bool LAST = decltype(last_)::value;
+    float2 gti[NB];
+    const float* hrow[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      gti[k] = float2{0.f, 0.f};
+      if constexpr (ADE) gti[k] = *reinterpret_cast<const float2*>(gt + ((size_t)b[k] * Tp + i) * 2);
+      hrow[k] = &hbuf[k][cur * 16 * SW_ALD + ln * SW_ALD + 320 + 4 * lg];
+    }
+    // ---- layer 1: z1 = W1h h + u ; a1 = lrelu(z1) --------------------------------------------------
+    {
+      f32x4 bh[NB][4], bp[NB][2];
+      f32x4 acc_a[NB], acc_b[NB], acc_p[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bh[k][j] = ld4(hrow[k] + 16 * j);
+        bp[k][0] = ld4(hrow[k] + 32 * hf);
+        bp[k][1] = ld4(hrow[k] + 32 * hf + 16);
+        acc_a[k] = ua[k];
+        acc_b[k] = ub[k];
+        acc_p[k] = up[k];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int k = 0; k < NB; ++k) {
+            acc_a[k] = SW_MFMA(w1a[j][r], bh[k][j][r], acc_a[k]);
+            acc_b[k] = SW_MFMA(w1b[j][r], bh[k][j][r], acc_b[k]);
+            if (j < 2) acc_p[k] = SW_MFMA(w1p[j][r], bp[k][j][r], acc_p[k]);
+          }
+        }
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc_a[k][r] = sw_lrelu(acc_a[k][r]);
+          acc_b[k][r] = sw_lrelu(acc_b[k][r]);
+        }
+        st4(&a1buf[k][ln * LD128 + m1a + 4 * lg], acc_a[k]);
+        st4(&a1buf[k][ln * LD128 + m1b + 4 * lg], acc_b[k]);
+        st4(&p1[k][hf * 16 * LD32 + ln * LD32 + 16 * t1p + 4 * lg], acc_p[k]);
+        if constexpr (SAVE) {
+          float* row = gsave + gs.a1 + ((size_t)i * B + b[k]) * 160 + 4 * lg;
+          st4g(row + m1a, acc_a[k]);
+          st4g(row + m1b, acc_b[k]);
+        }
+      }
+    }
+    sw_barrier();
+    // ---- layer 2: a2 = lrelu(W2 a1 + b2) ----------------------------------------------------------
+    {
+      f32x4 b1[NB][10];
+      f32x4 acc[NB], acc1[NB], accq[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b1[k][j] = ld4(&a1buf[k][ln * LD128 + 16 * j + 4 * lg]);
+#pragma unroll
+        for (int j = 8; j < 10; ++j) {
+          const f32x4 s = ld4(&p1[k][ln * LD32 + 16 * (j - 8) + 4 * lg]) + ld4(&p1[k][16 * LD32 + ln * LD32 + 16 * (j - 8) + 4 * lg]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) b1[k][j][r] = sw_lrelu(s[r]);
+        }
+        if constexpr (SAVE)
+          st4g(gsave + gs.a1 + ((size_t)i * B + b[k]) * 160 + 128 + 16 * (wave & 1) + 4 * lg, (wave & 1) ? b1[k][9] : b1[k][8]);
+        acc[k] = b2f;
+        acc1[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          acc[k] = SW_MFMA(w2f[j][0], b1[k][j][0], acc[k]);
+          acc1[k] = SW_MFMA(w2f[j][1], b1[k][j][1], acc1[k]);
+          acc[k] = SW_MFMA(w2f[j][2], b1[k][j][2], acc[k]);
+          acc1[k] = SW_MFMA(w2f[j][3], b1[k][j][3], acc1[k]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        if (wave == 0) accq[k] = fwd_l2_part<0, 3>(w2p, b1[k]);
+        else if (wave == 1) accq[k] = fwd_l2_part<3, 3>(w2p, b1[k]);
+        else if (wave == 2) accq[k] = fwd_l2_part<6, 2>(w2p, b1[k]);
+        else accq[k] = fwd_l2_part<8, 2>(w2p, b1[k]);
+        acc[k] = acc[k] + acc1[k];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[k][r] = sw_lrelu(acc[k][r]);
+        st4(&a2buf[k][ln * LD64 + m2 + 4 * lg], acc[k]);
+        st4(&q2[k][wave * 16 * LD16 + ln * LD16 + 4 * lg], accq[k]);
+        if constexpr (SAVE) st4g(gsave + gs.a2 + ((size_t)i * B + b[k]) * 80 + m2 + 4 * lg, acc[k]);
+      }
+    }
+    sw_barrier();
+    // ---- layers 3+4 composed (v = W43 a2 + b43 ; p += v) and the re-fed encoder step (train.py:422-430) ----
+    {
+      float vx[NB], vy[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        f32x4 b2v[5];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b2v[j] = ld4(&a2buf[k][ln * LD64 + 16 * j + 4 * lg]);
+        {
+          const float* q = &q2[k][ln * LD16 + 4 * lg];
+          const f32x4 s = ((b2p + ld4(q)) + ld4(q + 16 * LD16)) + (ld4(q + 2 * 16 * LD16) + ld4(q + 3 * 16 * LD16));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) b2v[4][r] = sw_lrelu(s[r]);
+        }
+        if constexpr (SAVE) st4g(gsave + gs.a2 + ((size_t)i * B + b[k]) * 80 + 64 + 4 * lg, b2v[4]);
+        float vx0 = 0.f, vx1 = 0.f, vy0 = 0.f, vy1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          vx0 = fmaf(w43[0][j][0], b2v[j][0], vx0);
+          vx1 = fmaf(w43[0][j][1], b2v[j][1], vx1);
+          vx0 = fmaf(w43[0][j][2], b2v[j][2], vx0);
+          vx1 = fmaf(w43[0][j][3], b2v[j][3], vx1);
+          vy0 = fmaf(w43[1][j][0], b2v[j][0], vy0);
+          vy1 = fmaf(w43[1][j][1], b2v[j][1], vy1);
+          vy0 = fmaf(w43[1][j][2], b2v[j][2], vy0);
+          vy1 = fmaf(w43[1][j][3], b2v[j][3], vy1);
+        }
+        float x = vx0 + vx1, y = vy0 + vy1;
+        x += __shfl_xor(x, 16);
+        y += __shfl_xor(y, 16);
+        x += __shfl_xor(x, 32);
+        y += __shfl_xor(y, 32);
+        x += b43i[0];
+        y += b43i[1];
+        vx[k] = x;
+        vy[k] = y;
+        px[k] += x;
+        py[k] += y;
+        if constexpr (ADE) {
+          const float dx = (px[k] - gti[k].x) * inv_ss, dy = (py[k] - gti[k].y) * inv_ss;
+          const float q = dx * dx + dy * dy;
+          const float e = sqrtf(q);
+          if (wave == 0 && lg == 0 && live[k]) {      // arithmetic only: no memory operation under this branch
+            e_sum[k] += e;
+            e_sq[k] += q;
+            if (LAST) e_last[k] = e;
+          }
+        }
+        {
+          const f32x4 x4 = {px[k], py[k], x, y};
+          st4(pred4 + ((size_t)b[k] * Tp + i) * 4, x4);
+          if constexpr (SAVE && !LAST) st4(gsave + gs.x4s + ((size_t)(To + i) * B + b[k]) * 4, x4);
+        }
+      }
+      auto lstm_step = [&](auto save_) {
+        float xb[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) xb[k] = lg == 0 ? px[k] : (lg == 1 ? py[k] : (lg == 2 ? vx[k] : vy[k]));
+        // the cell of both blocks: every W_hh operand against the two h tiles (lstm_cell, sw_lstm_dev.h, per block)
+        f32x4 acc[NB][4], bb[NB][4];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bb[k][j] = ld4(hrow[k] + 16 * j);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[k][g] = SW_MFMA(W.wx[g], xb[k], W.bias[g]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+              for (int k = 0; k < NB; ++k) acc[k][g] = SW_MFMA(W.whh[g][j][r], bb[k][j][r], acc[k][g]);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          f32x4 gate[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float ig = sw_sigmoid(acc[k][0][r]);
+            const float fg = sw_sigmoid(acc[k][1][r]);
+            const float gg = sw_tanh(acc[k][2][r]);
+            const float og = sw_sigmoid(acc[k][3][r]);
+            const float cn = fmaf(fg, c[k][r], ig * gg);
+            gate[0][r] = ig;
+            gate[1][r] = fg;
+            gate[2][r] = gg;
+            gate[3][r] = og;
+            c[k][r] = cn;
+            h[k][r] = og * sw_tanh(cn);
+          }
+          if constexpr (decltype(save_)::value) lstm_put_act_tile(&hbuf[k][(cur ^ 1) * 16 * SW_ALD], gate, c[k], h[k], ln, lg, u0);
+          else st4(&hbuf[k][(cur ^ 1) * 16 * SW_ALD + ln * SW_ALD + 320 + u0 + 4 * lg], h[k]);
+        }
+        cur ^= 1;
+      };
+      if constexpr (!LAST) {
+        if constexpr (SAVE) lstm_step(T_{});
+        else lstm_step(F_{});
+      } else {
+        if (h_end) lstm_step(F_{});
+      }
+      sw_barrier();
+      if constexpr (SAVE && !LAST) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+          lstm_store_act_tile(&hbuf[k][cur * 16 * SW_ALD], gsave + gs.act + (size_t)(To + i) * B * 384, a0[k], B, wave, lane);
+      }
+    }
+  };
+  for (int i = 0; i < Tp - 1; ++i) step(i, F_{});
+  step(Tp - 1, T_{});
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    if (h_end && live[k]) {
+      st4(h_end + (size_t)b[k] * 64 + u0 + 4 * lg, h[k]);
+      if (c_end) st4(c_end + (size_t)b[k] * 64 + u0 + 4 * lg, c[k]);
+    }
+    if (ADE && wave == 0) {   // fixed shuffle tree over the block's 16 agents -> one partial triple per 16-agent tile
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        e_sum[k] += __shfl_xor(e_sum[k], o);
+        e_last[k] += __shfl_xor(e_last[k], o);
+        e_sq[k] += __shfl_xor(e_sq[k], o);
+      }
+      const int t16 = 2 * (int)blockIdx.x + k;
+      if (lane == 0 && t16 < tiles16) {
+        ade_part[(size_t)t16 * 3 + 0] = e_sum[k] / (float)Tp;
+        ade_part[(size_t)t16 * 3 + 1] = e_last[k];
+        ade_part[(size_t)t16 * 3 + 2] = e_sq[k];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward of the decode loop.  Propagates data gradients only; every weight gradient is a
 // deferred GEMM over the time-major delta / activation rows written here (sw_wgrad.hip).
 //
@@ -863,6 +1245,33 @@ extern "C" int sw_dec_rollout_fwd_aux(const float* obsv, int To, const float* z,
   float* act = dsave;
   float* x4s = dsave ? dsave + (size_t)To * B * 384 : nullptr;
   const float* gimg = sw_gen_images_for(enc_w, dec_w);
+  // More tiles than CUs (dense crowds, large shards): two 16-agent column blocks per workgroup - every resident weight
+  // operand issued against both, the step's barrier / LDS turn-arounds paid once per 32 agents (dec_rollout_fwd2_kernel,
+  // bit-identical).  Needs the step's weight images; SW_DEC_FWD2=0 / 1 forces either kernel (A/B runs, tests).
+  static const int fwd2_env = getenv("SW_DEC_FWD2") ? atoi(getenv("SW_DEC_FWD2")) : -1;
+  if (gimg && !d_w && (fwd2_env >= 0 ? fwd2_env != 0 : tiles > 256)) {
+#define SW_DEC_FWD2(SV, AD)                                                                                          \
+  do {                                                                                                               \
+    static bool attr = false;                                                                                        \
+    if (!attr) {                                                                                                     \
+      if (int rc = set_lds((const void*)dec_rollout_fwd2_kernel<SV, AD>, 2 * FwdLds::total * 4)) return rc;          \
+      attr = true;                                                                                                   \
+    }                                                                                                                \
+    SW_LAUNCH((dec_rollout_fwd2_kernel<SV, AD>), dim3((tiles + 1) / 2), dim3(SW_THREADS), 2 * FwdLds::total * 4,     \
+              (hipStream_t)stream, obsv, To, z, S_pool, hT, cT, enc_w, dec_w, B, Tp, pred4, h_end, c_end, gsave, gt,  \
+              inv_ss, ade_part, gimg);                                                                               \
+  } while (0)
+    if (gsave) {
+      if (ade_part) SW_DEC_FWD2(true, true);
+      else SW_DEC_FWD2(true, false);
+    } else {
+      if (ade_part) SW_DEC_FWD2(false, true);
+      else SW_DEC_FWD2(false, false);
+    }
+#undef SW_DEC_FWD2
+    SW_CHECK_LAUNCH("dec_rollout_fwd2_kernel");
+    return SW_OK;
+  }
 #define SW_DEC_FWD(SV, AD)                                                                                           \
   do {                                                                                                               \
     static bool attr = false;                                                                                        \

@@ -570,3 +570,64 @@ def test_encoder_forward_on_eight_waves_equals_the_four_wave_kernel(tmp_path):
         for a, b, what in zip(res["0"][key], res["1"][key], ("hT", "cT", "act", "x4s")):
             assert torch.equal(a, b), "B, T = %s: %s differs (max |diff| %.3g)" % (key, what, float((a - b).abs().max()))
     assert float(res["0"][(2048, 8)][0].abs().max()) > 0.0
+
+
+_FWD2_SNIPPET = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+import socialways_amd as sw
+from socialways_amd import _lib as L
+torch.manual_seed(0)
+G = sw.Generator(use_social=True, device="cuda:0")
+G.unify()
+enc, dec, emb, att = G.encoder._flat, G.decoder._flat, G.feature_embedder._flat, G.attention._flat
+lib = L.load()
+img = torch.empty(lib.sw_gen_image_floats(), device="cuda")
+L.call("sw_gen_images", L.ptr(enc), L.ptr(dec), L.ptr(emb), L.ptr(att), L.ptr(img), L.stream())
+out = {}
+for B, To, Tp, social in ((1024, 8, 12, True), (1061, 8, 12, True), (37, 5, 3, False), (16, 2, 1, True), (48, 8, 12, True)):
+    gen = torch.Generator(device="cuda").manual_seed(B)
+    obsv = (torch.rand(B, To, 2, device="cuda", generator=gen).cumsum(1) * 0.1).contiguous()
+    gt = (torch.rand(B, Tp, 2, device="cuda", generator=gen).cumsum(1) * 0.1).contiguous()
+    z = torch.rand(B, 32, device="cuda", generator=gen)
+    S = torch.randn(B, 64, device="cuda", generator=gen) * 0.3 if social else None
+    hT, cT = torch.randn(B, 64, device="cuda", generator=gen) * 0.1, torch.randn(B, 64, device="cuda", generator=gen) * 0.1
+    for save in (True, False):
+        pred4 = torch.zeros(B, Tp, 4, device="cuda")
+        hE, cE = torch.zeros(B, 64, device="cuda"), torch.zeros(B, 64, device="cuda")
+        gsave = torch.zeros(L.workspace_floats(L.WS_GSAVE, B, To, Tp), device="cuda") if save else None
+        ade = torch.zeros((B + 15) // 16, 3, device="cuda")
+        L.call("sw_dec_rollout_fwd", L.ptr(obsv), To, L.ptr(z), L.ptr(S), L.ptr(hT), L.ptr(cT), L.ptr(enc), L.ptr(dec), B, Tp,
+               L.ptr(pred4), None if save else L.ptr(hE), None if save else L.ptr(cE), L.ptr(gsave), L.ptr(gt), 0.7, L.ptr(ade),
+               L.stream())
+        torch.cuda.synchronize()
+        keep = [pred4.cpu(), ade.cpu(), hE.cpu(), cE.cpu()]
+        if save:
+            keep.append(gsave.cpu())      # (zero-filled: the rows the decode loop does not write compare equal)
+        out[(B, To, Tp, social, save)] = keep
+torch.save(out, sys.argv[2])
+'''
+
+
+@pytest.mark.gpu
+def test_decode_forward_on_two_column_blocks_equals_the_16_agent_kernel(tmp_path):
+    """dec_rollout_fwd2_kernel (r5 verdict item 3: two 16-agent column blocks per workgroup against every register-resident
+    weight operand, selected above 256 tiles) against dec_rollout_fwd_kernel: the prediction, the ADE/FDE partial sums per
+    16-agent tile, the final state and every saved row bit for bit - an even and an odd number of tiles with a ragged last
+    tile, with and without the pooled social vector / the save buffer, the shortest horizons.  The switch is read once per
+    process: two subprocesses."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for v in ("0", "1"):
+        f = str(tmp_path / ("fwd2_%s.pt" % v))
+        p = subprocess.run([sys.executable, "-c", _FWD2_SNIPPET, root, f], env=dict(os.environ, SW_DEC_FWD2=v), capture_output=True,
+                           text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[v] = torch.load(f)
+    for key in res["0"]:
+        for i, (a, b) in enumerate(zip(res["0"][key], res["1"][key])):
+            assert torch.equal(a, b), "%s: output %d differs (max |diff| %.3g)" % (key, i, float((a - b).abs().max()))
+    assert float(res["0"][(1024, 8, 12, True, True)][0].abs().max()) > 0.0
