@@ -734,6 +734,19 @@ def exchange_child_main(args, world, rank, dev, pg, backend, KG):
         rep["direct_step"] = {"steps": n, "steps_s": n * (world if args.scaling == "weak" else 1) / d, "ms_per_step": 1e3 * d / n,
                               "collectives": "in-graph" if lg.tr._graph_collectives else "between graph segments",
                               "status": lg.tr._direct.status_all() if lg.tr._direct is not None else None}
+        save()
+        # ... and the HEADLINE's own procedure on the direct form (priming of every launch size, settle steps, W warmup steps,
+        # two rehearsals, then EXACTLY K steps between fences, max over ranks): the number to hold against the line's `value`
+        lg.prime((args.steps, args.warmup))
+        lg.run_steps(0, int(os.environ.get("SW_BENCH_SETTLE_STEPS", "1000")) // KG * KG)
+        lg.run_steps(0, args.warmup)
+        for r in range(2):
+            lg.timed(fence, args.warmup, args.steps)
+        dh = max_over_ranks(lg.timed(fence, args.warmup, args.steps))
+        rep["direct_headline"] = {"value": args.steps * (world if args.scaling == "weak" else 1) / dh, "unit": "steps/s",
+                                  "steps": args.steps, "ms_per_step": 1e3 * dh / args.steps,
+                                  "status": lg.tr._direct.status_all() if lg.tr._direct is not None else None,
+                                  "what": "the headline's procedure with SW_ALLREDUCE=direct, in this child job"}
         lg.tr.close()
     except Exception as e:      # noqa: BLE001
         rep["direct_error"] = _err(e)["error"]
@@ -743,29 +756,76 @@ def exchange_child_main(args, world, rank, dev, pg, backend, KG):
     return 0
 
 
-def run_exchange_child(args, world, tmpdir):
-    """Rank 0 of the N > 1 bench: the exchange report as a second job on the same GPUs (the parent's ranks idle on the host
-    meanwhile).  The library's direct exchange has never crossed an xGMI link on hardware this build has seen: a GPU fault, a
-    failed peer mapping or a wait that never ends there ends the CHILD; the line keeps config.exchange.error."""
+def run_child_job(args, world, tmpdir, mode, tag, timeout_s):
+    """Rank 0 of the N > 1 bench: a second job of `world` ranks on the same GPUs (`bench.py --gpus N --<mode>` under its own
+    torch.distributed.run), the parent's ranks idle on the host meanwhile.  Whatever happens in it - a GPU fault, a failed peer
+    mapping, a collective that never completes - ends the CHILD; the record keeps `error` and what was written before it."""
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    path = os.path.join(tmpdir, "exchange.json")
+    path = os.path.join(tmpdir, tag + ".json")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
-           "--gpus", str(world), "--exchange-only", "--side-out", path, "--workload", args.workload,
-           "--scaling", args.scaling, "--global-scenes", str(args.global_scenes)]
+           "--gpus", str(world), "--" + mode, "--side-out", path, "--workload", args.workload,
+           "--scaling", args.scaling, "--global-scenes", str(args.global_scenes), "--steps", str(args.steps),
+           "--warmup", str(args.warmup)]
     t0 = time.perf_counter()
-    rc, tail = run_child(cmd, child_timeout(300.0), {"OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS", "8")})
+    rc, tail = run_child(cmd, child_timeout(timeout_s), {"OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS", "8")})
     rep = _read_json(path) or {}
     if rc != 0:
-        rep["error"] = ("the exchange child job timed out after %.0f s" % (time.perf_counter() - t0)) if rc is None else \
-                       "the exchange child job exited with code %d" % rc
+        rep["error"] = ("the child job timed out after %.0f s" % (time.perf_counter() - t0)) if rc is None else \
+                       "the child job exited with code %d" % rc
         rep["stderr_tail"] = tail[-600:]
-    rep["how"] = "a child job of %d ranks on the same GPUs (bench.py --exchange-only), the parent's ranks idle" % world
+    rep["how"] = "a child job of %d ranks on the same GPUs (bench.py --%s), the parent's ranks idle; %.0f s" % (
+        world, mode, time.perf_counter() - t0)
     return rep
+
+
+def probe_child_main(args, world, rank, dev, pg, backend, KG):
+    """`bench.py --gpus N --probe-only --side-out FILE` - a CHILD JOB run BEFORE the headline of an N > 1 bench: can this
+    node replay the data-parallel step with the RCCL all-reduces recorded INSIDE the hipGraph?  The trainer probes that by
+    itself (a captured all-reduce replayed and checked), but a captured collective that never completes would take the
+    bench's ranks with it; here it takes a child.  The child then runs the real thing - eager steps, the capture, replays
+    of 4-step launches - and checks the replicas.  No verdict (crash, time-out) = graph segments with eager collectives."""
+    rep = {"backend": backend}
+    os.environ.pop("SW_GRAPH_COLLECTIVES", None)       # the trainer's own probe decides
+    lg = Leg(args.workload, dev, pg, world, rank, args.scaling, args.global_scenes, 4)
+    lg.run_steps(0, 24)
+    torch.cuda.synchronize()
+    ok = bool(torch.isfinite(lg.last).all())
+    chk = torch.stack([lg.tr.G._flat_all.double().sum(), lg.tr.D._flat.double().sum()])
+    hi, lo = chk.clone(), chk.clone()
+    torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+    torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+    rep["replicas_identical"] = bool(torch.equal(hi, lo))
+    rep["finite"] = ok
+    rep["graph_collectives"] = bool(lg.tr._graph_collectives) and ok and rep["replicas_identical"]
+    lg.tr.close()
+    torch.distributed.barrier()
+    if rank == 0:
+        _write_json(args.side_out, rep)
+    torch.distributed.destroy_process_group()
+    return 0
+
+
+def on_rank0(world, rank, dev, backend, tmpdir, tag, fn, wait_s):
+    """fn() on rank 0 (it returns a JSON-able record); the other ranks wait for it ON THE HOST - a file, not a collective: a
+    barrier's kernels would spin on the GPUs a child job measures on - and every rank returns the record."""
+    path, done = os.path.join(tmpdir, tag + ".result.json"), os.path.join(tmpdir, tag + ".done")
+    if rank == 0:
+        try:
+            rec = fn()
+        except Exception as e:      # noqa: BLE001
+            rec = _err(e)
+        _write_json(path, rec)
+        open(done, "w").close()
+        return rec
+    deadline = time.monotonic() + wait_s
+    while not os.path.exists(done) and time.monotonic() < deadline:
+        time.sleep(0.2)
+    return _read_json(path) or {"error": "rank 0 did not report within %.0f s" % wait_s}
 
 
 def main():
@@ -786,6 +846,7 @@ def main():
     ap.add_argument("--side-out", help=argparse.SUPPRESS)
     ap.add_argument("--ref-ms", type=float, default=0.0, help=argparse.SUPPRESS)
     ap.add_argument("--exchange-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--probe-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -832,6 +893,22 @@ def main():
         return side_legs_main(args, dev, KG, HOST_Z)
     if args.exchange_only:
         return exchange_child_main(args, world, rank, dev, pg, backend, KG)
+    if args.probe_only:
+        return probe_child_main(args, world, rank, dev, pg, backend, KG)
+    # N > 1 on RCCL: whether the all-reduces may be recorded INSIDE the step graph is decided by a child job that tries it
+    # (probe_child_main) - a captured collective that never completes must not take the ranks that will hold the headline.
+    # SW_GRAPH_COLLECTIVES=0 / 1 in the environment skips the child.
+    tmpdir, probe = None, None
+    if pg is not None and world > 1:
+        import tempfile
+        obj = [tempfile.mkdtemp(prefix="sw_bench_")] if rank == 0 else [None]
+        torch.distributed.broadcast_object_list(obj, src=0, device=dev if backend == "nccl" else None)
+        tmpdir = obj[0]
+        # (SW_BENCH_FORCE_PROBE=1: also on gloo ranks sharing a device - a rehearsal of the plumbing, the verdict is "segments")
+        if (backend == "nccl" or os.environ.get("SW_BENCH_FORCE_PROBE") == "1") and "SW_GRAPH_COLLECTIVES" not in os.environ:
+            probe = on_rank0(world, rank, dev, backend, tmpdir, "probe",
+                             lambda: run_child_job(args, world, tmpdir, "probe-only", "probe", 300.0), child_timeout(300.0) + 120.0)
+            os.environ["SW_GRAPH_COLLECTIVES"] = "1" if probe.get("graph_collectives") is True and "error" not in probe else "0"
     import gc
     leg = Leg(args.workload, dev, pg, world, rank, args.scaling, args.global_scenes, KG)
     # The headline step is the reference's: z = torch.rand(bs, noise_len) drawn on the HOST every step and copied
@@ -1017,6 +1094,7 @@ def main():
                        "backend": backend,       # "nccl" = RCCL; "gloo" = ranks sharing devices, a rehearsal, not a measurement
                        "allreduces_per_step": (3 if pg is not None else 0),
                        "allreduce": allreduce_form,
+                       "collectives_probe": probe,      # N > 1 on RCCL: the child job that tried in-graph collectives before the headline
                        "exchange": None,          # N > 1: us per all-reduce of each bucket on both forms + the step on the direct form (below)
                        "exchange_probe": exchange_probe,      # SW_ALLREDUCE=auto: what the probe measured / chose
                        "agent_steps_s": value * B if args.scaling == "weak" else value * leg.Bg,      # agents stepped per second, whole job
@@ -1086,7 +1164,6 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(leg.tracks, S if args.workload != "c4" else 16, A, To, Tp)
             except Exception as e:      # noqa: BLE001
                 res["cpu_baseline"] = dict(_err(e), value=None, unit="steps/s", cores=None, kind="port", sample=None)
-    tmpdir = None
     if world == 1 and pg is None and not args.no_other_workloads:
         tr.close()
         del tr
@@ -1098,22 +1175,11 @@ def main():
         except Exception as e:      # noqa: BLE001
             res["config"]["other_workloads"] = _err(e)
     if pg is not None and world > 1 and os.environ.get("SW_ALLREDUCE", "") != "direct" and not args.no_other_workloads:
-        # N > 1: the exchange report is a CHILD JOB of rank 0 on the same GPUs; the other ranks wait on the host (a file, no
-        # collective: a barrier's kernels would spin on the GPUs the child measures on)
-        obj = [tempfile.mkdtemp(prefix="sw_bench_")] if rank == 0 else [None]
-        torch.distributed.broadcast_object_list(obj, src=0, device=dev if backend == "nccl" else None)
-        tmpdir = obj[0]
-        done = os.path.join(tmpdir, "exchange.done")
+        # N > 1: the exchange report is a CHILD JOB of rank 0 on the same GPUs (exchange_child_main)
+        ex = on_rank0(world, rank, dev, backend, tmpdir, "exchange",
+                      lambda: run_child_job(args, world, tmpdir, "exchange-only", "exchange", 420.0), child_timeout(420.0) + 120.0)
         if rank == 0:
-            try:
-                res["config"]["exchange"] = run_exchange_child(args, world, tmpdir)
-            except Exception as e:      # noqa: BLE001
-                res["config"]["exchange"] = _err(e)
-            open(done, "w").close()
-        else:
-            deadline = time.monotonic() + child_timeout(300.0) + 120.0
-            while not os.path.exists(done) and time.monotonic() < deadline:
-                time.sleep(0.2)
+            res["config"]["exchange"] = ex
     if rank == 0:
         emit()
     if pg is not None:

@@ -48,12 +48,17 @@ def test_two_rank_bench_line_on_one_box():
     import torch
     backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
     p, lines = _run(["--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-other-workloads",
-                     "--no-sustained"], {"SW_BENCH_BACKEND": backend, "SW_BENCH_SETTLE_STEPS": "8"}, 850)
+                     "--no-sustained"], {"SW_BENCH_BACKEND": backend, "SW_BENCH_SETTLE_STEPS": "8", "SW_BENCH_FORCE_PROBE": "1"}, 850)
     assert p.returncode == 0, p.stderr[-3000:]
     assert len(lines) == 1, p.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["steps"] == 4
     cfg = rec["config"]
+    # the child job that tries in-graph collectives before the headline ran (forced here on gloo, where the answer is no)
+    pr = cfg["collectives_probe"]
+    assert pr is not None and "error" not in pr, pr
+    assert pr["replicas_identical"] is True and pr["graph_collectives"] == (backend == "nccl")
+    assert cfg["collectives"] == ("in-graph" if backend == "nccl" else "between graph segments")
     assert cfg["rccl_ranks"] == 2 and cfg["allreduces_per_step"] == 3 and cfg["replicas_identical"] is True
     assert cfg["backend"] == backend
     assert rec["value"] > 0 and abs(rec["value"] - 2 * 1e3 / rec["ms_per_step"]) < 1e-6 * rec["value"]
@@ -76,6 +81,9 @@ def test_two_rank_bench_line_reports_both_gradient_exchanges():
     assert ex["buckets_floats"] == [27942, 27942, 86124]      # packed D, D, G gradient buffers (tensors on 4-float boundaries)
     assert len(ex["group_us"]) == 3 and len(ex["direct_us"]) == 3 and min(ex["direct_us"]) > 0 and ex["direct_status"] == 0
     assert ex["direct_step"]["steps_s"] > 0 and ex["direct_step"]["collectives"] == "in-graph" and ex["direct_step"]["status"] == 0
+    assert ex["direct_headline"]["value"] > 0 and ex["direct_headline"]["steps"] == 4 and ex["direct_headline"]["status"] == 0
+    # (RCCL ranks only: a child job tries in-graph collectives before the headline; gloo ranks sharing the device skip it)
+    assert (rec["config"]["collectives_probe"] is None) == (backend != "nccl")
 
 
 @pytest.mark.gpu
