@@ -106,6 +106,7 @@ def kernel_alg_flops(B, P, To, Tp, one_launch_d=False, dfuse=None):
         "enc_lstm_bwd_kernel": 2.0 * B * To * lstm,
         "dec_rollout_fwd_kernel": 2.0 * B * (Tp * dec + (Tp - 1) * lstm)
                                   + (2.0 * B * To * d_lstm if rides else 0.0),   # + D's first obs LSTM (rides here)
+        "dec_rollout_fwd2_kernel": 2.0 * B * (Tp * dec + (Tp - 1) * lstm),       # two column blocks per workgroup (> 256 tiles: no riders)
         "dec_rollout_bwd_kernel": 2.0 * B * (Tp * dec + (Tp - 1) * lstm) + (g_phase if dfuse else 0.0),   # + the G-phase D pass
         "social_pool_fwd_kernel": 2.0 * soc,
         "social_pool_bwd_rows_kernel": 2.0 * 2 * soc,     # recomputes the pair MLP + its data gradients

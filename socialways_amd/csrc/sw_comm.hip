@@ -65,30 +65,32 @@ __device__ __forceinline__ void st_gran(char* p, float a, float b, unsigned e) {
   const u32x4 v = {__float_as_uint(a), e, __float_as_uint(b), e};
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
 }
-// One granule = one naturally aligned 8-byte {value bits, epoch}: read as ONE relaxed system-scope atomic load
-// (global_load_dwordx2 sc0 sc1: served from memory, not from this XCD's L2 or the CU's L1); the compiler places the waits.
-struct Gran2 { unsigned long long a, b; };      // the two granules of a 16-byte pair
-__device__ __forceinline__ Gran2 ld_gran(const char* p) {
-  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+// Two granules {value bits, epoch} = one 16-byte system-scope load (buffer_load_dwordx4 sc0 sc1: served from memory, not
+// from this XCD's L2 or the CU's L1) through the compiler's buffer-load builtin: the COMPILER places the waits (round 5 used
+// inline-asm loads with a hand-placed s_waitcnt - correct with that codegen, fragile across compilers; two 8-byte atomic
+// loads per pair cost ~2 us per launch).  The 8-byte halves of such a load have been observed untorn (MI355X_MICROARCH.md).
+typedef __amdgpu_buffer_rsrc_t comm_rsrc;
+__device__ __forceinline__ comm_rsrc comm_make_rsrc(const char* base) {     // wave-uniform base, byte offsets per lane
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0x7fffffff, 0x00020000);
+}
+struct Gran2 { u32x4 q; };      // the two granules of a 16-byte pair: {value a, tag a, value b, tag b}
+__device__ __forceinline__ Gran2 ld_gran(comm_rsrc r, unsigned off) {
   Gran2 g;
-  g.a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  g.b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  g.q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 1 | 16);      // aux: sc0 | sc1
   return g;
 }
-__device__ __forceinline__ float gran_val(unsigned long long g) { return __uint_as_float((unsigned)g); }
-__device__ __forceinline__ unsigned gran_tag(unsigned long long g) { return (unsigned)(g >> 32); }
-// the W granule pairs at base + k * stride (k < W), polled until every tag is e; false on a time-out
-__device__ __forceinline__ bool poll_grans(Gran2 (&v)[SW_COMM_MAXW], const char* base, size_t stride, int W, unsigned e,
+// the W granule pairs at byte offsets off + k * stride (k < W) of the own buffer, polled until every tag is e; false on a time-out
+__device__ __forceinline__ bool poll_grans(Gran2 (&v)[SW_COMM_MAXW], comm_rsrc r, unsigned off, unsigned stride, int W, unsigned e,
                                            unsigned long long timeout_ticks) {
   unsigned long long t0 = 0;
   for (;;) {
 #pragma unroll
     for (int k = 0; k < SW_COMM_MAXW; ++k)
-      if (k < W) v[k] = ld_gran(base + (size_t)k * stride);             // 2 W loads in flight
+      if (k < W) v[k] = ld_gran(r, off + (unsigned)k * stride);         // W loads in flight
     bool all = true;
 #pragma unroll
     for (int k = 0; k < SW_COMM_MAXW; ++k)
-      if (k < W) all = all && gran_tag(v[k].a) == e && gran_tag(v[k].b) == e;
+      if (k < W) all = all && v[k].q[1] == e && v[k].q[3] == e;
     if (all) return true;
     if (t0 == 0) t0 = wall_clock64();
     else if (wall_clock64() - t0 > timeout_ticks) return false;
@@ -107,6 +109,7 @@ __global__ __launch_bounds__(256) void allreduce_direct_kernel(CommArgs A, float
   if (ADAM && threadIdx.x == 64) wg_adam_bc_compute(ad.step, ad.beta1, ad.beta2, bcs[0], bcs[1]);
   const int b = blockIdx.x, W = A.W, r = A.rank;   // (b: this workgroup's chunk of every slice)
   char* mine = A.peer[r];
+  const comm_rsrc rs = comm_make_rsrc(mine);      // the own buffer: everything this rank polls
   unsigned* hdr = reinterpret_cast<unsigned*>(mine);
   // a wait of an EARLIER call on this buffer timed out: the exchange is dead (sw_comm_status says so to the host); nothing is
   // sent, nothing is written, nobody is waited for - one time-out costs one time-out, not one per remaining call of the epoch
@@ -133,19 +136,18 @@ __global__ __launch_bounds__(256) void allreduce_direct_kernel(CommArgs A, float
   }
   // ---- this rank's slice summed in rank order as the slots arrive, hop 2: the sum -> slice r of every rank's out region
   {
-    const char* rv = mine + A.recv + (size_t)c0 * 8;
     for (int i = threadIdx.x; i < np; i += 256) {
       Gran2 v[SW_COMM_MAXW];
-      if (!poll_grans(v, rv + (size_t)i * 16, (size_t)A.ls_cap * 8, W, e, A.timeout_ticks)) {
+      if (!poll_grans(v, rs, (unsigned)(A.recv + (size_t)c0 * 8 + (size_t)i * 16), (unsigned)(A.ls_cap * 8), W, e, A.timeout_ticks)) {
         ok = false;          // a peer never arrived: this pair is NOT published (its readers time out in turn)
         continue;
       }
-      float s0 = gran_val(v[0].a), s1 = gran_val(v[0].b);
+      float s0 = __uint_as_float(v[0].q[0]), s1 = __uint_as_float(v[0].q[2]);
 #pragma unroll
       for (int src = 1; src < SW_COMM_MAXW; ++src)
         if (src < W) {
-          s0 += gran_val(v[src].a);
-          s1 += gran_val(v[src].b);
+          s0 += __uint_as_float(v[src].q[0]);
+          s1 += __uint_as_float(v[src].q[2]);
         }
       for (int pp = 0; pp < W; ++pp) {
         const int p = (r + 1 + pp) % W;
@@ -156,11 +158,10 @@ __global__ __launch_bounds__(256) void allreduce_direct_kernel(CommArgs A, float
   if constexpr (ADAM) __syncthreads();      // bcs
   // ---- the all-reduced gradient back over the rank's buffer (and the optimizer step) ----------------------------------
   {
-    const char* ov = mine + A.out + (size_t)c0 * 8;
     for (int i = threadIdx.x; i < np; i += 256) {
       Gran2 vs[SW_COMM_MAXW];
       // (a thread that has already given up on a peer does not wait a second time: the call has failed)
-      if (!ok || !poll_grans(vs, ov + (size_t)i * 16, (size_t)A.ls_cap * 8, W, e, A.timeout_ticks)) {
+      if (!ok || !poll_grans(vs, rs, (unsigned)(A.out + (size_t)c0 * 8 + (size_t)i * 16), (unsigned)(A.ls_cap * 8), W, e, A.timeout_ticks)) {
         ok = false;          // no valid sum for these elements: neither the gradient nor the weights are touched
         continue;
       }
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void allreduce_direct_kernel(CommArgs A, float
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           if (g + k >= A.n) continue;
-          const float val = gran_val(k ? vs[p].b : vs[p].a);
+          const float val = __uint_as_float(vs[p].q[2 * k]);
           grad[g + k] = val;
           if constexpr (ADAM) wg_adam_fin(ad, wg_adam_pre(ad, grad + g + k), bcs[0], bcs[1], val);
         }

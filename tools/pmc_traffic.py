@@ -3,7 +3,7 @@ HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are i
 half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) - validated in round 1 on dec_rollout_bwd, whose
 reads (saved LSTM rows + a1/a2) are 58 MB by construction vs 2 x 27.4 MB counted.
 `_step` = per-step totals: sum over kernels of (mean bytes per launch) x (launches per step; counted against the one
-dec_rollout_fwd launch every step has).
+decode-forward launch every step has).
 Optional 4th argument: the SQ pass (SQ_VALU_MFMA_BUSY_CYCLES summed over the SIMDs).  A SIMD's matrix pipe retires 64 fp32
 FLOP per busy cycle (v_mfma_f32_16x16x4_f32: 2048 FLOP per 32-cycle issue slot), so EXECUTED matrix FLOP per launch = 64 x
 busy cycles - what the kernels really issued, next to the reference-formulation FLOP counts of bench.kernel_alg_flops (which
@@ -33,15 +33,17 @@ def mean_counter(db, name):
 fetch, nf = mean_counter(sys.argv[1], "FETCH_SIZE")
 write, nw = mean_counter(sys.argv[2], "WRITE_SIZE")
 abi = {"dec_rollout_bwd_kernel": "sw_dec_rollout_bwd", "dec_rollout_fwd_kernel": "sw_dec_rollout_fwd",
+       "dec_rollout_fwd2_kernel": "sw_dec_rollout_fwd",
        "enc_lstm_fwd_kernel": "sw_enc_lstm_fwd", "enc_lstm_bwd_kernel": "sw_enc_lstm_bwd",
        "disc_fwd_kernel": "sw_disc_fwd", "disc_bwd_kernel": "sw_disc_bwd", "disc_update_kernel": "sw_disc_update",
        "wgrad_partial_kernel": "wgrad_partial", "wgrad_reduce_kernel": "wgrad_reduce",
        "social_pool_fwd_kernel": "sw_social_pool_fwd", "social_pool_bwd_kernel": "sw_social_pool_bwd",
        "social_pool_bwd_rows_kernel": "sw_social_pool_bwd_rows", "stage_step_kernel": "sw_stage_step",
        "enc_compose_bwd_kernel": "enc_compose_bwd"}
-steps = max(nf.get("dec_rollout_fwd_kernel", 1), 1)
+# (the decode forward is ONE launch per step under either of its kernels: 16-agent tiles, or two blocks per workgroup)
+steps = max(nf.get("dec_rollout_fwd_kernel", 0) + nf.get("dec_rollout_fwd2_kernel", 0), 1)
 mfma, nm = mean_counter(sys.argv[4], "SQ_VALU_MFMA_BUSY_CYCLES") if len(sys.argv) > 4 else ({}, {})
-sq_steps = max(nm.get("dec_rollout_fwd_kernel", 1), 1)
+sq_steps = max(nm.get("dec_rollout_fwd_kernel", 0) + nm.get("dec_rollout_fwd2_kernel", 0), 1)
 out, step_bytes, step_k, step_mfma = {}, 0.0, {}, 0.0
 for k in sorted(set(fetch) | set(write)):
     if "at::" in k or "rocclr" in k or k in ("spin_kernel", "nop_kernel", "traj4d_kernel", "gen_images_kernel", "disc_images_kernel"):
