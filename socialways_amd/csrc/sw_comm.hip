@@ -191,7 +191,9 @@ __global__ __launch_bounds__(256) void allreduce_direct_kernel(CommArgs A, float
 
 extern "C" long long sw_comm_bytes(int world, long long max_floats) {
   if (world < 1 || world > SW_COMM_MAXW || max_floats < 1) return SW_EARG;
-  return (long long)comm_layout(world, max_floats).total;
+  const CommLayout L = comm_layout(world, max_floats);
+  if (L.total >= (size_t)0x7fffffff) return SW_ESHAPE;      // the kernel addresses its own buffer with 32-bit byte offsets
+  return (long long)L.total;
 }
 // The exchange buffer is device memory of its own (not the caller's allocator: it must be exportable as ONE hipIpc
 // allocation and should be uncached - every access to it is a hand-off).  Zero-filled: flags and epochs start at 0.
@@ -267,6 +269,7 @@ static int allreduce_direct_launch(void* const* peer_bufs, int rank, int world, 
     return SW_EARG;
   if (n == 0) return SW_OK;
   const CommLayout L = comm_layout(world, max_floats);
+  if (L.total >= (size_t)0x7fffffff) return SW_ESHAPE;      // (sw_comm_bytes refuses such a buffer too)
   CommArgs A;
   for (int p = 0; p < world; ++p) {
     if (!peer_bufs[p]) return SW_EARG;

@@ -46,6 +46,7 @@ def test_argument_validation_without_gpu():
     # the data-parallel exchange (csrc/sw_comm.hip): sizes and argument checks are host-side
     assert lib.sw_comm_bytes(0, 1000) == -1 and lib.sw_comm_bytes(17, 1000) == -1 and lib.sw_comm_bytes(8, 0) == -1
     assert lib.sw_comm_bytes(8, 86124) > 2 * 8 * 86124 and lib.sw_comm_bytes(2, 86124) % 16 == 0      # two granule regions
+    assert lib.sw_comm_bytes(8, 1 << 28) == -2                        # 32-bit byte offsets inside a buffer: refused, not wrapped
     assert lib.sw_allreduce_direct(None, 0, 2, 1000, None, 10, None) == -1
     assert lib.sw_allreduce_direct_adam(None, 0, 2, 1000, None, 10, None, None, None, None, 1e-3, 0.9, 0.999, 1e-8, 0, None) == -1
     assert lib.sw_comm_alloc(0, None) == -1 and lib.sw_comm_free(None) == 0 and lib.sw_comm_ipc_close(None) == 0
