@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SW_LIB_PATH") or os.path.join(_HERE, "libsocialways_hip.so")   # SW_LIB_PATH: tuning builds (tools/sweep.sh)
+LIB_PATH = os.environ.get("SW_LIB_PATH") or os.path.join(_HERE, "libsocialways_hip.so")   # SW_LIB_PATH: tuning builds (tools/build_variant.sh)
 
 GRP_ENC, GRP_EMB, GRP_ATT, GRP_DEC, GRP_DISC = 0, 1, 2, 3, 4
 WS_GSAVE, WS_GDELTA, WS_DSAVE, WS_DDELTA, WS_WGRAD, WS_PAIRS = 0, 1, 2, 3, 4, 5
