@@ -1053,19 +1053,52 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
     if constexpr (DFUSE) R.g4 = ld4(df.dpred + ((size_t)b * Tp + i) * 4);
     else R.g4 = ld4(dpred4 + ((size_t)b * Tp + i) * 4);
   };
+  // ROLLING prefetch (round 6): every group of saved rows is re-requested for step i - 1 right behind its last use in
+  // step i, into the SAME registers.  Rounds 1-5 fetched the whole row set of step i - 1 at the head of step i into a
+  // second set (52 registers: 490 in all, 234 of them AGPRs the vector ALU cannot read without a copy); in place the kernel
+  // needs 451 and the step is 10 % shorter (82.9 -> 75 us at m1, c4 -1.8 % per step; profiles/r06_bwd_roll_ab.txt)
+  auto roll_lstm = [&](int i, Rows& Q) {
+    const float* row = act_b + (size_t)i * B * 384;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) Q.gate[g] = ld4(row + g * 64);
+    Q.ct = ld4(row + 256);
+    Q.cprev = ld4(row - (size_t)B * 384 + 256);
+    asm volatile("" ::: "memory");
+  };
+  auto roll_g4 = [&](int i, Rows& Q) {
+    if constexpr (DFUSE) Q.g4 = ld4(df.dpred + ((size_t)b * Tp + i) * 4);
+    else Q.g4 = ld4(dpred4 + ((size_t)b * Tp + i) * 4);
+    asm volatile("" ::: "memory");
+  };
+  auto roll_a2 = [&](int i, Rows& Q) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) Q.a2[q] = ld4(a2_b + (size_t)i * B * 80 + m2q[q]);
+    asm volatile("" ::: "memory");
+  };
+  auto roll_a1 = [&](int i, Rows& Q) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) Q.a1[q] = ld4(a1_b + (size_t)i * B * 160 + 32 * wave + 16 * q);
+    asm volatile("" ::: "memory");
+  };
+  auto roll_a1s = [&](int i, Rows& Q) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) Q.a1s[q] = ld4(a1_b + (size_t)i * B * 160 + 128 + 16 * q);
+    asm volatile("" ::: "memory");
+  };
   Rows R;
   load_rows(Tp - 1, R, F_{});
   // one decode step backwards; lstm: the step has an LSTM step behind it (all but i = Tp-1); pf: prefetch i-1
   auto step = [&](int i, auto lstm, auto pf) {
     SW_STAMP(7);
-    Rows N;
-    if constexpr (decltype(pf)::value) load_rows(i - 1, N, T_{});
+    constexpr bool PF = decltype(pf)::value;      // the rows of step i - 1 are prefetched (all steps but i = 0)
+    if constexpr (PF && !decltype(lstm)::value) roll_lstm(i - 1, R);      // (step Tp - 1 has no LSTM step of its own)
     f32x4 dx4 = {0.f, 0.f, 0.f, 0.f};  // gradient through the LSTM input (p_i, v_i)
     if constexpr (decltype(lstm)::value) {
       // ---- LSTM step t = To+i (consumed x4_i, produced h_t) --------------------------------
       const int t = To + i;
       f32x4 dgate[4];
       lstm_cell_bwd(R.gate, R.ct, R.cprev, dh, dc, dgate);
+      if constexpr (PF) roll_lstm(i - 1, R);
 #pragma unroll
       for (int g = 0; g < 4; ++g) st4(&dgbuf[ln * SW_GLD + g * 64 + u0 + 4 * lg], dgate[g]);
       sw_barrier();
@@ -1085,6 +1118,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
     }
     // ---- decoder step i: dv (registers, every wave) ------------------------------------------------
     const f32x4 g4 = R.g4;
+    if constexpr (PF) roll_g4(i - 1, R);
     dpx += g4[0] + dx4[0];  // dL/dp_i  (p_i also feeds p_{i+1}: carried in dpx)
     dpy += g4[1] + dx4[1];
     const float dvx = g4[2] + dx4[2] + dpx;  // p_i = p_{i-1} + v_i
@@ -1106,6 +1140,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
       st4(&dz2buf[ln * LD80 + m2q[q2] + 4 * lg], acc);
       st4g(gdelta + gd.dz2 + ((size_t)i * B + b) * 80 + m2q[q2] + 4 * lg, acc);
     }
+    if constexpr (PF) roll_a2(i - 1, R);
     sw_barrier();
     SW_STAMP(3);
     // dz1 = (W2^T dz2) * lrelu'(a1)   (160): row tiles 2w, 2w+1 and this wave's K-part of the split tile
@@ -1146,6 +1181,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
       du_a += acc_a;
       du_b += acc_b;
     }
+    if constexpr (PF) roll_a1(i - 1, R);
     sw_barrier();
     SW_STAMP(4);
     // dh_{To+i-1} += W1h^T dz1   (wave w owns units 16w.. : same layout as dh)
@@ -1163,6 +1199,7 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
         st4g(gdelta + gd.dz1 + ((size_t)i * B + b) * 160 + 128 + 16 * q + 4 * lg, v);
         du_s[q] += v;
       }
+      if constexpr (PF) roll_a1s(i - 1, R);
       f32x4 acc = decltype(lstm)::value ? dh : f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 10; ++j) {
@@ -1174,12 +1211,6 @@ __global__ __launch_bounds__(SW_THREADS) void dec_rollout_bwd_kernel(
       dh = acc + acc1;
     }
     // (next iteration's first LDS writes are to dgbuf, whose readers are behind barriers)
-    if constexpr (decltype(pf)::value) {
-      // the prefetched rows are not touched before the products above have been issued
-      asm volatile("" : "+v"(N.gate[0]), "+v"(N.gate[1]), "+v"(N.gate[2]), "+v"(N.gate[3]), "+v"(N.ct), "+v"(N.cprev));
-      asm volatile("" : "+v"(N.a2[0]), "+v"(N.a2[1]), "+v"(N.a1[0]), "+v"(N.a1[1]), "+v"(N.a1s[0]), "+v"(N.a1s[1]), "+v"(N.g4));
-      R = N;
-    }
   };
   if (Tp > 1) {
     step(Tp - 1, F_{}, T_{});

@@ -288,9 +288,12 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_bwd_kernel(
   SW_STAMP(10);
   // one BPTT step; pf: rows of step t-1 are prefetched (pp: they have a predecessor row), nx: dh_{t-1} is needed
   auto step = [&](int t, auto pf, auto pp, auto nx) {
-    f32x4 ngate[4], nct, ncp, dgate[4];
-    if constexpr (decltype(pf)::value) load_row(t - 1, ngate, nct, ncp, pp);
+    f32x4 dgate[4];
     lstm_cell_bwd(gate, ct, cprev, dh, dc, dgate);
+    if constexpr (decltype(pf)::value) {      // rolling prefetch: the rows of step t - 1 into the registers just consumed
+      load_row(t - 1, gate, ct, cprev, pp);
+      asm volatile("" ::: "memory");
+    }
     float* dgl = &dgbuf[(t & 1) * 16 * SW_GLD + ln * SW_GLD + u0 + 4 * lg];
 #pragma unroll
     for (int g = 0; g < 4; ++g) st4(dgl + g * 64, dgate[g]);
@@ -300,12 +303,8 @@ __global__ __launch_bounds__(SW_THREADS, 2) void disc_bwd_kernel(
                            a0, B, wave, lane);
     SW_STAMP(13);
     if constexpr (decltype(nx)::value) dh = lstm_dh_prev(WT, &dgbuf[(t & 1) * 16 * SW_GLD + ln * SW_GLD + 4 * lg]);
-    if constexpr (decltype(pf)::value) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) gate[g] = ngate[g];
-      ct = nct;
-      cprev = ncp;
-    }
+    if constexpr (decltype(pf)::value)
+      asm volatile("" : "+v"(gate[0]), "+v"(gate[1]), "+v"(gate[2]), "+v"(gate[3]), "+v"(ct), "+v"(cprev));
     SW_STAMP(14);
   };
   // every load issued so far (the saved rows of the first step, W_hh^T) is waited for HERE: behind the heads' conditional

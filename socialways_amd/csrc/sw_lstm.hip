@@ -260,13 +260,18 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_bwd_kernel(
   else load_row(0, gate, ct, cprev, F_{});
   const float* dyp = DY ? dy + ((size_t)b * T + T - 1) * 64 + u0 + 4 * lg : nullptr;
   auto step = [&](int t, auto pf, auto pp) {   // pf: prefetch the rows of step t-1 (pp: which have a predecessor row)
-    f32x4 ngate[4], nct, ncp, dgate[4];
-    if constexpr (decltype(pf)::value) load_row(t - 1, ngate, nct, ncp, pp);
+    f32x4 dgate[4];
     if constexpr (DY) {
       dh += ld4(dyp);
       dyp -= 64;
     }
     lstm_cell_bwd(gate, ct, cprev, dh, dc, dgate);
+    // ROLLING prefetch (round 6, as in dec_rollout_bwd_kernel): the rows of step t - 1 are requested right behind the last
+    // use of the rows of step t, into the same registers (no second row set)
+    if constexpr (decltype(pf)::value) {
+      load_row(t - 1, gate, ct, cprev, pp);
+      asm volatile("" ::: "memory");
+    }
     float* dgl = &dgbuf[t & 1][ln * SW_GLD + u0 + 4 * lg];
 #pragma unroll
     for (int g = 0; g < 4; ++g) st4(dgl + g * 64, dgate[g]);
@@ -275,11 +280,7 @@ __global__ __launch_bounds__(SW_THREADS) void enc_lstm_bwd_kernel(
     dh = lstm_dh_prev(W, &dgbuf[t & 1][ln * SW_GLD + 4 * lg]);
     if constexpr (decltype(pf)::value) {
       // the prefetched rows are not touched before the matrix products above have been issued
-      asm volatile("" : "+v"(ngate[0]), "+v"(ngate[1]), "+v"(ngate[2]), "+v"(ngate[3]), "+v"(nct), "+v"(ncp));
-#pragma unroll
-      for (int g = 0; g < 4; ++g) gate[g] = ngate[g];
-      ct = nct;
-      cprev = ncp;
+      asm volatile("" : "+v"(gate[0]), "+v"(gate[1]), "+v"(gate[2]), "+v"(gate[3]), "+v"(ct), "+v"(cprev));
     }
   };
   for (int t = T - 1; t >= 2; --t) step(t, T_{}, T_{});
