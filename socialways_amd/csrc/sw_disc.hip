@@ -719,9 +719,12 @@ __global__ __launch_bounds__(SW_THREADS) void disc_update_kernel(
 #pragma unroll
   for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(WT.whhT[j]));
   auto step = [&](int t, auto pf, auto pp, auto nx) {
-    f32x4 ngate[4], nct, ncp, dgate[4];
-    if constexpr (decltype(pf)::value) load_row(t - 1, ngate, nct, ncp, pp);
+    f32x4 dgate[4];
     lstm_cell_bwd(gate, ct, cprev, dh, dc, dgate);
+    if constexpr (decltype(pf)::value) {      // rolling prefetch: the rows of step t - 1 into the registers just consumed
+      load_row(t - 1, gate, ct, cprev, pp);
+      asm volatile("" ::: "memory");
+    }
     float* dgl = &dgbuf[(t & 1) * 16 * SW_GLD + ln * SW_GLD + u0 + 4 * lg];
 #pragma unroll
     for (int g = 0; g < 4; ++g) st4(dgl + g * 64, dgate[g]);
@@ -729,12 +732,8 @@ __global__ __launch_bounds__(SW_THREADS) void disc_update_kernel(
     lstm_store_dgates_tile(&dgbuf[(t & 1) * 16 * SW_GLD], ddelta + dd.dgates + ((size_t)t * B + a0) * 256, ddelta + dd.trash,
                            a0, B, wave, lane);
     if constexpr (decltype(nx)::value) dh = lstm_dh_prev(WT, &dgbuf[(t & 1) * 16 * SW_GLD + ln * SW_GLD + 4 * lg]);
-    if constexpr (decltype(pf)::value) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) gate[g] = ngate[g];
-      ct = nct;
-      cprev = ncp;
-    }
+    if constexpr (decltype(pf)::value)
+      asm volatile("" : "+v"(gate[0]), "+v"(gate[1]), "+v"(gate[2]), "+v"(gate[3]), "+v"(ct), "+v"(cprev));
   };
   for (int t = To - 1; t >= 2; --t) step(t, T_{}, T_{}, T_{});
   if (To > 1) step(1, T_{}, F_{}, T_{});
