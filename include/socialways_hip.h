@@ -170,7 +170,9 @@ int sw_social_pool_bwd(const float* obsv, int To, const float* h, const int* sce
                        void* stream);
 
 /* ---- predict() decode loop (train.py:415-432): DecoderFC + position integration + the
- *      re-fed EncoderLstm step, Tp times, one persistent kernel -------------------------------- */
+ *      re-fed EncoderLstm step, Tp times, one persistent kernel (one workgroup per 16-agent tile; with the
+ *      step's weight images registered and more than 256 tiles: per 32 agents, two column blocks against
+ *      every register-resident weight operand - the same results bit for bit) ------------------------- */
 int sw_dec_rollout_fwd(const float* obsv /*[B,To,2]*/, int To, const float* z /*[B,32]*/,
                        const float* S_pool /*[B,64] or NULL = zeros*/, const float* hT, const float* cT,
                        const float* enc_w, const float* dec_w, int B, int Tp,
